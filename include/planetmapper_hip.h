@@ -1,0 +1,238 @@
+/*
+ * planetmapper_hip.h -- C ABI of libplanetmapper_hip.so
+ *
+ * MI355X (gfx950) engine for the per-pixel hot path of ortk95/planetmapper:
+ * backplane image generation and map reprojection. The reference has no FFI of
+ * its own for this path (it is pure Python calling CSPICE through spiceypy once
+ * per pixel); each entry point below therefore names the reference *Python*
+ * interface it replaces (file:line relative to the reference checkout). The
+ * Python package `planetmapper_amd` binds these symbols with ctypes and presents
+ * the reference's BodyXY / Observation method names on top.
+ *
+ * Conventions
+ *   - plain C types only; no C++ exceptions cross the boundary;
+ *   - every function returns PM_OK (0) or a negative pm_status; the message of the
+ *     most recent failure on a context is available from pm_last_error();
+ *   - images are row-major double[ny][nx], pixel (0,0) bottom-left, integer
+ *     coordinates are pixel centres (reference: planetmapper/__init__.py:19-23);
+ *     "not on the disc / not visible" is a quiet NaN;
+ *   - buffers are caller-owned. A pointer is a HOST pointer unless the call takes
+ *     a `mem` argument equal to PM_MEM_DEVICE, in which case it is a device (HBM)
+ *     pointer valid on the context's GPU;
+ *   - a context is bound to one GPU and one HIP stream; calls on one context must
+ *     not be made concurrently from several threads. Calls are synchronous for
+ *     host buffers; for device buffers work is enqueued on the context stream and
+ *     pm_synchronize() waits for it.
+ */
+#ifndef PLANETMAPPER_HIP_H
+#define PLANETMAPPER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PM_ABI_VERSION 1
+
+typedef enum pm_status {
+    PM_OK = 0,
+    PM_ERR_INVALID_ARGUMENT = -1, /* ValueError in the reference */
+    PM_ERR_NO_DEVICE = -2,        /* no usable gfx950 device / HIP runtime failure */
+    PM_ERR_HIP = -3,              /* a HIP call failed; see pm_last_error */
+    PM_ERR_STATE = -4,            /* geometry or disc not set yet */
+    PM_ERR_ALLOC = -5
+} pm_status;
+
+typedef enum pm_mem { PM_MEM_HOST = 0, PM_MEM_DEVICE = 1 } pm_mem;
+
+/*
+ * Backplane identifiers: bit positions of `plane_mask`, in the order of the
+ * reference's default registry (planetmapper/body_xy.py:4198-4356).
+ */
+typedef enum pm_plane {
+    PM_LON_GRAPHIC = 0,      /* body_xy.py:3302 get_lon_img            [deg] */
+    PM_LAT_GRAPHIC = 1,      /* body_xy.py:3324 get_lat_img            [deg] */
+    PM_LON_CENTRIC = 2,      /* body_xy.py:3346 _get_lonlat_centric_img [deg] */
+    PM_LAT_CENTRIC = 3,
+    PM_RA = 4,               /* body_xy.py:3409 _get_radec_img         [deg] */
+    PM_DEC = 5,
+    PM_PIXEL_X = 6,          /* body_xy.py:3494 get_x_img              [px]  */
+    PM_PIXEL_Y = 7,
+    PM_KM_X = 8,             /* body_xy.py:3545 _get_km_xy_img         [km]  */
+    PM_KM_Y = 9,
+    PM_ANGULAR_X = 10,       /* body_xy.py:3610 get_angular_x_img   [arcsec] */
+    PM_ANGULAR_Y = 11,
+    PM_PHASE = 12,           /* body_xy.py:3658 _get_illumination_gie_img [deg] */
+    PM_INCIDENCE = 13,
+    PM_EMISSION = 14,
+    PM_AZIMUTH = 15,         /* body_xy.py:3742 get_azimuth_angle_img  [deg] */
+    PM_LOCAL_SOLAR_TIME = 16,/* body_xy.py:3787 get_local_solar_time_img [h] */
+    PM_DISTANCE = 17,        /* body_xy.py:3869 get_distance_img       [km]  */
+    PM_RADIAL_VELOCITY = 18, /* body_xy.py:3895 get_radial_velocity_img [km/s] */
+    PM_DOPPLER = 19,         /* body_xy.py:3938 get_doppler_img              */
+    PM_LIMB_DISTANCE = 20,   /* body_xy.py:3964 _get_limb_coordinate_imgs [km] */
+    PM_LIMB_LON_GRAPHIC = 21,
+    PM_LIMB_LAT_GRAPHIC = 22,
+    PM_RING_RADIUS = 23,     /* body_xy.py:4059 _get_ring_plane_coordinate_imgs [km] */
+    PM_RING_LON_GRAPHIC = 24,
+    PM_RING_DISTANCE = 25,
+    PM_NUM_PLANES = 26
+} pm_plane;
+
+#define PM_PLANE_BIT(p) (((uint64_t)1) << (p))
+
+/*
+ * Geometry block: everything the per-pixel kernels need about one Body at one
+ * epoch, computed ONCE on the host (reference: SPICE calls in
+ * planetmapper/base.py:795-839 and planetmapper/body.py:501-606). All vectors
+ * are km (km/s, km/s^2) in J2000 unless stated; matrices are row-major.
+ *
+ * Light-time corrected quantities are reconstructed on the device as
+ *   T(t)  = T0 + VT (t - t0) + AT (t - t0)^2 / 2              t0 = et - lt_c
+ *   R(t)  = Rz_frame(wdot (t - t0)) R0                        (J2000 -> body-fixed)
+ *   S(t)  = S0 + VS (t - ts0) + AS (t - ts0)^2 / 2            (Sun wrt P_T(t0))
+ * which is exact to < 1e-9 km / 1e-13 rad over the <= 1 s (disc) to 1e3 s (ring
+ * plane) spans the path needs.
+ */
+typedef struct pm_geometry {
+    double et;          /* observation epoch, TDB seconds past J2000 (BodyBase.et) */
+    double lt_c;        /* one-way light time to target centre (BodyBase.target_light_time) */
+    double clight;      /* km/s, spice.clight() */
+    double radii[3];    /* Body.radii (a, b, c) WITHOUT altitude adjustment */
+
+    double T0[3];       /* Body._target_obsvec: target centre at t0 wrt observer at et */
+    double VT[3];       /* SSB velocity of target centre at t0 */
+    double AT[3];       /* SSB acceleration of target centre at t0 */
+    double VO[3];       /* SSB velocity of observer at et (radial velocity only) */
+
+    double ts0;         /* epoch at which S0/VS/AS are evaluated (~ t0 - Sun light time) */
+    double S0[3];       /* P_sun(ts0) - P_T(t0) */
+    double VS[3];       /* SSB velocity of the Sun at ts0 */
+    double AS[3];       /* SSB acceleration of the Sun at ts0 */
+
+    double R0[9];       /* pxform(J2000 -> target frame) at t0 */
+    double wdot;        /* spin rate about body +z, rad/s (dW/dt of the IAU model) */
+
+    double sub_sp[3];     /* Body._subpoint_targvec (body-fixed)          body.py:538 */
+    double sub_ray[3];    /* Body._subpoint_rayvec  (body-fixed, obs->sp) body.py:538 */
+    double sub_obsvec[3]; /* Body._subpoint_obsvec  (J2000)               body.py:551 */
+    double sub_et;        /* Body._subpoint_et */
+    double sub_dist;      /* Body.subpoint_distance */
+
+    double ring_n[3];   /* unit normal of Body._ring_plane (J2000)        body.py:583 */
+    double ring_k;      /* plane constant (>= 0), n . X = k */
+
+    double M[9];        /* Body._get_obsvec2angular_matrix()              body.py:1317 */
+    double diameter_arcsec; /* Body.target_diameter_arcsec                body.py:574 */
+    double km_per_arcsec;   /* Body.km_per_arcsec                         body.py:577 */
+    double np_angle_rad;    /* Body.north_pole_angle() in radians         body.py:2985 */
+    double lst_sun_lon;     /* planetocentric east longitude (rad) of the Sun in the
+                               target frame at t0, LT+S (et2lst)           body.py:2364 */
+
+    int32_t west_positive;  /* 1 if Body.positive_longitude_direction == 'W' body.py:528 */
+    int32_t reserved;
+} pm_geometry;
+
+/* Disc parameters + image size (reference: BodyXY.set_disc_params body_xy.py:700,
+ * set_img_size body_xy.py:941, `optimize_speed` base.py:229). */
+typedef struct pm_disc {
+    double x0, y0, r0;      /* pixels */
+    double rotation_rad;    /* BodyXY._rotation_radians, already reduced mod 2 pi */
+    int32_t nx, ny;
+    int32_t optimize_speed; /* enables the radius pre-mask of body_xy.py:3201-3218 */
+    int32_t reserved;
+} pm_disc;
+
+typedef enum pm_interpolation {
+    PM_INTERP_NEAREST = 0, /* body_xy.py:1633 _do_nearest_interpolation */
+    PM_INTERP_LINEAR = 1   /* body_xy.py:1651 _do_spline_interpolation, kx=ky=1, s=0 */
+} pm_interpolation;
+
+typedef enum pm_dtype {
+    PM_F64 = 0, PM_F32 = 1, PM_I16 = 2, PM_I32 = 3, PM_U8 = 4, PM_U16 = 5
+} pm_dtype;
+
+typedef struct pm_ctx pm_ctx; /* opaque */
+
+/* Library / device ---------------------------------------------------------- */
+int pm_abi_version(void);
+/* Number of usable gfx950 devices (0 if none); never fails. */
+int pm_device_count(void);
+/* Create a context on GPU `device`. Fails (NULL + *status) if there is no GPU:
+ * this library has no CPU fallback. */
+pm_ctx *pm_create(int device, int *status);
+void pm_destroy(pm_ctx *ctx);
+const char *pm_last_error(const pm_ctx *ctx);
+int pm_synchronize(pm_ctx *ctx);
+/* HIP stream the context launches on (as a void*), for event timing by callers. */
+void *pm_stream(pm_ctx *ctx);
+
+/* Device memory helpers so non-HIP callers can keep data resident in HBM. */
+int pm_device_malloc(pm_ctx *ctx, uint64_t bytes, void **dptr);
+int pm_device_free(pm_ctx *ctx, void *dptr);
+int pm_memcpy_h2d(pm_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes);
+int pm_memcpy_d2h(pm_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes);
+
+/* State ----------------------------------------------------------------------- */
+/* replaces Body.__init__ state (body.py:323-606) as seen by the pixel loops */
+int pm_set_geometry(pm_ctx *ctx, const pm_geometry *geometry);
+/* replaces BodyXY.set_disc_params / set_img_size (body_xy.py:700-961) */
+int pm_set_disc(pm_ctx *ctx, const pm_disc *disc);
+
+/* Image-space backplanes ------------------------------------------------------- */
+/*
+ * replaces the pixel loops BodyXY._get_targvec_img (body_xy.py:3195),
+ * _get_lonlat_img (:3281), _get_lonlat_centric_img (:3346), _get_radec_img (:3409),
+ * _get_km_xy_img (:3545), _get_illumination_gie_img (:3658), get_azimuth_angle_img
+ * (:3742), get_local_solar_time_img (:3787), _get_state_imgs (:3830),
+ * get_radial_velocity_img (:3895), get_doppler_img (:3938),
+ * _get_limb_coordinate_imgs (:3964) and _get_ring_plane_coordinate_imgs (:4059)
+ * with ONE fused kernel launch.
+ *
+ * plane_mask : OR of PM_PLANE_BIT(p) for the planes wanted.
+ * out        : array of PM_NUM_PLANES pointers; out[p] must point to ny*nx doubles
+ *              for every requested p (others are ignored and may be NULL).
+ * alt        : altitude adjustment in km (reference `alt` kwarg of
+ *              get_backplane_img, body_xy.py:2586; semantics of
+ *              _AdjustedSurfaceAltitude body.py:172-229).
+ */
+int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt,
+                      double *const *out, int mem);
+
+/* Map-space ---------------------------------------------------------------------- */
+/*
+ * replaces BodyXY._get_targvec_map (body_xy.py:3227), _get_illumf_map (:3667),
+ * _get_obsvec_map (:3273), _get_radec_map (:3419) and _get_xy_map (:3478):
+ * planetographic (lon, lat) grid [deg] -> image pixel coordinates of each map
+ * location, NaN where not visible or outside the image frame.
+ * lon_deg/lat_deg/x_map/y_map: n0*n1 doubles each.
+ */
+int pm_xy_map(pm_ctx *ctx, const double *lon_deg, const double *lat_deg, int n0,
+              int n1, double alt, double *x_map, double *y_map, int mem);
+
+/*
+ * Map-space backplanes (reference get_*_map family, e.g. body_xy.py:3290-3300,
+ * 3667-3675, 3843-3867): same plane ids as pm_backplanes_img, evaluated on a
+ * lon/lat grid. out[p] -> n0*n1 doubles.
+ */
+int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg,
+                      const double *lat_deg, int n0, int n1, double alt,
+                      double *const *out, int mem);
+
+/*
+ * replaces BodyXY.map_img (body_xy.py:1414-1631) applied to every plane of a cube,
+ * i.e. Observation._get_mapped_data (observation.py:876-905).
+ * cube: P planes of ny*nx elements of `dtype`, plane-major; out: P*n0*n1 doubles.
+ * interpolation: pm_interpolation; propagate_nan as in map_img.
+ * With propagate_nan == 0 the NaN pre-clean of
+ * _replace_nans_with_interpolated_values (body_xy.py:1871-1904) is applied.
+ */
+int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
+                const double *x_map, const double *y_map, int n0, int n1,
+                int interpolation, int propagate_nan, double *out, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLANETMAPPER_HIP_H */

@@ -1,0 +1,36 @@
+import os
+import sys
+
+import pytest
+
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def jupiter():
+    """Geometry block of Body('Jupiter', observer='HST', utc='2005-01-01T00:00:00')."""
+    from planetmapper_amd.scenarios import load_scenario
+
+    return load_scenario('jupiter_hst_2005')
+
+
+@pytest.fixture(scope='session')
+def saturn():
+    from planetmapper_amd.scenarios import load_scenario
+
+    return load_scenario('saturn_earth_2005')
+
+
+@pytest.fixture(scope='session')
+def jupiter_info():
+    from planetmapper_amd.scenarios import scenario_info
+
+    return scenario_info('jupiter_hst_2005')

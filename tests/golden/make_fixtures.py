@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""
+Generate the committed fixtures under tests/golden/ from the reference's own test
+DATA files (golden FITS outputs, the input cube and the SPICE kernels it ships under
+tests/data/). Run in the build container, where /root/reference exists:
+
+    python tests/golden/make_fixtures.py [/root/reference]
+
+Nothing here imports the reference (it is not importable in the container: astropy /
+spiceypy are absent) and no reference source text is copied: fixtures are data only -
+expected output planes, header scalars, PCK constants and the handful of Chebyshev
+ephemeris records that cover the test epoch.
+
+Outputs (geometry inputs go to planetmapper_amd/data/, they are also what bench.py
+uses; expected outputs stay in tests/golden/)
+    jupiter_hst_2005.json   geometry inputs for Body('Jupiter', observer='HST',
+                            utc='2005-01-01T00:00:00') (tests/test_body.py:29-31)
+    saturn_earth_2005.json  geometry inputs for the Saturn config (BASELINE config 4;
+                            not pinned by any reference golden)
+    golden_*.npz            planes of tests/data/outputs/*.fits
+    input_cube.npz          tests/data/inputs/test.fits primary HDU
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, '..', '..'))
+DATA = os.path.join(REPO, 'planetmapper_amd', 'data')
+sys.path.insert(0, REPO)
+
+from planetmapper_amd import ephem  # noqa: E402
+from planetmapper_amd.geometry import GeometryBuilder  # noqa: E402
+
+
+# ---------------------------------------------------------------------------- FITS
+def read_fits(path: str):
+    """Minimal FITS reader (2880-byte blocks, HIERARCH cards); returns [(hdr, data)]."""
+    b = open(path, 'rb').read()
+    pos = 0
+    hdus = []
+    while pos < len(b):
+        cards = []
+        end = False
+        while not end:
+            block = b[pos : pos + 2880]
+            pos += 2880
+            for i in range(36):
+                c = block[i * 80 : (i + 1) * 80].decode('ascii')
+                if c.startswith('END'):
+                    end = True
+                    break
+                cards.append(c)
+        hdr = {}
+        for c in cards:
+            if c.startswith('HIERARCH'):
+                k, _, v = c[9:].partition('=')
+                k = k.strip()
+            elif c[8:10] == '= ':
+                k = c[:8].strip()
+                v = c[10:]
+            else:
+                continue
+            v = v.strip()
+            if v.startswith("'"):
+                j = v.find("'", 1)
+                while j + 1 < len(v) and v[j + 1] == "'":
+                    j = v.find("'", j + 2)
+                val = v[1:j].rstrip()
+            else:
+                val = v.split('/')[0].strip()
+                if val in ('T', 'F'):
+                    val = val == 'T'
+                else:
+                    try:
+                        val = int(val)
+                    except ValueError:
+                        try:
+                            val = float(val)
+                        except ValueError:
+                            pass
+            hdr[k] = val
+        naxis = hdr.get('NAXIS', 0)
+        data = None
+        if naxis:
+            shape = [hdr[f'NAXIS{i}'] for i in range(naxis, 0, -1)]
+            bp = hdr['BITPIX']
+            dt = {-64: '>f8', -32: '>f4', 8: 'u1', 16: '>i2', 32: '>i4', 64: '>i8'}[bp]
+            n = int(np.prod(shape)) * abs(bp) // 8
+            data = np.frombuffer(b[pos : pos + n], dtype=dt).reshape(shape)
+            pos += (n + 2879) // 2880 * 2880
+        hdus.append((hdr, data))
+    return hdus
+
+
+def fits_to_npz(path: str, out: str) -> dict:
+    hdus = read_fits(path)
+    arrays = {}
+    for i, (hdr, data) in enumerate(hdus):
+        if data is None:
+            continue
+        name = 'PRIMARY' if i == 0 else hdr['EXTNAME']
+        arrays[name] = np.ascontiguousarray(data.astype(data.dtype.newbyteorder('=')))
+    np.savez_compressed(out, **arrays)
+    return hdus[0][0]
+
+
+PCK_KEYS = [
+    'RADII', 'POLE_RA', 'POLE_DEC', 'PM', 'NUT_PREC_RA', 'NUT_PREC_DEC', 'NUT_PREC_PM',
+]  # fmt: skip
+
+
+def main(ref: str) -> None:
+    kdir = os.path.join(ref, 'tests', 'data', 'kernels')
+    odir = os.path.join(ref, 'tests', 'data', 'outputs')
+    idir = os.path.join(ref, 'tests', 'data', 'inputs')
+    pool = ephem.parse_text_kernel(open(os.path.join(kdir, 'pck00010.tpc')).read())
+    # kernel precedence as sorted by the reference (planetmapper/base.py:939-977):
+    # jup120 is loaded after de410s and overrides it for bodies 3, 5, 10
+    eph = ephem.Ephemeris.from_spk_files(
+        [
+            os.path.join(kdir, 'file with spaces de410s.bsp'),
+            os.path.join(kdir, 'jup120_1996-2010.bsp'),
+        ]
+    )
+
+    # ------------------------------------------------------------------ golden planes
+    headers = {}
+    for name in [
+        'test_nav', 'test_nav_alt',
+        'map_rectangular-linear', 'map_rectangular-nearest', 'map_rectangular-nearest-alt',
+        'map_orthographic-1', 'map_azimuthal-1',
+    ]:  # fmt: skip
+        hdr = fits_to_npz(
+            os.path.join(odir, name + '.fits'),
+            os.path.join(HERE, 'golden_' + name.replace('-', '_') + '.npz'),
+        )
+        headers[name] = {k: v for k, v in hdr.items() if k.startswith('PLANMAP') or k.startswith('C')}
+    cube = read_fits(os.path.join(idir, 'test.fits'))[0][1]
+    np.savez_compressed(
+        os.path.join(HERE, 'input_cube.npz'),
+        data=np.ascontiguousarray(cube.astype(cube.dtype.newbyteorder('='))),
+    )
+
+    # ------------------------------------------------------------------ Jupiter / HST
+    h = headers['test_nav']
+    et = h['PLANMAP ET-OBS']
+    rot = ephem.RotationModel.from_pool(pool, 599)
+    mini = eph.trimmed([599, 10, 399], et - 86400.0, et + 86400.0)
+    fixture = {
+        'description': "Body('Jupiter', observer='HST', utc='2005-01-01T00:00:00')",
+        'target_id': 599,
+        'et': et,
+        'header': h,
+        'headers': headers,
+        'pck': rot.to_json(),
+        'ephemeris': mini.to_json(),
+    }
+    # The observer (HST) ephemeris is an SPK type 10 (TLE) segment that is not
+    # restated; its position follows from the header's apparent target RA/Dec/distance.
+    # Its velocity is not published anywhere, so it is recovered by a 3-parameter
+    # least-squares fit to the golden RADIAL-VELOCITY plane (40 on-disc pixels).
+    from oracle import oracle
+
+    gb = GeometryBuilder(mini, rot, 599)
+    tgt = (
+        h['PLANMAP TARGET RA'], h['PLANMAP TARGET DEC'],
+        h['PLANMAP DISTANCE'], h['PLANMAP LIGHT-TIME'],
+    )  # fmt: skip
+    nav = np.load(os.path.join(HERE, 'golden_test_nav.npz'))
+    rv_gold = nav['RADIAL-VELOCITY']
+    ok = np.isfinite(rv_gold)
+    disc = oracle.make_disc(
+        h['PLANMAP DISC X0'], h['PLANMAP DISC Y0'], h['PLANMAP DISC R0'], 123.456, 7, 10
+    )
+
+    def rv_of(vo):
+        g = gb.build(et, observer_velocity=vo, target_ra_dec_dist_lt=tgt)
+        return oracle.backplanes_img(g, disc, ['RADIAL-VELOCITY'])['RADIAL-VELOCITY'][ok]
+
+    vo = np.array(eph.ssb_state(399, et)[1])
+    for _ in range(4):
+        r0 = rv_of(vo) - rv_gold[ok]
+        jac = np.empty((ok.sum(), 3))
+        for i in range(3):
+            dv = np.zeros(3)
+            dv[i] = 1e-3
+            jac[:, i] = (rv_of(vo + dv) - rv_of(vo - dv)) / 2e-3
+        vo = vo - np.linalg.lstsq(jac, r0, rcond=None)[0]
+    resid = float(np.max(np.abs(rv_of(vo) - rv_gold[ok])))
+    fixture['observer_velocity_fit'] = [float(v) for v in vo]
+    fixture['observer_velocity_fit_residual_km_s'] = resid
+    print('fitted observer velocity', vo, 'residual', resid)
+    with open(os.path.join(DATA, 'jupiter_hst_2005.json'), 'w', encoding='utf-8') as f:
+        json.dump(fixture, f, indent=1)
+
+    # ------------------------------------------------------------------ Saturn / Earth
+    # Saturn system barycentre (6) stands in for the planet centre (no 699 segment in
+    # the bundled kernels, sat060.bsp is a stub); spheroid + pole from pck00010.tpc.
+    rot_s = ephem.RotationModel.from_pool(pool, 699)
+    de410 = ephem.Ephemeris.from_spk_files([os.path.join(kdir, 'file with spaces de410s.bsp')])
+    mini_s = de410.trimmed([6, 10, 399], et - 86400.0, et + 86400.0)
+    with open(os.path.join(DATA, 'saturn_earth_2005.json'), 'w', encoding='utf-8') as f:
+        json.dump(
+            {
+                'description': 'Saturn-like spheroid (body 6 barycentre) seen from Earth, '
+                '2005-01-01T00:00:00; BASELINE config 4; parity unpinned by the reference',
+                'target_id': 6,
+                'observer_id': 399,
+                'et': et,
+                'pck': rot_s.to_json(),
+                'ephemeris': mini_s.to_json(),
+            },
+            f,
+            indent=1,
+        )
+
+
+if __name__ == '__main__':
+    main(sys.argv[1] if len(sys.argv) > 1 else '/root/reference')

@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark (BASELINE.json): Mpix/s for the full backplane set
+(LON/LAT-GRAPHIC, PHASE, INCIDENCE, EMISSION) + map reprojection of a 4096 x 4096 frame.
+
+One step = one frame through the hot path, everything resident in HBM:
+  1. pm_backplanes_img   5 planes, 4096^2           (kernel k_disc<ILLUM>)
+  2. pm_xy_map           1 deg rectangular grid     (kernel k_map, 180 x 360)
+  3. pm_map_cube         1 data plane -> (180, 360) (kernel k_reproject<f64>)
+With N > 1 GPUs every rank processes its own frame (weak scaling, no data-path
+collective in the backplane stage) and the reprojected planes - one per rank, i.e. the
+wavelength planes of `Observation.get_mapped_data` sharded one per GPU - are combined
+by ONE RCCL all-gather, the only exchange step the path has.
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096]
+Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+                   --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HEADLINE = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION']
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def rectangular_grid(west_positive: bool, degree_interval: float = 1.0):
+    """BodyXY.generate_map_coordinates('rectangular') body_xy.py:2899-2907."""
+    lons = np.arange(degree_interval / 2, 360, degree_interval)
+    if west_positive:
+        lons = lons[::-1]
+    lats = np.arange(-90 + degree_interval / 2, 90, degree_interval)
+    lon, lat = np.meshgrid(lons, lats)
+    return np.ascontiguousarray(lon % 360), np.ascontiguousarray(lat)
+
+
+def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
+    """the image kernel reads nothing and writes 8 B per plane per pixel."""
+    return nx * ny * 8 * n_planes
+
+
+def cpu_baseline(g, sz: int, budget_s: float = 12.0) -> dict:
+    """
+    The CPU oracle (a port: the reference's own Python + CSPICE path cannot run here)
+    timed on this box's host cores on the same 5-plane frame; all cores via OpenMP.
+    """
+    from oracle import oracle
+
+    cores = len(os.sched_getaffinity(0))
+    oracle.set_num_threads(cores)
+    x0 = y0 = (sz - 1) / 2
+    disc = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)
+    lon, lat = rectangular_grid(bool(g.west_positive))
+    img = np.zeros((sz, sz))
+    # bounded sample: whole frames until the budget is used (at least one)
+    t0 = time.perf_counter()
+    frames = 0
+    while True:
+        oracle.backplanes_img(g, disc, HEADLINE)
+        xm, ym = oracle.xy_map(g, disc, lon, lat)
+        oracle.map_cube(img, xm, ym, 'linear', True)
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or frames >= 8:
+            break
+    return {
+        'value': round(frames * sz * sz / dt / 1e6, 3),
+        'unit': 'Mpix/s',
+        'cores': cores,
+        'kind': 'port',
+        'sample': f'{frames} full {sz}x{sz} frame(s), 5 planes + 1 deg reprojection, OpenMP over rows',
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--size', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from planetmapper_amd.engine import Engine
+    from planetmapper_amd.scenarios import load_scenario
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+
+    sz = args.size
+    g = load_scenario('jupiter_hst_2005')
+    x0 = y0 = (sz - 1) / 2
+    eng = Engine(local_rank)
+    # launch on torch's current stream so torch events / RCCL order with our kernels
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    eng.set_geometry(g)
+    eng.set_disc(x0, y0, 0.9 * x0, 0.0, sz, sz, True)  # BodyXY.centre_disc body_xy.py:791
+
+    planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in HEADLINE}
+    lon_h, lat_h = rectangular_grid(bool(g.west_positive))
+    n0, n1 = lon_h.shape
+    lon_d = torch.from_numpy(lon_h).to(dev)
+    lat_d = torch.from_numpy(lat_h).to(dev)
+    xm = torch.empty((n0, n1), dtype=torch.float64, device=dev)
+    ym = torch.empty((n0, n1), dtype=torch.float64, device=dev)
+    # synthetic data plane: limb-darkened disc + noise (SURVEY 8d config 3 recipe)
+    gen = torch.Generator(device=dev).manual_seed(20050101 + rank)
+    yy, xx = torch.meshgrid(
+        torch.arange(sz, device=dev, dtype=torch.float64),
+        torch.arange(sz, device=dev, dtype=torch.float64),
+        indexing='ij',
+    )
+    mu = torch.sqrt(torch.clamp(1 - ((xx - x0) ** 2 + (yy - y0) ** 2) / (0.9 * x0) ** 2, min=0))
+    data = mu + 0.05 * torch.randn((sz, sz), generator=gen, device=dev, dtype=torch.float64)
+    del yy, xx, mu
+    mapped = torch.empty((world, n0, n1), dtype=torch.float64, device=dev)
+    mine = mapped[rank]
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i: int | None) -> None:
+        if i is not None:
+            ev0[i].record()
+        eng.backplanes_img_device(planes)
+        if i is not None:
+            ev1[i].record()
+        eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
+        eng.map_cube_device(data, np.float64, 1, xm, ym, n0, n1, mine, 'linear', True)
+        if world > 1:
+            dist.all_gather_into_tensor(mapped.view(-1), mine.reshape(-1))
+
+    def barrier() -> None:
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(None)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.synchronize()  # surfaces deferred device-side errors
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    frac_on_disc = float(torch.isfinite(planes['LON-GRAPHIC']).double().mean().item())
+
+    if rank == 0:
+        alg = algorithmic_bytes(sz, sz, len(HEADLINE))
+        achieved = alg / (kernel_ms * 1e-3) / 1e9
+        line = {
+            'metric': 'Mpix/s full backplane set (lat/lon/inc/emi/phase) + map-reproject, 4096^2 frame',
+            'value': round(world * sz * sz * args.steps / dt / 1e6, 2),
+            'unit': 'Mpix/s',
+            'n_gpus': world,
+            'steps': args.steps,
+            'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True,
+            'scaling': 'weak',
+            'vs_baseline': None,
+            'dtype': 'f64',
+            'data': 'synthetic',
+            'config': {
+                'workload': f'Jupiter/HST 2005-01-01 geometry, {sz}x{sz} frame per GPU, centred disc '
+                f'(r0=0.9*x0, {frac_on_disc:.3f} of pixels on disc), planes {"/".join(HEADLINE)}, '
+                '+ x/y map and bilinear reprojection of 1 f64 plane to a 1 deg rectangular map (180x360)',
+                'frame': [sz, sz],
+                'planes': len(HEADLINE),
+                'map': [n0, n1],
+                'parallelism': f'frames (and their mapped planes) sharded 1 per GPU x{world}'
+                + (', RCCL all-gather of mapped planes' if world > 1 else ''),
+            },
+            'roofline': {
+                'kernel': 'k_disc<ILLUM>',
+                'bound': 'hbm',
+                'achieved': round(achieved, 2),
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': round(achieved / HBM_PEAK_GBS, 5),
+                'traffic': None,
+                'kernel_ms': round(kernel_ms, 4),
+                'algorithmic_bytes': alg,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line['cpu_baseline'] = cpu_baseline(g, sz)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == '__main__':
+    main()

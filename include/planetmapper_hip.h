@@ -41,7 +41,8 @@ typedef enum pm_status {
     PM_ERR_NO_DEVICE = -2,        /* no usable gfx950 device / HIP runtime failure */
     PM_ERR_HIP = -3,              /* a HIP call failed; see pm_last_error */
     PM_ERR_STATE = -4,            /* geometry or disc not set yet */
-    PM_ERR_ALLOC = -5
+    PM_ERR_ALLOC = -5,
+    PM_ERR_UNSUPPORTED = -6       /* valid in the reference, not implemented here yet */
 } pm_status;
 
 typedef enum pm_mem { PM_MEM_HOST = 0, PM_MEM_DEVICE = 1 } pm_mem;
@@ -165,8 +166,12 @@ pm_ctx *pm_create(int device, int *status);
 void pm_destroy(pm_ctx *ctx);
 const char *pm_last_error(const pm_ctx *ctx);
 int pm_synchronize(pm_ctx *ctx);
+/* For PM_MEM_DEVICE calls, errors detected on the device (pm_map_cube) are reported
+ * by the next pm_synchronize(). */
 /* HIP stream the context launches on (as a void*), for event timing by callers. */
 void *pm_stream(pm_ctx *ctx);
+/* Launch on a caller-owned hipStream_t instead (e.g. torch.cuda.current_stream()). */
+int pm_set_stream(pm_ctx *ctx, void *hip_stream);
 
 /* Device memory helpers so non-HIP callers can keep data resident in HBM. */
 int pm_device_malloc(pm_ctx *ctx, uint64_t bytes, void **dptr);

@@ -179,3 +179,8 @@ def radec_query(g, ra_deg, dec_deg, alt: float = 0.0, ring_only_visible: bool = 
     lib().pmo_radec_query(ctypes.byref(g), float(alt), len(ra), _dptr(ra), _dptr(dec),
                           1 if ring_only_visible else 0, _dptr(out))
     return out
+
+
+def set_num_threads(n: int) -> int:
+    """OpenMP threads of the oracle's row loops; returns the count in effect."""
+    return int(lib().pmo_set_num_threads(int(n)))

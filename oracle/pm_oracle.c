@@ -29,6 +29,9 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #include "../include/planetmapper_hip.h"
 
@@ -613,6 +616,8 @@ int pmo_backplanes_img(const pm_geometry *g, const pm_disc *d, double alt, uint6
     double kdet = k00 * k11 - k01 * k10;
     double ik00 = k11 / kdet, ik01 = -k01 / kdet, ik10 = -k10 / kdet, ik11 = k00 / kdet;
 
+    /* rows are independent; threads only speed up the checker / the CPU baseline */
+#pragma omp parallel for schedule(dynamic, 4)
     for (int y = 0; y < d->ny; y++) {
         for (int x = 0; x < d->nx; x++) {
             size_t idx = (size_t)y * d->nx + x;
@@ -756,6 +761,7 @@ int pmo_backplanes_map(const pm_geometry *g, const pm_disc *d, double alt, uint6
     int need_ring = WANT(PM_RING_RADIUS) || WANT(PM_RING_LON_GRAPHIC) || WANT(PM_RING_DISTANCE);
     int need_limb = WANT(PM_LIMB_DISTANCE) || WANT(PM_LIMB_LON_GRAPHIC) || WANT(PM_LIMB_LAT_GRAPHIC);
 
+#pragma omp parallel for schedule(dynamic, 256)
     for (size_t idx = 0; idx < (size_t)n0 * n1; idx++) {
         double lon_deg = lon_deg_in[idx], lat_deg = lat_deg_in[idx];
         /* _get_lonlat_map body_xy.py:3290-3300: non-finite -> NaN */
@@ -1041,6 +1047,18 @@ int pmo_rectangular_grid(const pm_geometry *g, double degree_interval, int n0, i
             lat_deg[(size_t)a * n1 + b] = -90.0 + degree_interval / 2.0 + a * degree_interval;
         }
     return PM_OK;
+}
+
+/* number of OpenMP threads used by the image / map loops (1 = the scalar port) */
+int pmo_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
 }
 
 int pmo_sizeof_geometry(void) { return (int)sizeof(pm_geometry); }

@@ -1,0 +1,118 @@
+"""
+ctypes binding of libplanetmapper_hip.so (C ABI: include/planetmapper_hip.h).
+
+The library is built in-tree by ``planetmapper_amd/csrc/Makefile`` (see
+``__graft_entry__.build``). There is no fallback: if the shared object is missing, or no
+gfx950 device is present when a context is created, an exception is raised.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+from .geometry import PMDisc, PMGeometry
+
+LIB_NAME = 'libplanetmapper_hip.so'
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+NUM_PLANES = 26
+PLANE_NAMES = (
+    'LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC', 'LAT-CENTRIC', 'RA', 'DEC',
+    'PIXEL-X', 'PIXEL-Y', 'KM-X', 'KM-Y', 'ANGULAR-X', 'ANGULAR-Y',
+    'PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH', 'LOCAL-SOLAR-TIME',
+    'DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER',
+    'LIMB-DISTANCE', 'LIMB-LON-GRAPHIC', 'LIMB-LAT-GRAPHIC',
+    'RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE',
+)  # fmt: skip
+PLANE_INDEX = {n: i for i, n in enumerate(PLANE_NAMES)}
+
+PM_OK = 0
+PM_ERR_INVALID_ARGUMENT = -1
+PM_ERR_NO_DEVICE = -2
+PM_ERR_HIP = -3
+PM_ERR_STATE = -4
+PM_ERR_ALLOC = -5
+PM_ERR_UNSUPPORTED = -6
+
+PM_MEM_HOST = 0
+PM_MEM_DEVICE = 1
+
+PM_INTERP_NEAREST = 0
+PM_INTERP_LINEAR = 1
+
+# every symbol declared in include/planetmapper_hip.h
+EXPORTS = (
+    'pm_abi_version', 'pm_device_count', 'pm_create', 'pm_destroy', 'pm_last_error',
+    'pm_synchronize', 'pm_stream', 'pm_set_stream', 'pm_device_malloc', 'pm_device_free',
+    'pm_memcpy_h2d', 'pm_memcpy_d2h', 'pm_set_geometry', 'pm_set_disc',
+    'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube',
+)  # fmt: skip
+
+
+class LibraryNotBuiltError(ImportError):
+    pass
+
+
+class NoDeviceError(RuntimeError):
+    pass
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class UnsupportedError(NotImplementedError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library, declaring argument types. Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryNotBuiltError(
+            f'{LIB_PATH} not found: build it with `make -C planetmapper_amd/csrc` '
+            '(or `python -c "import __graft_entry__ as g; g.build()"`). '
+            'planetmapper_amd has no CPU fallback.'
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp = ctypes.c_void_p
+    dp = ctypes.POINTER(ctypes.c_double)
+    dpp = ctypes.POINTER(ctypes.c_void_p)
+    c_int = ctypes.c_int
+    lib.pm_abi_version.restype = c_int
+    lib.pm_device_count.restype = c_int
+    lib.pm_create.restype = vp
+    lib.pm_create.argtypes = [c_int, ctypes.POINTER(c_int)]
+    lib.pm_destroy.restype = None
+    lib.pm_destroy.argtypes = [vp]
+    lib.pm_last_error.restype = ctypes.c_char_p
+    lib.pm_last_error.argtypes = [vp]
+    lib.pm_synchronize.argtypes = [vp]
+    lib.pm_stream.restype = vp
+    lib.pm_stream.argtypes = [vp]
+    lib.pm_set_stream.argtypes = [vp, vp]
+    lib.pm_device_malloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
+    lib.pm_device_free.argtypes = [vp, vp]
+    lib.pm_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    lib.pm_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_uint64]
+    lib.pm_set_geometry.argtypes = [vp, ctypes.POINTER(PMGeometry)]
+    lib.pm_set_disc.argtypes = [vp, ctypes.POINTER(PMDisc)]
+    lib.pm_backplanes_img.argtypes = [vp, ctypes.c_uint64, ctypes.c_double, dpp, c_int]
+    lib.pm_xy_map.argtypes = [vp, vp, vp, c_int, c_int, ctypes.c_double, vp, vp, c_int]
+    lib.pm_backplanes_map.argtypes = [
+        vp, ctypes.c_uint64, vp, vp, c_int, c_int, ctypes.c_double, dpp, c_int,
+    ]  # fmt: skip
+    lib.pm_map_cube.argtypes = [
+        vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int,
+    ]  # fmt: skip
+    del dp
+    if lib.pm_abi_version() != 1:
+        raise ImportError('libplanetmapper_hip.so ABI version mismatch')
+    _lib = lib
+    return lib

@@ -1,0 +1,541 @@
+// pm_capi.hip -- C ABI of libplanetmapper_hip.so (see include/planetmapper_hip.h).
+//
+// Host side only: context management, kernel-argument block construction, launches,
+// host<->device staging for callers that hand over host buffers. There is NO CPU
+// compute path here: without a gfx950 device pm_create() fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pm_device.hip.h"
+
+
+void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s);
+void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
+void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
+void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
+
+struct pm_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool have_geometry = false;
+    bool have_disc = false;
+    pm_geometry geometry{};
+    pm_disc disc{};
+    std::string error;
+    // grow-only device scratch for host-buffer callers
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int *flags = nullptr;  // per-plane flags of pm_map_cube
+    size_t flags_count = 0;
+    int pending_flag_planes = 0;  // device-mode pm_map_cube: flags to check at pm_synchronize
+};
+
+namespace {
+
+int fail(pm_ctx *ctx, int code, const char *fmt, ...)
+{
+    if (ctx) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        ctx->error = buf;
+    }
+    return code;
+}
+
+#define PM_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(ctx, PM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                  \
+    } while (0)
+
+int ensure_scratch(pm_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->scratch_bytes) return PM_OK;
+    if (ctx->scratch) {
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PM_HIP(ctx, hipFree(ctx->scratch));
+        ctx->scratch = nullptr;
+        ctx->scratch_bytes = 0;
+    }
+    hipError_t e = hipMalloc(&ctx->scratch, bytes);
+    if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    ctx->scratch_bytes = bytes;
+    return PM_OK;
+}
+
+int ensure_flags(pm_ctx *ctx, size_t count)
+{
+    if (count <= ctx->flags_count) return PM_OK;
+    if (ctx->flags) {
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PM_HIP(ctx, hipFree(ctx->flags));
+        ctx->flags = nullptr;
+        ctx->flags_count = 0;
+    }
+    hipError_t e = hipMalloc((void **)&ctx->flags, count * sizeof(int));
+    if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipMalloc flags failed: %s", hipGetErrorString(e));
+    ctx->flags_count = count;
+    return PM_OK;
+}
+
+size_t dtype_size(int dtype)
+{
+    switch (dtype) {
+    case PM_F64: return 8;
+    case PM_F32: return 4;
+    case PM_I16: return 2;
+    case PM_I32: return 4;
+    case PM_U8: return 1;
+    case PM_U16: return 2;
+    }
+    return 0;
+}
+
+// Kernel-argument block for the current geometry + disc + altitude.
+// A / Ai: BodyXY._get_xy2angular_matrix body_xy.py:354-373; r2: body_xy.py:3189-3203;
+// K: Body._get_angular2km_matrix body.py:1625-1641; radii: body.py:172-229.
+void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
+{
+    const pm_geometry &g = ctx->geometry;
+    const pm_disc &d = ctx->disc;
+    p.g = g;
+    for (int i = 0; i < 3; i++) p.radii[i] = g.radii[i] + alt;
+    double s = g.diameter_arcsec / (2.0 * d.r0);
+    double th = -d.rotation_rad;
+    double c = std::cos(th), sn = std::sin(th);
+    double m00 = s * c, m01 = s * sn, m10 = s * -sn, m11 = s * c;
+    p.A[0] = m00; p.A[1] = m01; p.A[2] = -(m00 * d.x0 + m01 * d.y0);
+    p.A[3] = m10; p.A[4] = m11; p.A[5] = -(m10 * d.x0 + m11 * d.y0);
+    double det = m00 * m11 - m01 * m10;
+    double i00 = m11 / det, i01 = -m01 / det, i10 = -m10 / det, i11 = m00 / det;
+    p.Ai[0] = i00; p.Ai[1] = i01; p.Ai[2] = -(i00 * p.A[2] + i01 * p.A[5]);
+    p.Ai[3] = i10; p.Ai[4] = i11; p.Ai[5] = -(i10 * p.A[2] + i11 * p.A[5]);
+    double rmax = std::fmax(p.radii[0], std::fmax(p.radii[1], p.radii[2]));
+    double r = d.r0 * rmax / p.radii[0];
+    double rc = r * 1.05 + 1.0;
+    p.r2 = rc * rc;
+    p.x0 = d.x0;
+    p.y0 = d.y0;
+    double ks = 1.0 / g.km_per_arcsec;
+    double kc = std::cos(g.np_angle_rad), ksn = std::sin(g.np_angle_rad);
+    double k00 = ks * kc, k01 = ks * ksn, k10 = -ks * ksn, k11 = ks * kc;
+    double kdet = k00 * k11 - k01 * k10;
+    p.K[0] = k11 / kdet; p.K[1] = -k01 / kdet; p.K[2] = -k10 / kdet; p.K[3] = k00 / kdet;
+    p.t0 = g.et - g.lt_c;
+    p.nx = d.nx;
+    p.ny = d.ny;
+    p.optimize_speed = d.optimize_speed;
+    p.n0 = p.n1 = 0;
+    p.mask = 0;
+    for (int i = 0; i < PM_NUM_PLANES; i++) p.out[i] = nullptr;
+}
+
+// report planes whose reprojection needed the (unimplemented) NaN pre-clean
+int check_plane_flags(pm_ctx *ctx, int n_planes)
+{
+    std::vector<int> hflags(n_planes);
+    PM_HIP(ctx, hipMemcpyAsync(hflags.data(), ctx->flags, (size_t)n_planes * sizeof(int), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n_planes; i++)
+        if (hflags[i] & 2)
+            return fail(ctx, PM_ERR_UNSUPPORTED,
+                        "plane %d: an infinite pixel is sampled; the reference replaces it by its NaN pre-clean "
+                        "(body_xy.py:1871-1904), which is not implemented on the GPU yet",
+                        i);
+    return PM_OK;
+}
+
+constexpr uint64_t bit(int p) { return ((uint64_t)1) << p; }
+constexpr uint64_t kIllumBits = bit(PM_PHASE) | bit(PM_INCIDENCE) | bit(PM_EMISSION) | bit(PM_AZIMUTH);
+constexpr uint64_t kStateBits = bit(PM_DISTANCE) | bit(PM_RADIAL_VELOCITY) | bit(PM_DOPPLER);
+constexpr uint64_t kRingBits = bit(PM_RING_RADIUS) | bit(PM_RING_LON_GRAPHIC) | bit(PM_RING_DISTANCE);
+constexpr uint64_t kLimbBits = bit(PM_LIMB_DISTANCE) | bit(PM_LIMB_LON_GRAPHIC) | bit(PM_LIMB_LAT_GRAPHIC);
+constexpr uint64_t kSkyBits = bit(PM_RA) | bit(PM_DEC) | bit(PM_PIXEL_X) | bit(PM_PIXEL_Y) | bit(PM_KM_X) |
+                              bit(PM_KM_Y) | bit(PM_ANGULAR_X) | bit(PM_ANGULAR_Y) | kLimbBits;
+constexpr uint64_t kDiscBits = bit(PM_LON_GRAPHIC) | bit(PM_LAT_GRAPHIC) | bit(PM_LON_CENTRIC) |
+                               bit(PM_LAT_CENTRIC) | bit(PM_LOCAL_SOLAR_TIME) | kIllumBits | kStateBits | kRingBits;
+constexpr uint64_t kAllBits = (bit(PM_NUM_PLANES) - 1);
+
+int check_ready(pm_ctx *ctx, bool need_disc)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    if (!ctx->have_geometry) return fail(ctx, PM_ERR_STATE, "pm_set_geometry has not been called");
+    if (need_disc && !ctx->have_disc) return fail(ctx, PM_ERR_STATE, "pm_set_disc has not been called");
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    return PM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pm_abi_version(void) { return PM_ABI_VERSION; }
+
+int pm_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+pm_ctx *pm_create(int device, int *status)
+{
+    auto set = [&](int s) {
+        if (status) *status = s;
+    };
+    int n = pm_device_count();
+    if (n <= 0 || device < 0 || device >= n) {
+        set(PM_ERR_NO_DEVICE);
+        return nullptr;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess || std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        // kernels are built for gfx950 only
+        set(PM_ERR_NO_DEVICE);
+        return nullptr;
+    }
+    pm_ctx *ctx = new (std::nothrow) pm_ctx();
+    if (!ctx) {
+        set(PM_ERR_ALLOC);
+        return nullptr;
+    }
+    ctx->device = device;
+    if (hipSetDevice(device) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        set(PM_ERR_HIP);
+        return nullptr;
+    }
+    ctx->own_stream = true;
+    set(PM_OK);
+    return ctx;
+}
+
+void pm_destroy(pm_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char *pm_last_error(const pm_ctx *ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+
+int pm_synchronize(pm_ctx *ctx)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->pending_flag_planes > 0) {
+        int n = ctx->pending_flag_planes;
+        ctx->pending_flag_planes = 0;
+        return check_plane_flags(ctx, n);
+    }
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+void *pm_stream(pm_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+int pm_set_stream(pm_ctx *ctx, void *stream)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) PM_HIP(ctx, hipStreamDestroy(ctx->stream));
+    ctx->stream = (hipStream_t)stream;
+    ctx->own_stream = false;
+    return PM_OK;
+}
+
+int pm_device_malloc(pm_ctx *ctx, uint64_t bytes, void **dptr)
+{
+    if (!ctx || !dptr) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(dptr, bytes);
+    if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return PM_OK;
+}
+
+int pm_device_free(pm_ctx *ctx, void *dptr)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PM_HIP(ctx, hipFree(dptr));
+    return PM_OK;
+}
+
+int pm_memcpy_h2d(pm_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+int pm_memcpy_d2h(pm_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+int pm_set_geometry(pm_ctx *ctx, const pm_geometry *geometry)
+{
+    if (!ctx || !geometry) return PM_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 3; i++)
+        if (!(geometry->radii[i] > 0.0)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "radii must be positive");
+    if (!(geometry->clight > 0.0) || !(geometry->diameter_arcsec > 0.0) || !(geometry->km_per_arcsec > 0.0))
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "clight, diameter_arcsec and km_per_arcsec must be positive");
+    ctx->geometry = *geometry;
+    ctx->have_geometry = true;
+    return PM_OK;
+}
+
+int pm_set_disc(pm_ctx *ctx, const pm_disc *disc)
+{
+    if (!ctx || !disc) return PM_ERR_INVALID_ARGUMENT;
+    // BodyXY.set_x0/y0/r0/rotation body_xy.py:805-890, set_img_size :941-961
+    if (!std::isfinite(disc->x0) || !std::isfinite(disc->y0) || !std::isfinite(disc->r0) ||
+        !std::isfinite(disc->rotation_rad))
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "disc parameters must be finite");
+    if (!(disc->r0 > 0.0)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "r0 must be greater than zero");
+    if (disc->nx < 0 || disc->ny < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "nx and ny must be non-negative");
+    ctx->disc = *disc;
+    ctx->have_disc = true;
+    return PM_OK;
+}
+
+int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *const *out, int mem)
+{
+    int rc = check_ready(ctx, true);
+    if (rc != PM_OK) return rc;
+    if (!out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "out is NULL");
+    if (plane_mask & ~kAllBits) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown plane bit in mask");
+    if (!std::isfinite(alt)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "alt must be finite");
+    const pm_disc &d = ctx->disc;
+    // BodyXY._make_empty_img body_xy.py:3166-3168
+    if (d.nx <= 0 || d.ny <= 0)
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "nx and ny must be positive to create a backplane image");
+    if (plane_mask == 0) return PM_OK;
+    for (int i = 0; i < 3; i++)
+        if (!(ctx->geometry.radii[i] + alt > 0.0))
+            return fail(ctx, PM_ERR_INVALID_ARGUMENT, "radii + alt must be positive");
+    size_t npx = (size_t)d.nx * d.ny;
+
+    pm::Params p;
+    fill_params(ctx, alt, p);
+    p.mask = plane_mask;
+    int nreq = 0;
+    for (int i = 0; i < PM_NUM_PLANES; i++)
+        if ((plane_mask >> i) & 1) {
+            if (!out[i]) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "out[%d] is NULL but plane %d is requested", i, i);
+            nreq++;
+        }
+    if (mem == PM_MEM_DEVICE) {
+        for (int i = 0; i < PM_NUM_PLANES; i++)
+            if ((plane_mask >> i) & 1) p.out[i] = out[i];
+    } else {
+        rc = ensure_scratch(ctx, (size_t)nreq * npx * sizeof(double));
+        if (rc != PM_OK) return rc;
+        int k = 0;
+        for (int i = 0; i < PM_NUM_PLANES; i++)
+            if ((plane_mask >> i) & 1) p.out[i] = (double *)ctx->scratch + (size_t)(k++) * npx;
+    }
+
+    if (plane_mask & kDiscBits) {
+        int flags = 0;
+        if (plane_mask & kIllumBits) flags |= 1;
+        if (plane_mask & kStateBits) flags |= 2;
+        if (plane_mask & kRingBits) flags |= 4;
+        pm::Params pd = p;
+        pd.mask = plane_mask & kDiscBits;
+        pm_launch_disc(pd, flags, ctx->stream);
+    }
+    if (plane_mask & kSkyBits) {
+        pm::Params ps = p;
+        ps.mask = plane_mask & kSkyBits;
+        pm_launch_sky(ps, (plane_mask & kLimbBits) != 0, ctx->stream);
+    }
+    PM_HIP(ctx, hipGetLastError());
+
+    if (mem != PM_MEM_DEVICE) {
+        for (int i = 0; i < PM_NUM_PLANES; i++)
+            if ((plane_mask >> i) & 1)
+                PM_HIP(ctx, hipMemcpyAsync(out[i], p.out[i], npx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PM_OK;
+}
+
+int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, const double *lat_deg, int n0, int n1,
+                      double alt, double *const *out, int mem)
+{
+    int rc = check_ready(ctx, true);
+    if (rc != PM_OK) return rc;
+    if (!out || !lon_deg || !lat_deg) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (plane_mask & ~kAllBits) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown plane bit in mask");
+    if (n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative map shape");
+    if (!std::isfinite(alt)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "alt must be finite");
+    size_t n = (size_t)n0 * n1;
+    if (n == 0 || plane_mask == 0) return PM_OK;
+    pm::Params p;
+    fill_params(ctx, alt, p);
+    p.mask = plane_mask;
+    p.n0 = n0;
+    p.n1 = n1;
+    int nreq = 0;
+    for (int i = 0; i < PM_NUM_PLANES; i++)
+        if ((plane_mask >> i) & 1) {
+            if (!out[i]) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "out[%d] is NULL but plane %d is requested", i, i);
+            nreq++;
+        }
+    const double *dlon = lon_deg, *dlat = lat_deg;
+    if (mem == PM_MEM_DEVICE) {
+        for (int i = 0; i < PM_NUM_PLANES; i++)
+            if ((plane_mask >> i) & 1) p.out[i] = out[i];
+    } else {
+        rc = ensure_scratch(ctx, (size_t)(nreq + 2) * n * sizeof(double));
+        if (rc != PM_OK) return rc;
+        double *base = (double *)ctx->scratch;
+        PM_HIP(ctx, hipMemcpyAsync(base, lon_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        PM_HIP(ctx, hipMemcpyAsync(base + n, lat_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        dlon = base;
+        dlat = base + n;
+        int k = 2;
+        for (int i = 0; i < PM_NUM_PLANES; i++)
+            if ((plane_mask >> i) & 1) p.out[i] = base + (size_t)(k++) * n;
+    }
+    pm_launch_map(p, dlon, dlat, ctx->stream);
+    PM_HIP(ctx, hipGetLastError());
+    if (mem != PM_MEM_DEVICE) {
+        for (int i = 0; i < PM_NUM_PLANES; i++)
+            if ((plane_mask >> i) & 1)
+                PM_HIP(ctx, hipMemcpyAsync(out[i], p.out[i], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PM_OK;
+}
+
+int pm_xy_map(pm_ctx *ctx, const double *lon_deg, const double *lat_deg, int n0, int n1, double alt, double *x_map,
+              double *y_map, int mem)
+{
+    double *out[PM_NUM_PLANES];
+    for (int i = 0; i < PM_NUM_PLANES; i++) out[i] = nullptr;
+    out[PM_PIXEL_X] = x_map;
+    out[PM_PIXEL_Y] = y_map;
+    return pm_backplanes_map(ctx, bit(PM_PIXEL_X) | bit(PM_PIXEL_Y), lon_deg, lat_deg, n0, n1, alt, out, mem);
+}
+
+int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map, const double *y_map,
+                int n0, int n1, int interpolation, int propagate_nan, double *out, int mem)
+{
+    int rc = check_ready(ctx, true);
+    if (rc != PM_OK) return rc;
+    if (!cube || !x_map || !y_map || !out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
+    size_t esz = dtype_size(dtype);
+    if (esz == 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    // BodyXY.map_img body_xy.py:1630: ValueError for unknown interpolation
+    if (interpolation != PM_INTERP_NEAREST && interpolation != PM_INTERP_LINEAR)
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Unknown interpolation method %d", interpolation);
+    const pm_disc &d = ctx->disc;
+    if (d.nx <= 0 || d.ny <= 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image size is empty");
+    if (n_planes < 0 || n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative shape");
+    if (interpolation == PM_INTERP_LINEAR && !propagate_nan)
+        return fail(ctx, PM_ERR_UNSUPPORTED,
+                    "propagate_nan=False (NaN pre-clean, body_xy.py:1871-1904) is not implemented on the GPU yet");
+    size_t nmap = (size_t)n0 * n1;
+    size_t npx = (size_t)d.nx * d.ny;
+    if (n_planes == 0 || nmap == 0) return PM_OK;
+
+    pm::ReprojectArgs a;
+    a.ny = d.ny;
+    a.nx = d.nx;
+    a.n_map = (int)nmap;
+    a.interpolation = interpolation;
+    a.propagate_nan = propagate_nan ? 1 : 0;
+
+    if (mem == PM_MEM_DEVICE) {
+        rc = ensure_flags(ctx, (size_t)n_planes);
+        if (rc != PM_OK) return rc;
+        PM_HIP(ctx, hipMemsetAsync(ctx->flags, 0, (size_t)n_planes * sizeof(int), ctx->stream));
+        a.cube = cube;
+        a.x_map = x_map;
+        a.y_map = y_map;
+        a.out = out;
+        a.plane_flags = ctx->flags;
+        a.n_planes = n_planes;
+        // blockIdx.y is limited to 65535 planes per launch
+        for (int p0 = 0; p0 < n_planes; p0 += 32768) {
+            pm::ReprojectArgs b = a;
+            b.n_planes = std::min(32768, n_planes - p0);
+            b.cube = (const char *)cube + (size_t)p0 * npx * esz;
+            b.out = out + (size_t)p0 * nmap;
+            b.plane_flags = ctx->flags + p0;
+            pm_launch_reproject(b, dtype, ctx->stream);
+        }
+        PM_HIP(ctx, hipGetLastError());
+        // asynchronous: the per-plane flags are examined by pm_synchronize()
+        ctx->pending_flag_planes = n_planes;
+        return PM_OK;
+    } else {
+        // host cube: stream it through the device in chunks of planes
+        size_t chunk = (size_t)(1ull << 30) / (npx * esz);
+        if (chunk < 1) chunk = 1;
+        if (chunk > (size_t)n_planes) chunk = (size_t)n_planes;
+        if (chunk > 32768) chunk = 32768;
+        size_t cube_bytes = chunk * npx * esz;
+        cube_bytes = (cube_bytes + 255) & ~(size_t)255;
+        size_t need = cube_bytes + (2 + chunk) * nmap * sizeof(double);
+        rc = ensure_scratch(ctx, need);
+        if (rc != PM_OK) return rc;
+        rc = ensure_flags(ctx, (size_t)n_planes);
+        if (rc != PM_OK) return rc;
+        PM_HIP(ctx, hipMemsetAsync(ctx->flags, 0, (size_t)n_planes * sizeof(int), ctx->stream));
+        char *dcube = (char *)ctx->scratch;
+        double *dxm = (double *)(dcube + cube_bytes);
+        double *dym = dxm + nmap;
+        double *dout = dym + nmap;
+        PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        for (size_t p0 = 0; p0 < (size_t)n_planes; p0 += chunk) {
+            size_t np = std::min(chunk, (size_t)n_planes - p0);
+            PM_HIP(ctx, hipMemcpyAsync(dcube, (const char *)cube + p0 * npx * esz, np * npx * esz,
+                                       hipMemcpyHostToDevice, ctx->stream));
+            pm::ReprojectArgs b = a;
+            b.cube = dcube;
+            b.x_map = dxm;
+            b.y_map = dym;
+            b.out = dout;
+            b.plane_flags = ctx->flags + p0;
+            b.n_planes = (int)np;
+            pm_launch_reproject(b, dtype, ctx->stream);
+            PM_HIP(ctx, hipGetLastError());
+            PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
+                                       ctx->stream));
+        }
+    }
+    return check_plane_flags(ctx, n_planes);
+}
+
+}  // extern "C"

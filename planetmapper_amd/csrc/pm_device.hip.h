@@ -1,0 +1,499 @@
+// pm_device.hip.h -- per-point device math of the planetmapper hot path (gfx950).
+//
+// Everything is IEEE binary64. One lane = one pixel (or one map location); all
+// geometry constants arrive through the kernel-argument block (scalar loads ->
+// SGPRs), so the only vector memory traffic of the image kernels is the final
+// coalesced plane stores.
+//
+// Each function names the reference Python / CSPICE routine it evaluates
+// (paths relative to the reference checkout).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/planetmapper_hip.h"
+
+namespace pm {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kTwoPi = 2.0 * kPi;
+constexpr double kHalfPi = 0.5 * kPi;
+constexpr double kDeg = 180.0 / kPi;  // numpy rad2deg factor
+constexpr double kRad = kPi / 180.0;  // numpy deg2rad factor
+
+struct V3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ V3 v3(double x, double y, double z) { return V3{x, y, z}; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(double s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ V3 neg(V3 a) { return {-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ double dot(V3 a, V3 b) { return fma(a.x, b.x, fma(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ double norm(V3 a) { return sqrt(dot(a, a)); }
+__device__ __forceinline__ V3 ld3(const double *p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b)
+{
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+__device__ __forceinline__ bool finite3(V3 a) { return isfinite(a.x) && isfinite(a.y) && isfinite(a.z); }
+
+struct M3 {
+    double m[9];  // row-major
+};
+__device__ __forceinline__ V3 mxv(const M3 &R, V3 v)
+{
+    return {fma(R.m[0], v.x, fma(R.m[1], v.y, R.m[2] * v.z)),
+            fma(R.m[3], v.x, fma(R.m[4], v.y, R.m[5] * v.z)),
+            fma(R.m[6], v.x, fma(R.m[7], v.y, R.m[8] * v.z))};
+}
+__device__ __forceinline__ V3 mtxv(const M3 &R, V3 v)
+{
+    return {fma(R.m[0], v.x, fma(R.m[3], v.y, R.m[6] * v.z)),
+            fma(R.m[1], v.x, fma(R.m[4], v.y, R.m[7] * v.z)),
+            fma(R.m[2], v.x, fma(R.m[5], v.y, R.m[8] * v.z))};
+}
+__device__ __forceinline__ V3 mxv(const double *m, V3 v)
+{
+    return {fma(m[0], v.x, fma(m[1], v.y, m[2] * v.z)), fma(m[3], v.x, fma(m[4], v.y, m[5] * v.z)),
+            fma(m[6], v.x, fma(m[7], v.y, m[8] * v.z))};
+}
+__device__ __forceinline__ V3 mtxv(const double *m, V3 v)
+{
+    return {fma(m[0], v.x, fma(m[3], v.y, m[6] * v.z)), fma(m[1], v.x, fma(m[4], v.y, m[7] * v.z)),
+            fma(m[2], v.x, fma(m[5], v.y, m[8] * v.z))};
+}
+
+// Kernel-argument block shared by all kernels (host fills it in pm_capi.hip).
+struct Params {
+    pm_geometry g;
+    double A[6];      // xy -> angular affine            BodyXY._get_xy2angular_matrix body_xy.py:354
+    double Ai[6];     // angular -> xy affine            BodyXY._get_angular2xy_matrix body_xy.py:371
+    double K[4];      // angular -> km 2x2               Body._get_angular2km_matrix   body.py:1637
+    double r2;        // squared radius of the pre-mask  body_xy.py:3201-3203
+    double x0, y0;    // disc centre
+    double radii[3];  // altitude-adjusted radii         _AdjustedSurfaceAltitude      body.py:172
+    double t0;        // et - lt_c
+    int32_t nx, ny;
+    int32_t optimize_speed;
+    int32_t n0, n1;   // map shape (map kernels)
+    uint64_t mask;
+    double *out[PM_NUM_PLANES];
+};
+
+// Arguments of the reprojection kernel (pm_map_cube).
+struct ReprojectArgs {
+    const void *cube;     // n_planes x ny x nx elements
+    const double *x_map;  // n_map
+    const double *y_map;
+    double *out;          // n_planes x n_map
+    int *plane_flags;     // n_planes: bit1 = a sampled pixel was +-inf, i.e. the reference
+                          // would have used its NaN-cleaned image there
+    int n_planes, ny, nx;
+    int n_map;
+    int interpolation;
+    int propagate_nan;
+};
+
+// ------------------------------------------------------------------ CSPICE basics
+// radrec_c
+__device__ __forceinline__ V3 radrec(double ra, double dec)
+{
+    double sr, cr, sd, cd;
+    sincos(ra, &sr, &cr);
+    sincos(dec, &sd, &cd);
+    return {cr * cd, sr * cd, sd};
+}
+// recrad_c: RA in [0, 2pi), Dec
+__device__ __forceinline__ void recrad(V3 v, double &ra, double &dec)
+{
+    dec = atan2(v.z, sqrt(fma(v.x, v.x, v.y * v.y)));
+    ra = (v.x == 0.0 && v.y == 0.0) ? 0.0 : atan2(v.y, v.x);
+    if (ra < 0.0) ra += kTwoPi;
+}
+// vsep_c for two UNIT vectors
+__device__ __forceinline__ double vsep_unit(V3 u, V3 v)
+{
+    double d = dot(u, v);
+    if (d > 0.0) return 2.0 * asin(0.5 * norm(u - v));
+    if (d < 0.0) return kPi - 2.0 * asin(0.5 * norm(u + v));
+    return kHalfPi;
+}
+__device__ __forceinline__ V3 unit(V3 a)
+{
+    double n = norm(a);
+    double s = (n > 0.0) ? 1.0 / n : 0.0;
+    return s * a;
+}
+
+// ------------------------------------------------------------------ time-dependent state
+// R(t) = rot3(wdot (t - t0)) R0   (pxform / pxfrm2 of the reference, body.py:940-1000)
+// `small` selects the series form, exact to < 1e-20 for |angle| < 1e-3 rad (the <= 1 s
+// light-time spans across a disc); otherwise full sincos.
+template <bool SMALL>
+__device__ __forceinline__ void rot_at(const Params &p, double t, M3 &R)
+{
+    double ang = p.g.wdot * (t - p.t0);
+    double s, c;
+    if (SMALL && fabs(ang) < 1e-3) {
+        double a2 = ang * ang;
+        s = ang * fma(a2, fma(a2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
+        c = fma(a2, fma(a2, fma(a2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
+    } else {
+        sincos(ang, &s, &c);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        R.m[j] = fma(c, p.g.R0[j], s * p.g.R0[3 + j]);
+        R.m[3 + j] = fma(c, p.g.R0[3 + j], -s * p.g.R0[j]);
+        R.m[6 + j] = p.g.R0[6 + j];
+    }
+}
+// target centre wrt observer(et) at epoch t
+__device__ __forceinline__ V3 target_at(const Params &p, double t)
+{
+    double d = t - p.t0;
+    double h = 0.5 * d * d;
+    return {fma(p.g.AT[0], h, fma(p.g.VT[0], d, p.g.T0[0])), fma(p.g.AT[1], h, fma(p.g.VT[1], d, p.g.T0[1])),
+            fma(p.g.AT[2], h, fma(p.g.VT[2], d, p.g.T0[2]))};
+}
+// displacement of the target centre between t0 and t
+__device__ __forceinline__ V3 target_shift(const Params &p, double t)
+{
+    double d = t - p.t0;
+    double h = 0.5 * d * d;
+    return {fma(p.g.AT[0], h, p.g.VT[0] * d), fma(p.g.AT[1], h, p.g.VT[1] * d), fma(p.g.AT[2], h, p.g.VT[2] * d)};
+}
+__device__ __forceinline__ V3 sun_at(const Params &p, double t)
+{
+    double d = t - p.g.ts0;
+    double h = 0.5 * d * d;
+    return {fma(p.g.AS[0], h, fma(p.g.VS[0], d, p.g.S0[0])), fma(p.g.AS[1], h, fma(p.g.VS[1], d, p.g.S0[1])),
+            fma(p.g.AS[2], h, fma(p.g.VS[2], d, p.g.S0[2]))};
+}
+
+// ------------------------------------------------------------------ ellipsoid
+// surfpt_c: nearest intersection of ray (o, u) with the ellipsoid, observer outside or
+// inside. Returns false if the ray misses.
+__device__ __forceinline__ bool surfpt(V3 o, V3 u, const double *radii, V3 &pt)
+{
+    V3 X = {u.x / radii[0], u.y / radii[1], u.z / radii[2]};
+    V3 Y = {o.x / radii[0], o.y / radii[1], o.z / radii[2]};
+    double xx = dot(X, X);
+    if (xx == 0.0) return false;
+    double yx = dot(Y, X);
+    double k = yx / xx;
+    V3 P = {fma(-k, X.x, Y.x), fma(-k, X.y, Y.y), fma(-k, X.z, Y.z)};
+    double p2 = dot(P, P), y2 = dot(Y, Y);
+    double sign;
+    if (y2 > 1.0) {
+        if (p2 > 1.0 || yx > 0.0) return false;
+        sign = -1.0;
+    } else if (y2 == 1.0) {
+        pt = o;
+        return true;
+    } else {
+        sign = 1.0;
+    }
+    double s = sign * sqrt(fmax(0.0, 1.0 - p2)) * rsqrt(xx);
+    pt = {fma(s, X.x, P.x) * radii[0], fma(s, X.y, P.y) * radii[1], fma(s, X.z, P.z) * radii[2]};
+    return true;
+}
+
+// sincpt_c('ELLIPSOID', ..., 'CN', ..., ray): Body._obsvec_norm2targvec body.py:1008-1020.
+// Fixed 3 intercept evaluations: the light-time error contracts by v/c ~ 4e-5 per pass
+// (0.25 s -> 1e-5 s -> 4e-10 s), i.e. < 1e-11 deg after the third.
+// Outputs the body-fixed point and its light time.
+__device__ __forceinline__ bool sincpt(const Params &p, V3 ray, V3 &sp, double &lt)
+{
+    lt = p.g.lt_c;
+#pragma unroll 1
+    for (int it = 0; it < 3; it++) {
+        double te = p.g.et - lt;
+        M3 R;
+        rot_at<true>(p, te, R);
+        V3 obs = neg(mxv(R, target_at(p, te)));
+        V3 u = mxv(R, ray);
+        if (!surfpt(obs, u, p.radii, sp)) return false;
+        lt = norm(sp - obs) / p.g.clight;
+    }
+    return true;
+}
+
+// recpgr_c for a point ON the surface (body.py:1030-1035): planetographic lon [0, 2pi),
+// geodetic latitude from the surface normal (x/a^2, y/a^2, z/c^2).
+__device__ __forceinline__ void recpgr_surface(const Params &p, V3 v, double &lon, double &lat)
+{
+    double a = p.radii[0], c = p.radii[2];
+    double m = fmin(a, c);
+    double a1 = m / a, c1 = m / c;
+    double nx = v.x * (a1 * a1), ny = v.y * (a1 * a1), nz = v.z * (c1 * c1);
+    if (nx == 0.0 && ny == 0.0 && nz == 0.0) {
+        lon = 0.0;
+        lat = kHalfPi;
+        return;
+    }
+    lat = atan2(nz, sqrt(fma(nx, nx, ny * ny)));
+    double l = (v.x == 0.0 && v.y == 0.0) ? 0.0 : atan2(v.y, v.x);
+    if (p.g.west_positive) l = -l;
+    if (l < 0.0) l += kTwoPi;
+    lon = l;
+}
+
+// nearpt_c restated for a spheroid (a, a, c): signed altitude of `v` and the geodetic
+// latitude of its near point; Newton iteration on the Lagrange multiplier.
+__device__ __forceinline__ void recpgr_general(const Params &p, V3 v, double &lon, double &lat, double &alt)
+{
+    const double a = p.radii[0], c = p.radii[2];
+    const double a2 = a * a, c2 = c * c;
+    double rho2 = fma(v.x, v.x, v.y * v.y);
+    double rho = sqrt(rho2);
+    double q = rho2 / a2 + (v.z * v.z) / c2;
+    double bx, bz;  // near point in the meridian plane
+    if (q == 0.0) {
+        bool pole = c <= a;
+        bx = pole ? 0.0 : a;
+        bz = pole ? c : 0.0;
+        alt = -fmin(a, c);
+    } else {
+        double lam;
+        if (q >= 1.0) {
+            lam = 0.0;
+        } else {
+            double l1 = (rho != 0.0) ? -a2 + a * rho : -1e300;
+            double l2 = (v.z != 0.0) ? -c2 + c * fabs(v.z) : -1e300;
+            lam = fmax(l1, l2);
+        }
+#pragma unroll 1
+        for (int it = 0; it < 60; it++) {
+            double da = a2 + lam, dc = c2 + lam;
+            double ta = a * rho / da, tc = c * v.z / dc;
+            double f = fma(ta, ta, fma(tc, tc, -1.0));
+            double df = -2.0 * (ta * ta / da + tc * tc / dc);
+            if (df == 0.0) break;
+            double step = f / df;
+            double nl = lam - step;
+            if (nl == lam) break;
+            lam = nl;
+            if (fabs(step) <= 1e-16 * fabs(lam)) break;
+        }
+        bx = a2 * rho / (a2 + lam);
+        bz = c2 * v.z / (c2 + lam);
+        double s = sqrt(bx * bx / a2 + bz * bz / c2);
+        bx /= s;
+        bz /= s;
+        double dx = rho - bx, dz = v.z - bz;
+        alt = sqrt(fma(dx, dx, dz * dz));
+        if (q < 1.0) alt = -alt;
+    }
+    double m = fmin(a, c);
+    double a1 = m / a, c1 = m / c;
+    double nr = bx * (a1 * a1), nz = bz * (c1 * c1);
+    lat = (nr == 0.0 && nz == 0.0) ? kHalfPi : atan2(nz, nr);
+    double l = (v.x == 0.0 && v.y == 0.0) ? 0.0 : atan2(v.y, v.x);
+    if (p.g.west_positive) l = -l;
+    if (l < 0.0) l += kTwoPi;
+    lon = l;
+}
+
+// pgrrec_c (body.py:903-910) at altitude 0
+__device__ __forceinline__ V3 pgrrec_surface(const Params &p, double lon, double lat)
+{
+    double a = p.radii[0], b = p.radii[2];
+    double le = p.g.west_positive ? -lon : lon;
+    double sl, cl, so, co;
+    sincos(lat, &sl, &cl);
+    sincos(le, &so, &co);
+    double big = fmax(fabs(a * cl), fabs(b * sl));
+    double x = a * cl / big, y = b * sl / big;
+    double scale = 1.0 / (big * sqrt(fma(x, x, y * y)));
+    return {scale * a * a * co * cl, scale * a * a * so * cl, scale * b * b * sl};
+}
+
+// ------------------------------------------------------------------ light time of a body-fixed point
+// spkcpt_c / first half of illumf_c. `lt` is an initial guess on entry; NITER fixed-point
+// passes (the contraction factor is v/c ~ 4e-5), then pos and R are evaluated at the
+// final epoch. pos = point wrt observer, J2000.
+template <int NITER>
+__device__ __forceinline__ void point_lt(const Params &p, V3 sp, double &lt, V3 &pos, M3 &R)
+{
+#pragma unroll 1
+    for (int it = 0; it < NITER; it++) {
+        double te = p.g.et - lt;
+        rot_at<true>(p, te, R);
+        pos = target_at(p, te) + mtxv(R, sp);
+        lt = norm(pos) / p.g.clight;
+    }
+    double te = p.g.et - lt;
+    rot_at<true>(p, te, R);
+    pos = target_at(p, te) + mtxv(R, sp);
+}
+
+// illumf_c(..., 'SUN', ..., 'CN', ...): Body._illumf_from_targvec_radians body.py:1915.
+// Given the converged pos/R/lt of the point. Angles in radians.
+__device__ __forceinline__ void illum_angles(const Params &p, V3 sp, double lt, V3 pos, const M3 &R,
+                                             double &phase, double &inc, double &emi)
+{
+    double te = p.g.et - lt;
+    V3 obsv = neg(mxv(R, pos));
+    V3 q = target_shift(p, te) + mtxv(R, sp);
+    // Sun light time (spkcpo_c, CN): two passes from the centre value; the Sun moves
+    // 0.01 km/s so the second pass is already converged to 1e-9 km.
+    double lts = te - p.g.ts0;
+    V3 sv;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        sv = sun_at(p, te - lts) - q;
+        lts = norm(sv) / p.g.clight;
+    }
+    sv = sun_at(p, te - lts) - q;
+    V3 sunb = unit(mxv(R, sv));
+    V3 ob = unit(obsv);
+    // surfnm_c
+    double m = fmin(p.radii[0], fmin(p.radii[1], p.radii[2]));
+    double a1 = m / p.radii[0], b1 = m / p.radii[1], c1 = m / p.radii[2];
+    V3 n = unit(v3(sp.x * (a1 * a1), sp.y * (b1 * b1), sp.z * (c1 * c1)));
+    phase = vsep_unit(sunb, ob);
+    inc = vsep_unit(n, sunb);
+    emi = vsep_unit(n, ob);
+}
+
+// Body._azimuth_angle_from_gie_radians body.py:2319 on degree images (body_xy.py:3742)
+__device__ __forceinline__ double azimuth_deg(double ph_deg, double in_deg, double em_deg)
+{
+    double phr = ph_deg * kRad, inr = in_deg * kRad, emr = em_deg * kRad;
+    double ce = cos(emr), ci = cos(inr);
+    double a = cos(phr) - ce * ci;
+    double b = sqrt(1.0 - ce * ce) * sqrt(1.0 - ci * ci);
+    return (kPi - acos(a / b)) * kDeg;
+}
+
+// spkcpt_c velocity with the light-time rate; Body._radial_velocity_from_state body.py:2847
+__device__ __forceinline__ double radial_velocity(const Params &p, V3 sp, double lt, V3 pos, const M3 &R)
+{
+    double te = p.g.et - lt;
+    double d = te - p.t0;
+    V3 off = mtxv(R, sp);
+    V3 z = {R.m[6], R.m[7], R.m[8]};
+    V3 w = p.g.wdot * cross(z, off);
+    V3 vp = {fma(p.g.AT[0], d, p.g.VT[0]) + w.x, fma(p.g.AT[1], d, p.g.VT[1]) + w.y,
+             fma(p.g.AT[2], d, p.g.VT[2]) + w.z};
+    V3 rh = unit(pos);
+    V3 vo = ld3(p.g.VO);
+    double dlt = (dot(rh, vp - vo) / p.g.clight) / (1.0 + dot(rh, vp) / p.g.clight);
+    V3 vel = (1.0 - dlt) * vp - vo;
+    return dot(vel, rh);
+}
+
+// ------------------------------------------------------------------ PM's own transforms
+// Body._targvec2obsvec body.py:917-948
+__device__ __forceinline__ V3 targvec2obsvec(const Params &p, V3 tv)
+{
+    V3 off = tv - ld3(p.g.sub_sp);
+    double dist = norm(ld3(p.g.sub_ray) + off) - p.g.sub_dist;
+    double t = p.g.sub_et - dist / p.g.clight;
+    M3 R;
+    rot_at<false>(p, t, R);
+    return ld3(p.g.sub_obsvec) + mtxv(R, off);
+}
+// Body._obsvec2targvec body.py:972-1006
+__device__ __forceinline__ V3 obsvec2targvec(const Params &p, V3 ov)
+{
+    V3 off = ov - ld3(p.g.sub_obsvec);
+    double dist = norm(off - ld3(p.g.sub_ray)) - p.g.sub_dist;
+    double t = p.g.sub_et - dist / p.g.clight;
+    M3 R;
+    rot_at<false>(p, t, R);
+    return ld3(p.g.sub_sp) + mxv(R, off);
+}
+
+// Body._obsvec2angular body.py:1345-1361 (arcsec)
+__device__ __forceinline__ void obsvec2angular(const Params &p, V3 ov, double &ax, double &ay)
+{
+    V3 w = mxv(p.g.M, ov);
+    double ra, dec;
+    recrad(w, ra, dec);
+    double x = fmod(-(ra * kDeg), 360.0);
+    if (x < 0.0) x += 360.0;
+    if (x > 180.0) x -= 360.0;
+    ax = x * 3600.0;
+    ay = (dec * kDeg) * 3600.0;
+}
+
+// Body._ring_coordinates_from_obsvec(only_visible=False) body.py:2577-2615
+__device__ __forceinline__ void ring_coords(const Params &p, V3 ov, double &radius, double &lon_deg, double &dist)
+{
+    const double nan = __builtin_nan("");
+    radius = lon_deg = dist = nan;
+    if (!finite3(ov)) return;
+    double n = norm(ov);
+    if (n == 0.0) return;
+    V3 u = (1.0 / n) * ov;
+    double k = p.g.ring_k;
+    double pd = dot(u, ld3(p.g.ring_n));
+    V3 ip;
+    if (k == 0.0) {
+        if (pd == 0.0) return;
+        ip = {0.0, 0.0, 0.0};
+    } else {
+        if (!(pd > 0.0)) return;
+        if (k >= pd * (1.7976931348623157e308 / 3.0)) return;
+        ip = (k / pd) * u;
+    }
+    V3 tv = obsvec2targvec(p, ip);
+    double lon, lat, alt;
+    recpgr_general(p, tv, lon, lat, alt);
+    dist = norm(ip);
+    lon_deg = lon * kDeg;
+    radius = alt + p.radii[0];
+}
+
+// Body._limb_coordinates_from_obsvec body.py:2081-2110
+__device__ __forceinline__ void limb_coords(const Params &p, V3 ray, double &lon_deg, double &lat_deg, double &dist)
+{
+    const double nan = __builtin_nan("");
+    lon_deg = lat_deg = dist = nan;
+    if (!finite3(ray)) return;
+    V3 T0 = ld3(p.g.T0);
+    double k = dot(T0, ray) / dot(ray, ray);
+    V3 near = k * ray;
+    double nd = norm(near - T0);
+    V3 tv = obsvec2targvec(p, near);
+    V3 s;
+    if (!surfpt(v3(0.0, 0.0, 0.0), tv, p.radii, s)) return;
+    double lon, lat;
+    recpgr_surface(p, s, lon, lat);
+    lon_deg = lon * kDeg;
+    lat_deg = lat * kDeg;
+    dist = nd - norm(s);
+}
+
+// Body.local_solar_time_from_lon body.py:2376-2398 (et2lst_c, truncated to whole seconds)
+__device__ __forceinline__ double local_solar_time(const Params &p, double lon_deg)
+{
+    if (!isfinite(lon_deg)) return __builtin_nan("");
+    double lon = lon_deg * kRad;
+    double le = p.g.west_positive ? -lon : lon;
+    double angle = le - p.g.lst_sun_lon;
+    double frac = angle / kTwoPi + 0.5;
+    double secnds = fmod(86400.0 * frac, 86400.0);
+    if (secnds < 0.0) secnds += 86400.0;
+    double hr = floor(secnds / 3600.0);
+    double rem = secnds - 3600.0 * hr;
+    double mn = floor(rem / 60.0);
+    double sc = floor(rem - 60.0 * mn);
+    return hr + mn / 60.0 + sc / 3600.0;
+}
+
+// pixel -> unit ray: BodyXY._xy2obsvec_norm body_xy.py:375 -> Body._angular2obsvec_norm body.py:1363
+__device__ __forceinline__ V3 xy2ray(const Params &p, double x, double y)
+{
+    double ax = fma(p.A[0], x, fma(p.A[1], y, p.A[2]));
+    double ay = fma(p.A[3], x, fma(p.A[4], y, p.A[5]));
+    V3 v = radrec(-((ax / 3600.0) * kRad), (ay / 3600.0) * kRad);
+    return mtxv(p.g.M, v);
+}
+
+}  // namespace pm

@@ -1,0 +1,426 @@
+// pm_kernels.hip -- gfx950 kernels of the planetmapper hot path.
+//
+//   k_disc<FLAGS>   image-space planes that need the ray/ellipsoid intercept
+//                   (lon/lat, centric, illumination, azimuth, LST, state, ring)
+//   k_sky<LIMB>     image-space planes defined for every pixel
+//                   (RA/Dec, pixel x/y, km, angular, limb)
+//   k_map           map-space planes + x_map/y_map for a lon/lat grid
+//   k_reproject<T>  bilinear / nearest reprojection of a cube onto the map grid
+//
+// Launch geometry of the image kernels: one lane per pixel, a wave covers 64
+// consecutive x of one row, so every plane store is one 512-byte fully coalesced
+// write per wave; blockIdx.y = row. No loads besides the kernel-argument block.
+#include "pm_device.hip.h"
+
+namespace pm {
+
+constexpr int kBlock = 256;
+
+enum DiscFlags : int {
+    DF_ILLUM = 1,  // PHASE / INCIDENCE / EMISSION / AZIMUTH
+    DF_STATE = 2,  // DISTANCE / RADIAL-VELOCITY / DOPPLER
+    DF_RING = 4,   // RING-RADIUS / RING-LON-GRAPHIC / RING-DISTANCE
+};
+
+#define PM_WANT(pl) ((p.mask >> (pl)) & 1ull)
+#define PM_PUT(pl, val)                            \
+    do {                                           \
+        if (PM_WANT(pl)) p.out[pl][idx] = (val);   \
+    } while (0)
+
+// Reference loops fused here: BodyXY._get_targvec_img body_xy.py:3195, _get_lonlat_img
+// :3281, _get_lonlat_centric_img :3346, _get_illumination_gie_img :3658,
+// get_azimuth_angle_img :3742, get_local_solar_time_img :3787, _get_state_imgs :3830,
+// get_radial_velocity_img :3895, get_doppler_img :3938,
+// _get_ring_plane_coordinate_imgs :4059.
+template <int FLAGS>
+__global__ __launch_bounds__(kBlock) void k_disc(const Params p)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int y = blockIdx.y;
+    const bool inside = x < p.nx;
+    const size_t idx = (size_t)y * p.nx + (inside ? x : 0);
+    const double nan = __builtin_nan("");
+
+    // radius pre-mask of _get_targvec_img (only with optimize_speed)
+    const double dx = (double)x - p.x0, dy = (double)y - p.y0;
+    bool cand = inside && !(p.optimize_speed && (dx * dx + dy * dy) > p.r2);
+
+    V3 ray = xy2ray(p, (double)x, (double)y);
+
+    // rays rebuilt from the RA/Dec degree images for the ring planes
+    // (_get_obsvec_norm_img body_xy.py:3262-3271)
+    V3 ray2 = ray;
+    if (FLAGS & DF_RING) {
+        double ra, dec;
+        recrad(ray, ra, dec);
+        ray2 = radrec((ra * kDeg) * kRad, (dec * kDeg) * kRad);
+    }
+
+    V3 sp = {nan, nan, nan};
+    double lt = 0.0;
+    bool on_disc = false;
+    // wave-uniform skip of the intercept when no lane of the wave can be on the disc
+    if (__any(cand)) {
+        if (cand) on_disc = sincpt(p, ray, sp, lt);
+    }
+
+    double lon_deg = nan, lat_deg = nan;
+    if (on_disc) {
+        double lon, lat;
+        recpgr_surface(p, sp, lon, lat);
+        lon_deg = lon * kDeg;
+        lat_deg = lat * kDeg;
+    }
+    if (inside) {
+        PM_PUT(PM_LON_GRAPHIC, lon_deg);
+        PM_PUT(PM_LAT_GRAPHIC, lat_deg);
+    }
+    if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
+        double lc = nan, bc = nan;
+        if (on_disc) {
+            // reclat_c: Body._targvec2lonlat_centric body.py:2905
+            bc = atan2(sp.z, sqrt(fma(sp.x, sp.x, sp.y * sp.y))) * kDeg;
+            lc = ((sp.x == 0.0 && sp.y == 0.0) ? 0.0 : atan2(sp.y, sp.x)) * kDeg;
+        }
+        if (inside) {
+            PM_PUT(PM_LON_CENTRIC, lc);
+            PM_PUT(PM_LAT_CENTRIC, bc);
+        }
+    }
+    if (PM_WANT(PM_LOCAL_SOLAR_TIME)) {
+        double v = local_solar_time(p, lon_deg);
+        if (inside) PM_PUT(PM_LOCAL_SOLAR_TIME, v);
+    }
+
+    double surf_dist = nan;
+    if (FLAGS & (DF_ILLUM | DF_STATE | DF_RING)) {
+        double ph = nan, in = nan, em = nan, az = nan, rv = nan, dop = nan;
+        if (on_disc) {
+            // the intercept's light time is already the fixed point of the point's own
+            // light-time equation to ~4e-10 s: one more pass converges it
+            V3 pos;
+            M3 R;
+            point_lt<1>(p, sp, lt, pos, R);
+            if (FLAGS & DF_ILLUM) {
+                illum_angles(p, sp, lt, pos, R, ph, in, em);
+                ph *= kDeg;
+                in *= kDeg;
+                em *= kDeg;
+                if (PM_WANT(PM_AZIMUTH)) az = azimuth_deg(ph, in, em);
+            }
+            if (FLAGS & (DF_STATE | DF_RING)) surf_dist = lt * p.g.clight;
+            if (FLAGS & DF_STATE) {
+                rv = radial_velocity(p, sp, lt, pos, R);
+                double beta = rv / p.g.clight;  // SpiceBase.calculate_doppler_factor base.py:550
+                dop = sqrt((1.0 + beta) / (1.0 - beta));
+            }
+        }
+        if (inside) {
+            if (FLAGS & DF_ILLUM) {
+                PM_PUT(PM_PHASE, ph);
+                PM_PUT(PM_INCIDENCE, in);
+                PM_PUT(PM_EMISSION, em);
+                PM_PUT(PM_AZIMUTH, az);
+            }
+            if (FLAGS & DF_STATE) {
+                PM_PUT(PM_DISTANCE, surf_dist);
+                PM_PUT(PM_RADIAL_VELOCITY, rv);
+                PM_PUT(PM_DOPPLER, dop);
+            }
+        }
+    }
+
+    if (FLAGS & DF_RING) {
+        double rr, rl, rd;
+        ring_coords(p, ray2, rr, rl, rd);
+        // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
+        if (rd > surf_dist) rr = rl = rd = nan;
+        if (inside) {
+            PM_PUT(PM_RING_RADIUS, rr);
+            PM_PUT(PM_RING_LON_GRAPHIC, rl);
+            PM_PUT(PM_RING_DISTANCE, rd);
+        }
+    }
+}
+
+// Reference loops fused here: BodyXY._get_radec_img body_xy.py:3409, get_x_img :3494,
+// get_y_img :3519, _get_km_xy_img :3545, get_angular_x_img :3610,
+// _get_limb_coordinate_imgs :3964.
+template <bool LIMB>
+__global__ __launch_bounds__(kBlock) void k_sky(const Params p)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= p.nx) return;
+    const size_t idx = (size_t)y * p.nx + x;
+    V3 ray = xy2ray(p, (double)x, (double)y);
+    double ra, dec;
+    recrad(ray, ra, dec);
+    double ra_deg = ra * kDeg, dec_deg = dec * kDeg;
+    PM_PUT(PM_RA, ra_deg);
+    PM_PUT(PM_DEC, dec_deg);
+    PM_PUT(PM_PIXEL_X, (double)x);
+    PM_PUT(PM_PIXEL_Y, (double)y);
+    const bool km = PM_WANT(PM_KM_X) || PM_WANT(PM_KM_Y) || PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y);
+    if (km || LIMB) {
+        V3 ray2 = radrec(ra_deg * kRad, dec_deg * kRad);
+        if (km) {
+            double ax, ay;
+            obsvec2angular(p, ray2, ax, ay);
+            double kx = fma(p.K[0], ax, p.K[1] * ay), ky = fma(p.K[2], ax, p.K[3] * ay);
+            PM_PUT(PM_KM_X, kx);
+            PM_PUT(PM_KM_Y, ky);
+            PM_PUT(PM_ANGULAR_X, kx / p.g.km_per_arcsec);
+            PM_PUT(PM_ANGULAR_Y, ky / p.g.km_per_arcsec);
+        }
+        if (LIMB) {
+            double ll, lb, ld;
+            limb_coords(p, ray2, ll, lb, ld);
+            PM_PUT(PM_LIMB_LON_GRAPHIC, ll);
+            PM_PUT(PM_LIMB_LAT_GRAPHIC, lb);
+            PM_PUT(PM_LIMB_DISTANCE, ld);
+        }
+    }
+}
+
+// Map-space chain: BodyXY._get_targvec_map body_xy.py:3227, _get_illumf_map :3667,
+// _get_obsvec_map :3273, _get_radec_map :3419, _get_xy_map :3478 and the get_*_map
+// planes. One lane per map location; lon/lat grids are read coalesced.
+__global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__restrict__ lon_in,
+                                                const double *__restrict__ lat_in)
+{
+    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t n = (size_t)p.n0 * p.n1;
+    if (idx >= n) return;
+    const double nan = __builtin_nan("");
+    double lon_deg = lon_in[idx], lat_deg = lat_in[idx];
+    if (!isfinite(lon_deg) || !isfinite(lat_deg)) lon_deg = lat_deg = nan;
+    PM_PUT(PM_LON_GRAPHIC, lon_deg);
+    PM_PUT(PM_LAT_GRAPHIC, lat_deg);
+    const bool have = !isnan(lon_deg);
+    V3 tv = {nan, nan, nan};
+    if (have) tv = pgrrec_surface(p, lon_deg * kRad, lat_deg * kRad);
+
+    double ph = nan, in = nan, em = nan, surf_dist = nan, rv = nan, dop = nan;
+    bool vis = false, lit = false;
+    if (have) {
+        double lt = p.g.lt_c;
+        V3 pos;
+        M3 R;
+        point_lt<3>(p, tv, lt, pos, R);
+        illum_angles(p, tv, lt, pos, R, ph, in, em);
+        vis = em < kHalfPi;
+        lit = in < kHalfPi;
+        ph *= kDeg;
+        in *= kDeg;
+        em *= kDeg;
+        surf_dist = lt * p.g.clight;
+        rv = radial_velocity(p, tv, lt, pos, R);
+        double beta = rv / p.g.clight;
+        dop = sqrt((1.0 + beta) / (1.0 - beta));
+    }
+    PM_PUT(PM_PHASE, ph);
+    PM_PUT(PM_INCIDENCE, in);
+    PM_PUT(PM_EMISSION, em);
+    if (PM_WANT(PM_AZIMUTH)) PM_PUT(PM_AZIMUTH, have ? azimuth_deg(ph, in, em) : nan);
+    PM_PUT(PM_DISTANCE, surf_dist);
+    PM_PUT(PM_RADIAL_VELOCITY, rv);
+    PM_PUT(PM_DOPPLER, dop);
+    if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
+        double lc = nan, bc = nan;
+        if (have) {
+            bc = atan2(tv.z, sqrt(fma(tv.x, tv.x, tv.y * tv.y))) * kDeg;
+            lc = ((tv.x == 0.0 && tv.y == 0.0) ? 0.0 : atan2(tv.y, tv.x)) * kDeg;
+        }
+        PM_PUT(PM_LON_CENTRIC, lc);
+        PM_PUT(PM_LAT_CENTRIC, bc);
+    }
+    if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
+
+    V3 ov = {nan, nan, nan};
+    if (have) ov = targvec2obsvec(p, tv);
+    double ra_deg = nan, dec_deg = nan;
+    if (have && vis) {
+        double ra, dec;
+        recrad(ov, ra, dec);
+        ra_deg = ra * kDeg;
+        dec_deg = dec * kDeg;
+    }
+    PM_PUT(PM_RA, ra_deg);
+    PM_PUT(PM_DEC, dec_deg);
+
+    double px = nan, py = nan, kx = nan, ky = nan;
+    if (!isnan(ra_deg)) {
+        V3 u = radrec(ra_deg * kRad, dec_deg * kRad);
+        double ax, ay;
+        obsvec2angular(p, u, ax, ay);
+        double xx = fma(p.Ai[0], ax, fma(p.Ai[1], ay, p.Ai[2]));
+        double yy = fma(p.Ai[3], ax, fma(p.Ai[4], ay, p.Ai[5]));
+        // BodyXY._xy_in_image_frame body_xy.py:1868
+        if (-0.5 < xx && xx < p.nx - 0.5 && -0.5 < yy && yy < p.ny - 0.5) {
+            px = xx;
+            py = yy;
+        }
+        kx = fma(p.K[0], ax, p.K[1] * ay);
+        ky = fma(p.K[2], ax, p.K[3] * ay);
+    }
+    PM_PUT(PM_PIXEL_X, px);
+    PM_PUT(PM_PIXEL_Y, py);
+    PM_PUT(PM_KM_X, kx);
+    PM_PUT(PM_KM_Y, ky);
+    PM_PUT(PM_ANGULAR_X, kx / p.g.km_per_arcsec);
+    PM_PUT(PM_ANGULAR_Y, ky / p.g.km_per_arcsec);
+
+    const bool need_limb =
+        PM_WANT(PM_LIMB_DISTANCE) || PM_WANT(PM_LIMB_LON_GRAPHIC) || PM_WANT(PM_LIMB_LAT_GRAPHIC);
+    const bool need_ring =
+        PM_WANT(PM_RING_RADIUS) || PM_WANT(PM_RING_LON_GRAPHIC) || PM_WANT(PM_RING_DISTANCE);
+    if (need_limb || need_ring) {
+        // gated on illumf column 4 (lit) like the reference (body_xy.py:3981, 4097)
+        double ll = nan, lb = nan, ld = nan, rr = nan, rl = nan, rd = nan;
+        if (have && lit) {
+            if (need_limb) limb_coords(p, ov, ll, lb, ld);
+            if (need_ring) ring_coords(p, ov, rr, rl, rd);
+        }
+        if (rd > surf_dist) rr = rl = rd = nan;
+        PM_PUT(PM_LIMB_LON_GRAPHIC, ll);
+        PM_PUT(PM_LIMB_LAT_GRAPHIC, lb);
+        PM_PUT(PM_LIMB_DISTANCE, ld);
+        PM_PUT(PM_RING_RADIUS, rr);
+        PM_PUT(PM_RING_LON_GRAPHIC, rl);
+        PM_PUT(PM_RING_DISTANCE, rd);
+    }
+}
+
+// ------------------------------------------------------------------ reprojection
+template <typename T>
+__device__ __forceinline__ double load_as_f64(const T *p, size_t i)
+{
+    return (double)p[i];
+}
+
+
+// One lane per (map location, plane): BodyXY.map_img body_xy.py:1414 for every plane of
+// Observation._get_mapped_data observation.py:876. blockIdx.y = plane, so the 64 lanes
+// of a wave gather from one plane around neighbouring (x, y) -> the 4-point footprints
+// overlap in L2; the store is coalesced along the map row.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const int pl = blockIdx.y;
+    if (m >= a.n_map) return;
+    const double nan = __builtin_nan("");
+    const int nx = a.nx, ny = a.ny;
+    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
+    double *o = a.out + (size_t)pl * a.n_map;
+    double x = a.x_map[m], y = a.y_map[m];
+    double val = nan;
+    if (!isnan(x)) {
+        if (a.interpolation == PM_INTERP_NEAREST) {
+            // _do_nearest_interpolation body_xy.py:1633: np.round = half to even
+            long xi = (long)rint(x), yi = (long)rint(y);
+            if (xi < 0) xi += nx;
+            if (yi < 0) yi += ny;
+            val = load_as_f64(img, (size_t)yi * nx + xi);
+        } else {
+            bool skip = false;
+            double xa = fmax(floor(x), 0.0), xb = fmin(ceil(x), nx - 1.0);
+            double ya = fmax(floor(y), 0.0), yb = fmin(ceil(y), ny - 1.0);
+            const bool in_hull = !(x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1);
+            if (a.propagate_nan) {
+                // _should_propagate_nan_to_map body_xy.py:1855-1866
+                if (!in_hull) {
+                    skip = true;
+                } else {
+                    long ia = (long)xa, ib = (long)xb, ja = (long)ya, jb = (long)yb;
+                    double t0 = load_as_f64(img, (size_t)ja * nx + ia), t1 = load_as_f64(img, (size_t)ja * nx + ib);
+                    double t2 = load_as_f64(img, (size_t)jb * nx + ia), t3 = load_as_f64(img, (size_t)jb * nx + ib);
+                    skip = isnan(t0) || isnan(t1) || isnan(t2) || isnan(t3);
+                }
+            }
+            if (!skip) {
+                // RectBivariateSpline(kx=ky=1, s=0).ev == bilinear; FITPACK clamps the
+                // evaluation point to the knot range. Zero-weight corners are excluded so
+                // that NaNs the reference would have replaced beforehand cannot leak in.
+                double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
+                long x0 = (long)floor(xc), y0 = (long)floor(yc);
+                if (x0 > nx - 2) x0 = nx - 2;
+                if (y0 > ny - 2) y0 = ny - 2;
+                if (x0 < 0) x0 = 0;
+                if (y0 < 0) y0 = 0;
+                long x1 = x0 + 1 < nx ? x0 + 1 : x0, y1 = y0 + 1 < ny ? y0 + 1 : y0;
+                double fx = xc - (double)x0, fy = yc - (double)y0;
+                double v00 = load_as_f64(img, (size_t)y0 * nx + x0), v01 = load_as_f64(img, (size_t)y0 * nx + x1);
+                double v10 = load_as_f64(img, (size_t)y1 * nx + x0), v11 = load_as_f64(img, (size_t)y1 * nx + x1);
+                double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
+                bool bad = (w00 != 0.0 && !isfinite(v00)) || (w01 != 0.0 && !isfinite(v01)) ||
+                           (w10 != 0.0 && !isfinite(v10)) || (w11 != 0.0 && !isfinite(v11));
+                if (bad) atomicOr(&a.plane_flags[pl], 2);
+                double r0 = (fx == 0.0 ? v00 : (fx == 1.0 ? v01 : fma(fx, v01, (1.0 - fx) * v00)));
+                double r1 = (fx == 0.0 ? v10 : (fx == 1.0 ? v11 : fma(fx, v11, (1.0 - fx) * v10)));
+                val = (fy == 0.0 ? r0 : (fy == 1.0 ? r1 : fma(fy, r1, (1.0 - fy) * r0)));
+            }
+        }
+    }
+    o[m] = val;
+}
+
+}  // namespace pm
+
+// ------------------------------------------------------------------ launchers (called from pm_capi.hip)
+extern "C++" {
+
+void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
+{
+    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.ny);
+    dim3 block(pm::kBlock);
+    switch (flags & 7) {
+    case 0: hipLaunchKernelGGL(pm::k_disc<0>, grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL(pm::k_disc<1>, grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(pm::k_disc<2>, grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(pm::k_disc<3>, grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pm::k_disc<4>, grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL(pm::k_disc<5>, grid, block, 0, s, p); break;
+    case 6: hipLaunchKernelGGL(pm::k_disc<6>, grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL(pm::k_disc<7>, grid, block, 0, s, p); break;
+    }
+}
+
+void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s)
+{
+    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.ny);
+    dim3 block(pm::kBlock);
+    if (limb)
+        hipLaunchKernelGGL(pm::k_sky<true>, grid, block, 0, s, p);
+    else
+        hipLaunchKernelGGL(pm::k_sky<false>, grid, block, 0, s, p);
+}
+
+void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s)
+{
+    size_t n = (size_t)p.n0 * p.n1;
+    dim3 grid((unsigned)((n + pm::kBlock - 1) / pm::kBlock));
+    hipLaunchKernelGGL(pm::k_map, grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+}
+
+template <typename T>
+static void launch_reproject_t(const pm::ReprojectArgs &a, hipStream_t s)
+{
+    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes);
+    hipLaunchKernelGGL(pm::k_reproject<T>, grid, dim3(pm::kBlock), 0, s, a);
+}
+
+void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_reproject_t<double>(a, s); break;
+    case PM_F32: launch_reproject_t<float>(a, s); break;
+    case PM_I16: launch_reproject_t<int16_t>(a, s); break;
+    case PM_I32: launch_reproject_t<int32_t>(a, s); break;
+    case PM_U8: launch_reproject_t<uint8_t>(a, s); break;
+    case PM_U16: launch_reproject_t<uint16_t>(a, s); break;
+    }
+}
+}

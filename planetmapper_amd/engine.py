@@ -1,0 +1,247 @@
+"""
+`Engine`: a thin object wrapper over one `pm_ctx` (one GPU, one HIP stream).
+
+This is the only module that calls into libplanetmapper_hip.so. The BodyXY /
+Observation classes (the reference-compatible API) are built on it.
+"""
+
+from __future__ import annotations
+
+import ctypes
+from typing import Iterable, Mapping
+
+import numpy as np
+
+from . import _lib
+from ._lib import PLANE_INDEX, PLANE_NAMES, NUM_PLANES
+from .geometry import PMDisc, PMGeometry
+
+_DTYPE_CODES = {
+    np.dtype('float64'): 0,
+    np.dtype('float32'): 1,
+    np.dtype('int16'): 2,
+    np.dtype('int32'): 3,
+    np.dtype('uint8'): 4,
+    np.dtype('uint16'): 5,
+}
+
+_INTERP_CODES = {'nearest': _lib.PM_INTERP_NEAREST, 'linear': _lib.PM_INTERP_LINEAR, 1: _lib.PM_INTERP_LINEAR}
+
+
+def dtype_code(dtype) -> int:
+    dt = np.dtype(dtype)
+    if dt not in _DTYPE_CODES:
+        raise TypeError(f'unsupported cube dtype {dt}')
+    return _DTYPE_CODES[dt]
+
+
+def plane_mask(names: Iterable[str]) -> int:
+    m = 0
+    for n in names:
+        m |= 1 << PLANE_INDEX[n]
+    return m
+
+
+def _ptr(x) -> int:
+    """Address of a numpy array (host) / torch tensor (device) / raw int pointer."""
+    if isinstance(x, int):
+        return x
+    if isinstance(x, np.ndarray):
+        return x.ctypes.data
+    if hasattr(x, 'data_ptr'):
+        return int(x.data_ptr())
+    raise TypeError(f'cannot take the address of {type(x)!r}')
+
+
+class Engine:
+    """One GPU context of the HIP engine. Raises `NoDeviceError` without a gfx950 GPU."""
+
+    def __init__(self, device: int = 0) -> None:
+        self._lib = _lib.load()
+        status = ctypes.c_int(0)
+        self._ctx = self._lib.pm_create(int(device), ctypes.byref(status))
+        if not self._ctx:
+            if status.value == _lib.PM_ERR_NO_DEVICE:
+                raise _lib.NoDeviceError(
+                    f'no usable gfx950 (MI355X) device {device}: planetmapper_amd has no CPU '
+                    'fallback'
+                )
+            raise _lib.EngineError(f'pm_create failed with status {status.value}')
+        self.device = int(device)
+        self._disc: PMDisc | None = None
+        self._geometry: PMGeometry | None = None
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self) -> None:
+        if getattr(self, '_ctx', None):
+            self._lib.pm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self) -> None:  # pragma: no cover - best effort
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc == _lib.PM_OK:
+            return
+        msg = self._lib.pm_last_error(self._ctx).decode('utf-8', 'replace')
+        if rc == _lib.PM_ERR_INVALID_ARGUMENT:
+            raise ValueError(msg)
+        if rc == _lib.PM_ERR_UNSUPPORTED:
+            raise _lib.UnsupportedError(msg)
+        if rc == _lib.PM_ERR_ALLOC:
+            raise MemoryError(msg)
+        raise _lib.EngineError(f'{msg} (status {rc})')
+
+    def synchronize(self) -> None:
+        self._check(self._lib.pm_synchronize(self._ctx))
+
+    @property
+    def stream(self) -> int:
+        """The context's `hipStream_t` as an integer."""
+        return int(self._lib.pm_stream(self._ctx) or 0)
+
+    def set_stream(self, hip_stream: int) -> None:
+        self._check(self._lib.pm_set_stream(self._ctx, ctypes.c_void_p(hip_stream)))
+
+    def device_malloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._check(self._lib.pm_device_malloc(self._ctx, int(nbytes), ctypes.byref(p)))
+        return int(p.value)
+
+    def device_free(self, dptr: int) -> None:
+        self._check(self._lib.pm_device_free(self._ctx, ctypes.c_void_p(dptr)))
+
+    def h2d(self, dptr: int, arr: np.ndarray) -> None:
+        arr = np.ascontiguousarray(arr)
+        self._check(self._lib.pm_memcpy_h2d(self._ctx, ctypes.c_void_p(dptr), arr.ctypes.data, arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, dptr: int) -> None:
+        assert arr.flags.c_contiguous
+        self._check(self._lib.pm_memcpy_d2h(self._ctx, arr.ctypes.data, ctypes.c_void_p(dptr), arr.nbytes))
+
+    # ------------------------------------------------------------------ state
+    def set_geometry(self, g: PMGeometry) -> None:
+        self._check(self._lib.pm_set_geometry(self._ctx, ctypes.byref(g)))
+        self._geometry = g
+
+    def set_disc(self, x0, y0, r0, rotation_rad, nx, ny, optimize_speed=True) -> None:
+        d = PMDisc()
+        d.x0, d.y0, d.r0, d.rotation_rad = float(x0), float(y0), float(r0), float(rotation_rad)
+        d.nx, d.ny = int(nx), int(ny)
+        d.optimize_speed = 1 if optimize_speed else 0
+        self._check(self._lib.pm_set_disc(self._ctx, ctypes.byref(d)))
+        self._disc = d
+
+    # ------------------------------------------------------------------ image backplanes
+    def backplanes_img(self, names: Iterable[str], alt: float = 0.0) -> dict[str, np.ndarray]:
+        """Compute image-space backplanes into fresh host arrays of shape (ny, nx)."""
+        names = list(names)
+        assert self._disc is not None
+        shape = (self._disc.ny, self._disc.nx)
+        if shape[0] <= 0 or shape[1] <= 0:
+            raise ValueError('nx and ny must be positive to create a backplane image')
+        outs = {n: np.empty(shape, dtype=np.float64) for n in names}
+        ptrs = (ctypes.c_void_p * NUM_PLANES)()
+        for n, a in outs.items():
+            ptrs[PLANE_INDEX[n]] = a.ctypes.data
+        self._check(
+            self._lib.pm_backplanes_img(self._ctx, plane_mask(names), float(alt), ptrs, _lib.PM_MEM_HOST)
+        )
+        return outs
+
+    def backplanes_img_device(self, outs: Mapping[str, object], alt: float = 0.0) -> None:
+        """Enqueue image backplanes into device buffers (`name -> pointer / torch tensor`)."""
+        ptrs = (ctypes.c_void_p * NUM_PLANES)()
+        for n, a in outs.items():
+            ptrs[PLANE_INDEX[n]] = _ptr(a)
+        self._check(
+            self._lib.pm_backplanes_img(self._ctx, plane_mask(outs.keys()), float(alt), ptrs, _lib.PM_MEM_DEVICE)
+        )
+
+    # ------------------------------------------------------------------ map space
+    def backplanes_map(self, names, lon_deg, lat_deg, alt: float = 0.0) -> dict[str, np.ndarray]:
+        names = list(names)
+        lon = np.ascontiguousarray(lon_deg, dtype=np.float64)
+        lat = np.ascontiguousarray(lat_deg, dtype=np.float64)
+        if lon.shape != lat.shape or lon.ndim != 2:
+            raise ValueError('lon/lat grids must be 2D arrays of the same shape')
+        n0, n1 = lon.shape
+        outs = {n: np.empty((n0, n1), dtype=np.float64) for n in names}
+        ptrs = (ctypes.c_void_p * NUM_PLANES)()
+        for n, a in outs.items():
+            ptrs[PLANE_INDEX[n]] = a.ctypes.data
+        self._check(
+            self._lib.pm_backplanes_map(
+                self._ctx, plane_mask(names), lon.ctypes.data, lat.ctypes.data, n0, n1, float(alt), ptrs,
+                _lib.PM_MEM_HOST,
+            )
+        )
+        return outs
+
+    def xy_map(self, lon_deg, lat_deg, alt: float = 0.0):
+        o = self.backplanes_map(['PIXEL-X', 'PIXEL-Y'], lon_deg, lat_deg, alt)
+        return o['PIXEL-X'], o['PIXEL-Y']
+
+    def xy_map_device(self, lon, lat, n0: int, n1: int, x_map, y_map, alt: float = 0.0) -> None:
+        self._check(
+            self._lib.pm_xy_map(
+                self._ctx, _ptr(lon), _ptr(lat), int(n0), int(n1), float(alt), _ptr(x_map), _ptr(y_map),
+                _lib.PM_MEM_DEVICE,
+            )
+        )
+
+    # ------------------------------------------------------------------ reprojection
+    def map_cube(self, cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True) -> np.ndarray:
+        """Reproject host cube (P, ny, nx) [or one (ny, nx) image] -> (P, n0, n1) float64."""
+        if interpolation not in _INTERP_CODES:
+            raise ValueError(f'Unknown interpolation method {interpolation!r}')
+        cube = np.asarray(cube)
+        if cube.dtype.byteorder not in ('=', '|') and cube.dtype.byteorder != ('<' if np.little_endian else '>'):
+            cube = cube.astype(cube.dtype.newbyteorder('='))
+        if cube.dtype not in _DTYPE_CODES:
+            cube = cube.astype(np.float64)
+        cube = np.ascontiguousarray(cube)
+        if cube.ndim == 2:
+            cube = cube[None]
+        assert self._disc is not None
+        if cube.shape[1:] != (self._disc.ny, self._disc.nx):
+            raise ValueError(
+                f'The input `img` shape {cube.shape[1:]!r} is inconsistent with the body\'s image size '
+                f'(ny={self._disc.ny}, nx={self._disc.nx})'
+            )
+        xm = np.ascontiguousarray(x_map, dtype=np.float64)
+        ym = np.ascontiguousarray(y_map, dtype=np.float64)
+        n0, n1 = xm.shape
+        out = np.empty((cube.shape[0], n0, n1), dtype=np.float64)
+        self._check(
+            self._lib.pm_map_cube(
+                self._ctx, cube.ctypes.data, dtype_code(cube.dtype), cube.shape[0], xm.ctypes.data,
+                ym.ctypes.data, n0, n1, _INTERP_CODES[interpolation], 1 if propagate_nan else 0,
+                out.ctypes.data, _lib.PM_MEM_HOST,
+            )
+        )
+        return out
+
+    def map_cube_device(
+        self, cube, dtype, n_planes: int, x_map, y_map, n0: int, n1: int, out,
+        interpolation='linear', propagate_nan=True,
+    ) -> None:  # fmt: skip
+        """Enqueue the reprojection of a device-resident cube into a device output."""
+        if interpolation not in _INTERP_CODES:
+            raise ValueError(f'Unknown interpolation method {interpolation!r}')
+        self._check(
+            self._lib.pm_map_cube(
+                self._ctx, _ptr(cube), dtype_code(dtype), int(n_planes), _ptr(x_map), _ptr(y_map), int(n0),
+                int(n1), _INTERP_CODES[interpolation], 1 if propagate_nan else 0, _ptr(out), _lib.PM_MEM_DEVICE,
+            )
+        )
+
+
+def device_count() -> int:
+    return int(_lib.load().pm_device_count())
+
+
+__all__ = ['Engine', 'device_count', 'plane_mask', 'PLANE_NAMES', 'PLANE_INDEX']

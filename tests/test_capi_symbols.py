@@ -1,0 +1,62 @@
+"""
+CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every
+symbol declared in include/planetmapper_hip.h, struct layouts agree between the header
+(as compiled into the oracle) and the ctypes mirrors, and the product fails loudly
+when there is no GPU (no CPU fallback).
+"""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import REPO
+from planetmapper_amd import _lib
+from planetmapper_amd.geometry import PMDisc, PMGeometry
+
+
+def _declared_functions():
+    hdr = open(os.path.join(REPO, 'include', 'planetmapper_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    return sorted(set(re.findall(r'\b(pm_[a-z0-9_]+)\s*\(', hdr)))
+
+
+def test_header_declares_what_python_binds():
+    assert _declared_functions() == sorted(_lib.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _declared_functions():
+        assert hasattr(lib, name), f'{name} missing from libplanetmapper_hip.so'
+    assert lib.pm_abi_version() == 1
+
+
+def test_struct_layouts_match_the_header():
+    from oracle import oracle
+
+    o = oracle.lib()
+    assert o.pmo_sizeof_geometry() == ctypes.sizeof(PMGeometry)
+    assert o.pmo_sizeof_disc() == ctypes.sizeof(PMDisc)
+
+
+def test_no_gpu_means_loud_failure():
+    """On a box without a gfx950 device the engine must refuse to work (no fallback)."""
+    from planetmapper_amd.engine import Engine, device_count
+
+    if device_count() > 0:
+        pytest.skip('a GPU is present')
+    with pytest.raises(_lib.NoDeviceError):
+        Engine(0)
+
+
+def test_product_does_not_import_the_oracle():
+    """Nothing under planetmapper_amd/ may reference oracle/ (it is test infrastructure)."""
+    pkg = os.path.join(REPO, 'planetmapper_amd')
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h', '.cpp')):
+                text = open(os.path.join(root, f), encoding='utf-8').read()
+                assert 'import oracle' not in text and 'from oracle' not in text, f
+                assert 'pm_oracle' not in text and 'libpm_oracle' not in text, f

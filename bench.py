@@ -50,6 +50,18 @@ def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
     return nx * ny * 8 * n_planes
 
 
+def host_cores() -> int:
+    """CPU cores this process may actually use: cgroup quota if set, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(g, sz: int, budget_s: float = 12.0) -> dict:
     """
     The CPU oracle (a port: the reference's own Python + CSPICE path cannot run here)
@@ -57,7 +69,7 @@ def cpu_baseline(g, sz: int, budget_s: float = 12.0) -> dict:
     """
     from oracle import oracle
 
-    cores = len(os.sched_getaffinity(0))
+    cores = host_cores()
     oracle.set_num_threads(cores)
     x0 = y0 = (sz - 1) / 2
     disc = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)

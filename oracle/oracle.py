@@ -48,7 +48,7 @@ def build(force: bool = False) -> str:
         for p in (src, hdr)
     )
     if force or stale:
-        subprocess.run(['make', '-C', _HERE, '-B', 'libpm_oracle.so'], check=True,
+        subprocess.run(['make', '-C', _HERE, '-B', 'all'], check=True,
                        capture_output=True)
     return _LIB_PATH
 
@@ -56,10 +56,22 @@ def build(force: bool = False) -> str:
 _lib = None
 
 
+def use_variant(name: str | None) -> None:
+    """
+    Switch the module to another build of the same source (`'fma'` ->
+    libpm_oracle_fma.so, None -> the strict build). Only tests/test_noise_floor.py
+    uses this, to measure the rounding-noise floor of the formulation.
+    """
+    global _lib, _LIB_PATH
+    _LIB_PATH = os.path.join(_HERE, 'libpm_oracle.so' if name is None else f'libpm_oracle_{name}.so')
+    _lib = None
+
+
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        build()
+        if not os.path.exists(_LIB_PATH) or _LIB_PATH.endswith('libpm_oracle.so'):
+            build()
         _lib = ctypes.CDLL(_LIB_PATH)
         dpp = ctypes.POINTER(ctypes.POINTER(ctypes.c_double))
         dp = ctypes.POINTER(ctypes.c_double)

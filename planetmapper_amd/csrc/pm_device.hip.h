@@ -203,21 +203,26 @@ __device__ __forceinline__ bool surfpt(V3 o, V3 u, const double *radii, V3 &pt)
 }
 
 // sincpt_c('ELLIPSOID', ..., 'CN', ..., ray): Body._obsvec_norm2targvec body.py:1008-1020.
-// Fixed 3 intercept evaluations: the light-time error contracts by v/c ~ 4e-5 per pass
-// (0.25 s -> 1e-5 s -> 4e-10 s), i.e. < 1e-11 deg after the third.
-// Outputs the body-fixed point and its light time.
+// Converged-Newtonian light time: repeat the intercept at te = et - lt until the light
+// time moves by <= 1e-17 |te| (CSPICE's rule), at most 10 evaluations. The contraction
+// factor is (v/c) / cos(emission): ~4e-5 over most of the disc (3 evaluations), but
+// it approaches 1 at grazing incidence, so limb lanes need more - a fixed count is
+// not enough there. Outputs the body-fixed point and its light time.
 __device__ __forceinline__ bool sincpt(const Params &p, V3 ray, V3 &sp, double &lt)
 {
     lt = p.g.lt_c;
 #pragma unroll 1
-    for (int it = 0; it < 3; it++) {
+    for (int it = 0; it < 10; it++) {
         double te = p.g.et - lt;
         M3 R;
         rot_at<true>(p, te, R);
         V3 obs = neg(mxv(R, target_at(p, te)));
         V3 u = mxv(R, ray);
         if (!surfpt(obs, u, p.radii, sp)) return false;
-        lt = norm(sp - obs) / p.g.clight;
+        double nlt = norm(sp - obs) / p.g.clight;
+        double err = fabs(nlt - lt);
+        lt = nlt;
+        if (err <= 1e-17 * fabs(p.g.et - lt)) break;
     }
     return true;
 }

@@ -1,0 +1,641 @@
+"""
+`BodyXY`: the reference's image-plane / backplane API (`planetmapper/body_xy.py`) on top
+of the HIP engine.
+
+The method names, argument meanings, array shapes/dtypes, copy-vs-read-only-view rules,
+cache invalidation rules and error behaviour follow the reference class so that code
+written against `planetmapper.BodyXY` for the backplane / mapping path runs unchanged:
+
+    body = BodyXY(scenario='jupiter_hst_2005', sz=500)
+    body.set_disc_params(x0=250, y0=250, r0=200)
+    lon = body.get_lon_img()                      # read-only (ny, nx) float64 view
+    emi = body.get_backplane_img('EMISSION')      # fresh copy
+    img_map = body.map_img(img, degree_interval=1)
+
+Only the per-pixel numerics differ: every pixel loop of the reference is one fused
+kernel launch here. What is NOT provided (plotting, GUI, wireframes, SPICE kernel
+management, pyproj projections) is out of scope for this path.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Any, Callable, Iterable, NamedTuple
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine
+from .geometry import PMGeometry
+from .scenarios import load_scenario
+
+
+class Backplane(NamedTuple):
+    """`planetmapper.Backplane` (body_xy.py:79-107)."""
+
+    name: str
+    description: str
+    get_img: Callable[[], np.ndarray]
+    get_map: Callable[..., np.ndarray]
+
+
+class BackplaneNotFoundError(Exception):
+    """body_xy.py:4359"""
+
+
+MAP_KWARG_KEYS = (
+    'projection', 'degree_interval', 'lon', 'lat', 'size', 'lon_coords', 'lat_coords',
+    'projection_x_coords', 'projection_y_coords', 'xlim', 'ylim', 'alt',
+)  # MapKwargs body_xy.py:51-69  # fmt: skip
+
+
+def _readonly(a: np.ndarray) -> np.ndarray:
+    """Read-only view (`_as_readonly_view` base.py:115-121)."""
+    v = a.view()
+    v.flags.writeable = False
+    return v
+
+
+def _freeze(v: Any) -> Any:
+    """Hashable stand-in for a kwarg value (`_replace_np_arrr_args_with_tuples` base.py:41)."""
+    if isinstance(v, np.ndarray):
+        return ('ndarray', v.shape, v.dtype.str, v.tobytes())
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    return v
+
+
+_ENGINES: dict[int, Engine] = {}
+
+
+def _shared_engine(device: int) -> Engine:
+    """One HIP context per device per process, shared by every BodyXY on that device."""
+    eng = _ENGINES.get(device)
+    if eng is None or eng._ctx is None:
+        eng = Engine(device)
+        _ENGINES[device] = eng
+    return eng
+
+
+class BodyXY:
+    """
+    Image-plane view of a body observed at one epoch (reference `BodyXY`,
+    body_xy.py:114).
+
+    Args:
+        target, utc, observer: kept for signature compatibility; used only for
+            `repr`/metadata when `geometry`/`scenario` supplies the numbers.
+        nx, ny / sz: image size in pixels (body_xy.py:186-199).
+        geometry: a filled `PMGeometry` block (from `GeometryBuilder` or from a
+            spiceypy-backed reference `Body`).
+        scenario: name of a packaged scenario (`planetmapper_amd.scenarios`).
+        optimize_speed: enables the radius pre-mask exactly like the reference
+            (`SpiceBase(optimize_speed=True)`, base.py:229; body_xy.py:3201-3218).
+        device: GPU index.
+    """
+
+    def __init__(
+        self,
+        target: str | None = None,
+        utc: Any = None,
+        observer: str | int = 'EARTH',
+        nx: int = 0,
+        ny: int = 0,
+        *,
+        sz: int | None = None,
+        geometry: PMGeometry | None = None,
+        scenario: str | None = None,
+        optimize_speed: bool = True,
+        device: int = 0,
+        engine: Engine | None = None,
+    ) -> None:
+        if sz is not None:
+            if nx != 0 or ny != 0:
+                raise ValueError('`sz` cannot be used if `nx` and/or `ny` are nonzero')
+            nx = sz
+            ny = sz
+        if geometry is None:
+            if scenario is None:
+                raise ValueError(
+                    'BodyXY needs `geometry=` (a PMGeometry block) or `scenario=`: this package '
+                    'does not load SPICE kernels itself (see INTEGRATION.md)'
+                )
+            geometry = load_scenario(scenario)
+        self._geometry = geometry.copy()
+        self.target = None if target is None else str(target).strip().upper()
+        self.utc = utc
+        self.observer = observer
+        self._optimize_speed = bool(optimize_speed)
+        self._engine = engine if engine is not None else _shared_engine(device)
+
+        g = self._geometry
+        # Body attributes used on this path (body.py:501-614, base.py:795-839)
+        self.et = g.et
+        self.radii = np.array(g.radii[:])
+        self.r_eq = float(g.radii[0])
+        self.r_polar = float(g.radii[2])
+        self.flattening = (self.r_eq - self.r_polar) / self.r_eq
+        self.target_light_time = g.lt_c
+        self.target_distance = g.lt_c * g.clight
+        self.target_diameter_arcsec = g.diameter_arcsec
+        self.km_per_arcsec = g.km_per_arcsec
+        self.positive_longitude_direction = 'W' if g.west_positive else 'E'
+        self.subpoint_distance = g.sub_dist
+        self._alt_adjustment = 0.0
+
+        self._cache: dict = {}  # cleared when the disc parameters change (base.py:58-88)
+        self._stable_cache: dict = {}  # map-space results (base.py:91-112)
+        self._nx = int(nx)
+        self._ny = int(ny)
+        self._x0 = 0.0
+        self._y0 = 0.0
+        self._r0 = 10.0
+        self._rotation_radians = 0.0
+        self._disc_method = 'default'
+        self.backplanes: dict[str, Backplane] = {}
+        self._register_default_backplanes()
+        self.reset_disc_params()
+
+    def __repr__(self) -> str:
+        return f'BodyXY({self.target!r}, {self.utc!r}, observer={self.observer!r}, nx={self._nx}, ny={self._ny})'
+
+    # ------------------------------------------------------------------ caches
+    def _clear_cache(self) -> None:
+        self._cache.clear()
+
+    def _invalidate_disc_parameters(self) -> None:  # body_xy.py:696-698
+        self._clear_cache()
+
+    # ------------------------------------------------------------------ disc parameters
+    def set_disc_params(self, x0=None, y0=None, r0=None, rotation=None) -> None:
+        """body_xy.py:700-729"""
+        if x0 is not None:
+            self.set_x0(x0)
+        if y0 is not None:
+            self.set_y0(y0)
+        if r0 is not None:
+            self.set_r0(r0)
+        if rotation is not None:
+            self.set_rotation(rotation)
+
+    def adjust_disc_params(self, dx=0, dy=0, dr=0, drotation=0) -> None:
+        self.set_x0(self.get_x0() + dx)
+        self.set_y0(self.get_y0() + dy)
+        self.set_r0(self.get_r0() + dr)
+        self.set_rotation(self.get_rotation() + drotation)
+
+    def get_disc_params(self) -> tuple[float, float, float, float]:
+        return self.get_x0(), self.get_y0(), self.get_r0(), self.get_rotation()
+
+    def reset_disc_params(self) -> str:
+        """body_xy.py:772-789"""
+        self.set_rotation(0.0)
+        if self._test_if_img_size_valid():
+            self.centre_disc()
+        else:
+            self.set_disc_params(x0=0, y0=0, r0=10)
+            self.set_disc_method('zero')
+        return self.get_disc_method()
+
+    def centre_disc(self) -> None:
+        """body_xy.py:791-803"""
+        self.set_x0((self._nx - 1) / 2)
+        self.set_y0((self._ny - 1) / 2)
+        self.set_r0(0.9 * (min(self.get_x0(), self.get_y0())))
+        self.set_disc_method('centre_disc')
+
+    def set_x0(self, x0: float) -> None:
+        if not math.isfinite(x0):
+            raise ValueError('x0 must be finite')
+        self._x0 = float(x0)
+        self._invalidate_disc_parameters()
+
+    def get_x0(self) -> float:
+        return self._x0
+
+    def set_y0(self, y0: float) -> None:
+        if not math.isfinite(y0):
+            raise ValueError('y0 must be finite')
+        self._y0 = float(y0)
+        self._invalidate_disc_parameters()
+
+    def get_y0(self) -> float:
+        return self._y0
+
+    def set_r0(self, r0: float) -> None:
+        if not math.isfinite(r0):
+            raise ValueError('r0 must be finite')
+        if not r0 > 0:
+            raise ValueError('r0 must be greater than zero')
+        self._r0 = float(r0)
+        self._invalidate_disc_parameters()
+
+    def get_r0(self) -> float:
+        return self._r0
+
+    def set_rotation(self, rotation: float) -> None:
+        """Degrees; stored in radians modulo 2 pi (body_xy.py:867-890)."""
+        if not math.isfinite(rotation):
+            raise ValueError('rotation must be finite')
+        self._rotation_radians = float(np.deg2rad(rotation) % (2 * np.pi))
+        self._invalidate_disc_parameters()
+
+    def get_rotation(self) -> float:
+        return float(np.rad2deg(self._rotation_radians))
+
+    def set_plate_scale_arcsec(self, arcsec_per_px: float) -> None:
+        self.set_r0(self.target_diameter_arcsec / (2 * arcsec_per_px))
+
+    def set_plate_scale_km(self, km_per_px: float) -> None:
+        self.set_plate_scale_arcsec(km_per_px / self.km_per_arcsec)
+
+    def get_plate_scale_arcsec(self) -> float:
+        return self.target_diameter_arcsec / (2 * self.get_r0())
+
+    def get_plate_scale_km(self) -> float:
+        return self.get_plate_scale_arcsec() * self.km_per_arcsec
+
+    def set_img_size(self, nx: int | None = None, ny: int | None = None) -> None:
+        """body_xy.py:941-961"""
+        nx = self._nx if nx is None else int(nx)
+        ny = self._ny if ny is None else int(ny)
+        if nx < 0 or ny < 0:
+            raise ValueError('nx and ny must be non-negative')
+        self._nx = nx
+        self._ny = ny
+        self._clear_cache()
+
+    def get_img_size(self) -> tuple[int, int]:
+        return (self._nx, self._ny)
+
+    def set_disc_method(self, method: str) -> None:
+        self._disc_method = method
+
+    def get_disc_method(self) -> str:
+        return self._disc_method
+
+    def _test_if_img_size_valid(self) -> bool:
+        return (self._nx > 0) and (self._ny > 0)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def _bind(self) -> Engine:
+        """Point the (shared) context at this body's geometry and disc."""
+        eng = self._engine
+        eng.set_geometry(self._geometry)
+        eng.set_disc(
+            self._x0, self._y0, self._r0, self._rotation_radians, self._nx, self._ny, self._optimize_speed
+        )
+        return eng
+
+    def _img_planes(self, names: Iterable[str]) -> dict[str, np.ndarray]:
+        """
+        Cached image-space planes; every missing one is produced by a single fused
+        launch. Cache key includes the altitude adjustment like
+        `_cache_clearable_alt_dependent_result` (body.py:255-272).
+        """
+        names = list(names)
+        alt = self._alt_adjustment
+        missing = [n for n in names if ('img', n, alt) not in self._cache]
+        if missing:
+            if not self._test_if_img_size_valid():
+                # BodyXY._make_empty_img body_xy.py:3166-3168
+                raise ValueError('nx and ny must be positive to create a backplane image')
+            out = self._bind().backplanes_img(missing, alt=alt)
+            for n, a in out.items():
+                self._cache[('img', n, alt)] = _readonly(a)
+        return {n: self._cache[('img', n, alt)] for n in names}
+
+    def prefetch_backplane_imgs(self, names: Iterable[str] | None = None, *, alt: float = 0.0) -> None:
+        """
+        Compute several backplane images with ONE kernel launch and leave them in the
+        cache (what `Observation.save_observation` needs, observation.py:1269-1279).
+        Not in the reference API; purely an optimisation hook.
+        """
+        if names is None:
+            names = [n for n in self.backplanes if n in _lib.PLANE_INDEX]
+        names = [self.standardise_backplane_name(n) for n in names]
+        with _AltitudeContext(self, alt):
+            self._img_planes([n for n in names if n in _lib.PLANE_INDEX])
+
+    # ------------------------------------------------------------------ map coordinates
+    def generate_map_coordinates(
+        self,
+        projection: str = 'rectangular',
+        *,
+        degree_interval: float = 1,
+        lon: float = 0,
+        lat: float = 0,
+        size: int = 100,
+        lon_coords=None,
+        lat_coords=None,
+        projection_x_coords=None,
+        projection_y_coords=None,
+        xlim=None,
+        ylim=None,
+        alt: float = 0.0,
+    ):
+        """
+        body_xy.py:2755-3012 for `'rectangular'` and `'manual'` projections (the pyproj
+        based ones are out of scope: feed their lon/lat grids in as `'manual'`).
+        Returns `(lons, lats, xx, yy, transformer, info)` with `transformer = None`.
+        """
+        if projection == 'rectangular':
+            lons = np.arange(degree_interval / 2, 360, degree_interval)
+            if self.positive_longitude_direction == 'W':
+                lons = lons[::-1]
+            lats = np.arange(-90 + degree_interval / 2, 90, degree_interval)
+            lons, lats = np.meshgrid(lons, lats)
+            info: dict[str, Any] = dict(projection=projection, degree_interval=degree_interval)
+        elif projection == 'manual':
+            if lon_coords is None or lat_coords is None:
+                raise ValueError('lon_coords and lat_coords must be provided for manual projection')
+            lons = np.asarray(lon_coords, dtype=float)
+            lats = np.asarray(lat_coords, dtype=float)
+            if lons.ndim != lats.ndim:
+                raise ValueError('lon_coords and lat_coords must have the same number of dimensions')
+            if lons.ndim == 1:
+                lons, lats = np.meshgrid(lons, lats)
+            if lons.ndim != 2:
+                raise ValueError('lon_coords and lat_coords must be 1D or 2D arrays')
+            if lons.shape != lats.shape:
+                raise ValueError('lon_coords and lat_coords must have the same shape')
+            lons = np.array(lons, dtype=float)
+            lats = np.array(lats, dtype=float)
+            info = dict(projection=projection)
+        else:
+            raise _lib.UnsupportedError(
+                f'projection {projection!r} needs pyproj in the reference and is not part of this path; '
+                "pass its lon/lat grids with projection='manual'"
+            )
+        xx, yy = lons, lats
+        info['xlim'] = xlim
+        info['ylim'] = ylim
+        if xlim is not None:
+            keep = (xx[0] >= min(xlim)) & (xx[0] <= max(xlim))
+            xx, yy, lons, lats = xx[:, keep], yy[:, keep], lons[:, keep], lats[:, keep]
+        if ylim is not None:
+            keep = (yy[:, 0] >= min(ylim)) & (yy[:, 0] <= max(ylim))
+            xx, yy, lons, lats = xx[keep, :], yy[keep, :], lons[keep, :], lats[keep, :]
+        lons = np.array(lons, dtype=float)
+        lats = np.array(lats, dtype=float)
+        lons[~np.isfinite(lons)] = np.nan
+        lats[~np.isfinite(lats)] = np.nan
+        if alt != 0.0:
+            info['alt'] = alt
+        return _readonly(lons), _readonly(lats), _readonly(np.array(xx)), _readonly(np.array(yy)), None, info
+
+    @staticmethod
+    def _split_map_kwargs(map_kwargs: dict) -> tuple[dict, float]:
+        for k in map_kwargs:
+            if k not in MAP_KWARG_KEYS:
+                raise TypeError(f'unexpected map keyword argument {k!r}')
+        alt = float(map_kwargs.get('alt', 0.0))
+        return map_kwargs, alt
+
+    def _map_key(self, map_kwargs: dict) -> tuple:
+        return tuple(sorted((k, _freeze(v)) for k, v in map_kwargs.items()))
+
+    def _get_lonlat_map(self, **map_kwargs) -> np.ndarray:
+        """body_xy.py:3290-3300: (n0, n1, 2) with longitudes modulo 360."""
+        key = ('lonlat_map', self._map_key(map_kwargs))
+        if key not in self._stable_cache:
+            lons, lats, *_ = self.generate_map_coordinates(**map_kwargs)
+            lons = lons % 360
+            m = np.stack([lons, lats], axis=-1)
+            m[~np.isfinite(m)] = np.nan
+            self._stable_cache[key] = _readonly(m)
+        return self._stable_cache[key]
+
+    def _map_planes(self, names: Iterable[str], map_kwargs: dict) -> dict[str, np.ndarray]:
+        """
+        Cached map-space planes. Disc-independent planes live in the stable cache; x/y
+        maps depend on the disc parameters (body_xy.py:3478) and live in the clearable one.
+        """
+        names = list(names)
+        map_kwargs, alt = self._split_map_kwargs(dict(map_kwargs))
+        mkey = self._map_key(map_kwargs)
+
+        def slot(n: str):
+            disc_dep = n in ('PIXEL-X', 'PIXEL-Y')
+            cache = self._cache if disc_dep else self._stable_cache
+            return cache, ('map', n, mkey)
+
+        missing = [n for n in names if slot(n)[1] not in slot(n)[0]]
+        if missing:
+            ll = self._get_lonlat_map(**map_kwargs)
+            lon = np.ascontiguousarray(ll[:, :, 0])
+            lat = np.ascontiguousarray(ll[:, :, 1])
+            out = self._bind().backplanes_map(missing, lon, lat, alt=alt)
+            for n, a in out.items():
+                cache, key = slot(n)
+                cache[key] = _readonly(a)
+        return {n: slot(n)[0][slot(n)[1]] for n in names}
+
+    def get_x_map(self, **map_kwargs) -> np.ndarray:
+        return self._map_planes(['PIXEL-X', 'PIXEL-Y'], map_kwargs)['PIXEL-X']
+
+    def get_y_map(self, **map_kwargs) -> np.ndarray:
+        return self._map_planes(['PIXEL-X', 'PIXEL-Y'], map_kwargs)['PIXEL-Y']
+
+    # ------------------------------------------------------------------ reprojection
+    def map_img(
+        self,
+        img: np.ndarray,
+        *,
+        interpolation: str | int | tuple[int, int] = 'linear',
+        spline_smoothing: float = 0,
+        propagate_nan: bool = True,
+        warn_nan: bool = False,
+        smooth_oversample_by: int = 5,
+        smooth_max_oversampled_img_size: int = 10_000,
+        **map_kwargs,
+    ) -> np.ndarray:
+        """
+        body_xy.py:1414-1631: project an image (ny, nx) - or a cube (P, ny, nx) - onto
+        the map grid. `'linear'` (RectBivariateSpline k=1, s=0 == bilinear) and
+        `'nearest'` run on the GPU; the other interpolations of the reference are not
+        part of this path yet and raise `UnsupportedError`.
+        """
+        img = np.asarray(img)
+        interp = interpolation
+        if interp == 1 or interp == (1, 1):
+            interp = 'linear'
+        if interp not in ('linear', 'nearest'):
+            if interp in ('quadratic', 'cubic', 'smooth') or isinstance(interp, (int, tuple)):
+                raise _lib.UnsupportedError(
+                    f'interpolation {interpolation!r} (FITPACK splines / PCHIP, body_xy.py:1651-1853) '
+                    'is not implemented on the GPU path'
+                )
+            raise ValueError(f'Unknown interpolation method {interpolation!r}')
+        if interp == 'linear' and spline_smoothing != 0:
+            raise _lib.UnsupportedError('spline_smoothing != 0 is not implemented on the GPU path')
+        single = img.ndim == 2
+        if img.ndim not in (2, 3) or img.shape[-2:] != (self._ny, self._nx):
+            raise ValueError(
+                f'The input `img` shape {img.shape!r} is inconsistent with the body\'s image size '
+                f'(ny={self._ny}, nx={self._nx})'
+            )
+        x_map = self.get_x_map(**map_kwargs)
+        y_map = self.get_y_map(**map_kwargs)
+        if warn_nan and interp == 'linear' and not np.all(np.isfinite(img)):
+            print('Warning, image contains NaN values which will be corrected')
+        out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan)
+        return out[0] if single else out
+
+    # ------------------------------------------------------------------ backplane registry
+    @staticmethod
+    def standardise_backplane_name(name: str) -> str:
+        return name.strip().upper()
+
+    def register_backplane(self, name: str, description: str, get_img, get_map) -> None:
+        """body_xy.py:2512-2539"""
+        name = self.standardise_backplane_name(name)
+        if name in self.backplanes:
+            raise ValueError(f'Backplane named {name!r} is already registered')
+        self.backplanes[name] = Backplane(name=name, description=description, get_img=get_img, get_map=get_map)
+
+    def backplane_summary_string(self) -> str:
+        return '\n'.join(f'{bp.name}: {bp.description}' for bp in self.backplanes.values())
+
+    def print_backplanes(self) -> None:
+        print(self.backplane_summary_string())
+
+    def get_backplane(self, name: str) -> Backplane:
+        name = self.standardise_backplane_name(name)
+        try:
+            return self.backplanes[name]
+        except KeyError as exc:
+            raise BackplaneNotFoundError(
+                '{n!r} not found. Currently registered backplanes are: {r}.'.format(
+                    n=name, r=', '.join([repr(n) for n in self.backplanes.keys()])
+                )
+            ) from exc
+
+    def get_backplane_img(self, name: str, *, alt: float = 0.0) -> np.ndarray:
+        """Fresh copy of a backplane image (body_xy.py:2586-2630)."""
+        with _AltitudeContext(self, alt):
+            return self.backplanes[self.standardise_backplane_name(name)].get_img().copy()
+
+    def get_backplane_map(self, name: str, **map_kwargs) -> np.ndarray:
+        """Fresh copy of a backplane map (body_xy.py:2632-2664)."""
+        return self.backplanes[self.standardise_backplane_name(name)].get_map(**map_kwargs).copy()
+
+    def _register_default_backplanes(self) -> None:
+        """The 26 default backplanes, same names/order/descriptions as body_xy.py:4198-4356."""
+        ew = self.positive_longitude_direction
+        table = [
+            ('LON-GRAPHIC', f'Planetographic longitude, positive {ew} [deg]', 'lon'),
+            ('LAT-GRAPHIC', 'Planetographic latitude [deg]', 'lat'),
+            ('LON-CENTRIC', 'Planetocentric longitude [deg]', 'lon_centric'),
+            ('LAT-CENTRIC', 'Planetocentric latitude [deg]', 'lat_centric'),
+            ('RA', 'Right ascension [deg]', 'ra'),
+            ('DEC', 'Declination [deg]', 'dec'),
+            ('PIXEL-X', 'Observation x pixel coordinate [pixels]', 'x'),
+            ('PIXEL-Y', 'Observation y pixel coordinate [pixels]', 'y'),
+            ('KM-X', 'East-West distance in target plane [km]', 'km_x'),
+            ('KM-Y', 'North-South distance in target plane [km]', 'km_y'),
+            ('ANGULAR-X', 'East-West distance in target plane [arcsec]', 'angular_x'),
+            ('ANGULAR-Y', 'North-South distance in target plane [arcsec]', 'angular_y'),
+            ('PHASE', 'Phase angle [deg]', 'phase_angle'),
+            ('INCIDENCE', 'Incidence angle [deg]', 'incidence_angle'),
+            ('EMISSION', 'Emission angle [deg]', 'emission_angle'),
+            ('AZIMUTH', 'Azimuth angle [deg]', 'azimuth_angle'),
+            ('LOCAL-SOLAR-TIME', 'Local solar time [local hours]', 'local_solar_time'),
+            ('DISTANCE', 'Distance to observer [km]', 'distance'),
+            ('RADIAL-VELOCITY', 'Radial velocity away from observer [km/s]', 'radial_velocity'),
+            ('DOPPLER', 'Doppler factor, sqrt((1 + v/c)/(1 - v/c)) where v is radial velocity', 'doppler'),
+            ('LIMB-DISTANCE', 'Distance above limb [km]', 'limb_distance'),
+            ('LIMB-LON-GRAPHIC', 'Planetographic longitude of closest point on the limb [deg]', 'limb_lon'),
+            ('LIMB-LAT-GRAPHIC', 'Planetographic latitude of closest point on the limb [deg]', 'limb_lat'),
+            ('RING-RADIUS', 'Equatorial (ring) plane radius [km]', 'ring_plane_radius'),
+            ('RING-LON-GRAPHIC', 'Equatorial (ring) plane planetographic longitude [deg]', 'ring_plane_longitude'),
+            ('RING-DISTANCE', 'Equatorial (ring) plane distance to observer [km]', 'ring_plane_distance'),
+        ]  # fmt: skip
+        for name, desc, stem in table:
+            self.register_backplane(
+                name, desc, getattr(self, f'get_{stem}_img'), getattr(self, f'get_{stem}_map')
+            )
+
+
+# Families computed together by the reference (one cached pixel loop each); a request
+# for one member computes - and caches - its whole family with one launch.
+_FAMILIES = {
+    'lon': ('LON-GRAPHIC', ('LON-GRAPHIC', 'LAT-GRAPHIC')),  # _get_lonlat_img :3281
+    'lat': ('LAT-GRAPHIC', ('LON-GRAPHIC', 'LAT-GRAPHIC')),
+    'lon_centric': ('LON-CENTRIC', ('LON-CENTRIC', 'LAT-CENTRIC')),  # :3346
+    'lat_centric': ('LAT-CENTRIC', ('LON-CENTRIC', 'LAT-CENTRIC')),
+    'ra': ('RA', ('RA', 'DEC')),  # _get_radec_img :3409
+    'dec': ('DEC', ('RA', 'DEC')),
+    'x': ('PIXEL-X', ('PIXEL-X', 'PIXEL-Y')),  # :3494
+    'y': ('PIXEL-Y', ('PIXEL-X', 'PIXEL-Y')),
+    'km_x': ('KM-X', ('KM-X', 'KM-Y')),  # _get_km_xy_img :3545
+    'km_y': ('KM-Y', ('KM-X', 'KM-Y')),
+    'angular_x': ('ANGULAR-X', ('ANGULAR-X', 'ANGULAR-Y')),  # :3610
+    'angular_y': ('ANGULAR-Y', ('ANGULAR-X', 'ANGULAR-Y')),
+    'phase_angle': ('PHASE', ('PHASE', 'INCIDENCE', 'EMISSION')),  # _get_illumination_gie_img :3658
+    'incidence_angle': ('INCIDENCE', ('PHASE', 'INCIDENCE', 'EMISSION')),
+    'emission_angle': ('EMISSION', ('PHASE', 'INCIDENCE', 'EMISSION')),
+    'azimuth_angle': ('AZIMUTH', ('PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH')),  # :3742
+    'local_solar_time': ('LOCAL-SOLAR-TIME', ('LON-GRAPHIC', 'LAT-GRAPHIC', 'LOCAL-SOLAR-TIME')),  # :3787
+    'distance': ('DISTANCE', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER')),  # _get_state_imgs :3830
+    'radial_velocity': ('RADIAL-VELOCITY', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER')),
+    'doppler': ('DOPPLER', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER')),
+    'limb_distance': ('LIMB-DISTANCE', ('LIMB-DISTANCE', 'LIMB-LON-GRAPHIC', 'LIMB-LAT-GRAPHIC')),  # :3964
+    'limb_lon': ('LIMB-LON-GRAPHIC', ('LIMB-DISTANCE', 'LIMB-LON-GRAPHIC', 'LIMB-LAT-GRAPHIC')),
+    'limb_lat': ('LIMB-LAT-GRAPHIC', ('LIMB-DISTANCE', 'LIMB-LON-GRAPHIC', 'LIMB-LAT-GRAPHIC')),
+    'ring_plane_radius': ('RING-RADIUS', ('RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE')),  # :4059
+    'ring_plane_longitude': ('RING-LON-GRAPHIC', ('RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE')),
+    'ring_plane_distance': ('RING-DISTANCE', ('RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE')),
+}
+
+
+def _make_getters(stem: str, plane: str, family: tuple[str, ...]):
+    def get_img(self: BodyXY) -> np.ndarray:
+        return self._img_planes(family)[plane]
+
+    def get_map(self: BodyXY, **map_kwargs) -> np.ndarray:
+        return self._map_planes(family, map_kwargs)[plane]
+
+    get_img.__name__ = f'get_{stem}_img'
+    get_map.__name__ = f'get_{stem}_map'
+    get_img.__doc__ = (
+        f'Read-only (ny, nx) float64 array of the {plane} backplane (reference `BodyXY.get_{stem}_img`); '
+        'NaN where undefined.'
+    )
+    get_map.__doc__ = (
+        f'Read-only (n0, n1) float64 map of the {plane} backplane (reference `BodyXY.get_{stem}_map`).'
+    )
+    return get_img, get_map
+
+
+for _stem, (_plane, _family) in _FAMILIES.items():
+    _gi, _gm = _make_getters(_stem, _plane, _family)
+    setattr(BodyXY, f'get_{_stem}_img', _gi)
+    if _stem not in ('x', 'y'):  # get_x_map / get_y_map are defined explicitly above
+        setattr(BodyXY, f'get_{_stem}_map', _gm)
+
+
+class _AltitudeContext:
+    """
+    `_AdjustedSurfaceAltitude` (body.py:172-229): temporarily add `alt` km to all three
+    radii. Here it only switches the altitude passed to the kernels (and the cache key);
+    like the reference it cannot be nested with two different non-zero altitudes.
+    """
+
+    def __init__(self, body: BodyXY, alt: float = 0.0) -> None:
+        self.body = body
+        self.do = alt != 0.0 and alt != body._alt_adjustment
+        if self.do:
+            self.alt = float(alt)
+            if not math.isfinite(self.alt):
+                raise ValueError('Cannot adjust surface altitude with non-finite alt value')
+            if body._alt_adjustment != 0.0:
+                raise ValueError('Cannot nest _AdjustedSurfaceAltitude context managers with alt != 0')
+
+    def __enter__(self) -> None:
+        if self.do:
+            self.body._alt_adjustment = self.alt
+
+    def __exit__(self, *exc) -> None:
+        if self.do:
+            self.body._alt_adjustment = 0.0

@@ -1,0 +1,45 @@
+"""
+Test double for `planetmapper_amd.engine.Engine` backed by the CPU oracle, so the
+host-side Python layer (BodyXY / Observation: caches, read-only views, registry, map
+kwargs, error behaviour) can be tested without a GPU. Lives in tests/ because only
+tests may touch the oracle; the product never falls back to it.
+"""
+
+import numpy as np
+
+from oracle import oracle
+
+
+class OracleEngine:
+    def __init__(self):
+        self._g = None
+        self._d = None
+        self._ctx = object()
+        self.calls = []  # (kind, names) log, used to assert caching behaviour
+
+    def set_geometry(self, g):
+        self._g = g
+
+    def set_disc(self, x0, y0, r0, rotation_rad, nx, ny, optimize_speed=True):
+        d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny, optimize_speed)
+        d.rotation_rad = rotation_rad
+        self._d = d
+
+    def backplanes_img(self, names, alt=0.0):
+        names = list(names)
+        self.calls.append(('img', tuple(names), alt))
+        return oracle.backplanes_img(self._g, self._d, names, alt=alt)
+
+    def backplanes_map(self, names, lon, lat, alt=0.0):
+        names = list(names)
+        self.calls.append(('map', tuple(names), alt))
+        return oracle.backplanes_map(self._g, self._d, names, lon, lat, alt=alt)
+
+    def map_cube(self, cube, x_map, y_map, interpolation='linear', propagate_nan=True):
+        cube = np.asarray(cube)
+        if cube.ndim == 2:
+            cube = cube[None]
+        if cube.dtype not in oracle.DTYPES:
+            cube = cube.astype(np.float64)
+        self.calls.append(('cube', cube.shape, interpolation))
+        return oracle.map_cube(cube, x_map, y_map, interpolation, propagate_nan)

@@ -1,0 +1,312 @@
+"""
+Host-side behaviour of the reference-compatible API (no GPU: the engine is replaced by
+tests/oracle_engine.OracleEngine). Mirrors the reference's own tests:
+tests/test_body_xy.py (disc params :140-266, map_img :1085-1327, backplanes :1990-2170,
+cache invalidation :2495-2590) and tests/test_observation.py (mapped data).
+"""
+
+import numpy as np
+import pytest
+
+from oracle_engine import OracleEngine
+from planetmapper_amd import BackplaneNotFoundError, BodyXY, Observation
+from planetmapper_amd._lib import UnsupportedError
+
+nan = np.nan
+
+
+@pytest.fixture()
+def body(jupiter):
+    return BodyXY('Jupiter', '2005-01-01T00:00:00', observer='HST', geometry=jupiter, engine=OracleEngine())
+
+
+def test_constructor_and_disc_params(jupiter):
+    """tests/test_body_xy.py:78-138, body_xy.py:186-199, 772-803"""
+    with pytest.raises(ValueError):
+        BodyXY('jupiter', geometry=jupiter, nx=3, sz=5, engine=OracleEngine())
+    with pytest.raises(ValueError):
+        BodyXY('jupiter', engine=OracleEngine())  # neither geometry nor scenario
+    b = BodyXY('jupiter', geometry=jupiter, engine=OracleEngine())
+    assert b.get_img_size() == (0, 0)
+    assert b.get_disc_params() == (0.0, 0.0, 10.0, 0.0)
+    assert b.get_disc_method() == 'zero'
+    b = BodyXY('jupiter', geometry=jupiter, nx=21, ny=31, engine=OracleEngine())
+    assert b.get_disc_params() == (10.0, 15.0, 9.0, 0.0)  # centre_disc docstring example
+    assert b.get_disc_method() == 'centre_disc'
+    b.set_disc_params(x0=1.5, rotation=123.456)
+    assert b.get_x0() == 1.5
+    assert b.get_rotation() == 123.45600000000002  # stored modulo 2 pi (golden header DISC ROT)
+    b.set_rotation(-90)
+    assert b.get_rotation() == pytest.approx(270)
+    b.adjust_disc_params(dx=1, dy=-1, dr=2, drotation=10)
+    assert b.get_disc_params() == pytest.approx((2.5, 14.0, 11.0, 280.0))
+    for bad in (nan, np.inf):
+        for setter in (b.set_x0, b.set_y0, b.set_r0, b.set_rotation):
+            with pytest.raises(ValueError):
+                setter(bad)
+    for bad in (0, -1.5):
+        with pytest.raises(ValueError):
+            b.set_r0(bad)
+    with pytest.raises(ValueError):
+        b.set_img_size(-1, 5)
+    b.set_plate_scale_arcsec(0.1)
+    assert b.get_plate_scale_arcsec() == pytest.approx(0.1)
+    assert b.get_r0() == pytest.approx(b.target_diameter_arcsec / 0.2)
+    b.set_plate_scale_km(1000)
+    assert b.get_plate_scale_km() == pytest.approx(1000)
+
+
+def test_empty_image_raises(body):
+    """body_xy.py:3166-3168"""
+    with pytest.raises(ValueError):
+        body.get_lon_img()
+    with pytest.raises(ValueError):
+        body.get_backplane_img('EMISSION')
+
+
+def test_backplane_registry(body):
+    """tests/test_body_xy.py:1990-2118; body_xy.py:2492-2584"""
+    assert len(body.backplanes) == 26
+    assert list(body.backplanes)[:3] == ['LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC']
+    assert body.backplanes['LON-GRAPHIC'].description == 'Planetographic longitude, positive W [deg]'
+    assert body.standardise_backplane_name('  emission ') == 'EMISSION'
+    assert body.get_backplane(' dec ').name == 'DEC'
+    with pytest.raises(BackplaneNotFoundError):
+        body.get_backplane('<<< test >>>')
+    with pytest.raises(ValueError):
+        body.register_backplane('emission', 'dup', lambda: None, lambda **kw: None)
+    body.set_img_size(4, 3)
+    body.register_backplane(
+        'custom', 'ones', lambda: np.ones((3, 4)), lambda **kw: np.ones((2, 2)) * kw.get('degree_interval', 1)
+    )
+    assert np.array_equal(body.get_backplane_img('Custom'), np.ones((3, 4)))
+    assert np.array_equal(body.get_backplane_map('CUSTOM', degree_interval=90), np.full((2, 2), 90.0))
+    assert 'CUSTOM: ones' in body.backplane_summary_string()
+
+
+def test_emission_img_and_map_kat(body):
+    """tests/test_body_xy.py:2120-2154: disc (2, 1, 1.5, 45.678), 4x3 image"""
+    body.set_img_size(4, 3)
+    body.set_disc_params(2, 1, 1.5, 45.678)
+    img = body.get_backplane_img('EMISSION')
+    assert img.shape == (3, 4)
+    assert np.isfinite(img).sum() == np.isfinite(body.get_lon_img()).sum() > 0
+    m = body.get_backplane_map('EMISSION', degree_interval=90)
+    assert m.shape == (2, 4) and np.isfinite(m).all()
+    assert np.array_equal(m, body.get_emission_angle_map(degree_interval=90))
+
+
+def test_readonly_views_and_copies(body):
+    """tests/test_body_xy.py:2156-2170 (test_backplane_readonly); base.py:115-138"""
+    body.set_img_size(7, 10)
+    body.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    for name, bp in body.backplanes.items():
+        img = bp.get_img()
+        assert not img.flags.writeable, name
+        with pytest.raises(ValueError):
+            img[0, 0] = 1
+        mp = bp.get_map(degree_interval=30)
+        assert not mp.flags.writeable, name
+        cp = body.get_backplane_img(name)
+        assert cp.flags.writeable and cp is not img
+        cp[:] = 0  # modifying the copy must not touch the cache
+        assert np.array_equal(bp.get_img(), img, equal_nan=True)
+        cm = body.get_backplane_map(name, degree_interval=30)
+        assert cm.flags.writeable
+    lons, lats, xx, yy, tr, info = body.generate_map_coordinates(degree_interval=30)
+    assert not lons.flags.writeable and info == {
+        'projection': 'rectangular', 'degree_interval': 30, 'xlim': None, 'ylim': None,
+    }  # fmt: skip
+
+
+def test_golden_planes_through_the_api(body, jupiter_info):
+    """The reference-compatible getters return the golden FITS planes (atol 1e-6)."""
+    import os
+
+    from conftest import GOLDEN
+
+    gold = np.load(os.path.join(GOLDEN, 'golden_test_nav.npz'))
+    body.set_img_size(7, 10)
+    body.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    for name in body.backplanes:
+        assert np.allclose(body.get_backplane_img(name), gold[name], rtol=1e-5, atol=1e-6, equal_nan=True), name
+    gold_alt = np.load(os.path.join(GOLDEN, 'golden_test_nav_alt.npz'))
+    for name in ('LON-GRAPHIC', 'EMISSION', 'RING-RADIUS', 'DISTANCE'):
+        a = body.get_backplane_img(name, alt=34567.8912)
+        assert np.allclose(a, gold_alt[name], rtol=1e-5, atol=1e-6, equal_nan=True), name
+    assert body._alt_adjustment == 0.0
+    gmap = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_nearest_alt.npz'))
+    for name in ('PIXEL-X', 'EMISSION', 'LIMB-DISTANCE'):
+        a = body.get_backplane_map(name, degree_interval=30, alt=34567.8912)
+        assert np.allclose(a, gmap[name], rtol=1e-5, atol=1e-6, equal_nan=True), name
+
+
+def test_caching_and_invalidation(body):
+    """
+    tests/test_body_xy.py:2495-2590: image planes are cached until a disc parameter or
+    the image size changes; disc-independent maps survive; x/y maps do not.
+    """
+    eng = body._engine
+    body.set_img_size(7, 10)
+    body.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    a = body.get_lon_img()
+    n = len(eng.calls)
+    assert body.get_lat_img() is not None and len(eng.calls) == n  # same family: one launch
+    assert body.get_lon_img() is a
+    em = body.get_emission_angle_map(degree_interval=30)
+    xm = body.get_x_map(degree_interval=30)
+    n = len(eng.calls)
+    body.get_emission_angle_map(degree_interval=30)
+    body.get_x_map(degree_interval=30)
+    assert len(eng.calls) == n
+    mutations = [
+        lambda: body.set_x0(3.0), lambda: body.set_y0(2.0), lambda: body.set_r0(4.4),
+        lambda: body.set_rotation(10.0), lambda: body.set_img_size(8, 9),
+    ]  # fmt: skip
+    for mutate in mutations:
+        before = body.get_lon_img()
+        mutate()
+        n = len(eng.calls)
+        after = body.get_lon_img()
+        assert len(eng.calls) == n + 1 and after is not before
+        # stable (disc independent) map cache survives, x/y map is recomputed
+        n = len(eng.calls)
+        assert body.get_emission_angle_map(degree_interval=30) is em
+        assert len(eng.calls) == n
+        body.get_x_map(degree_interval=30)
+        assert len(eng.calls) == n + 1
+    # altitude is part of the cache key (body.py:255-272)
+    a0 = body.get_backplane_img('EMISSION')
+    a1 = body.get_backplane_img('EMISSION', alt=1000.0)
+    assert not np.array_equal(a0, a1, equal_nan=True)
+    n = len(eng.calls)
+    body.get_backplane_img('EMISSION', alt=1000.0)
+    body.get_backplane_img('EMISSION')
+    assert len(eng.calls) == n
+    assert xm is not None
+    with pytest.raises(ValueError):
+        body.get_backplane_img('EMISSION', alt=nan)
+
+
+def test_prefetch_uses_one_launch(body):
+    body.set_img_size(7, 10)
+    eng = body._engine
+    n = len(eng.calls)
+    body.prefetch_backplane_imgs()
+    assert len(eng.calls) == n + 1 and len(eng.calls[-1][1]) == 26
+    for name in body.backplanes:
+        body.get_backplane_img(name)
+    assert len(eng.calls) == n + 1
+
+
+def test_generate_map_coordinates(body):
+    """tests/test_body_xy.py:1551-1700; body_xy.py:2899-2929, 2982-3012"""
+    lons, lats, xx, yy, tr, info = body.generate_map_coordinates(degree_interval=90)
+    assert np.array_equal(lons, [[315, 225, 135, 45], [315, 225, 135, 45]])  # W-positive: reversed
+    assert np.array_equal(lats, [[-45] * 4, [45] * 4])
+    lons, lats, *_ = body.generate_map_coordinates(degree_interval=90, xlim=(100, 250), ylim=(0, 90))
+    assert np.array_equal(lons, [[225, 135]]) and np.array_equal(lats, [[45, 45]])
+    lons, lats, *_ = body.generate_map_coordinates('manual', lon_coords=[0, 10, 20], lat_coords=[-5, 5])
+    assert lons.shape == (2, 3) and np.array_equal(lats[:, 0], [-5, 5])
+    lons, lats, *_ = body.generate_map_coordinates(
+        'manual', lon_coords=np.array([[0, np.inf]]), lat_coords=np.array([[1.0, 2.0]])
+    )
+    assert np.isnan(lons[0, 1])
+    with pytest.raises(ValueError):
+        body.generate_map_coordinates('manual')
+    with pytest.raises(ValueError):
+        body.generate_map_coordinates('manual', lon_coords=[1, 2], lat_coords=[[1, 2]])
+    with pytest.raises(ValueError):
+        body.generate_map_coordinates('manual', lon_coords=np.zeros((2, 2)), lat_coords=np.zeros((2, 3)))
+    with pytest.raises(ValueError):
+        body.generate_map_coordinates('manual', lon_coords=np.zeros((1, 2, 2)), lat_coords=np.zeros((1, 2, 2)))
+    with pytest.raises(UnsupportedError):
+        body.generate_map_coordinates('orthographic')
+    assert body.get_lon_map(degree_interval=90).shape == (2, 4)
+    assert body.get_lon_map(projection='manual', lon_coords=[-10, 370], lat_coords=[0])[0].tolist() == [350, 10]
+
+
+IMAGE = np.array(
+    [
+        [0.0, 100.0, -1.0, 2.2, 3.3, 4.4],
+        [0.0, 75.0, 999.0, 50.0, 1.0, 123.456789],
+        [0.0, 25.0, 0.0, 123.45, nan, 3],
+        [0.0, 0.123, 0.0, 3.0, 0.1, nan],
+        [100.0, -100.0, 100.0, -100.0, 100.0, nan],
+    ]
+)
+
+
+def test_map_img_kats(body):
+    """tests/test_body_xy.py:1086-1200: 6x5 image, disc (2.75, 1.3, 2.3, 45.678), 45 deg map"""
+    body.set_img_size(6, 5)
+    body.set_disc_params(2.75, 1.3, 2.3, 45.678)
+    # fmt: off
+    expected = {
+        'nearest': [[nan, nan, 100.0, 100.0, -1.0, nan, nan, nan], [nan, nan, nan, 75.0, 999.0, 3.3, 3.3, nan], [nan, nan, nan, 0.0, 123.45, nan, 123.456789, nan], [nan, nan, nan, 3.0, 3.0, 0.1, nan, nan]],
+        'linear': [[nan, nan, nan, nan, nan, nan, nan, nan], [nan, nan, nan, 61.591824124152424, 488.0893412811879, 4.181692402514696, nan, nan], [nan, nan, nan, 3.678385742930187, 94.03788871233297, nan, nan, nan], [nan, nan, nan, -25.28910210942658, -1.6502703714050462, nan, nan, nan]],
+    }
+    no_propagation = [[nan, nan, 83.42502054006614, 61.410255547165704, 1.0972142916279704, nan, nan, nan], [nan, nan, nan, 61.591824124152424, 488.0893412811879, 4.181692402514696, 3.8032713799190443, nan], [nan, nan, nan, 3.678385742930187, 94.03788871233297, 35.721226497463014, 94.00305287602345, nan], [nan, nan, nan, -25.28910210942658, -1.6502703714050462, 4.265385156596395, nan, nan]]
+    # fmt: on
+    for interp, exp in expected.items():
+        got = body.map_img(IMAGE, degree_interval=45, interpolation=interp)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), interp
+    assert np.array_equal(
+        body.map_img(IMAGE, degree_interval=45),
+        body.map_img(IMAGE, degree_interval=45, interpolation='linear', spline_smoothing=0.0, propagate_nan=True),
+        equal_nan=True,
+    )
+    for alias in (1, (1, 1)):
+        assert np.array_equal(
+            body.map_img(IMAGE, degree_interval=45, interpolation=alias),
+            body.map_img(IMAGE, degree_interval=45), equal_nan=True,
+        )  # fmt: skip
+    assert np.isnan(body.map_img(IMAGE * nan, degree_interval=45)).all()
+    got = body.map_img(IMAGE, degree_interval=45, propagate_nan=False)
+    assert np.allclose(got, no_propagation, rtol=1e-5, atol=1e-8, equal_nan=True)
+    # cube input -> stack of maps (body_xy.py:1571-1585)
+    cube = np.stack([IMAGE, IMAGE * 2])
+    out = body.map_img(cube, degree_interval=45)
+    assert out.shape == (2, 4, 8)
+    assert np.allclose(out[1], np.array(expected['linear']) * 2, equal_nan=True)
+    with pytest.raises(ValueError):
+        body.map_img(IMAGE[:, :-1], degree_interval=45)
+    with pytest.raises(ValueError):
+        body.map_img(IMAGE, degree_interval=45, interpolation='<<<test>>>')
+    for interp in ('quadratic', 'cubic', 'smooth', 2, (1, 2)):
+        with pytest.raises(UnsupportedError):
+            body.map_img(IMAGE, degree_interval=45, interpolation=interp)
+
+
+def test_observation_mapped_data(jupiter):
+    """tests/test_observation.py golden: map_rectangular-linear / -nearest primary HDUs"""
+    import os
+
+    from conftest import GOLDEN
+
+    cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
+    obs = Observation(data=cube, geometry=jupiter, engine=OracleEngine())
+    assert obs.get_img_size() == (7, 10)
+    obs.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    for interp, name in (('linear', 'map_rectangular_linear'), ('nearest', 'map_rectangular_nearest')):
+        gold = np.load(os.path.join(GOLDEN, f'golden_{name}.npz'))['PRIMARY']
+        m = obs.get_mapped_data(interpolation=interp, degree_interval=30)
+        assert m.shape == (10, 6, 12)
+        assert np.allclose(m, gold, rtol=1e-5, atol=1e-6, equal_nan=True)
+        m[:] = 0  # a copy: the cache is untouched (observation.py:864-872)
+        assert np.allclose(obs.get_mapped_data(interpolation=interp, degree_interval=30), gold, equal_nan=True)
+    n = len(obs._engine.calls)
+    obs.get_mapped_data(degree_interval=30)
+    assert len(obs._engine.calls) == n  # cached
+    obs.set_x0(2.6)
+    obs.get_mapped_data(degree_interval=30)
+    assert len(obs._engine.calls) > n  # disc change invalidates
+    with pytest.raises(TypeError):
+        obs.set_img_size(3, 3)
+    with pytest.raises(TypeError):
+        Observation(data=cube, geometry=jupiter, nx=3, engine=OracleEngine())
+    with pytest.raises(ValueError):
+        Observation(geometry=jupiter, engine=OracleEngine())
+    # a 2D image is a one-plane cube
+    obs2 = Observation(data=cube[0], geometry=jupiter, engine=OracleEngine())
+    assert obs2.data.shape == (1, 10, 7) and obs2.get_mapped_data(degree_interval=90).shape == (1, 2, 4)

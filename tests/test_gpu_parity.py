@@ -216,3 +216,32 @@ def test_headline_frame_4096_vs_oracle_and_round_trip(engine, oracle, jupiter):
     # not exact by design: Body._targvec2obsvec ignores the target's translation during the
     # light-time offset (body.py:917-948), worth ~0.04 km = 1e-3 px at this plate scale
     assert np.max(np.abs(xm[ok] - xx[ok])) < 5e-3 and np.max(np.abs(ym[ok] - yy[ok])) < 5e-3
+
+
+def test_reference_api_on_gpu(jupiter):
+    """The drop-in surface (BodyXY / Observation method names) on the real engine vs goldens."""
+    from planetmapper_amd import BodyXY, Observation
+
+    gold = np.load(os.path.join(GOLDEN, 'golden_test_nav.npz'))
+    body = BodyXY('Jupiter', '2005-01-01T00:00:00', observer='HST', scenario='jupiter_hst_2005', nx=7, ny=10)
+    body.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    lon = body.get_lon_img()
+    assert lon.shape == (10, 7) and lon.dtype == np.float64 and not lon.flags.writeable
+    for name in body.backplanes:
+        img = body.get_backplane_img(name)
+        assert np.allclose(img, gold[name], rtol=1e-5, atol=1e-6, equal_nan=True), name
+    assert np.array_equal(body.get_emission_angle_img(), body.backplanes['EMISSION'].get_img(), equal_nan=True)
+    gmap = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_linear.npz'))
+    for name in body.backplanes:
+        m = body.get_backplane_map(name, degree_interval=30)
+        assert np.allclose(m, gmap[name], rtol=1e-5, atol=1e-6, equal_nan=True), name
+    cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
+    obs = Observation(data=cube, geometry=jupiter)
+    obs.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    assert np.allclose(obs.get_mapped_data(degree_interval=30), gmap['PRIMARY'], rtol=1e-5, atol=1e-6, equal_nan=True)
+    gn = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_nearest.npz'))['PRIMARY']
+    assert np.array_equal(obs.get_mapped_data('nearest', degree_interval=30), gn, equal_nan=True)
+    # BASELINE config 1: 128 x 128 get_lon_img + get_emission_angle_img through the API
+    b = BodyXY('jupiter', scenario='jupiter_hst_2005', sz=128)
+    assert b.get_disc_params() == (63.5, 63.5, 57.15, 0.0)
+    assert np.isfinite(b.get_lon_img()).sum() == np.isfinite(b.get_emission_angle_img()).sum() > 9000

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -17,6 +18,7 @@
 
 
 void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s);
+void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
 void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
@@ -36,6 +38,7 @@ struct pm_ctx {
     int *flags = nullptr;  // per-plane flags of pm_map_cube
     size_t flags_count = 0;
     int pending_flag_planes = 0;  // device-mode pm_map_cube: flags to check at pm_synchronize
+    bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
 };
 
 namespace {
@@ -135,6 +138,27 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     double kdet = k00 * k11 - k01 * k10;
     p.K[0] = k11 / kdet; p.K[1] = -k01 / kdet; p.K[2] = -k10 / kdet; p.K[3] = k00 / kdet;
     p.t0 = g.et - g.lt_c;
+    // spheroid fast-path constants (B0 frame)
+    auto rot = [&](const double *v, double *o, double sgn) {
+        for (int i = 0; i < 3; i++) o[i] = sgn * (g.R0[3 * i] * v[0] + g.R0[3 * i + 1] * v[1] + g.R0[3 * i + 2] * v[2]);
+    };
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double acc = 0.0;
+            for (int k = 0; k < 3; k++) acc += g.R0[3 * i + k] * g.M[3 * j + k];  // R0 * M^T
+            p.C[3 * i + j] = acc;
+        }
+    rot(g.T0, p.O0, -1.0);
+    rot(g.VT, p.VB, 1.0);
+    rot(g.AT, p.AB, 1.0);
+    rot(g.S0, p.SB0, 1.0);
+    rot(g.VS, p.VSB, 1.0);
+    rot(g.AS, p.ASB, 1.0);
+    rot(g.VO, p.VOB, 1.0);
+    p.ira = 1.0 / p.radii[0];
+    p.irc = 1.0 / p.radii[2];
+    p.inv_c = 1.0 / g.clight;
+    p.lat_k = (p.radii[0] / p.radii[2]) * (p.radii[0] / p.radii[2]);
     p.nx = d.nx;
     p.ny = d.ny;
     p.optimize_speed = d.optimize_speed;
@@ -221,6 +245,8 @@ pm_ctx *pm_create(int device, int *status)
         return nullptr;
     }
     ctx->own_stream = true;
+    const char *fg = std::getenv("PM_FORCE_GENERAL");
+    ctx->force_general = fg && fg[0] == '1';
     set(PM_OK);
     return ctx;
 }
@@ -370,7 +396,13 @@ int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *cons
         if (plane_mask & kRingBits) flags |= 4;
         pm::Params pd = p;
         pd.mask = plane_mask & kDiscBits;
-        pm_launch_disc(pd, flags, ctx->stream);
+        // spheroids (every planet in pck00010) take the rotation-free fast path; triaxial
+        // bodies and ring-plane requests use the general kernel
+        const bool spheroid = pd.radii[0] == pd.radii[1] && !(flags & 4) && !ctx->force_general;
+        if (spheroid)
+            pm_launch_disc_spheroid(pd, flags, ctx->stream);
+        else
+            pm_launch_disc(pd, flags, ctx->stream);
     }
     if (plane_mask & kSkyBits) {
         pm::Params ps = p;

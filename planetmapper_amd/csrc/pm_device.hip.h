@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #include "../../include/planetmapper_hip.h"
+#include "pm_fastmath.hip.h"
 
 namespace pm {
 
@@ -81,6 +82,21 @@ struct Params {
     int32_t n0, n1;   // map shape (map kernels)
     uint64_t mask;
     double *out[PM_NUM_PLANES];
+    // Spheroid fast path (radii[0] == radii[1]): everything expressed in the body-fixed
+    // frame frozen at t0 ("B0"); a spheroid is invariant under the spin about its z
+    // axis, so the light-time iteration needs no rotations at all and the spin enters
+    // only as a longitude offset at the end. Host-precomputed in pm_capi.hip.
+    double C[9];    // R0 M^T : angular-frame unit vector -> ray in B0
+    double O0[3];   // -R0 T0 : observer position in B0 at t0
+    double VB[3];   // R0 VT
+    double AB[3];   // R0 AT
+    double SB0[3];  // R0 S0
+    double VSB[3];  // R0 VS
+    double ASB[3];  // R0 AS
+    double VOB[3];  // R0 VO
+    double ira, irc;  // 1 / radii[0], 1 / radii[2]
+    double inv_c;     // 1 / clight
+    double lat_k;     // (radii[0] / radii[2])^2
 };
 
 // Arguments of the reprojection kernel (pm_map_cube).

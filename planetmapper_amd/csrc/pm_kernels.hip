@@ -144,6 +144,170 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
     }
 }
 
+// ------------------------------------------------------------------ spheroid fast path
+// Same planes as k_disc (without the ring planes) for bodies with radii[0] == radii[1].
+//
+// All vectors live in B0, the body-fixed frame frozen at t0 = et - lt_c. Because a
+// spheroid is invariant under rotation about its spin axis, the ray/ellipsoid intercept
+// at the light-time corrected epoch te can be evaluated in B0 with the un-rotated body:
+// only the target's translation VB (te - t0) enters the light-time iteration, and the
+// spin shows up once, as the longitude offset wdot (te - t0). No 3x3 products inside the
+// loop, no separate light-time solve for the illumination (the point lies ON the ray, so
+// its position relative to the observer is tau * ray), one sqrt per intercept.
+// vsep angles use asin on |x| <= 0.5 only: 2 asin(|u-v|/2) for angles < 60 deg (and the
+// supplement form > 120 deg) like CSPICE's vsep_c, pi/2 - asin(u.v) in between.
+__device__ __forceinline__ double vsep_fast(V3 u, V3 v)
+{
+    const double d = dot(u, v);
+    const V3 w = (d > 0.0) ? u - v : u + v;
+    const double s = 0.5 * sqrt(dot(w, w));
+    const bool mid = fabs(d) < 0.5;
+    const double r = asin_half(mid ? d : s);
+    return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
+}
+
+template <int FLAGS>
+__global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int y = blockIdx.y;
+    const bool inside = x < p.nx;
+    const size_t idx = (size_t)y * p.nx + (inside ? x : 0);
+    const double nan = __builtin_nan("");
+
+    const double dx = (double)x - p.x0, dy = (double)y - p.y0;
+    const bool cand = inside && !(p.optimize_speed && (dx * dx + dy * dy) > p.r2);
+
+    double lon_deg = nan, lat_deg = nan, lc_deg = nan, bc_deg = nan;
+    double ph = nan, in = nan, em = nan, az = nan, dist = nan, rv = nan, dop = nan;
+
+    if (__any(cand)) {
+        // pixel -> unit ray, directly in B0 (BodyXY._xy2obsvec_norm body_xy.py:375)
+        const double fx = (double)x, fy = (double)y;
+        const double ax = fma(p.A[0], fx, fma(p.A[1], fy, p.A[2]));
+        const double ay = fma(p.A[3], fx, fma(p.A[4], fy, p.A[5]));
+        double sr, cr, sd, cd;
+        sincos_auto(-((ax / 3600.0) * kRad), sr, cr);
+        sincos_auto((ay / 3600.0) * kRad, sd, cd);
+        const V3 u = mxv(p.C, v3(cr * cd, sr * cd, sd));
+
+        // surfpt_c in scaled coordinates; X and 1/(X.X) are fixed for the pixel
+        const V3 X = {u.x * p.ira, u.y * p.ira, u.z * p.irc};
+        const double ixx = 1.0 / dot(X, X);
+
+        // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
+        double lt = p.g.lt_c, d = 0.0, k = 0.0, root = 0.0;
+        V3 P = {0.0, 0.0, 0.0};
+        bool hit = cand;
+#pragma unroll 1
+        for (int it = 0; it < 10; it++) {
+            // wave-uniform exit once no lane is still iterating
+            const double te = p.g.et - lt;
+            d = te - p.t0;
+            const double h = 0.5 * d * d;
+            const V3 obs = {fma(-p.AB[0], h, fma(-p.VB[0], d, p.O0[0])), fma(-p.AB[1], h, fma(-p.VB[1], d, p.O0[1])),
+                            fma(-p.AB[2], h, fma(-p.VB[2], d, p.O0[2]))};
+            const V3 Y = {obs.x * p.ira, obs.y * p.ira, obs.z * p.irc};
+            const double yx = dot(Y, X);
+            k = yx * ixx;
+            P = {fma(-k, X.x, Y.x), fma(-k, X.y, Y.y), fma(-k, X.z, Y.z)};
+            const double p2 = dot(P, P);
+            // (an observer inside the body, Y.Y <= 1, never reaches this kernel: the
+            //  launcher requires |O0| scaled > 1 and the target moves km, not radii)
+            if (p2 > 1.0 || yx > 0.0) hit = false;
+            root = sqrt(fmax(0.0, 1.0 - p2) * ixx);
+            const double nlt = (-k - root) * p.inv_c;
+            const double err = fabs(nlt - lt);
+            const bool done = !hit || err <= 1e-17 * fabs(p.g.et - nlt);
+            if (hit) lt = nlt;
+            if (__all(done)) break;
+        }
+
+        if (hit) {
+            // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
+            const double tau = -k - root;  // distance observer -> point along the ray
+            const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
+            const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[0], Xf.z * p.radii[2]};
+            const double delta = p.g.wdot * d;
+            const double rho = sqrt(fma(sp.x, sp.x, sp.y * sp.y));
+            const bool polar = (sp.x == 0.0 && sp.y == 0.0);
+            // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - delta
+            const double le = polar ? 0.0 : atan2_fast(sp.y, sp.x) - delta;
+            double l = p.g.west_positive ? -le : le;
+            if (l < 0.0) l += kTwoPi;
+            if (l >= kTwoPi) l -= kTwoPi;
+            lon_deg = l * kDeg;
+            lat_deg = ((polar && sp.z == 0.0) ? kHalfPi : atan2_fast(sp.z * p.lat_k, rho)) * kDeg;
+            if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
+                // reclat_c body.py:2905: east-positive, (-pi, pi]
+                double lc = le;
+                if (lc <= -kPi) lc += kTwoPi;
+                if (lc > kPi) lc -= kTwoPi;
+                lc_deg = lc * kDeg;
+                bc_deg = ((polar && sp.z == 0.0) ? 0.0 : atan2_fast(sp.z, rho)) * kDeg;
+            }
+            if (FLAGS & DF_ILLUM) {
+                // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
+                const double h = 0.5 * d * d;
+                const V3 q = {fma(p.AB[0], h, fma(p.VB[0], d, sp.x)), fma(p.AB[1], h, fma(p.VB[1], d, sp.y)),
+                              fma(p.AB[2], h, fma(p.VB[2], d, sp.z))};
+                const double te = p.g.et - lt;
+                double lts = te - p.g.ts0;
+                V3 sv = ld3(p.SB0) - q;  // Sun at ts0 exactly: te - lts == ts0
+#pragma unroll
+                for (int pass = 0; pass < 2; pass++) {
+                    lts = sqrt(dot(sv, sv)) * p.inv_c;
+                    const double ds = (te - lts) - p.g.ts0;
+                    const double hs = 0.5 * ds * ds;
+                    sv = v3(fma(p.ASB[0], hs, fma(p.VSB[0], ds, p.SB0[0])) - q.x,
+                            fma(p.ASB[1], hs, fma(p.VSB[1], ds, p.SB0[1])) - q.y,
+                            fma(p.ASB[2], hs, fma(p.VSB[2], ds, p.SB0[2])) - q.z);
+                }
+                const V3 sunb = rsqrt(dot(sv, sv)) * sv;
+                const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
+                const double ia2 = p.ira * p.ira, ic2 = p.irc * p.irc;
+                V3 n = {sp.x * ia2, sp.y * ia2, sp.z * ic2};  // surfnm_c
+                n = rsqrt(dot(n, n)) * n;
+                ph = vsep_fast(sunb, ob) * kDeg;
+                in = vsep_fast(n, sunb) * kDeg;
+                em = vsep_fast(n, ob) * kDeg;
+                if (PM_WANT(PM_AZIMUTH)) az = azimuth_deg(ph, in, em);
+            }
+            if (FLAGS & DF_STATE) {
+                // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
+                dist = lt * p.g.clight;
+                const V3 vp = {fma(p.AB[0], d, p.VB[0]) - p.g.wdot * sp.y, fma(p.AB[1], d, p.VB[1]) + p.g.wdot * sp.x,
+                               fma(p.AB[2], d, p.VB[2])};
+                const V3 vo = ld3(p.VOB);
+                const double dlt = (dot(u, vp - vo) * p.inv_c) / (1.0 + dot(u, vp) * p.inv_c);
+                rv = dot((1.0 - dlt) * vp - vo, u);
+                const double beta = rv / p.g.clight;
+                dop = sqrt((1.0 + beta) / (1.0 - beta));
+                (void)tau;
+            }
+        }
+    }
+
+    if (inside) {
+        PM_PUT(PM_LON_GRAPHIC, lon_deg);
+        PM_PUT(PM_LAT_GRAPHIC, lat_deg);
+        PM_PUT(PM_LON_CENTRIC, lc_deg);
+        PM_PUT(PM_LAT_CENTRIC, bc_deg);
+        if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
+        if (FLAGS & DF_ILLUM) {
+            PM_PUT(PM_PHASE, ph);
+            PM_PUT(PM_INCIDENCE, in);
+            PM_PUT(PM_EMISSION, em);
+            PM_PUT(PM_AZIMUTH, az);
+        }
+        if (FLAGS & DF_STATE) {
+            PM_PUT(PM_DISTANCE, dist);
+            PM_PUT(PM_RADIAL_VELOCITY, rv);
+            PM_PUT(PM_DOPPLER, dop);
+        }
+    }
+}
+
 // Reference loops fused here: BodyXY._get_radec_img body_xy.py:3409, get_x_img :3494,
 // get_y_img :3519, _get_km_xy_img :3545, get_angular_x_img :3610,
 // _get_limb_coordinate_imgs :3964.
@@ -385,6 +549,18 @@ void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
     case 5: hipLaunchKernelGGL(pm::k_disc<5>, grid, block, 0, s, p); break;
     case 6: hipLaunchKernelGGL(pm::k_disc<6>, grid, block, 0, s, p); break;
     case 7: hipLaunchKernelGGL(pm::k_disc<7>, grid, block, 0, s, p); break;
+    }
+}
+
+void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
+{
+    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.ny);
+    dim3 block(pm::kBlock);
+    switch (flags & 3) {
+    case 0: hipLaunchKernelGGL(pm::k_disc_sph<0>, grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL(pm::k_disc_sph<1>, grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL(pm::k_disc_sph<2>, grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL(pm::k_disc_sph<3>, grid, block, 0, s, p); break;
     }
 }
 

@@ -161,6 +161,15 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     p.lat_k = (p.radii[0] / p.radii[2]) * (p.radii[0] / p.radii[2]);
     p.nx = d.nx;
     p.ny = d.ny;
+    {
+        // golden-ratio row stride, made coprime with ny so the row map is a bijection
+        auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
+        long s = (long)(0.6180339887498949 * d.ny);
+        if (s < 1) s = 1;
+        while (gcd(s, d.ny > 0 ? d.ny : 1) != 1) s++;
+        p.row_stride = (int32_t)s;
+        p.pad_ = 0;
+    }
     p.optimize_speed = d.optimize_speed;
     p.n0 = p.n1 = 0;
     p.mask = 0;

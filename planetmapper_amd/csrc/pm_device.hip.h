@@ -97,6 +97,8 @@ struct Params {
     double ira, irc;  // 1 / radii[0], 1 / radii[2]
     double inv_c;     // 1 / clight
     double lat_k;     // (radii[0] / radii[2])^2
+    int32_t row_stride;  // row visiting order of the image kernels (coprime with ny)
+    int32_t pad_;
 };
 
 // Arguments of the reprojection kernel (pm_map_cube).

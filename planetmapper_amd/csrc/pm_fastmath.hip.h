@@ -20,22 +20,76 @@ namespace pm {
 constexpr double kPiF = 3.14159265358979323846;
 constexpr double kTanPi8 = 0.41421356237309503;
 
+// ---- reciprocal / division / square roots without the libm range scaffolding ----------
+// v_rcp_f64 / v_rsq_f64 deliver ~26 good bits; Newton / Goldschmidt steps as in the
+// compiler's own expansion, minus the exponent rescaling and class checks that only
+// matter for subnormal / huge operands (never the case here: km, seconds, unit vectors).
+
+// 1 / b, |b| in the normal range
+__device__ __forceinline__ double rcp_fast(double b)
+{
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
+    r = fma(fma(-b, r, 1.0), r, r);
+    return r;
+}
+// a / b to ~1 ulp
+__device__ __forceinline__ double div_fast(double a, double b)
+{
+    const double r = rcp_fast(b);
+    const double q = a * r;
+    return fma(fma(-b, q, a), r, q);
+}
+// sqrt(x), x >= 0 in the normal range (exact 0 handled)
+__device__ __forceinline__ double sqrt_fast(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    return (x == 0.0) ? 0.0 : g;
+}
+// 1 / sqrt(x), x > 0 in the normal range, full precision
+__device__ __forceinline__ double rsqrt_fast(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * e, fma(e, 0.375, 0.5), y);
+    e = fma(-x * y, y, 1.0);
+    y = fma(y * e, 0.5, y);
+    return y;
+}
+
+// q * z + C with the constant C as a scalar (SGPR) operand of ONE v_fma_f64. Left to
+// itself hipcc emits the two-address v_fmac_f64, which needs C copied into a VGPR pair
+// first (two v_mov_b32 per Horner step, tripling the VALU cost of a polynomial); the
+// s_mov pairs this form needs instead issue on the scalar unit, beside the VALU.
+__device__ __forceinline__ double fma_c(double q, double z, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(q), "v"(z), "s"(c));
+    return r;
+}
+
 // asin(x) for |x| <= 0.5
 __device__ __forceinline__ double asin_half(double x)
 {
     const double z = x * x;
     double q = 0.028169218060881414;
-    q = fma(q, z, -0.010749050339697808);
-    q = fma(q, z, 0.01603551434914882);
-    q = fma(q, z, 0.0078029494773533175);
-    q = fma(q, z, 0.011875494382636922);
-    q = fma(q, z, 0.013929652902326633);
-    q = fma(q, z, 0.017355259955786323);
-    q = fma(q, z, 0.02237204763174451);
-    q = fma(q, z, 0.03038194736709848);
-    q = fma(q, z, 0.044642857103423646);
-    q = fma(q, z, 0.07500000000020764);
-    q = fma(q, z, 0.1666666666666665);
+    q = fma_c(q, z, -0.010749050339697808);
+    q = fma_c(q, z, 0.01603551434914882);
+    q = fma_c(q, z, 0.0078029494773533175);
+    q = fma_c(q, z, 0.011875494382636922);
+    q = fma_c(q, z, 0.013929652902326633);
+    q = fma_c(q, z, 0.017355259955786323);
+    q = fma_c(q, z, 0.02237204763174451);
+    q = fma_c(q, z, 0.03038194736709848);
+    q = fma_c(q, z, 0.044642857103423646);
+    q = fma_c(q, z, 0.07500000000020764);
+    q = fma_c(q, z, 0.1666666666666665);
     return fma(x * z, q, x);
 }
 
@@ -44,15 +98,15 @@ __device__ __forceinline__ double atan_small(double t)
 {
     const double z = t * t;
     double q = 0.02275052699336167;
-    q = fma(q, z, -0.04483334622272886);
-    q = fma(q, z, 0.05736332165907643);
-    q = fma(q, z, -0.06649613695291669);
-    q = fma(q, z, 0.0769105515839315);
-    q = fma(q, z, -0.09090852557176049);
-    q = fma(q, z, 0.11111109636534361);
-    q = fma(q, z, -0.1428571426609662);
-    q = fma(q, z, 0.19999999999898407);
-    q = fma(q, z, -0.3333333333333325);
+    q = fma_c(q, z, -0.04483334622272886);
+    q = fma_c(q, z, 0.05736332165907643);
+    q = fma_c(q, z, -0.06649613695291669);
+    q = fma_c(q, z, 0.0769105515839315);
+    q = fma_c(q, z, -0.09090852557176049);
+    q = fma_c(q, z, 0.11111109636534361);
+    q = fma_c(q, z, -0.1428571426609662);
+    q = fma_c(q, z, 0.19999999999898407);
+    q = fma_c(q, z, -0.3333333333333325);
     return fma(t * z, q, t);
 }
 
@@ -67,7 +121,7 @@ __device__ __forceinline__ double atan2_fast(double y, double x)
     const bool big = mn > kTanPi8 * mx;
     const double num = big ? mn - mx : mn;
     const double den = big ? mn + mx : mx;
-    double a = atan_small(num / den);
+    double a = atan_small(div_fast(num, den));
     a = big ? a + 0.25 * kPiF : a;
     a = (ay > ax) ? 0.5 * kPiF - a : a;
     a = (x < 0.0) ? kPiF - a : a;
@@ -79,14 +133,14 @@ __device__ __forceinline__ void sincos_small(double x, double &s, double &c)
 {
     const double z = x * x;
     double qs = 2.7526021333363912e-06;
-    qs = fma(qs, z, -0.00019841257617613103);
-    qs = fma(qs, z, 0.008333333331805479);
-    qs = fma(qs, z, -0.1666666666666637);
+    qs = fma_c(qs, z, -0.00019841257617613103);
+    qs = fma_c(qs, z, 0.008333333331805479);
+    qs = fma_c(qs, z, -0.1666666666666637);
     s = fma(x * z, qs, x);
     double qc = -2.753123559604959e-07;
-    qc = fma(qc, z, 2.4801577114157226e-05);
-    qc = fma(qc, z, -0.0013888888887615533);
-    qc = fma(qc, z, 0.041666666666666415);
+    qc = fma_c(qc, z, 2.4801577114157226e-05);
+    qc = fma_c(qc, z, -0.0013888888887615533);
+    qc = fma_c(qc, z, 0.041666666666666415);
     c = fma(z * z, qc, fma(-0.5, z, 1.0));
 }
 

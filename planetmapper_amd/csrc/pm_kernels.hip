@@ -159,8 +159,9 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
 __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
 {
     const double d = dot(u, v);
-    const V3 w = (d > 0.0) ? u - v : u + v;
-    const double s = 0.5 * sqrt(dot(w, w));
+    const double sg = (d > 0.0) ? -1.0 : 1.0;
+    const V3 w = {fma(sg, v.x, u.x), fma(sg, v.y, u.y), fma(sg, v.z, u.z)};
+    const double s = 0.5 * sqrt_fast(dot(w, w));
     const bool mid = fabs(d) < 0.5;
     const double r = asin_half(mid ? d : s);
     return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
@@ -169,8 +170,15 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
 template <int FLAGS>
 __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
 {
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int y = blockIdx.y;
+    // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8); with a row-major grid
+    // each XCD would always get the same image columns, and the columns through the disc
+    // centre cost far more than the ones at the frame edge. Rotating the column block by the
+    // row index gives every XCD the same mix.
+    const int x = (int)((blockIdx.x + blockIdx.y) % gridDim.x) * kBlock + threadIdx.x;
+    // Rows are visited in a golden-ratio stride order (a bijection: gcd(row_stride, ny) = 1)
+    // so that store-only rows off the disc and FP64-heavy rows through it are resident on the
+    // chip at the same time: HBM writes of the former overlap the VALU work of the latter.
+    const int y = (int)(((long long)blockIdx.y * p.row_stride) % p.ny);
     const bool inside = x < p.nx;
     const size_t idx = (size_t)y * p.nx + (inside ? x : 0);
     const double nan = __builtin_nan("");
@@ -187,15 +195,18 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
         const double ax = fma(p.A[0], fx, fma(p.A[1], fy, p.A[2]));
         const double ay = fma(p.A[3], fx, fma(p.A[4], fy, p.A[5]));
         double sr, cr, sd, cd;
-        sincos_auto(-((ax / 3600.0) * kRad), sr, cr);
-        sincos_auto((ay / 3600.0) * kRad, sd, cd);
+        constexpr double kArcsec = kRad / 3600.0;  // arcsec -> rad (1 ulp from (a / 3600) * kRad)
+        sincos_auto(-(ax * kArcsec), sr, cr);
+        sincos_auto(ay * kArcsec, sd, cd);
         const V3 u = mxv(p.C, v3(cr * cd, sr * cd, sd));
 
         // surfpt_c in scaled coordinates; X and 1/(X.X) are fixed for the pixel
         const V3 X = {u.x * p.ira, u.y * p.ira, u.z * p.irc};
-        const double ixx = 1.0 / dot(X, X);
+        const double ixx = rcp_fast(dot(X, X));
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
+        // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
+        const double lt_tol = 1e-17 * fabs(p.t0);
         double lt = p.g.lt_c, d = 0.0, k = 0.0, root = 0.0;
         V3 P = {0.0, 0.0, 0.0};
         bool hit = cand;
@@ -215,10 +226,10 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
             // (an observer inside the body, Y.Y <= 1, never reaches this kernel: the
             //  launcher requires |O0| scaled > 1 and the target moves km, not radii)
             if (p2 > 1.0 || yx > 0.0) hit = false;
-            root = sqrt(fmax(0.0, 1.0 - p2) * ixx);
+            root = sqrt_fast(fmax(0.0, 1.0 - p2) * ixx);
             const double nlt = (-k - root) * p.inv_c;
             const double err = fabs(nlt - lt);
-            const bool done = !hit || err <= 1e-17 * fabs(p.g.et - nlt);
+            const bool done = !hit || err <= lt_tol;
             if (hit) lt = nlt;
             if (__all(done)) break;
         }
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
             const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
             const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[0], Xf.z * p.radii[2]};
             const double delta = p.g.wdot * d;
-            const double rho = sqrt(fma(sp.x, sp.x, sp.y * sp.y));
+            const double rho = sqrt_fast(fma(sp.x, sp.x, sp.y * sp.y));
             const bool polar = (sp.x == 0.0 && sp.y == 0.0);
             // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - delta
             const double le = polar ? 0.0 : atan2_fast(sp.y, sp.x) - delta;
@@ -252,22 +263,21 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
                 const V3 q = {fma(p.AB[0], h, fma(p.VB[0], d, sp.x)), fma(p.AB[1], h, fma(p.VB[1], d, sp.y)),
                               fma(p.AB[2], h, fma(p.VB[2], d, sp.z))};
                 const double te = p.g.et - lt;
-                double lts = te - p.g.ts0;
-                V3 sv = ld3(p.SB0) - q;  // Sun at ts0 exactly: te - lts == ts0
-#pragma unroll
-                for (int pass = 0; pass < 2; pass++) {
-                    lts = sqrt(dot(sv, sv)) * p.inv_c;
-                    const double ds = (te - lts) - p.g.ts0;
-                    const double hs = 0.5 * ds * ds;
-                    sv = v3(fma(p.ASB[0], hs, fma(p.VSB[0], ds, p.SB0[0])) - q.x,
-                            fma(p.ASB[1], hs, fma(p.VSB[1], ds, p.SB0[1])) - q.y,
-                            fma(p.ASB[2], hs, fma(p.VSB[2], ds, p.SB0[2])) - q.z);
-                }
-                const V3 sunb = rsqrt(dot(sv, sv)) * sv;
+                // Sun light time (spkcpo_c 'CN'): at lts0 = te - ts0 the Sun sits at S0 exactly;
+                // one correction pass leaves |d lts| ~ (v_sun / c) * 0.25 s = 1e-8 s, i.e. 1e-10 km
+                V3 sv = ld3(p.SB0) - q;
+                const double s2 = dot(sv, sv);
+                const double lts = s2 * rsqrt_fast(s2) * p.inv_c;
+                const double ds = (te - lts) - p.g.ts0;
+                const double hs = 0.5 * ds * ds;
+                sv = v3(fma(p.ASB[0], hs, fma(p.VSB[0], ds, p.SB0[0])) - q.x,
+                        fma(p.ASB[1], hs, fma(p.VSB[1], ds, p.SB0[1])) - q.y,
+                        fma(p.ASB[2], hs, fma(p.VSB[2], ds, p.SB0[2])) - q.z);
+                const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
                 const double ia2 = p.ira * p.ira, ic2 = p.irc * p.irc;
                 V3 n = {sp.x * ia2, sp.y * ia2, sp.z * ic2};  // surfnm_c
-                n = rsqrt(dot(n, n)) * n;
+                n = rsqrt_fast(dot(n, n)) * n;
                 ph = vsep_fast(sunb, ob) * kDeg;
                 in = vsep_fast(n, sunb) * kDeg;
                 em = vsep_fast(n, ob) * kDeg;

@@ -150,8 +150,9 @@ def main() -> None:
     mu = torch.sqrt(torch.clamp(1 - ((xx - x0) ** 2 + (yy - y0) ** 2) / (0.9 * x0) ** 2, min=0))
     data = mu + 0.05 * torch.randn((sz, sz), generator=gen, device=dev, dtype=torch.float64)
     del yy, xx, mu
-    mapped = torch.empty((world, n0, n1), dtype=torch.float64, device=dev)
-    mine = mapped[rank]
+    from planetmapper_amd.distributed import map_cube_sharded_device
+
+    gathered = torch.empty((world, 1, n0, n1), dtype=torch.float64, device=dev)
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -163,9 +164,8 @@ def main() -> None:
         if i is not None:
             ev1[i].record()
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-        eng.map_cube_device(data, np.float64, 1, xm, ym, n0, n1, mine, 'linear', True)
-        if world > 1:
-            dist.all_gather_into_tensor(mapped.view(-1), mine.reshape(-1))
+        # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only)
+        map_cube_sharded_device(eng, data, np.float64, 1, xm, ym, n0, n1, gathered, rank, 'linear', True)
 
     def barrier() -> None:
         if world > 1:

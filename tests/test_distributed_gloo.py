@@ -1,0 +1,81 @@
+"""
+N > 1 path on CPU: world_size = 2 `gloo` process group, planes of a cube sharded over
+the ranks and re-assembled by one all-gather (planetmapper_amd/distributed.py). The
+engine is the oracle-backed test double, so this checks the sharding arithmetic, the
+padding of uneven shards and the collective - not the kernels.
+"""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from planetmapper_amd.distributed import shard_bounds
+
+
+def test_shard_bounds():
+    assert shard_bounds(10, 2, 0) == (0, 5, 5) and shard_bounds(10, 2, 1) == (5, 10, 5)
+    assert shard_bounds(10, 4, 3) == (9, 10, 3)  # ceil(10/4) = 3: last rank gets one plane
+    assert shard_bounds(3, 8, 5) == (3, 3, 1)  # more ranks than planes: empty shard
+    assert shard_bounds(512, 8, 7) == (448, 512, 64)  # BASELINE config 5
+    covered = []
+    for r in range(8):
+        a, b, _ = shard_bounds(13, 8, r)
+        covered += list(range(a, b))
+    assert covered == list(range(13))
+    with pytest.raises(ValueError):
+        shard_bounds(4, 2, 2)
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, n_planes: int, tmpdir: str) -> None:
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle_engine import OracleEngine
+        from planetmapper_amd import Observation
+        from planetmapper_amd.distributed import get_mapped_data_sharded
+        from planetmapper_amd.scenarios import load_scenario
+
+        g = load_scenario('jupiter_hst_2005')
+        rng = np.random.default_rng(5)
+        cube = rng.standard_normal((n_planes, 24, 20))
+        cube[rng.random(cube.shape) < 0.01] = np.nan
+        obs = Observation(data=cube, geometry=g, engine=OracleEngine())
+        obs.set_disc_params(9.5, 12.0, 8.0, 30.0)
+        full = obs.get_mapped_data(degree_interval=15)
+        eng = obs._engine
+        n_before = len([c for c in eng.calls if c[0] == 'cube'])
+        sharded = get_mapped_data_sharded(obs, degree_interval=15)
+        assert sharded.shape == full.shape == (n_planes, 12, 24)
+        assert np.array_equal(sharded, full, equal_nan=True)
+        # this rank only mapped its own block of planes
+        cube_calls = [c for c in eng.calls if c[0] == 'cube'][n_before:]
+        a, b, _ = shard_bounds(n_planes, world, rank)
+        assert sum(c[1][0] for c in cube_calls) == b - a
+        nearest = get_mapped_data_sharded(obs, 'nearest', degree_interval=15)
+        assert np.array_equal(nearest, obs.get_mapped_data('nearest', degree_interval=15), equal_nan=True)
+        open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_planes', [6, 5, 1])
+def test_sharded_mapping_world_size_2(tmp_path, n_planes):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_planes, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))

@@ -230,8 +230,11 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg,
  * i.e. Observation._get_mapped_data (observation.py:876-905).
  * cube: P planes of ny*nx elements of `dtype`, plane-major; out: P*n0*n1 doubles.
  * interpolation: pm_interpolation; propagate_nan as in map_img.
- * With propagate_nan == 0 the NaN pre-clean of
- * _replace_nans_with_interpolated_values (body_xy.py:1871-1904) is applied.
+ * The NaN pre-clean of _replace_nans_with_interpolated_values (body_xy.py:1871-1904)
+ * is honoured for propagate_nan == 0 and for +-inf pixels (window means on the fly,
+ * plane nanmedian by a GPU radix select when a sampled pixel needs it).
+ * PM_MEM_DEVICE: asynchronous; planes that need the nanmedian are completed by
+ * pm_synchronize(), until which cube / maps / out must stay valid.
  */
 int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
                 const double *x_map, const double *y_map, int n0, int n1,

@@ -22,6 +22,8 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
 void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
+void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
+                             unsigned int *hist, hipStream_t s);
 
 struct pm_ctx {
     int device = -1;
@@ -37,7 +39,14 @@ struct pm_ctx {
     size_t scratch_bytes = 0;
     int *flags = nullptr;  // per-plane flags of pm_map_cube
     size_t flags_count = 0;
-    int pending_flag_planes = 0;  // device-mode pm_map_cube: flags to check at pm_synchronize
+    pm::PlaneStats *stats = nullptr;  // per-plane nanmedian state (NaN pre-clean)
+    unsigned int *hist = nullptr;
+    size_t stats_count = 0;
+    // device-mode pm_map_cube is asynchronous: planes that turn out to need the nanmedian
+    // are finished by pm_synchronize(), which replays the call with the statistics
+    bool pending = false;
+    pm::ReprojectArgs pending_args{};
+    int pending_dtype = 0;
     bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
 };
 
@@ -91,6 +100,22 @@ int ensure_flags(pm_ctx *ctx, size_t count)
     hipError_t e = hipMalloc((void **)&ctx->flags, count * sizeof(int));
     if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipMalloc flags failed: %s", hipGetErrorString(e));
     ctx->flags_count = count;
+    return PM_OK;
+}
+
+int ensure_stats(pm_ctx *ctx, size_t count)
+{
+    if (count <= ctx->stats_count) return PM_OK;
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stats) PM_HIP(ctx, hipFree(ctx->stats));
+    if (ctx->hist) PM_HIP(ctx, hipFree(ctx->hist));
+    ctx->stats = nullptr;
+    ctx->hist = nullptr;
+    ctx->stats_count = 0;
+    if (hipMalloc((void **)&ctx->stats, count * sizeof(pm::PlaneStats)) != hipSuccess ||
+        hipMalloc((void **)&ctx->hist, count * 512 * sizeof(unsigned int)) != hipSuccess)
+        return fail(ctx, PM_ERR_ALLOC, "hipMalloc of plane statistics failed");
+    ctx->stats_count = count;
     return PM_OK;
 }
 
@@ -176,19 +201,62 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     for (int i = 0; i < PM_NUM_PLANES; i++) p.out[i] = nullptr;
 }
 
-// report planes whose reprojection needed the (unimplemented) NaN pre-clean
-int check_plane_flags(pm_ctx *ctx, int n_planes)
+// Reproject `a.n_planes` planes that are resident on the device. First pass without plane
+// statistics; if a plane reports that it needs its nanmedian (flags bit 1), the medians are
+// computed and the planes are mapped again. `sync_now`: examine the flags immediately
+// (host-buffer callers) or leave that to pm_synchronize().
+int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_now);
+
+int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype)
 {
-    std::vector<int> hflags(n_planes);
-    PM_HIP(ctx, hipMemcpyAsync(hflags.data(), ctx->flags, (size_t)n_planes * sizeof(int), hipMemcpyDeviceToHost,
+    std::vector<int> hflags(a.n_planes);
+    PM_HIP(ctx, hipMemcpyAsync(hflags.data(), a.plane_flags, (size_t)a.n_planes * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < n_planes; i++)
-        if (hflags[i] & 2)
-            return fail(ctx, PM_ERR_UNSUPPORTED,
-                        "plane %d: an infinite pixel is sampled; the reference replaces it by its NaN pre-clean "
-                        "(body_xy.py:1871-1904), which is not implemented on the GPU yet",
-                        i);
+    bool any = false;
+    for (int f : hflags) any = any || (f & 2);
+    if (!any) return PM_OK;
+    int rc = ensure_stats(ctx, (size_t)a.n_planes);
+    if (rc != PM_OK) return rc;
+    size_t plane_elems = (size_t)a.ny * a.nx;
+    PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)a.n_planes * sizeof(pm::PlaneStats), ctx->stream));
+    PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)a.n_planes * 512 * sizeof(unsigned int), ctx->stream));
+    for (int p0 = 0; p0 < a.n_planes; p0 += 32768) {
+        int np = std::min(32768, a.n_planes - p0);
+        pm_launch_plane_medians((const char *)a.cube + (size_t)p0 * plane_elems * dtype_size(dtype), dtype, np, plane_elems,
+                                ctx->stats + p0, ctx->hist + (size_t)p0 * 512, ctx->stream);
+        pm::ReprojectArgs b = a;
+        b.n_planes = np;
+        b.cube = (const char *)a.cube + (size_t)p0 * plane_elems * dtype_size(dtype);
+        b.out = a.out + (size_t)p0 * a.n_map;
+        b.plane_flags = a.plane_flags + p0;
+        b.plane_stats = ctx->stats + p0;
+        pm_launch_reproject(b, dtype, ctx->stream);
+    }
+    PM_HIP(ctx, hipGetLastError());
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
+int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_now)
+{
+    size_t plane_elems = (size_t)a.ny * a.nx;
+    PM_HIP(ctx, hipMemsetAsync(a.plane_flags, 0, (size_t)a.n_planes * sizeof(int), ctx->stream));
+    a.plane_stats = nullptr;
+    // blockIdx.y is limited to 65535 planes per launch
+    for (int p0 = 0; p0 < a.n_planes; p0 += 32768) {
+        pm::ReprojectArgs b = a;
+        b.n_planes = std::min(32768, a.n_planes - p0);
+        b.cube = (const char *)a.cube + (size_t)p0 * plane_elems * dtype_size(dtype);
+        b.out = a.out + (size_t)p0 * a.n_map;
+        b.plane_flags = a.plane_flags + p0;
+        pm_launch_reproject(b, dtype, ctx->stream);
+    }
+    PM_HIP(ctx, hipGetLastError());
+    if (sync_now) return finish_reproject(ctx, a, dtype);
+    ctx->pending = true;
+    ctx->pending_args = a;
+    ctx->pending_dtype = dtype;
     return PM_OK;
 }
 
@@ -267,6 +335,8 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->stats) (void)hipFree(ctx->stats);
+    if (ctx->hist) (void)hipFree(ctx->hist);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -277,10 +347,9 @@ int pm_synchronize(pm_ctx *ctx)
 {
     if (!ctx) return PM_ERR_INVALID_ARGUMENT;
     PM_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->pending_flag_planes > 0) {
-        int n = ctx->pending_flag_planes;
-        ctx->pending_flag_planes = 0;
-        return check_plane_flags(ctx, n);
+    if (ctx->pending) {
+        ctx->pending = false;
+        return finish_reproject(ctx, ctx->pending_args, ctx->pending_dtype);
     }
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PM_OK;
@@ -502,12 +571,14 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     const pm_disc &d = ctx->disc;
     if (d.nx <= 0 || d.ny <= 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image size is empty");
     if (n_planes < 0 || n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative shape");
-    if (interpolation == PM_INTERP_LINEAR && !propagate_nan)
-        return fail(ctx, PM_ERR_UNSUPPORTED,
-                    "propagate_nan=False (NaN pre-clean, body_xy.py:1871-1904) is not implemented on the GPU yet");
     size_t nmap = (size_t)n0 * n1;
     size_t npx = (size_t)d.nx * d.ny;
     if (n_planes == 0 || nmap == 0) return PM_OK;
+    // a previous asynchronous call must be completed before its flags / statistics are reused
+    if (ctx->pending) {
+        rc = pm_synchronize(ctx);
+        if (rc != PM_OK) return rc;
+    }
 
     pm::ReprojectArgs a;
     a.ny = d.ny;
@@ -515,68 +586,52 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     a.n_map = (int)nmap;
     a.interpolation = interpolation;
     a.propagate_nan = propagate_nan ? 1 : 0;
+    a.plane_stats = nullptr;
+    rc = ensure_flags(ctx, (size_t)n_planes);
+    if (rc != PM_OK) return rc;
 
     if (mem == PM_MEM_DEVICE) {
-        rc = ensure_flags(ctx, (size_t)n_planes);
-        if (rc != PM_OK) return rc;
-        PM_HIP(ctx, hipMemsetAsync(ctx->flags, 0, (size_t)n_planes * sizeof(int), ctx->stream));
         a.cube = cube;
         a.x_map = x_map;
         a.y_map = y_map;
         a.out = out;
         a.plane_flags = ctx->flags;
         a.n_planes = n_planes;
-        // blockIdx.y is limited to 65535 planes per launch
-        for (int p0 = 0; p0 < n_planes; p0 += 32768) {
-            pm::ReprojectArgs b = a;
-            b.n_planes = std::min(32768, n_planes - p0);
-            b.cube = (const char *)cube + (size_t)p0 * npx * esz;
-            b.out = out + (size_t)p0 * nmap;
-            b.plane_flags = ctx->flags + p0;
-            pm_launch_reproject(b, dtype, ctx->stream);
-        }
-        PM_HIP(ctx, hipGetLastError());
-        // asynchronous: the per-plane flags are examined by pm_synchronize()
-        ctx->pending_flag_planes = n_planes;
-        return PM_OK;
-    } else {
-        // host cube: stream it through the device in chunks of planes
-        size_t chunk = (size_t)(1ull << 30) / (npx * esz);
-        if (chunk < 1) chunk = 1;
-        if (chunk > (size_t)n_planes) chunk = (size_t)n_planes;
-        if (chunk > 32768) chunk = 32768;
-        size_t cube_bytes = chunk * npx * esz;
-        cube_bytes = (cube_bytes + 255) & ~(size_t)255;
-        size_t need = cube_bytes + (2 + chunk) * nmap * sizeof(double);
-        rc = ensure_scratch(ctx, need);
-        if (rc != PM_OK) return rc;
-        rc = ensure_flags(ctx, (size_t)n_planes);
-        if (rc != PM_OK) return rc;
-        PM_HIP(ctx, hipMemsetAsync(ctx->flags, 0, (size_t)n_planes * sizeof(int), ctx->stream));
-        char *dcube = (char *)ctx->scratch;
-        double *dxm = (double *)(dcube + cube_bytes);
-        double *dym = dxm + nmap;
-        double *dout = dym + nmap;
-        PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        for (size_t p0 = 0; p0 < (size_t)n_planes; p0 += chunk) {
-            size_t np = std::min(chunk, (size_t)n_planes - p0);
-            PM_HIP(ctx, hipMemcpyAsync(dcube, (const char *)cube + p0 * npx * esz, np * npx * esz,
-                                       hipMemcpyHostToDevice, ctx->stream));
-            pm::ReprojectArgs b = a;
-            b.cube = dcube;
-            b.x_map = dxm;
-            b.y_map = dym;
-            b.out = dout;
-            b.plane_flags = ctx->flags + p0;
-            b.n_planes = (int)np;
-            pm_launch_reproject(b, dtype, ctx->stream);
-            PM_HIP(ctx, hipGetLastError());
-            PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
-                                       ctx->stream));
-        }
+        return reproject_resident(ctx, a, dtype, /*sync_now=*/false);
     }
-    return check_plane_flags(ctx, n_planes);
+    // host cube: stream it through the device in chunks of planes
+    size_t chunk = (size_t)(1ull << 30) / (npx * esz);
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)n_planes) chunk = (size_t)n_planes;
+    size_t cube_bytes = chunk * npx * esz;
+    cube_bytes = (cube_bytes + 255) & ~(size_t)255;
+    size_t need = cube_bytes + (2 + chunk) * nmap * sizeof(double);
+    rc = ensure_scratch(ctx, need);
+    if (rc != PM_OK) return rc;
+    char *dcube = (char *)ctx->scratch;
+    double *dxm = (double *)(dcube + cube_bytes);
+    double *dym = dxm + nmap;
+    double *dout = dym + nmap;
+    PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    for (size_t p0 = 0; p0 < (size_t)n_planes; p0 += chunk) {
+        size_t np = std::min(chunk, (size_t)n_planes - p0);
+        PM_HIP(ctx, hipMemcpyAsync(dcube, (const char *)cube + p0 * npx * esz, np * npx * esz, hipMemcpyHostToDevice,
+                                   ctx->stream));
+        pm::ReprojectArgs b = a;
+        b.cube = dcube;
+        b.x_map = dxm;
+        b.y_map = dym;
+        b.out = dout;
+        b.plane_flags = ctx->flags;
+        b.n_planes = (int)np;
+        rc = reproject_resident(ctx, b, dtype, /*sync_now=*/true);
+        if (rc != PM_OK) return rc;
+        PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PM_OK;
 }
 
 }  // extern "C"

@@ -101,6 +101,17 @@ struct Params {
     int32_t pad_;
 };
 
+// Per-plane statistics for the NaN pre-clean of map_img (k_median_* kernels).
+struct PlaneStats {
+    unsigned long long prefix[2];  // radix-select state of the two middle ranks
+    unsigned long long rank[2];
+    unsigned long long n_finite;
+    unsigned long long n_nan;
+    double median;                 // np.nanmedian of the plane (0.0 if nothing finite)
+    int all_nan;                   // np.all(np.isnan(plane))
+    int pad_;
+};
+
 // Arguments of the reprojection kernel (pm_map_cube).
 struct ReprojectArgs {
     const void *cube;     // n_planes x ny x nx elements
@@ -109,6 +120,7 @@ struct ReprojectArgs {
     double *out;          // n_planes x n_map
     int *plane_flags;     // n_planes: bit1 = a sampled pixel was +-inf, i.e. the reference
                           // would have used its NaN-cleaned image there
+    const PlaneStats *plane_stats;  // n_planes (CLEAN kernels only)
     int n_planes, ny, nx;
     int n_map;
     int interpolation;

@@ -474,11 +474,41 @@ __device__ __forceinline__ double load_as_f64(const T *p, size_t i)
     return (double)p[i];
 }
 
+// Value the reference would interpolate from at pixel (i, j): the pixel itself if finite,
+// else the mean of the finite pixels of its clipped 3x3 window, else the plane's nanmedian
+// (BodyXY._replace_nans_with_interpolated_values body_xy.py:1871-1904; the reflect-mode
+// `uniform_filter(bad, size=3)` test there is equivalent to "the clipped window holds no
+// finite pixel" because reflection only repeats pixels of the window).
+template <typename T>
+__device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int ny, int nx, double median,
+                                             bool &needs_median)
+{
+    const double v = load_as_f64(img, (size_t)i * nx + j);
+    if (isfinite(v)) return v;
+    double sum = 0.0;
+    int cnt = 0;
+    for (long ii = (i > 0 ? i - 1 : 0); ii <= i + 1 && ii < ny; ii++)
+        for (long jj = (j > 0 ? j - 1 : 0); jj <= j + 1 && jj < nx; jj++) {
+            const double w = load_as_f64(img, (size_t)ii * nx + jj);
+            if (isfinite(w)) {
+                sum += w;
+                cnt++;
+            }
+        }
+    if (cnt > 0) return sum / (double)cnt;
+    needs_median = true;
+    return median;
+}
 
 // One lane per (map location, plane): BodyXY.map_img body_xy.py:1414 for every plane of
 // Observation._get_mapped_data observation.py:876. blockIdx.y = plane, so the 64 lanes
 // of a wave gather from one plane around neighbouring (x, y) -> the 4-point footprints
 // overlap in L2; the store is coalesced along the map row.
+//
+// The reference interpolates a NaN-cleaned copy of each plane; here the cleaned value of a
+// non-finite corner is computed on the fly from its 3x3 window. Only a corner whose whole
+// window is non-finite needs the plane's nanmedian: with plane_stats == NULL (first pass)
+// such a plane is flagged (plane_flags bit 1) and the host reruns it after k_median_*.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 {
@@ -499,16 +529,15 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
             if (yi < 0) yi += ny;
             val = load_as_f64(img, (size_t)yi * nx + xi);
         } else {
-            bool skip = false;
-            double xa = fmax(floor(x), 0.0), xb = fmin(ceil(x), nx - 1.0);
-            double ya = fmax(floor(y), 0.0), yb = fmin(ceil(y), ny - 1.0);
-            const bool in_hull = !(x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1);
-            if (a.propagate_nan) {
+            const bool have_stats = a.plane_stats != nullptr;
+            bool skip = have_stats && a.plane_stats[pl].all_nan;  // body_xy.py:1668-1670
+            if (a.propagate_nan && !skip) {
                 // _should_propagate_nan_to_map body_xy.py:1855-1866
-                if (!in_hull) {
+                if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
                     skip = true;
                 } else {
-                    long ia = (long)xa, ib = (long)xb, ja = (long)ya, jb = (long)yb;
+                    long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
+                    long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
                     double t0 = load_as_f64(img, (size_t)ja * nx + ia), t1 = load_as_f64(img, (size_t)ja * nx + ib);
                     double t2 = load_as_f64(img, (size_t)jb * nx + ia), t3 = load_as_f64(img, (size_t)jb * nx + ib);
                     skip = isnan(t0) || isnan(t1) || isnan(t2) || isnan(t3);
@@ -516,8 +545,7 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
             }
             if (!skip) {
                 // RectBivariateSpline(kx=ky=1, s=0).ev == bilinear; FITPACK clamps the
-                // evaluation point to the knot range. Zero-weight corners are excluded so
-                // that NaNs the reference would have replaced beforehand cannot leak in.
+                // evaluation point to the knot range.
                 double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
                 long x0 = (long)floor(xc), y0 = (long)floor(yc);
                 if (x0 > nx - 2) x0 = nx - 2;
@@ -526,19 +554,110 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
                 if (y0 < 0) y0 = 0;
                 long x1 = x0 + 1 < nx ? x0 + 1 : x0, y1 = y0 + 1 < ny ? y0 + 1 : y0;
                 double fx = xc - (double)x0, fy = yc - (double)y0;
-                double v00 = load_as_f64(img, (size_t)y0 * nx + x0), v01 = load_as_f64(img, (size_t)y0 * nx + x1);
-                double v10 = load_as_f64(img, (size_t)y1 * nx + x0), v11 = load_as_f64(img, (size_t)y1 * nx + x1);
-                double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
-                bool bad = (w00 != 0.0 && !isfinite(v00)) || (w01 != 0.0 && !isfinite(v01)) ||
-                           (w10 != 0.0 && !isfinite(v10)) || (w11 != 0.0 && !isfinite(v11));
-                if (bad) atomicOr(&a.plane_flags[pl], 2);
-                double r0 = (fx == 0.0 ? v00 : (fx == 1.0 ? v01 : fma(fx, v01, (1.0 - fx) * v00)));
-                double r1 = (fx == 0.0 ? v10 : (fx == 1.0 ? v11 : fma(fx, v11, (1.0 - fx) * v10)));
-                val = (fy == 0.0 ? r0 : (fy == 1.0 ? r1 : fma(fy, r1, (1.0 - fy) * r0)));
+                const double med = have_stats ? a.plane_stats[pl].median : 0.0;
+                bool nm = false;
+                // corners with zero weight contribute exactly 0 in the reference (their cleaned
+                // value is finite), so they are not evaluated at all
+                const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
+                const double v00 = (fx != 1.0 && fy != 1.0) ? cleaned_at(img, y0, x0, ny, nx, med, nm) : 0.0;
+                const double v01 = (fx != 0.0 && fy != 1.0) ? cleaned_at(img, y0, x1, ny, nx, med, nm) : 0.0;
+                const double v10 = (fx != 1.0 && fy != 0.0) ? cleaned_at(img, y1, x0, ny, nx, med, nm) : 0.0;
+                const double v11 = (fx != 0.0 && fy != 0.0) ? cleaned_at(img, y1, x1, ny, nx, med, nm) : 0.0;
+                (void)w00; (void)w01; (void)w10; (void)w11;
+                val = (1.0 - fy) * ((1.0 - fx) * v00 + fx * v01) + fy * ((1.0 - fx) * v10 + fx * v11);
+                if (nm && !have_stats) atomicOr(&a.plane_flags[pl], 2);
             }
         }
     }
     o[m] = val;
+}
+
+// ------------------------------------------------------------------ per-plane nanmedian
+// np.nanmedian of each plane (+-inf treated as NaN, body_xy.py:1882-1890) by an 8-pass
+// radix select over the order-preserving 64-bit key of the doubles. Two ranks are tracked
+// at once (the two middle elements of an even count). All planes are processed by the
+// same launches; one pass = one streaming read of the cube.
+__device__ __forceinline__ unsigned long long sortable_key(double v)
+{
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_to_double(unsigned long long k)
+{
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_median_hist(const T *cube, size_t plane_elems, int shift, PlaneStats *stats,
+                                                        unsigned int *hist /* [P][2][256] */)
+{
+    __shared__ unsigned int h[2][256];
+    const int pl = blockIdx.y;
+    h[0][threadIdx.x] = 0;
+    h[1][threadIdx.x] = 0;
+    __syncthreads();
+    const T *img = cube + (size_t)pl * plane_elems;
+    const unsigned long long mask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
+    const unsigned long long pa = stats[pl].prefix[0], pb = stats[pl].prefix[1];
+    unsigned int n_nan = 0;
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < plane_elems; i += (size_t)gridDim.x * kBlock) {
+        const double v = (double)img[i];
+        if (!isfinite(v)) {
+            n_nan += isnan(v) ? 1u : 0u;
+            continue;
+        }
+        const unsigned long long key = sortable_key(v);
+        const unsigned int bin = (unsigned int)(key >> shift) & 255u;
+        if ((key & mask) == pa) atomicAdd(&h[0][bin], 1u);
+        if ((key & mask) == pb) atomicAdd(&h[1][bin], 1u);
+    }
+    __syncthreads();
+    unsigned int *g = hist + (size_t)pl * 512;
+    if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
+    if (h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
+    if (shift == 56 && n_nan) atomicAdd(&stats[pl].n_nan, (unsigned long long)n_nan);
+}
+
+// one 256-thread block per plane: pick the bin holding each tracked rank, extend the prefix
+__global__ __launch_bounds__(kBlock) void k_median_pick(int shift, size_t plane_elems, PlaneStats *stats, unsigned int *hist)
+{
+    const int pl = blockIdx.x;
+    unsigned int *g = hist + (size_t)pl * 512;
+    __shared__ unsigned long long cum[2][256];
+    cum[0][threadIdx.x] = g[threadIdx.x];
+    cum[1][threadIdx.x] = g[256 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        const int s = threadIdx.x;
+        PlaneStats &st = stats[pl];
+        if (shift == 56) {
+            unsigned long long n = 0;
+            for (int b = 0; b < 256; b++) n += cum[s][b];
+            st.n_finite = n;
+            st.rank[s] = (n == 0) ? 0 : (s == 0 ? (n - 1) / 2 : n / 2);
+        }
+        unsigned long long k = st.rank[s], acc = 0;
+        int bin = 0;
+        for (int b = 0; b < 256; b++) {
+            if (acc + cum[s][b] > k) {
+                bin = b;
+                break;
+            }
+            acc += cum[s][b];
+        }
+        st.rank[s] = k - acc;
+        st.prefix[s] |= ((unsigned long long)bin) << shift;
+    }
+    __syncthreads();
+    g[threadIdx.x] = 0;
+    g[256 + threadIdx.x] = 0;
+    if (shift == 0 && threadIdx.x == 0) {
+        PlaneStats &st = stats[pl];
+        // np.nanmedian: mean of the two middle values; 0.0 if nothing is finite (:1887-1890)
+        st.median = st.n_finite ? 0.5 * (key_to_double(st.prefix[0]) + key_to_double(st.prefix[1])) : 0.0;
+        st.all_nan = (st.n_nan == (unsigned long long)plane_elems) ? 1 : 0;
+    }
 }
 
 }  // namespace pm
@@ -598,6 +717,20 @@ static void launch_reproject_t(const pm::ReprojectArgs &a, hipStream_t s)
     hipLaunchKernelGGL(pm::k_reproject<T>, grid, dim3(pm::kBlock), 0, s, a);
 }
 
+template <typename T>
+static void launch_median_t(const void *cube, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
+                            unsigned int *hist, hipStream_t s)
+{
+    unsigned gx = (unsigned)((plane_elems + pm::kBlock * 16 - 1) / (pm::kBlock * 16));
+    if (gx < 1) gx = 1;
+    if (gx > 256) gx = 256;
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hipLaunchKernelGGL(pm::k_median_hist<T>, dim3(gx, n_planes), dim3(pm::kBlock), 0, s, (const T *)cube,
+                           plane_elems, shift, stats, hist);
+        hipLaunchKernelGGL(pm::k_median_pick, dim3(n_planes), dim3(pm::kBlock), 0, s, shift, plane_elems, stats, hist);
+    }
+}
+
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)
 {
     switch (dtype) {
@@ -607,6 +740,20 @@ void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)
     case PM_I32: launch_reproject_t<int32_t>(a, s); break;
     case PM_U8: launch_reproject_t<uint8_t>(a, s); break;
     case PM_U16: launch_reproject_t<uint16_t>(a, s); break;
+    }
+}
+
+// stats / hist must be zero-filled by the caller (hipMemsetAsync) before this call
+void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
+                             unsigned int *hist, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_median_t<double>(cube, n_planes, plane_elems, stats, hist, s); break;
+    case PM_F32: launch_median_t<float>(cube, n_planes, plane_elems, stats, hist, s); break;
+    case PM_I16: launch_median_t<int16_t>(cube, n_planes, plane_elems, stats, hist, s); break;
+    case PM_I32: launch_median_t<int32_t>(cube, n_planes, plane_elems, stats, hist, s); break;
+    case PM_U8: launch_median_t<uint8_t>(cube, n_planes, plane_elems, stats, hist, s); break;
+    case PM_U16: launch_median_t<uint16_t>(cube, n_planes, plane_elems, stats, hist, s); break;
     }
 }
 }

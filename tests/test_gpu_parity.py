@@ -246,3 +246,63 @@ def test_reference_api_on_gpu(jupiter):
     b = BodyXY('jupiter', scenario='jupiter_hst_2005', sz=128)
     assert b.get_disc_params() == (63.5, 63.5, 57.15, 0.0)
     assert np.isfinite(b.get_lon_img()).sum() == np.isfinite(b.get_emission_angle_img()).sum() > 9000
+
+
+def test_nan_preclean_and_median_paths(engine, oracle, jupiter):
+    """
+    propagate_nan=False and +-inf pixels: the NaN pre-clean of
+    BodyXY._replace_nans_with_interpolated_values (body_xy.py:1871-1904) incl. the plane
+    nanmedian (GPU radix select), vs the oracle; plus the reference KAT
+    tests/test_body_xy.py:1177-1190 through the real engine.
+    """
+    nan = np.nan
+    image = np.array(
+        [
+            [0.0, 100.0, -1.0, 2.2, 3.3, 4.4],
+            [0.0, 75.0, 999.0, 50.0, 1.0, 123.456789],
+            [0.0, 25.0, 0.0, 123.45, nan, 3],
+            [0.0, 0.123, 0.0, 3.0, 0.1, nan],
+            [100.0, -100.0, 100.0, -100.0, 100.0, nan],
+        ]
+    )
+    # fmt: off
+    no_propagation = [[nan, nan, 83.42502054006614, 61.410255547165704, 1.0972142916279704, nan, nan, nan], [nan, nan, nan, 61.591824124152424, 488.0893412811879, 4.181692402514696, 3.8032713799190443, nan], [nan, nan, nan, 3.678385742930187, 94.03788871233297, 35.721226497463014, 94.00305287602345, nan], [nan, nan, nan, -25.28910210942658, -1.6502703714050462, 4.265385156596395, nan, nan]]
+    # fmt: on
+    from planetmapper_amd import BodyXY
+
+    body = BodyXY('Jupiter', geometry=jupiter, nx=6, ny=5)
+    body.set_disc_params(2.75, 1.3, 2.3, 45.678)
+    got = body.map_img(image, degree_interval=45, propagate_nan=False)
+    assert np.allclose(got, no_propagation, rtol=1e-5, atol=1e-8, equal_nan=True)
+
+    sz = 256
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, 0.9 * x0, 0.3, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 2.0)
+    d = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)
+    d.rotation_rad = 0.3
+    xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+    rng = np.random.default_rng(7)
+    cube = rng.standard_normal((7, sz, sz)) * 10 + 3
+    cube[0][rng.random((sz, sz)) < 0.02] = np.nan  # isolated NaNs: window means only
+    cube[1][60:140, 80:200] = np.nan  # a hole: its interior needs the plane median
+    cube[2][:] = np.nan  # all NaN
+    cube[3][:] = np.inf  # nothing finite, but not all NaN: median 0.0
+    cube[4][rng.random((sz, sz)) < 0.01] = np.inf  # isolated infs
+    cube[4][100:120, 100:130] = -np.inf
+    cube[5][::2] = np.nan  # even count / striped
+    cube[6][rng.random((sz, sz)) < 0.5] = np.nan
+    for prop in (False, True):
+        a = engine.map_cube(cube, xm, ym, 'linear', prop)
+        b = oracle.map_cube(cube, xm, ym, 'linear', prop)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), prop
+        assert np.array_equal(np.isinf(a), np.isinf(b)), prop
+        fin = np.isfinite(b)
+        assert np.max(np.abs(a[fin] - b[fin])) <= 1e-11, prop
+    assert np.isnan(engine.map_cube(cube[2], xm, ym, 'linear', False)).all()
+    # float32 and int16 cubes through the median path
+    c32 = cube[1].astype(np.float32)
+    a = engine.map_cube(c32, xm, ym, 'linear', False)
+    b = oracle.map_cube(c32, xm, ym, 'linear', False)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) <= 1e-5

@@ -95,6 +95,114 @@ def cpu_baseline(g, sz: int, budget_s: float = 12.0) -> dict:
     }
 
 
+def other_workloads(args) -> None:
+    """Secondary BASELINE configs (4 and 5); same JSON contract, their own metric names."""
+    import torch
+    import torch.distributed as dist
+
+    from planetmapper_amd.distributed import map_cube_sharded_device, shard_bounds
+    from planetmapper_amd.engine import Engine
+    from planetmapper_amd.scenarios import load_scenario
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+    eng = Engine(local_rank)
+    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.workload == 'saturn':
+        # SURVEY 8d config 4: Saturn-like spheroid, 4096^2, r0 = 800 px, rotation 20 deg
+        sz = args.size
+        names = HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']
+        g = load_scenario('saturn_earth_2005')
+        eng.set_geometry(g)
+        x0 = (sz - 1) / 2
+        eng.set_disc(x0, x0, 800.0 * sz / 4096, float(np.deg2rad(20.0)), sz, sz, True)
+        planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
+
+        def step():
+            eng.backplanes_img_device(planes)
+
+        units = sz * sz
+        metric = 'Mpix/s Saturn + rings backplane set (lon/lat/phase/inc/emi/ring radius/lon/distance), 4096^2 frame'
+        workload = f'Saturn-like spheroid seen from Earth 2005-01-01, {sz}x{sz}, r0={800.0 * sz / 4096:g} px, 8 planes'
+        alg = sz * sz * 8 * len(names)
+        scaling = 'weak'
+    else:
+        # SURVEY 8d config 5: IFU cube P x 1024 x 1024 f64, 1 deg map, planes sharded over ranks
+        sz = 1024
+        g = load_scenario('jupiter_hst_2005')
+        eng.set_geometry(g)
+        x0 = (sz - 1) / 2
+        eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+        a, b, per_rank = shard_bounds(args.planes, world, rank)
+        gen = torch.Generator(device=dev).manual_seed(5 + rank)
+        cube = torch.randn((per_rank, sz, sz), generator=gen, device=dev, dtype=torch.float64)
+        cube[torch.rand((per_rank, sz, sz), generator=gen, device=dev) < 1e-3] = float('nan')
+        lon_h, lat_h = rectangular_grid(bool(g.west_positive))
+        n0, n1 = lon_h.shape
+        lon_d, lat_d = torch.from_numpy(lon_h).to(dev), torch.from_numpy(lat_h).to(dev)
+        xm = torch.empty((n0, n1), dtype=torch.float64, device=dev)
+        ym = torch.empty((n0, n1), dtype=torch.float64, device=dev)
+        gathered = torch.empty((world, per_rank, n0, n1), dtype=torch.float64, device=dev)
+
+        def step():
+            eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
+            map_cube_sharded_device(eng, cube, np.float64, per_rank, xm, ym, n0, n1, gathered, rank)
+
+        units = args.planes * sz * sz
+        metric = 'Mpix/s of cube pixels map-projected (get_mapped_data, 1 deg rectangular map, bilinear)'
+        workload = (
+            f'synthetic IFU cube {args.planes}x{sz}x{sz} f64 resident in HBM, {per_rank} planes per GPU, '
+            f'map {n0}x{n1}, RCCL all-gather of mapped planes' + ('' if world > 1 else ' (skipped at N=1)')
+        )
+        alg = n0 * n1 * (16 + 40 * per_rank)
+        scaling = 'strong'
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for e0, e1 in evs:
+        e0.record()
+        step()
+        e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.synchronize()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    step_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    if rank == 0:
+        n_units = units * (world if scaling == 'weak' else 1)
+        print(json.dumps({
+            'metric': metric, 'value': round(n_units * args.steps / dt / 1e6, 2), 'unit': 'Mpix/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': scaling,
+            'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': workload},
+            'roofline': {'bound': 'hbm', 'achieved': round(alg / (step_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         'traffic': None, 'kernel_ms': round(step_ms, 4), 'algorithmic_bytes': alg},
+        }), flush=True)  # fmt: skip
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -102,7 +210,15 @@ def main() -> None:
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--size', type=int, default=4096)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument(
+        '--workload', default='frame', choices=['frame', 'saturn', 'cube'],
+        help="frame: BASELINE headline (default); saturn: config 4 (Saturn + rings, 8 planes); "
+        "cube: config 5 (512 x 1024^2 f64 cube -> 1 deg map, planes sharded over the GPUs)",
+    )  # fmt: skip
+    ap.add_argument('--planes', type=int, default=512, help='cube workload: total planes')
     args = ap.parse_args()
+    if args.workload != 'frame':
+        return other_workloads(args)
 
     import torch
     import torch.distributed as dist

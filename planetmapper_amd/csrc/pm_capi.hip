@@ -475,8 +475,8 @@ int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *cons
         pm::Params pd = p;
         pd.mask = plane_mask & kDiscBits;
         // spheroids (every planet in pck00010) take the rotation-free fast path; triaxial
-        // bodies and ring-plane requests use the general kernel
-        const bool spheroid = pd.radii[0] == pd.radii[1] && !(flags & 4) && !ctx->force_general;
+        // bodies use the general kernel
+        const bool spheroid = pd.radii[0] == pd.radii[1] && !ctx->force_general;
         if (spheroid)
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else

@@ -333,6 +333,51 @@ __device__ __forceinline__ void recpgr_general(const Params &p, V3 v, double &lo
     lon = l;
 }
 
+// recpgr_c of an arbitrary point for a spheroid, fast form for the ring planes: signed
+// altitude and EAST longitude only. Same Lagrange-multiplier equation as recpgr_general,
+// but Newton starts from the tightest lower bound lam0 = max(a rho - a^2, c|z| - c^2, 0 if
+// outside) - for ring-plane points (z ~ 0) that IS the root, so 1-2 steps suffice - and each
+// step uses reciprocals instead of five divisions.
+__device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lon_east, double &alt)
+{
+    const double a = p.radii[0], c = p.radii[2];
+    const double a2 = a * a, c2 = c * c;
+    const double rho2 = fma(v.x, v.x, v.y * v.y);
+    const double rho = sqrt_fast(rho2);
+    const double q = rho2 * (p.ira * p.ira) + (v.z * v.z) * (p.irc * p.irc);
+    lon_east = (rho2 == 0.0) ? 0.0 : atan2_fast(v.y, v.x);
+    if (q == 0.0) {
+        alt = -fmin(a, c);
+        return;
+    }
+    const double l1 = (rho != 0.0) ? fma(a, rho, -a2) : -1e300;
+    const double l2 = (v.z != 0.0) ? fma(c, fabs(v.z), -c2) : -1e300;
+    double lam = fmax(fmax(l1, l2), (q >= 1.0) ? 0.0 : -1e300);
+    const double ar = a * rho, cz = c * v.z;
+    // Newton from a lower bound is monotone and quadratic; once the step falls to the rounding
+    // floor (a few ulps of lam) it only dithers, so stop there: 1e-15 |lam| moves the near
+    // point by < 1e-9 km.
+#pragma unroll 1
+    for (int it = 0; it < 12; it++) {
+        const double ra = rcp_fast(a2 + lam), rc = rcp_fast(c2 + lam);
+        const double ta = ar * ra, tc = cz * rc;
+        const double f = fma(ta, ta, fma(tc, tc, -1.0));
+        const double df = -2.0 * fma(ta * ta, ra, tc * tc * rc);
+        const double step = div_fast(f, df);
+        const double nl = lam - step;
+        const bool stop = (nl == lam) || fabs(step) <= 1e-15 * fabs(nl);
+        lam = nl;
+        if (__all(stop)) break;
+    }
+    double bx = a2 * rho * rcp_fast(a2 + lam), bz = c2 * v.z * rcp_fast(c2 + lam);
+    const double s = rsqrt_fast(bx * bx * (p.ira * p.ira) + bz * bz * (p.irc * p.irc));
+    bx *= s;
+    bz *= s;
+    const double dx = rho - bx, dz = v.z - bz;
+    alt = sqrt_fast(fma(dx, dx, dz * dz));
+    if (q < 1.0) alt = -alt;
+}
+
 // pgrrec_c (body.py:903-910) at altitude 0
 __device__ __forceinline__ V3 pgrrec_surface(const Params &p, double lon, double lat)
 {

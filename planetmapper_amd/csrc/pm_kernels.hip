@@ -188,9 +188,13 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
 
     double lon_deg = nan, lat_deg = nan, lc_deg = nan, bc_deg = nan;
     double ph = nan, in = nan, em = nan, az = nan, dist = nan, rv = nan, dop = nan;
+    double rr = nan, rl = nan, rd = nan;
+    double dist_lt = nan;  // observer -> surface distance (lt * c) of on-disc pixels
 
-    if (__any(cand)) {
-        // pixel -> unit ray, directly in B0 (BodyXY._xy2obsvec_norm body_xy.py:375)
+    const bool any_cand = __any(cand);
+    V3 va = {0.0, 0.0, 0.0};  // unit vector of the pixel in the angular frame
+    if (any_cand || (FLAGS & DF_RING)) {
+        // pixel -> unit ray (BodyXY._xy2obsvec_norm body_xy.py:375)
         const double fx = (double)x, fy = (double)y;
         const double ax = fma(p.A[0], fx, fma(p.A[1], fy, p.A[2]));
         const double ay = fma(p.A[3], fx, fma(p.A[4], fy, p.A[5]));
@@ -198,7 +202,11 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
         constexpr double kArcsec = kRad / 3600.0;  // arcsec -> rad (1 ulp from (a / 3600) * kRad)
         sincos_auto(-(ax * kArcsec), sr, cr);
         sincos_auto(ay * kArcsec, sd, cd);
-        const V3 u = mxv(p.C, v3(cr * cd, sr * cd, sd));
+        va = v3(cr * cd, sr * cd, sd);
+    }
+
+    if (any_cand) {
+        const V3 u = mxv(p.C, va);  // ray in B0
 
         // surfpt_c in scaled coordinates; X and 1/(X.X) are fixed for the pixel
         const V3 X = {u.x * p.ira, u.y * p.ira, u.z * p.irc};
@@ -237,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
         if (hit) {
             // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
             const double tau = -k - root;  // distance observer -> point along the ray
+            if (FLAGS & (DF_RING | DF_STATE)) dist_lt = lt * p.g.clight;
             const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
             const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[0], Xf.z * p.radii[2]};
             const double delta = p.g.wdot * d;
@@ -285,7 +294,7 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
             }
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
-                dist = lt * p.g.clight;
+                dist = dist_lt;
                 const V3 vp = {fma(p.AB[0], d, p.VB[0]) - p.g.wdot * sp.y, fma(p.AB[1], d, p.VB[1]) + p.g.wdot * sp.x,
                                fma(p.AB[2], d, p.VB[2])};
                 const V3 vo = ld3(p.VOB);
@@ -298,7 +307,49 @@ __global__ __launch_bounds__(kBlock) void k_disc_sph(const Params p)
         }
     }
 
+    if (FLAGS & DF_RING) {
+        // Body._ring_coordinates_from_obsvec(only_visible=False) body.py:2577-2615 for EVERY
+        // pixel: inrypl_c with the J2000 ray, PM's _obsvec2targvec (body.py:972-1006; it mixes
+        // J2000 and body-fixed components by design) and recpgr_c of the in-plane point. (The
+        // reference rebuilds the ray from RA/Dec in degrees, body_xy.py:3262; that round trip
+        // perturbs it by < 1 ulp - below the rounding of the ray itself - and is not replayed.)
+        const V3 ray = mtxv(p.g.M, va);
+        const double pd = dot(ray, ld3(p.g.ring_n));
+        const double kk = p.g.ring_k;
+        const bool ok = (kk == 0.0) ? (pd != 0.0) : (pd > 0.0 && kk < pd * (1.7976931348623157e308 / 3.0));
+        if (__any(ok)) {
+            // lanes without an intersection carry a harmless finite point through the math
+            const double s = !ok ? 1.0 : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
+            const V3 ip = s * ray;
+            const V3 off = ip - ld3(p.g.sub_obsvec);
+            const V3 w = off - ld3(p.g.sub_ray);
+            const double dd = sqrt_fast(dot(w, w)) - p.g.sub_dist;
+            const double t = p.g.sub_et - dd * p.inv_c;
+            double sa, ca;
+            sincos_auto(p.g.wdot * (t - p.t0), sa, ca);
+            const V3 ob = mxv(p.g.R0, off);  // R(t) off = Rz_frame(ang) (R0 off)
+            const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1],
+                           ob.z + p.g.sub_sp[2]};
+            double le, alt;
+            recpgr_alt_lon(p, tv, le, alt);
+            double l = p.g.west_positive ? -le : le;
+            if (l < 0.0) l += kTwoPi;
+            // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
+            const double rdist = sqrt_fast(dot(ip, ip));
+            if (ok && !(rdist > dist_lt)) {
+                rr = alt + p.radii[0];
+                rl = l * kDeg;
+                rd = rdist;
+            }
+        }
+    }
+
     if (inside) {
+        if (FLAGS & DF_RING) {
+            PM_PUT(PM_RING_RADIUS, rr);
+            PM_PUT(PM_RING_LON_GRAPHIC, rl);
+            PM_PUT(PM_RING_DISTANCE, rd);
+        }
         PM_PUT(PM_LON_GRAPHIC, lon_deg);
         PM_PUT(PM_LAT_GRAPHIC, lat_deg);
         PM_PUT(PM_LON_CENTRIC, lc_deg);
@@ -685,11 +736,15 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 {
     dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.ny);
     dim3 block(pm::kBlock);
-    switch (flags & 3) {
+    switch (flags & 7) {
     case 0: hipLaunchKernelGGL(pm::k_disc_sph<0>, grid, block, 0, s, p); break;
     case 1: hipLaunchKernelGGL(pm::k_disc_sph<1>, grid, block, 0, s, p); break;
     case 2: hipLaunchKernelGGL(pm::k_disc_sph<2>, grid, block, 0, s, p); break;
     case 3: hipLaunchKernelGGL(pm::k_disc_sph<3>, grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL(pm::k_disc_sph<4>, grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL(pm::k_disc_sph<5>, grid, block, 0, s, p); break;
+    case 6: hipLaunchKernelGGL(pm::k_disc_sph<6>, grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL(pm::k_disc_sph<7>, grid, block, 0, s, p); break;
     }
 }
 

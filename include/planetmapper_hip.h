@@ -233,8 +233,10 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg,
  * The NaN pre-clean of _replace_nans_with_interpolated_values (body_xy.py:1871-1904)
  * is honoured for propagate_nan == 0 and for +-inf pixels (window means on the fly,
  * plane nanmedian by a GPU radix select when a sampled pixel needs it).
- * PM_MEM_DEVICE: asynchronous; planes that need the nanmedian are completed by
- * pm_synchronize(), until which cube / maps / out must stay valid.
+ * PM_MEM_DEVICE: asynchronous (no host round trip per call); planes that turn out to
+ * need the nanmedian are completed by the next pm_synchronize(), until which cube / maps /
+ * out must stay valid; if another pm_map_cube was enqueued in between, pm_synchronize()
+ * reports PM_ERR_STATE instead. Calls with propagate_nan == 0 complete synchronously.
  */
 int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
                 const double *x_map, const double *y_map, int n0, int n1,

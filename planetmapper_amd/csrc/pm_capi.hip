@@ -47,6 +47,8 @@ struct pm_ctx {
     bool pending = false;
     pm::ReprojectArgs pending_args{};
     int pending_dtype = 0;
+    int map_seq = 0;        // sequence number of the latest pm_map_cube call
+    int checked_seq = 0;    // calls up to this number have had their flags examined
     bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
 };
 
@@ -99,6 +101,7 @@ int ensure_flags(pm_ctx *ctx, size_t count)
     }
     hipError_t e = hipMalloc((void **)&ctx->flags, count * sizeof(int));
     if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipMalloc flags failed: %s", hipGetErrorString(e));
+    PM_HIP(ctx, hipMemsetAsync(ctx->flags, 0, count * sizeof(int), ctx->stream));
     ctx->flags_count = count;
     return PM_OK;
 }
@@ -213,8 +216,17 @@ int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype)
     PM_HIP(ctx, hipMemcpyAsync(hflags.data(), a.plane_flags, (size_t)a.n_planes * sizeof(int), hipMemcpyDeviceToHost,
                                ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    bool any = false;
-    for (int f : hflags) any = any || (f & 2);
+    bool any = false, stale = false;
+    for (int f : hflags) {
+        any = any || (f == a.seq);
+        stale = stale || (f > ctx->checked_seq && f < a.seq);
+    }
+    ctx->checked_seq = a.seq;
+    if (stale)
+        return fail(ctx, PM_ERR_STATE,
+                    "an earlier asynchronous pm_map_cube call sampled pixels that need the plane nanmedian (+-inf "
+                    "or all-NaN neighbourhoods) and was superseded before pm_synchronize(); synchronize after each "
+                    "call for such data");
     if (!any) return PM_OK;
     int rc = ensure_stats(ctx, (size_t)a.n_planes);
     if (rc != PM_OK) return rc;
@@ -241,8 +253,8 @@ int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype)
 int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_now)
 {
     size_t plane_elems = (size_t)a.ny * a.nx;
-    PM_HIP(ctx, hipMemsetAsync(a.plane_flags, 0, (size_t)a.n_planes * sizeof(int), ctx->stream));
     a.plane_stats = nullptr;
+    a.seq = ++ctx->map_seq;
     // blockIdx.y is limited to 65535 planes per launch
     for (int p0 = 0; p0 < a.n_planes; p0 += 32768) {
         pm::ReprojectArgs b = a;
@@ -476,7 +488,11 @@ int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *cons
         pd.mask = plane_mask & kDiscBits;
         // spheroids (every planet in pck00010) take the rotation-free fast path; triaxial
         // bodies use the general kernel
-        const bool spheroid = pd.radii[0] == pd.radii[1] && !ctx->force_general;
+        // the fast path assumes an observer well outside the body (|O0| > 2 radii in scaled
+        // coordinates); anything else, e.g. a lander, goes through the general kernel
+        double y2 = 0.0;
+        for (int i = 0; i < 3; i++) y2 += (pd.O0[i] / pd.radii[i]) * (pd.O0[i] / pd.radii[i]);
+        const bool spheroid = pd.radii[0] == pd.radii[1] && y2 > 4.0 && !ctx->force_general;
         if (spheroid)
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else
@@ -574,8 +590,10 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     size_t nmap = (size_t)n0 * n1;
     size_t npx = (size_t)d.nx * d.ny;
     if (n_planes == 0 || nmap == 0) return PM_OK;
-    // a previous asynchronous call must be completed before its flags / statistics are reused
-    if (ctx->pending) {
+    // propagate_nan == 0 almost always needs the statistics pass: complete such calls (and
+    // whatever is pending before them) synchronously
+    const bool force_sync = (interpolation == PM_INTERP_LINEAR && !propagate_nan);
+    if (force_sync && ctx->pending) {
         rc = pm_synchronize(ctx);
         if (rc != PM_OK) return rc;
     }
@@ -597,7 +615,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         a.out = out;
         a.plane_flags = ctx->flags;
         a.n_planes = n_planes;
-        return reproject_resident(ctx, a, dtype, /*sync_now=*/false);
+        return reproject_resident(ctx, a, dtype, /*sync_now=*/force_sync);
     }
     // host cube: stream it through the device in chunks of planes
     size_t chunk = (size_t)(1ull << 30) / (npx * esz);

@@ -118,8 +118,10 @@ struct ReprojectArgs {
     const double *x_map;  // n_map
     const double *y_map;
     double *out;          // n_planes x n_map
-    int *plane_flags;     // n_planes: bit1 = a sampled pixel was +-inf, i.e. the reference
-                          // would have used its NaN-cleaned image there
+    int *plane_flags;     // n_planes: set to `seq` (atomicMax) when a sampled pixel of the plane
+                          // needs the plane's nanmedian, i.e. the call must be finished with
+                          // plane statistics; never cleared, seq only grows
+    int seq;              // sequence number of this pm_map_cube call (> 0)
     const PlaneStats *plane_stats;  // n_planes (CLEAN kernels only)
     int n_planes, ny, nx;
     int n_map;

@@ -40,17 +40,18 @@ __device__ __forceinline__ double div_fast(double a, double b)
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
-// sqrt(x), x >= 0 in the normal range (exact 0 handled)
+// sqrt(x), x >= 0 in the normal range. x == 0 needs no select: the seed is taken from
+// max(x, 1e-300), so g = 0 * finite = 0 and every correction term stays 0.
 __device__ __forceinline__ double sqrt_fast(double x)
 {
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
     g = fma(fma(-g, g, x), h, g);
     g = fma(fma(-g, g, x), h, g);
-    return (x == 0.0) ? 0.0 : g;
+    return g;
 }
 // 1 / sqrt(x), x > 0 in the normal range, full precision
 __device__ __forceinline__ double rsqrt_fast(double x)

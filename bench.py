@@ -45,6 +45,24 @@ def rectangular_grid(west_positive: bool, degree_interval: float = 1.0):
     return np.ascontiguousarray(lon % 360), np.ascontiguousarray(lat)
 
 
+def measured_traffic(kernel_prefix: str):
+    """
+    HBM bytes per launch of the dominant kernel from the PMC passes of tools/pmc_profile.sh
+    (WRITE_SIZE + FETCH_SIZE, separate rocprofv3 --pmc runs; profiles/traffic.json). PMC
+    counters cannot be collected inside this process, so the last profiled value is reported;
+    None if no profile has been recorded.
+    """
+    try:
+        with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
+            t = json.load(f)
+        for k, v in t.items():
+            if k.startswith(kernel_prefix):
+                return int(v['hbm_bytes'])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
     """the image kernel reads nothing and writes 8 B per plane per pixel."""
     return nx * ny * 8 * n_planes
@@ -332,13 +350,13 @@ def main() -> None:
                 + (', RCCL all-gather of mapped planes' if world > 1 else ''),
             },
             'roofline': {
-                'kernel': 'k_disc<ILLUM>',
+                'kernel': 'pm::k_disc_sph<1> (DF_ILLUM)',
                 'bound': 'hbm',
                 'achieved': round(achieved, 2),
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                'traffic': None,
+                'traffic': measured_traffic('pm::k_disc_sph<1>') if sz == 4096 else None,
                 'kernel_ms': round(kernel_ms, 4),
                 'algorithmic_bytes': alg,
             },

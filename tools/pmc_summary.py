@@ -1,15 +1,28 @@
 #!/usr/bin/env python3
-"""Summarise rocprofv3 --pmc CSVs: mean counter value per kernel."""
-import csv, glob, os, sys, collections
+"""Summarise rocprofv3 --pmc CSVs: mean counter value per pm:: kernel, + traffic JSON."""
+import collections, csv, glob, json, os, sys
+
 root = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, '**', '*counter_collection.csv'), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row['Kernel_Name'].split('(')[0][:60]
         acc[k][row['Counter_Name']].append(float(row['Counter_Value']))
+traffic = {}
 for k, cs in sorted(acc.items()):
     if not k.startswith(('void pm::', 'pm::')):
         continue
     print(k)
     for c, v in sorted(cs.items()):
         print(f'   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}')
+    if 'WRITE_SIZE' in cs and 'FETCH_SIZE' in cs:
+        # rocprofv3 reports KiB. FETCH_SIZE under-reports wide coalesced streaming reads by 2x on
+        # gfx950 (MI355X_MICROARCH.md, HBM); the image kernels read nothing but kernel arguments and
+        # the gather kernel reads scattered 8-byte words (uncalibrated pattern), so the raw value is
+        # kept and only named here.
+        w = sum(cs['WRITE_SIZE']) / len(cs['WRITE_SIZE']) * 1024
+        r = sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE']) * 1024
+        name = k.replace('void ', '')
+        traffic[name] = {'write_bytes': w, 'fetch_bytes_raw': r, 'hbm_bytes': w + r}
+with open(os.path.join(root, 'traffic.json'), 'w') as f:
+    json.dump(traffic, f, indent=1)

@@ -154,6 +154,18 @@ typedef enum pm_dtype {
     PM_F64 = 0, PM_F32 = 1, PM_I16 = 2, PM_I32 = 3, PM_U8 = 4, PM_U16 = 5
 } pm_dtype;
 
+/* Coordinate systems of pm_transform (reference: "coordinate systems" of
+ * planetmapper/__init__.py:12-60). */
+typedef enum pm_coord {
+    PM_COORD_XY = 0,      /* image pixels                                      */
+    PM_COORD_RADEC = 1,   /* observer RA/Dec [deg]                             */
+    PM_COORD_ANGULAR = 2, /* arcsec from the target centre, East / North        */
+    PM_COORD_KM = 3,      /* km in the target plane, North pole up             */
+    PM_COORD_LONLAT = 4   /* planetographic lon/lat [deg]                      */
+} pm_coord;
+#define PM_TF_NOT_VISIBLE_NAN 1 /* from lon/lat: NaN when hidden from the observer */
+#define PM_TF_PLANETOCENTRIC 2  /* lon/lat are planetocentric                      */
+
 typedef struct pm_ctx pm_ctx; /* opaque */
 
 /* Library / device ---------------------------------------------------------- */
@@ -204,6 +216,23 @@ int pm_set_disc(pm_ctx *ctx, const pm_disc *disc);
  */
 int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt,
                       double *const *out, int mem);
+
+/* Point transforms --------------------------------------------------------------- */
+/*
+ * replaces the array-valued coordinate transforms built on
+ * SpiceBase._maybe_transform_as_arrays (base.py:719-757):
+ *   BodyXY.xy2radec / radec2xy / xy2lonlat / lonlat2xy / xy2km / km2xy / xy2angular /
+ *   angular2xy (body_xy.py:385-561); Body.lonlat2radec / radec2lonlat / radec2angular /
+ *   angular2radec / angular2lonlat / lonlat2angular / km2radec / radec2km / km2lonlat /
+ *   lonlat2km / km2angular / angular2km (body.py:1083-1217, 1375-1800).
+ * n points (a[i], b[i]) in system `from` -> (out_a[i], out_b[i]) in system `to`.
+ * alt: TO lon/lat = altitude adjustment of the surface (radii + alt); FROM lon/lat =
+ * altitude of the point above the surface. flags: PM_TF_*. Points that miss the body /
+ * are not visible / are non-finite give NaN (not_found_nan=True semantics).
+ */
+int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a,
+                 const double *b, double alt, int flags, double *out_a, double *out_b,
+                 int mem);
 
 /* Map-space ---------------------------------------------------------------------- */
 /*

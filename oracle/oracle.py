@@ -93,6 +93,10 @@ def lib() -> ctypes.CDLL:
         _lib.pmo_radec_query.argtypes = [
             ctypes.POINTER(PMGeometry), ctypes.c_double, ctypes.c_int, dp, dp, ctypes.c_int, dp,
         ]
+        _lib.pmo_transform.argtypes = [
+            ctypes.POINTER(PMGeometry), ctypes.POINTER(PMDisc), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
+            dp, dp, ctypes.c_double, ctypes.c_int, dp, dp,
+        ]
         assert _lib.pmo_sizeof_geometry() == ctypes.sizeof(PMGeometry)
         assert _lib.pmo_sizeof_disc() == ctypes.sizeof(PMDisc)
     return _lib
@@ -196,3 +200,22 @@ def radec_query(g, ra_deg, dec_deg, alt: float = 0.0, ring_only_visible: bool = 
 def set_num_threads(n: int) -> int:
     """OpenMP threads of the oracle's row loops; returns the count in effect."""
     return int(lib().pmo_set_num_threads(int(n)))
+
+
+COORDS = {'xy': 0, 'radec': 1, 'angular': 2, 'km': 3, 'lonlat': 4}
+
+
+def transform(g, d, src: str, dst: str, a, b, alt: float = 0.0, not_visible_nan=False, planetocentric=False):
+    """Array-valued coordinate transform (see pmo_transform)."""
+    a, b = np.broadcast_arrays(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+    shape = a.shape
+    a = np.ascontiguousarray(a).ravel()
+    b = np.ascontiguousarray(b).ravel()
+    oa = np.empty_like(a)
+    ob = np.empty_like(b)
+    flags = (1 if not_visible_nan else 0) | (2 if planetocentric else 0)
+    rc = lib().pmo_transform(ctypes.byref(g), ctypes.byref(d), COORDS[src], COORDS[dst], a.size, _dptr(a), _dptr(b),
+                             float(alt), flags, _dptr(oa), _dptr(ob))
+    if rc != 0:
+        raise ValueError(f'oracle error {rc}')
+    return oa.reshape(shape), ob.reshape(shape)

@@ -1107,3 +1107,129 @@ int pmo_radec_query(const pm_geometry *g, double alt, int n, const double *ra_de
     }
     return PM_OK;
 }
+
+/* ------------------------------------------------------------------ coordinate transforms */
+/*
+ * Array-valued coordinate transforms of the reference, one point at a
+ * time like SpiceBase._maybe_transform_as_arrays (base.py:719-757):
+ *   BodyXY.xy2radec/radec2xy/xy2lonlat/lonlat2xy/xy2km/km2xy/xy2angular/angular2xy
+ *     body_xy.py:385-561
+ *   Body.lonlat2radec/radec2lonlat/radec2angular/angular2radec/angular2lonlat/
+ *     lonlat2angular/km2radec/radec2km/km2lonlat/lonlat2km/km2angular/angular2km
+ *     body.py:1083-1217, 1375-1800
+ * Coordinate systems: 0 = xy [px], 1 = RA/Dec [deg], 2 = angular [arcsec], 3 = km,
+ * 4 = planetographic lon/lat [deg]. flags bit 0: not_visible_nan (from lon/lat), bit 1:
+ * planetocentric lon/lat. `alt`: for TO lon/lat the altitude adjustment of the surface
+ * (_AdjustedSurfaceAltitude), for FROM lon/lat the altitude of the point (pgrrec alt).
+ */
+enum { CS_XY = 0, CS_RADEC = 1, CS_ANGULAR = 2, CS_KM = 3, CS_LONLAT = 4 };
+
+/* Body._test_if_targvec_visible body.py:2112-2150 */
+static int targvec_visible(const pm_geometry *g, const double *radii, const double *tv, int on_surface)
+{
+    if (on_surface) {
+        double ph, in, em;
+        int vis, lit;
+        illumf(g, radii, tv, &ph, &in, &em, &vis, &lit);
+        return vis;
+    }
+    double ov[3], sp[3];
+    targvec2obsvec(g, tv, ov);
+    if (!sincpt(g, radii, ov, sp)) return 1;
+    double pos[3], vel[3], lt_i, lt_p;
+    spkcpt(g, sp, pos, vel, &lt_i);
+    spkcpt(g, tv, pos, vel, &lt_p);
+    return lt_p < lt_i;
+}
+
+int pmo_transform(const pm_geometry *g, const pm_disc *d, int from, int to, size_t n, const double *a,
+                  const double *b, double alt, int flags, double *oa, double *ob)
+{
+    if (from < 0 || from > 4 || to < 0 || to > 4) return PM_ERR_INVALID_ARGUMENT;
+    pmo_frame f0, falt;
+    make_frame(g, d, 0.0, &f0);
+    make_frame(g, d, alt, &falt);
+    double ks = 1.0 / g->km_per_arcsec;
+    double kc = cos(g->np_angle_rad), ksn = sin(g->np_angle_rad);
+    double k00 = ks * kc, k01 = ks * ksn, k10 = -ks * ksn, k11 = ks * kc; /* km -> angular */
+    double kdet = k00 * k11 - k01 * k10;
+    double ik00 = k11 / kdet, ik01 = -k01 / kdet, ik10 = -k10 / kdet, ik11 = k00 / kdet;
+    const int nvn = flags & 1, centric = (flags >> 1) & 1;
+#pragma omp parallel for schedule(static, 256)
+    for (size_t i = 0; i < n; i++) {
+        double p = a[i], q = b[i];
+        double ov[3]; /* observer-frame vector (unit for ray sources) */
+        int have_ov = 1;
+        oa[i] = ob[i] = NAN;
+        /* ---- source -> obsvec */
+        if (from == CS_LONLAT) {
+            /* Body._lonlat2obsvec body.py:1038-1056 */
+            double lon = p, lat = q;
+            if (centric) {
+                /* centric2graphic_lonlat body.py:2970: latsrf + targvec2lonlat(alt) */
+                if (!(isfinite(lon) && isfinite(lat))) { lon = lat = NAN; }
+                else {
+                    double lr = lon * PMO_RAD, br = lat * PMO_RAD;
+                    double dir[3] = {cos(br) * cos(lr), cos(br) * sin(lr), sin(br)};
+                    double s[3], o0[3] = {0, 0, 0};
+                    surfpt(o0, dir, g->radii[0], g->radii[1], g->radii[2], s);
+                    double lo, la, al;
+                    recpgr(g, falt.radii, s, alt == 0.0, &lo, &la, &al);
+                    lon = lo * PMO_DEG; lat = la * PMO_DEG;
+                }
+            }
+            double tv[3];
+            double lr = lon * PMO_RAD, br = lat * PMO_RAD;
+            if (!(isfinite(lr) && isfinite(br) && isfinite(alt))) { nan3(tv); }
+            else {
+                pgrrec(g, g->radii, lr, br, alt, tv);
+                if (nvn && !targvec_visible(g, g->radii, tv, alt == 0.0)) nan3(tv);
+            }
+            if (finite3(tv)) targvec2obsvec(g, tv, ov); else nan3(ov);
+        } else {
+            double ax, ay;
+            if (from == CS_XY) { ax = f0.A[0] * p + f0.A[1] * q + f0.A[2]; ay = f0.A[3] * p + f0.A[4] * q + f0.A[5]; }
+            else if (from == CS_KM) { ax = k00 * p + k01 * q; ay = k10 * p + k11 * q; }
+            else { ax = p; ay = q; }
+            if (from == CS_RADEC) {
+                /* Body._radec2obsvec_norm body.py:964-970 */
+                double ra = p * PMO_RAD, dec = q * PMO_RAD;
+                if (!(isfinite(ra) && isfinite(dec))) nan3(ov); else radrec(1.0, ra, dec, ov);
+            } else {
+                /* Body._angular2obsvec_norm body.py:1363 */
+                double v[3];
+                radrec(1.0, -((ax / 3600.0) * PMO_RAD), (ay / 3600.0) * PMO_RAD, v);
+                mtxv(g->M, v, ov);
+            }
+        }
+        have_ov = finite3(ov);
+        /* ---- obsvec -> destination */
+        if (to == CS_RADEC) {
+            if (have_ov) { double r, ra, dec; recrad(ov, &r, &ra, &dec); oa[i] = ra * PMO_DEG; ob[i] = dec * PMO_DEG; }
+        } else if (to == CS_LONLAT) {
+            /* Body._obsvec_norm2lonlat body.py:1058-1081 (not_found_nan = True) */
+            double sp[3];
+            if (have_ov && sincpt(g, falt.radii, ov, sp)) {
+                double lo, la, al;
+                recpgr(g, falt.radii, sp, 1, &lo, &la, &al);
+                double lon = lo * PMO_DEG, lat = la * PMO_DEG;
+                if (centric) {
+                    /* graphic2centric_lonlat(lon, lat, alt=alt) INSIDE the altitude context:
+                     * pgrrec with the adjusted radii and alt again (body.py:1079-1080, 2940) */
+                    double tv[3], r, l, bb;
+                    pgrrec(g, falt.radii, lon * PMO_RAD, lat * PMO_RAD, alt, tv);
+                    reclat(tv, &r, &l, &bb);
+                    lon = l * PMO_DEG; lat = bb * PMO_DEG;
+                }
+                oa[i] = lon; ob[i] = lat;
+            }
+        } else {
+            double ax, ay;
+            obsvec2angular(g, ov, &ax, &ay);
+            if (to == CS_ANGULAR) { oa[i] = ax; ob[i] = ay; }
+            else if (to == CS_KM) { oa[i] = ik00 * ax + ik01 * ay; ob[i] = ik10 * ax + ik11 * ay; }
+            else { oa[i] = f0.Ai[0] * ax + f0.Ai[1] * ay + f0.Ai[2]; ob[i] = f0.Ai[3] * ax + f0.Ai[4] * ay + f0.Ai[5]; }
+        }
+    }
+    return PM_OK;
+}

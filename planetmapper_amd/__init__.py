@@ -7,7 +7,7 @@ include/planetmapper_hip.h); this package is the thin ctypes layer on top. There
 CPU fallback: without the built library or without a GPU the engine raises.
 """
 
-from .body_xy import Backplane, BackplaneNotFoundError, BodyXY  # noqa: F401
+from .body_xy import Backplane, BackplaneNotFoundError, BodyXY, NotFoundError  # noqa: F401
 from .engine import Engine, device_count  # noqa: F401
 from .geometry import GeometryBuilder, PMDisc, PMGeometry  # noqa: F401
 from .observation import Observation  # noqa: F401

@@ -38,6 +38,10 @@ PM_ERR_UNSUPPORTED = -6
 PM_MEM_HOST = 0
 PM_MEM_DEVICE = 1
 
+COORDS = {'xy': 0, 'radec': 1, 'angular': 2, 'km': 3, 'lonlat': 4}
+PM_TF_NOT_VISIBLE_NAN = 1
+PM_TF_PLANETOCENTRIC = 2
+
 PM_INTERP_NEAREST = 0
 PM_INTERP_LINEAR = 1
 
@@ -46,7 +50,7 @@ EXPORTS = (
     'pm_abi_version', 'pm_device_count', 'pm_create', 'pm_destroy', 'pm_last_error',
     'pm_synchronize', 'pm_stream', 'pm_set_stream', 'pm_device_malloc', 'pm_device_free',
     'pm_memcpy_h2d', 'pm_memcpy_d2h', 'pm_set_geometry', 'pm_set_disc',
-    'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube',
+    'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube', 'pm_transform',
 )  # fmt: skip
 
 
@@ -107,6 +111,9 @@ def load() -> ctypes.CDLL:
     lib.pm_xy_map.argtypes = [vp, vp, vp, c_int, c_int, ctypes.c_double, vp, vp, c_int]
     lib.pm_backplanes_map.argtypes = [
         vp, ctypes.c_uint64, vp, vp, c_int, c_int, ctypes.c_double, dpp, c_int,
+    ]  # fmt: skip
+    lib.pm_transform.argtypes = [
+        vp, c_int, c_int, ctypes.c_uint64, vp, vp, ctypes.c_double, c_int, vp, vp, c_int,
     ]  # fmt: skip
     lib.pm_map_cube.argtypes = [
         vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int,

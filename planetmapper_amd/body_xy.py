@@ -43,6 +43,10 @@ class BackplaneNotFoundError(Exception):
     """body_xy.py:4359"""
 
 
+class NotFoundError(Exception):
+    """Stand-in for spiceypy's NotFoundError (raised when `not_found_nan=False`)."""
+
+
 MAP_KWARG_KEYS = (
     'projection', 'degree_interval', 'lon', 'lat', 'size', 'lon_coords', 'lat_coords',
     'projection_x_coords', 'projection_y_coords', 'xlim', 'ylim', 'alt',
@@ -316,6 +320,87 @@ class BodyXY:
         names = [self.standardise_backplane_name(n) for n in names]
         with _AltitudeContext(self, alt):
             self._img_planes([n for n in names if n in _lib.PLANE_INDEX])
+
+    # ------------------------------------------------------------------ coordinate transforms
+    def _transform(self, src, dst, a, b, *, alt=0.0, not_visible_nan=False, planetocentric=False, not_found_nan=True):
+        """
+        Array-valued transform with the reference's broadcasting rule
+        (`SpiceBase._maybe_transform_as_arrays`, base.py:719-757): two floats in -> a tuple of
+        floats, otherwise the inputs are broadcast together and arrays are returned.
+        """
+        scalar = np.ndim(a) == 0 and np.ndim(b) == 0
+        oa, ob = self._bind().transform(
+            src, dst, a, b, alt=alt, not_visible_nan=not_visible_nan, planetocentric=planetocentric
+        )
+        if not not_found_nan:
+            bad = np.isnan(oa) & np.isfinite(np.broadcast_to(a, oa.shape)) & np.isfinite(np.broadcast_to(b, oa.shape))
+            if np.any(bad):
+                raise NotFoundError('ray does not intercept the target body')
+        if scalar:
+            return float(oa), float(ob)
+        return oa, ob
+
+    # BodyXY: body_xy.py:385-690
+    def xy2radec(self, x, y):
+        return self._transform('xy', 'radec', x, y)
+
+    def radec2xy(self, ra, dec):
+        return self._transform('radec', 'xy', ra, dec)
+
+    def xy2lonlat(self, x, y, *, not_found_nan=True, alt=0.0, planetocentric=False):
+        return self._transform('xy', 'lonlat', x, y, alt=alt, planetocentric=planetocentric, not_found_nan=not_found_nan)
+
+    def lonlat2xy(self, lon, lat, *, alt=0.0, not_visible_nan=True, planetocentric=False):
+        return self._transform('lonlat', 'xy', lon, lat, alt=alt, not_visible_nan=not_visible_nan, planetocentric=planetocentric)
+
+    def xy2km(self, x, y):
+        return self._transform('xy', 'km', x, y)
+
+    def km2xy(self, km_x, km_y):
+        return self._transform('km', 'xy', km_x, km_y)
+
+    def xy2angular(self, x, y):
+        return self._transform('xy', 'angular', x, y)
+
+    def angular2xy(self, angular_x, angular_y):
+        return self._transform('angular', 'xy', angular_x, angular_y)
+
+    # Body: body.py:1083-1217, 1375-1900 (default angular origin only)
+    def lonlat2radec(self, lon, lat, *, alt=0.0, not_visible_nan=True, planetocentric=False):
+        return self._transform('lonlat', 'radec', lon, lat, alt=alt, not_visible_nan=not_visible_nan, planetocentric=planetocentric)
+
+    def radec2lonlat(self, ra, dec, *, not_found_nan=True, alt=0.0, planetocentric=False):
+        return self._transform('radec', 'lonlat', ra, dec, alt=alt, planetocentric=planetocentric, not_found_nan=not_found_nan)
+
+    def radec2angular(self, ra, dec):
+        return self._transform('radec', 'angular', ra, dec)
+
+    def angular2radec(self, angular_x, angular_y):
+        return self._transform('angular', 'radec', angular_x, angular_y)
+
+    def angular2lonlat(self, angular_x, angular_y, *, not_found_nan=True, alt=0.0, planetocentric=False):
+        return self._transform('angular', 'lonlat', angular_x, angular_y, alt=alt, planetocentric=planetocentric, not_found_nan=not_found_nan)
+
+    def lonlat2angular(self, lon, lat, *, alt=0.0, not_visible_nan=True, planetocentric=False):
+        return self._transform('lonlat', 'angular', lon, lat, alt=alt, not_visible_nan=not_visible_nan, planetocentric=planetocentric)
+
+    def km2radec(self, km_x, km_y):
+        return self._transform('km', 'radec', km_x, km_y)
+
+    def radec2km(self, ra, dec):
+        return self._transform('radec', 'km', ra, dec)
+
+    def km2lonlat(self, km_x, km_y, *, not_found_nan=True, alt=0.0, planetocentric=False):
+        return self._transform('km', 'lonlat', km_x, km_y, alt=alt, planetocentric=planetocentric, not_found_nan=not_found_nan)
+
+    def lonlat2km(self, lon, lat, *, alt=0.0, not_visible_nan=True, planetocentric=False):
+        return self._transform('lonlat', 'km', lon, lat, alt=alt, not_visible_nan=not_visible_nan, planetocentric=planetocentric)
+
+    def km2angular(self, km_x, km_y):
+        return self._transform('km', 'angular', km_x, km_y)
+
+    def angular2km(self, angular_x, angular_y):
+        return self._transform('angular', 'km', angular_x, angular_y)
 
     # ------------------------------------------------------------------ map coordinates
     def generate_map_coordinates(

@@ -21,6 +21,7 @@ void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
 void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
+void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
@@ -560,6 +561,55 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, c
                 PM_HIP(ctx, hipMemcpyAsync(out[i], p.out[i], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return PM_OK;
+}
+
+int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a, const double *b, double alt, int flags,
+                 double *out_a, double *out_b, int mem)
+{
+    int rc = check_ready(ctx, true);
+    if (rc != PM_OK) return rc;
+    if (from < 0 || from > PM_COORD_LONLAT || to < 0 || to > PM_COORD_LONLAT)
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown coordinate system");
+    if (n == 0) return PM_OK;
+    if (!a || !b || !out_a || !out_b) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > 0xffffffffull * 256ull) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "too many points");
+    // `alt` adjusts the surface for transforms TO lon/lat and is the point's altitude for
+    // transforms FROM lon/lat (non-finite alt there gives NaN like the reference)
+    double surf_alt = (to == PM_COORD_LONLAT || from == PM_COORD_LONLAT) && std::isfinite(alt) ? alt : 0.0;
+    if (to == PM_COORD_LONLAT && !std::isfinite(alt))
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Cannot adjust surface altitude with non-finite alt value");
+    pm::Params p;
+    fill_params(ctx, surf_alt, p);
+    pm::TransformArgs t;
+    t.n = n;
+    t.alt = alt;
+    t.from = from;
+    t.to = to;
+    t.flags = flags;
+    for (int i = 0; i < 3; i++) t.radii0[i] = ctx->geometry.radii[i];
+    {
+        const pm_geometry &g = ctx->geometry;
+        double ks = 1.0 / g.km_per_arcsec, kc = std::cos(g.np_angle_rad), ksn = std::sin(g.np_angle_rad);
+        t.Kf[0] = ks * kc; t.Kf[1] = ks * ksn; t.Kf[2] = -ks * ksn; t.Kf[3] = ks * kc;
+    }
+    if (mem == PM_MEM_DEVICE) {
+        t.a = a; t.b = b; t.oa = out_a; t.ob = out_b;
+        pm_launch_transform(p, t, ctx->stream);
+        PM_HIP(ctx, hipGetLastError());
+        return PM_OK;
+    }
+    rc = ensure_scratch(ctx, (size_t)n * 4 * sizeof(double));
+    if (rc != PM_OK) return rc;
+    double *base = (double *)ctx->scratch;
+    PM_HIP(ctx, hipMemcpyAsync(base, a, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP(ctx, hipMemcpyAsync(base + n, b, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    t.a = base; t.b = base + n; t.oa = base + 2 * n; t.ob = base + 3 * n;
+    pm_launch_transform(p, t, ctx->stream);
+    PM_HIP(ctx, hipGetLastError());
+    PM_HIP(ctx, hipMemcpyAsync(out_a, t.oa, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipMemcpyAsync(out_b, t.ob, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PM_OK;
 }
 

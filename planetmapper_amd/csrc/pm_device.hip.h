@@ -101,6 +101,17 @@ struct Params {
     int32_t pad_;
 };
 
+// Arguments of the point-transform kernel (pm_transform).
+struct TransformArgs {
+    const double *a, *b;
+    double *oa, *ob;
+    unsigned long long n;
+    double alt;
+    double radii0[3];  // radii WITHOUT the altitude adjustment (p.radii holds radii + alt)
+    double Kf[4];      // km -> angular (p.K is angular -> km)
+    int from, to, flags;
+};
+
 // Per-plane statistics for the NaN pre-clean of map_img (k_median_* kernels).
 struct PlaneStats {
     unsigned long long prefix[2];  // radix-select state of the two middle ranks
@@ -378,6 +389,21 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     const double dx = rho - bx, dz = v.z - bz;
     alt = sqrt_fast(fma(dx, dx, dz * dz));
     if (q < 1.0) alt = -alt;
+}
+
+// pgrrec_c (body.py:903-910): surface point of the spheroid `radii` + alt along its normal
+__device__ __forceinline__ V3 pgrrec_alt(const Params &p, const double *radii, double lon, double lat, double alt)
+{
+    double a = radii[0], b = radii[2];
+    double le = p.g.west_positive ? -lon : lon;
+    double sl, cl, so, co;
+    sincos(lat, &sl, &cl);
+    sincos(le, &so, &co);
+    double big = fmax(fabs(a * cl), fabs(b * sl));
+    double x = a * cl / big, y = b * sl / big;
+    double scale = 1.0 / (big * sqrt(fma(x, x, y * y)));
+    return {fma(alt, co * cl, scale * a * a * co * cl), fma(alt, so * cl, scale * a * a * so * cl),
+            fma(alt, sl, scale * b * b * sl)};
 }
 
 // pgrrec_c (body.py:903-910) at altitude 0

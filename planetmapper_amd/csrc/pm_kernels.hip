@@ -521,6 +521,127 @@ __global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__
     }
 }
 
+// ------------------------------------------------------------------ coordinate transforms
+// Array-valued coordinate transforms (reference: SpiceBase._maybe_transform_as_arrays
+// base.py:719-757 around BodyXY.xy2radec ... angular2xy body_xy.py:385-561 and
+// Body.lonlat2radec ... angular2km body.py:1083-1217, 1375-1800). One lane per point.
+
+// Body._test_if_targvec_visible body.py:2112-2150 (p.radii must be the unadjusted radii)
+__device__ __forceinline__ bool targvec_visible(const Params &p, V3 tv, bool on_surface)
+{
+    if (on_surface) {
+        double lt = p.g.lt_c, ph, in, em;
+        V3 pos;
+        M3 R;
+        point_lt<3>(p, tv, lt, pos, R);
+        illum_angles(p, tv, lt, pos, R, ph, in, em);
+        return em < kHalfPi;
+    }
+    V3 ov = targvec2obsvec(p, tv), sp;
+    double lt_i;
+    if (!sincpt(p, ov, sp, lt_i)) return true;
+    V3 pos;
+    M3 R;
+    point_lt<1>(p, sp, lt_i, pos, R);
+    double lt_p = p.g.lt_c;
+    point_lt<3>(p, tv, lt_p, pos, R);
+    return lt_p < lt_i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_transform(const Params p, const TransformArgs t)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= t.n) return;
+    const double nan = __builtin_nan("");
+    enum { CS_XY = 0, CS_RADEC = 1, CS_ANGULAR = 2, CS_KM = 3, CS_LONLAT = 4 };
+    const bool nvn = t.flags & 1, centric = t.flags & 2;
+    // a copy of the block whose `radii` are the unadjusted ones (source side of lon/lat)
+    double pa = t.a[i], pb = t.b[i], ra_out = nan, rb_out = nan;
+    V3 ov = {nan, nan, nan};
+    if (t.from == CS_LONLAT) {
+        Params p0 = p;
+        p0.radii[0] = t.radii0[0];
+        p0.radii[1] = t.radii0[1];
+        p0.radii[2] = t.radii0[2];
+        double lon = pa, lat = pb;
+        if (centric) {
+            // centric2graphic_lonlat body.py:2970: latsrf_c + targvec2lonlat(alt)
+            if (!(isfinite(lon) && isfinite(lat))) {
+                lon = lat = nan;
+            } else {
+                V3 dir = radrec(lon * kRad, lat * kRad), s;
+                surfpt(v3(0.0, 0.0, 0.0), dir, p0.radii, s);
+                double lo, la, al;
+                if (t.alt == 0.0)
+                    recpgr_surface(p, s, lo, la);
+                else
+                    recpgr_general(p, s, lo, la, al);  // p.radii = radii + alt
+                lon = lo * kDeg;
+                lat = la * kDeg;
+            }
+        }
+        const double lr = lon * kRad, br = lat * kRad;
+        if (isfinite(lr) && isfinite(br) && isfinite(t.alt)) {
+            V3 tv = pgrrec_alt(p0, p0.radii, lr, br, t.alt);
+            if (!nvn || targvec_visible(p0, tv, t.alt == 0.0)) ov = targvec2obsvec(p0, tv);
+        }
+    } else if (t.from == CS_RADEC) {
+        const double ra = pa * kRad, dec = pb * kRad;
+        if (isfinite(ra) && isfinite(dec)) ov = radrec(ra, dec);
+    } else {
+        double ax = pa, ay = pb;
+        if (t.from == CS_XY) {
+            ax = p.A[0] * pa + p.A[1] * pb + p.A[2];
+            ay = p.A[3] * pa + p.A[4] * pb + p.A[5];
+        } else if (t.from == CS_KM) {
+            ax = t.Kf[0] * pa + t.Kf[1] * pb;
+            ay = t.Kf[2] * pa + t.Kf[3] * pb;
+        }
+        V3 v = radrec(-((ax / 3600.0) * kRad), (ay / 3600.0) * kRad);
+        ov = mtxv(p.g.M, v);
+    }
+    const bool have = finite3(ov);
+    if (t.to == CS_RADEC) {
+        if (have) {
+            double ra, dec;
+            recrad(ov, ra, dec);
+            ra_out = ra * kDeg;
+            rb_out = dec * kDeg;
+        }
+    } else if (t.to == CS_LONLAT) {
+        V3 sp;
+        double lt;
+        if (have && sincpt(p, ov, sp, lt)) {  // p.radii = radii + alt
+            double lo, la;
+            recpgr_surface(p, sp, lo, la);
+            double lon = lo * kDeg, lat = la * kDeg;
+            if (centric) {
+                // graphic2centric_lonlat(lon, lat, alt=alt) inside the altitude context
+                V3 tv = pgrrec_alt(p, p.radii, lon * kRad, lat * kRad, t.alt);
+                lat = atan2(tv.z, sqrt(fma(tv.x, tv.x, tv.y * tv.y))) * kDeg;
+                lon = ((tv.x == 0.0 && tv.y == 0.0) ? 0.0 : atan2(tv.y, tv.x)) * kDeg;
+            }
+            ra_out = lon;
+            rb_out = lat;
+        }
+    } else if (have) {
+        double ax, ay;
+        obsvec2angular(p, ov, ax, ay);
+        if (t.to == CS_ANGULAR) {
+            ra_out = ax;
+            rb_out = ay;
+        } else if (t.to == CS_KM) {
+            ra_out = p.K[0] * ax + p.K[1] * ay;
+            rb_out = p.K[2] * ax + p.K[3] * ay;
+        } else {
+            ra_out = p.Ai[0] * ax + p.Ai[1] * ay + p.Ai[2];
+            rb_out = p.Ai[3] * ax + p.Ai[4] * ay + p.Ai[5];
+        }
+    }
+    t.oa[i] = ra_out;
+    t.ob[i] = rb_out;
+}
+
 // ------------------------------------------------------------------ reprojection
 template <typename T>
 __device__ __forceinline__ double load_as_f64(const T *p, size_t i)
@@ -760,6 +881,12 @@ void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s)
         hipLaunchKernelGGL(pm::k_sky<true>, grid, block, 0, s, p);
     else
         hipLaunchKernelGGL(pm::k_sky<false>, grid, block, 0, s, p);
+}
+
+void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s)
+{
+    unsigned long long blocks = (t.n + pm::kBlock - 1) / pm::kBlock;
+    hipLaunchKernelGGL(pm::k_transform, dim3((unsigned)blocks), dim3(pm::kBlock), 0, s, p, t);
 }
 
 void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s)

@@ -193,6 +193,29 @@ class Engine:
             )
         )
 
+    # ------------------------------------------------------------------ point transforms
+    def transform(self, src: str, dst: str, a, b, *, alt: float = 0.0, not_visible_nan=False, planetocentric=False):
+        """
+        Array-valued coordinate transform between 'xy', 'radec', 'angular', 'km' and 'lonlat'
+        (inputs are broadcast together; returns two arrays of the broadcast shape).
+        """
+        a, b = np.broadcast_arrays(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+        shape = a.shape
+        a = np.ascontiguousarray(a).ravel()
+        b = np.ascontiguousarray(b).ravel()
+        oa = np.empty_like(a)
+        ob = np.empty_like(b)
+        flags = (_lib.PM_TF_NOT_VISIBLE_NAN if not_visible_nan else 0) | (
+            _lib.PM_TF_PLANETOCENTRIC if planetocentric else 0
+        )
+        self._check(
+            self._lib.pm_transform(
+                self._ctx, _lib.COORDS[src], _lib.COORDS[dst], a.size, a.ctypes.data, b.ctypes.data, float(alt),
+                flags, oa.ctypes.data, ob.ctypes.data, _lib.PM_MEM_HOST,
+            )
+        )
+        return oa.reshape(shape), ob.reshape(shape)
+
     # ------------------------------------------------------------------ reprojection
     def map_cube(self, cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True) -> np.ndarray:
         """Reproject host cube (P, ny, nx) [or one (ny, nx) image] -> (P, n0, n1) float64."""

@@ -43,3 +43,8 @@ class OracleEngine:
             cube = cube.astype(np.float64)
         self.calls.append(('cube', cube.shape, interpolation))
         return oracle.map_cube(cube, x_map, y_map, interpolation, propagate_nan)
+
+    def transform(self, src, dst, a, b, *, alt=0.0, not_visible_nan=False, planetocentric=False):
+        self.calls.append(('transform', src, dst))
+        return oracle.transform(self._g, self._d, src, dst, a, b, alt=alt, not_visible_nan=not_visible_nan,
+                                planetocentric=planetocentric)

@@ -310,3 +310,59 @@ def test_observation_mapped_data(jupiter):
     # a 2D image is a one-plane cube
     obs2 = Observation(data=cube[0], geometry=jupiter, engine=OracleEngine())
     assert obs2.data.shape == (1, 10, 7) and obs2.get_mapped_data(degree_interval=90).shape == (1, 2, 4)
+
+
+def test_xy_conversions_kat(jupiter):
+    """tests/test_body_xy.py:267-486: disc (5, 8, 3, 45), 15 x 10 image"""
+    from planetmapper_amd import NotFoundError
+
+    body = BodyXY('Jupiter', geometry=jupiter, nx=15, ny=10, engine=OracleEngine())
+    body.set_disc_params(5, 8, 3, 45)
+    # xy, radec, lonlat, km, angular
+    coordinates = [
+        [(0, 0), (196.3684350770821, -5.581107015413806), (nan, nan), (-43515.54503863168, -220566.4464649765), (12.721709080506116, -55.12740601573759)],
+        [(5, 8), (196.37198562427025, -5.565793847134351), (153.1235185909613, -3.0887371238645795), (0.0, 0.0), (0.0, 0.0)],
+        [(4.1, 7.1), (196.37198562427025, -5.567914131973045), (164.3872136538264, -28.87847195832716), (-12411.924521414994, -27675.679236383432), (0.0, -7.633025448335383)],
+        [(1.234, 5.678), (196.37369462098349, -5.572965121633222), (nan, nan), (-64181.931835415264, -83648.1756567178), (-6.1233826374518685, -25.81658829413859)],
+    ]  # fmt: skip
+    close = lambda a, b, **kw: np.allclose(a, b, equal_nan=True, **kw)  # noqa: E731
+    for xy, radec, lonlat, km, angular in coordinates:
+        assert close(body.xy2radec(*xy), radec)
+        assert close(body.xy2lonlat(*xy), lonlat)
+        assert close(body.xy2km(*xy), km, atol=1e-3)
+        assert close(body.xy2angular(*xy), angular, atol=1e-6)
+        assert close(body.radec2xy(*radec), xy, atol=1e-3)
+        assert close(body.km2xy(*km), xy, atol=1e-3)
+        assert close(body.angular2xy(*angular), xy, atol=1e-3)
+        assert close(body.radec2km(*body.xy2radec(*xy)), km, atol=1e-3)
+        assert close(body.km2angular(*km), angular, atol=1e-6)
+        if not any(np.isnan(lonlat)):
+            assert close(body.lonlat2xy(*lonlat), xy, atol=1e-3)
+            assert close(body.radec2lonlat(*radec), lonlat, atol=1e-4)
+    assert isinstance(body.xy2radec(0, 0)[0], float)
+    ra, dec = body.xy2radec(np.array([0, 5]), 8.0)  # broadcasting -> arrays
+    assert ra.shape == (2,) and close((ra[1], dec[1]), coordinates[1][1])
+    for a in [(nan, nan), (nan, 0), (0, nan), (np.inf, np.inf)]:
+        for fn in (body.xy2radec, body.xy2lonlat, body.xy2km, body.radec2xy, body.lonlat2xy, body.km2xy):
+            assert not all(np.isfinite(fn(*a)))
+    # altitude semantics: point altitude for lonlat -> xy, surface adjustment for xy -> lonlat
+    for (lon, lat, alt), expected in [
+        ((42, 23.4, 0), (7.781497231832574, 8.015145501618983)),
+        ((42, 23.4, -123.456), (7.776650117803703, 8.014878507462662)),
+        ((42, 23.4, 1234.567), (7.829968623728911, 8.017815455484365)),
+        ((42, 23.4, nan), (nan, nan)),
+    ]:
+        assert close(body.lonlat2xy(lon, lat, alt=alt, not_visible_nan=False), expected)
+    assert close(body.xy2lonlat(7.781497231832574, 8.015145501618983), (86.30139500952406, 21.109249946237032))
+    assert close(
+        body.xy2lonlat(7.781497231832574, 8.015145501618983, alt=123456.789), (134.58218536012419, 4.708273802335033)
+    )
+    with pytest.raises(NotFoundError):
+        body.xy2lonlat(0, 0, not_found_nan=False)
+    # far side: not visible -> NaN by default, coordinates with not_visible_nan=False
+    assert np.isnan(body.lonlat2radec(0, 0)[0]) and np.isfinite(body.lonlat2radec(0, 0, not_visible_nan=False)[0])
+    # tests/test_body.py:873-881 (radec2lonlat) through the API
+    assert close(body.radec2lonlat(196.372, -5.566), (154.24480750302573, -5.475831082435726))
+    # planetocentric round trip
+    lc = body.xy2lonlat(4.1, 7.1, planetocentric=True)
+    assert close(body.lonlat2xy(*lc, planetocentric=True), (4.1, 7.1), atol=1e-3)

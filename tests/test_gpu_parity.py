@@ -306,3 +306,61 @@ def test_nan_preclean_and_median_paths(engine, oracle, jupiter):
     a = engine.map_cube(c32, xm, ym, 'linear', False)
     b = oracle.map_cube(c32, xm, ym, 'linear', False)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) <= 1e-5
+
+
+def test_point_transforms_vs_oracle(engine, oracle, jupiter):
+    """
+    pm_transform (reference xy2lonlat, lonlat2radec, ... on arrays) against the oracle:
+    every pair of coordinate systems on a cloud of points, altitude and flag variants.
+    """
+    nx, ny = 300, 200
+    engine.set_geometry(jupiter)
+    engine.set_disc(140.5, 90.25, 80.0, float(np.deg2rad(33.0)), nx, ny, True)
+    d = oracle.make_disc(140.5, 90.25, 80.0, 33.0, nx, ny)
+    rng = np.random.default_rng(11)
+    n = 20000
+    xy = (rng.uniform(-20, nx + 20, n), rng.uniform(-20, ny + 20, n))
+    pts = {'xy': xy}
+    for cs in ('radec', 'angular', 'km', 'lonlat'):
+        pts[cs] = oracle.transform(jupiter, d, 'xy', cs, *xy)
+    pts['lonlat'] = (rng.uniform(0, 360, n), rng.uniform(-90, 90, n))
+    ps = jupiter.diameter_arcsec / 160.0
+    tol = {'xy': 2e-9 / ps * 4, 'radec': 1e-12, 'angular': 3e-9, 'km': 1e-5}
+    for src in pts:
+        for dst in ('xy', 'radec', 'angular', 'km', 'lonlat'):
+            for kw in ({}, {'alt': 543.21}, {'planetocentric': True}, {'not_visible_nan': True}):
+                if 'not_visible_nan' in kw and src != 'lonlat':
+                    continue
+                if kw and 'lonlat' not in (src, dst):
+                    continue
+                a = engine.transform(src, dst, *pts[src], **kw)
+                b = oracle.transform(jupiter, d, src, dst, *pts[src], **kw)
+                assert np.array_equal(np.isnan(a[0]), np.isnan(b[0])), (src, dst, kw)
+                fin = np.isfinite(b[0])
+                assert fin.sum() > 100, (src, dst, kw)
+                if dst == 'lonlat':
+                    # conditioned like the image planes: compare on the sphere, scaled by the
+                    # emission-angle amplification
+                    lon_a, lat_a, lon_b, lat_b = (np.deg2rad(v[fin]) for v in (a[0], a[1], b[0], b[1]))
+                    dang = np.hypot((lon_a - lon_b + np.pi) % (2 * np.pi) - np.pi, lat_a - lat_b) * np.cos(lat_b)
+                    em = np.deg2rad(
+                        oracle.backplanes_map(jupiter, d, ['EMISSION'], b[0][fin][None], b[1][fin][None])['EMISSION'][0]
+                    ) if 'planetocentric' not in kw and 'alt' not in kw else None
+                    if em is not None:
+                        assert np.all(np.rad2deg(dang) <= 5e-9 / np.clip(np.abs(np.cos(em)), 1e-7, None)), (src, dst)
+                    else:
+                        assert np.median(np.rad2deg(dang)) < 1e-9 and np.max(np.rad2deg(dang)) < 1e-5, (src, dst, kw)
+                else:
+                    for u, v in zip(a, b):
+                        dd = np.abs(u[fin] - v[fin])
+                        if dst == 'radec':
+                            dd = np.minimum(dd, 360 - dd)
+                        assert dd.max() <= tol[dst], (src, dst, kw, dd.max())
+    # scalars and broadcasting through the reference-compatible API
+    from planetmapper_amd import BodyXY
+
+    body = BodyXY('Jupiter', geometry=jupiter, nx=15, ny=10)
+    body.set_disc_params(5, 8, 3, 45)
+    assert np.allclose(body.xy2lonlat(5, 8), (153.1235185909613, -3.0887371238645795))
+    assert np.allclose(body.lonlat2xy(42, 23.4, alt=1234.567, not_visible_nan=False), (7.829968623728911, 8.017815455484365))
+    assert np.isnan(body.xy2lonlat(0, 0)[0])

@@ -93,6 +93,8 @@ class BodyXY:
         geometry: a filled `PMGeometry` block (from `GeometryBuilder` or from a
             spiceypy-backed reference `Body`).
         scenario: name of a packaged scenario (`planetmapper_amd.scenarios`).
+        kernels: directory searched recursively for `*.bsp` / `*.tpc` / `*.tls` kernels like
+            the reference's `kernel_path` (`planetmapper_amd.kernels`; SPK types 2/3 only).
         optimize_speed: enables the radius pre-mask exactly like the reference
             (`SpiceBase(optimize_speed=True)`, base.py:229; body_xy.py:3201-3218).
         device: GPU index.
@@ -109,6 +111,7 @@ class BodyXY:
         sz: int | None = None,
         geometry: PMGeometry | None = None,
         scenario: str | None = None,
+        kernels: str | None = None,
         optimize_speed: bool = True,
         device: int = 0,
         engine: Engine | None = None,
@@ -119,12 +122,17 @@ class BodyXY:
             nx = sz
             ny = sz
         if geometry is None:
-            if scenario is None:
+            if kernels is not None:
+                from .kernels import geometry_from_kernels
+
+                geometry = geometry_from_kernels(target, utc, observer, kernels)
+            elif scenario is not None:
+                geometry = load_scenario(scenario)
+            else:
                 raise ValueError(
-                    'BodyXY needs `geometry=` (a PMGeometry block) or `scenario=`: this package '
-                    'does not load SPICE kernels itself (see INTEGRATION.md)'
+                    'BodyXY needs `geometry=` (a PMGeometry block), `kernels=` (a directory of '
+                    '*.bsp/*.tpc/*.tls files) or `scenario=` (see INTEGRATION.md)'
                 )
-            geometry = load_scenario(scenario)
         self._geometry = geometry.copy()
         self.target = None if target is None else str(target).strip().upper()
         self.utc = utc

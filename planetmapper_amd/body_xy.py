@@ -428,8 +428,9 @@ class BodyXY:
         alt: float = 0.0,
     ):
         """
-        body_xy.py:2755-3012 for `'rectangular'` and `'manual'` projections (the pyproj
-        based ones are out of scope: feed their lon/lat grids in as `'manual'`).
+        body_xy.py:2755-3012: `'rectangular'`, `'manual'`, `'orthographic'`, `'azimuthal'` and
+        `'azimuthal equal area'` (closed forms of the PROJ transforms, `projections.py`);
+        custom proj strings need pyproj and are not supported.
         Returns `(lons, lats, xx, yy, transformer, info)` with `transformer = None`.
         """
         if projection == 'rectangular':
@@ -438,6 +439,7 @@ class BodyXY:
                 lons = lons[::-1]
             lats = np.arange(-90 + degree_interval / 2, 90, degree_interval)
             lons, lats = np.meshgrid(lons, lats)
+            xx, yy = lons, lats
             info: dict[str, Any] = dict(projection=projection, degree_interval=degree_interval)
         elif projection == 'manual':
             if lon_coords is None or lat_coords is None:
@@ -454,13 +456,25 @@ class BodyXY:
                 raise ValueError('lon_coords and lat_coords must have the same shape')
             lons = np.array(lons, dtype=float)
             lats = np.array(lats, dtype=float)
+            xx, yy = lons, lats
             info = dict(projection=projection)
+        elif projection in ('orthographic', 'azimuthal', 'azimuthal equal area'):
+            # closed forms of the PROJ inverse the reference uses (body_xy.py:2930-2968)
+            from . import projections
+
+            west = self.positive_longitude_direction == 'W'
+            if projection == 'orthographic':
+                lons, lats, xx, yy = projections.orthographic(self.r_eq, self.r_polar, lon, lat, size, west)
+            elif projection == 'azimuthal':
+                lons, lats, xx, yy = projections.azimuthal(lon, lat, size, west)
+            else:
+                lons, lats, xx, yy = projections.azimuthal_equal_area(lon, lat, size, west)
+            info = dict(projection=projection, lon=lon, lat=lat, size=size)
         else:
             raise _lib.UnsupportedError(
-                f'projection {projection!r} needs pyproj in the reference and is not part of this path; '
-                "pass its lon/lat grids with projection='manual'"
+                f'custom proj string {projection!r} needs pyproj in the reference and is not part of this '
+                "path; pass its lon/lat grids with projection='manual'"
             )
-        xx, yy = lons, lats
         info['xlim'] = xlim
         info['ylim'] = ylim
         if xlim is not None:

@@ -134,7 +134,8 @@ def main(ref: str) -> None:
     for name in [
         'test_nav', 'test_nav_alt',
         'map_rectangular-linear', 'map_rectangular-nearest', 'map_rectangular-nearest-alt',
-        'map_orthographic-1', 'map_azimuthal-1',
+        'map_orthographic-1', 'map_orthographic-2', 'map_orthographic-3',
+        'map_azimuthal-1', 'map_azimuthal-2', 'map_azimuthal-3',
     ]:  # fmt: skip
         hdr = fits_to_npz(
             os.path.join(odir, name + '.fits'),

@@ -221,7 +221,7 @@ def test_generate_map_coordinates(body):
     with pytest.raises(ValueError):
         body.generate_map_coordinates('manual', lon_coords=np.zeros((1, 2, 2)), lat_coords=np.zeros((1, 2, 2)))
     with pytest.raises(UnsupportedError):
-        body.generate_map_coordinates('orthographic')
+        body.generate_map_coordinates('+proj=ortho +axis=wnu +type=crs', projection_x_coords=[0, 1])
     assert body.get_lon_map(degree_interval=90).shape == (2, 4)
     assert body.get_lon_map(projection='manual', lon_coords=[-10, 370], lat_coords=[0])[0].tolist() == [350, 10]
 
@@ -366,3 +366,44 @@ def test_xy_conversions_kat(jupiter):
     # planetocentric round trip
     lc = body.xy2lonlat(4.1, 7.1, planetocentric=True)
     assert close(body.lonlat2xy(*lc, planetocentric=True), (4.1, 7.1), atol=1e-3)
+
+
+@pytest.mark.parametrize(
+    'name,kw',
+    [
+        ('map_orthographic_1', dict(projection='orthographic', size=10)),
+        ('map_orthographic_2', dict(projection='orthographic', lat=90, size=5)),
+        ('map_orthographic_3', dict(projection='orthographic', lat=-21.3, lon=-42, size=4)),
+        ('map_azimuthal_1', dict(projection='azimuthal', size=10)),
+        ('map_azimuthal_2', dict(projection='azimuthal', lat=-90, size=5)),
+        ('map_azimuthal_3', dict(projection='azimuthal', lat=42, lon=12.345, size=4)),
+    ],
+)
+def test_pyproj_free_projections_match_golden_maps(body, name, kw):
+    """
+    tests/test_observation.py:1123-1153: the orthographic / azimuthal golden maps (all
+    map-space backplanes and the mapped cube) with the closed-form projection grids.
+    """
+    import os
+
+    from conftest import GOLDEN
+
+    gold = np.load(os.path.join(GOLDEN, f'golden_{name}.npz'))
+    body.set_img_size(7, 10)
+    body.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    lons, lats, xx, yy, tr, info = body.generate_map_coordinates(**kw)
+    assert np.array_equal(np.isnan(lons), np.isnan(gold['LON-GRAPHIC']))
+    assert info['projection'] == kw['projection'] and info['size'] == kw['size']
+    for n in body.backplanes:
+        if n in gold.files:
+            m = body.get_backplane_map(n, **kw)
+            assert np.allclose(m, gold[n], rtol=1e-5, atol=1e-6, equal_nan=True), n
+    cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
+    assert np.allclose(body.map_img(cube, **kw), gold['PRIMARY'], rtol=1e-5, atol=1e-6, equal_nan=True)
+
+
+def test_azimuthal_equal_area_grid(body):
+    """`laea` on a sphere: equal areas - the lon/lat cell Jacobian is constant."""
+    lons, lats, xx, yy, _, _ = body.generate_map_coordinates('azimuthal equal area', size=41, lat=30, lon=100)
+    assert np.isnan(lons[0, 0]) and np.isfinite(lons[20, 20])
+    assert lats[20, 20] == pytest.approx(30.0) and (lons[20, 20] % 360) == pytest.approx(100.0)

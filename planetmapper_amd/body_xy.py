@@ -168,6 +168,11 @@ class BodyXY:
         self._register_default_backplanes()
         self.reset_disc_params()
 
+    @property
+    def geometry(self) -> PMGeometry:
+        """A copy of the geometry block this body was built from (reusable for other instances)."""
+        return self._geometry.copy()
+
     def __repr__(self) -> str:
         return f'BodyXY({self.target!r}, {self.utc!r}, observer={self.observer!r}, nx={self._nx}, ny={self._ny})'
 

@@ -147,8 +147,14 @@ typedef struct pm_disc {
 
 typedef enum pm_interpolation {
     PM_INTERP_NEAREST = 0, /* body_xy.py:1633 _do_nearest_interpolation */
-    PM_INTERP_LINEAR = 1   /* body_xy.py:1651 _do_spline_interpolation, kx=ky=1, s=0 */
+    PM_INTERP_LINEAR = 1,  /* body_xy.py:1651 _do_spline_interpolation, kx=ky=1, s=0 */
+    /* RectBivariateSpline(kx=k_rows, ky=k_cols, s=0) interpolating splines ('quadratic' =
+     * (2, 2), 'cubic' = (3, 3), mixed degrees), body_xy.py:1651-1702:
+     * PM_INTERP_SPLINE(k_rows, k_cols); k_rows is the degree along image rows (axis 0),
+     * which the reference calls kx. Degrees 1..5. */
+    PM_INTERP_SPLINE_FLAG = 0x100
 } pm_interpolation;
+#define PM_INTERP_SPLINE(k_rows, k_cols) (PM_INTERP_SPLINE_FLAG | ((k_rows) << 4) | (k_cols))
 
 typedef enum pm_dtype {
     PM_F64 = 0, PM_F32 = 1, PM_I16 = 2, PM_I32 = 3, PM_U8 = 4, PM_U16 = 5

@@ -93,6 +93,10 @@ def lib() -> ctypes.CDLL:
         _lib.pmo_radec_query.argtypes = [
             ctypes.POINTER(PMGeometry), ctypes.c_double, ctypes.c_int, dp, dp, ctypes.c_int, dp,
         ]
+        _lib.pmo_map_cube_spline.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp,
+        ]
         _lib.pmo_transform.argtypes = [
             ctypes.POINTER(PMGeometry), ctypes.POINTER(PMDisc), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
             dp, dp, ctypes.c_double, ctypes.c_int, dp, dp,
@@ -177,7 +181,18 @@ def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_n
     ym = np.ascontiguousarray(y_map, dtype=np.float64)
     n0, n1 = xm.shape
     out = np.empty((p, n0, n1), dtype=np.float64)
-    interp = {'nearest': 0, 'linear': 1, 1: 1}[interpolation]
+    spline = {'quadratic': (2, 2), 'cubic': (3, 3), 2: (2, 2), 3: (3, 3)}.get(interpolation)
+    if isinstance(interpolation, tuple):
+        spline = interpolation
+    if spline is not None and spline != (1, 1):
+        rc = lib().pmo_map_cube_spline(
+            cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym), n0, n1,
+            int(spline[0]), int(spline[1]), 1 if propagate_nan else 0, _dptr(out),
+        )
+        if rc != 0:
+            raise ValueError(f'oracle error {rc}')
+        return out
+    interp = {'nearest': 0, 'linear': 1, 1: 1, (1, 1): 1}[interpolation]
     rc = lib().pmo_map_cube(
         cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym),
         n0, n1, interp, 1 if propagate_nan else 0, _dptr(out),

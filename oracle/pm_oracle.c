@@ -1035,6 +1035,150 @@ int pmo_map_cube(const void *cube, int dtype, int n_planes, int ny, int nx, cons
     return PM_OK;
 }
 
+/* ------------------------------------------------------------------ spline reprojection */
+/*
+ * scipy.interpolate.RectBivariateSpline(arange(ny), arange(nx), img, kx, ky, s=0).ev(y, x)
+ * as used by BodyXY._do_spline_interpolation (body_xy.py:1651-1702) for 'quadratic',
+ * 'cubic' and (k0, k1) interpolation: FITPACK `regrid` with s = 0 is the INTERPOLATING
+ * tensor-product B-spline. Knots (FITPACK fpgrre/fpcurf, s = 0): k+1-fold end knots at the
+ * first / last sample; interior knots at the samples x[k/2+1 ...] for odd k and at the
+ * midpoints between them for even k. Restated: collocation matrix per axis, banded Gaussian
+ * elimination (B-spline collocation matrices are totally positive: no pivoting needed),
+ * de Boor-Cox basis evaluation (fpbspl). Note PM's naming: `kx` is the degree along image
+ * ROWS (axis 0), `ky` along columns (body_xy.py:1673-1680).
+ */
+typedef struct pmo_axis {
+    int n, k;
+    double *t;  /* n + k + 1 knots */
+    double *a;  /* n x (2k + 1) banded collocation matrix, row i col j at a[i*(2k+1) + (j - i + k)] */
+} pmo_axis;
+
+static void bspl_basis(const double *t, int k, double x, int l, double *h)
+{
+    /* fpbspl: the k+1 non-zero B-splines of degree k at t[l] <= x < t[l+1] */
+    double hh[6];
+    h[0] = 1.0;
+    for (int j = 1; j <= k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; i++) {
+            int li = l + i, lj = li - j;
+            double f = hh[i - 1] / (t[li] - t[lj]);
+            h[i - 1] += f * (t[li] - x);
+            h[i] = f * (x - t[lj]);
+        }
+    }
+}
+static int find_interval(const pmo_axis *ax, double x)
+{
+    /* l with t[l] <= x < t[l+1], k <= l <= n-1 (the last knot span is closed on the right) */
+    int l = ax->k;
+    while (l < ax->n - 1 && x >= ax->t[l + 1]) l++;
+    return l;
+}
+static int axis_init(pmo_axis *ax, int n, int k)
+{
+    ax->n = n; ax->k = k;
+    ax->t = (double *)calloc((size_t)n + k + 1, sizeof(double));
+    int w = 2 * k + 1;
+    ax->a = (double *)calloc((size_t)n * w, sizeof(double));
+    if (!ax->t || !ax->a) return 0;
+    for (int i = 0; i <= k; i++) { ax->t[i] = 0.0; ax->t[n + i] = (double)(n - 1); }
+    int k3 = k / 2;
+    for (int l = 0; l < n - k - 1; l++) {
+        int j = k3 + 1 + l; /* 0-based sample index */
+        ax->t[k + 1 + l] = (k3 * 2 == k) ? 0.5 * ((double)j + (double)(j - 1)) : (double)j;
+    }
+    for (int i = 0; i < n; i++) {
+        double h[6];
+        int l = find_interval(ax, (double)i);
+        bspl_basis(ax->t, k, (double)i, l, h);
+        for (int q = 0; q <= k; q++) {
+            int j = l - k + q;
+            ax->a[(size_t)i * w + (j - i + k)] = h[q];
+        }
+    }
+    /* in-place banded LU without pivoting */
+    for (int p = 0; p < n; p++) {
+        double piv = ax->a[(size_t)p * w + k];
+        for (int i = p + 1; i <= p + k && i < n; i++) {
+            double f = ax->a[(size_t)i * w + (p - i + k)] / piv;
+            if (f == 0.0) continue;
+            ax->a[(size_t)i * w + (p - i + k)] = f;
+            for (int j = p + 1; j <= p + k && j < n; j++)
+                ax->a[(size_t)i * w + (j - i + k)] -= f * ax->a[(size_t)p * w + (j - p + k)];
+        }
+    }
+    return 1;
+}
+static void axis_free(pmo_axis *ax) { free(ax->t); free(ax->a); }
+/* solve B c = v in place for a strided vector */
+static void axis_solve(const pmo_axis *ax, double *v, size_t stride)
+{
+    int n = ax->n, k = ax->k, w = 2 * k + 1;
+    for (int i = 0; i < n; i++)
+        for (int j = (i - k < 0 ? 0 : i - k); j < i; j++) v[i * stride] -= ax->a[(size_t)i * w + (j - i + k)] * v[j * stride];
+    for (int i = n - 1; i >= 0; i--) {
+        for (int j = i + 1; j <= i + k && j < n; j++) v[i * stride] -= ax->a[(size_t)i * w + (j - i + k)] * v[j * stride];
+        v[i * stride] /= ax->a[(size_t)i * w + k];
+    }
+}
+
+int pmo_map_cube_spline(const void *cube, int dtype, int n_planes, int ny, int nx, const double *x_map,
+                        const double *y_map, int n0, int n1, int k_rows, int k_cols, int propagate_nan,
+                        double *out)
+{
+    size_t npx = (size_t)ny * nx, nmap = (size_t)n0 * n1;
+    size_t esz = dtype_size(dtype);
+    if (esz == 0 || k_rows < 1 || k_rows > 5 || k_cols < 1 || k_cols > 5) return PM_ERR_INVALID_ARGUMENT;
+    if (ny <= k_rows || nx <= k_cols) return PM_ERR_INVALID_ARGUMENT; /* FITPACK: m > k */
+    pmo_axis ay, ax;
+    if (!axis_init(&ay, ny, k_rows) || !axis_init(&ax, nx, k_cols)) return PM_ERR_ALLOC;
+    double *img = (double *)malloc(npx * sizeof(double));
+    double *c = (double *)malloc(npx * sizeof(double));
+    for (int p = 0; p < n_planes; p++) {
+        const char *src = (const char *)cube + (size_t)p * npx * esz;
+        double *o = out + (size_t)p * nmap;
+        int all_nan = 1;
+        for (size_t i = 0; i < npx; i++) {
+            img[i] = load_px(src, dtype, i);
+            if (!isnan(img[i])) all_nan = 0;
+        }
+        for (size_t m = 0; m < nmap; m++) o[m] = NAN;
+        if (all_nan) continue;
+        clean_nans(img, ny, nx, c);
+        for (int j = 0; j < nx; j++) axis_solve(&ay, c + j, (size_t)nx);       /* along rows index (axis 0) */
+        for (int i = 0; i < ny; i++) axis_solve(&ax, c + (size_t)i * nx, 1);    /* along columns (axis 1) */
+        for (size_t m = 0; m < nmap; m++) {
+            double x = x_map[m], y = y_map[m];
+            if (isnan(x)) continue;
+            if (propagate_nan) {
+                if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) continue;
+                long xa = (long)fmax(floor(x), 0.0), xb = (long)fmin(ceil(x), nx - 1.0);
+                long ya = (long)fmax(floor(y), 0.0), yb = (long)fmin(ceil(y), ny - 1.0);
+                if (isnan(img[ya * nx + xa]) || isnan(img[ya * nx + xb]) || isnan(img[yb * nx + xa]) ||
+                    isnan(img[yb * nx + xb]))
+                    continue;
+            }
+            double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
+            double hy[6], hx[6];
+            int ly = find_interval(&ay, yc), lx = find_interval(&ax, xc);
+            bspl_basis(ay.t, k_rows, yc, ly, hy);
+            bspl_basis(ax.t, k_cols, xc, lx, hx);
+            double s = 0.0;
+            for (int a = 0; a <= k_rows; a++) {
+                double r = 0.0;
+                for (int b = 0; b <= k_cols; b++) r += hx[b] * c[(size_t)(ly - k_rows + a) * nx + (lx - k_cols + b)];
+                s += hy[a] * r;
+            }
+            o[m] = s;
+        }
+    }
+    free(img); free(c);
+    axis_free(&ay); axis_free(&ax);
+    return PM_OK;
+}
+
 /* rectangular map grid: BodyXY.generate_map_coordinates body_xy.py:2899-2907 */
 int pmo_rectangular_grid(const pm_geometry *g, double degree_interval, int n0, int n1,
                          double *lon_deg, double *lat_deg)

@@ -564,23 +564,21 @@ class BodyXY:
     ) -> np.ndarray:
         """
         body_xy.py:1414-1631: project an image (ny, nx) - or a cube (P, ny, nx) - onto
-        the map grid. `'linear'` (RectBivariateSpline k=1, s=0 == bilinear) and
-        `'nearest'` run on the GPU; the other interpolations of the reference are not
-        part of this path yet and raise `UnsupportedError`.
+        the map grid. `'nearest'`, `'linear'`, `'quadratic'`, `'cubic'`, integer degrees and
+        `(k_rows, k_cols)` tuples (RectBivariateSpline with s=0) run on the GPU; `'smooth'` and
+        `spline_smoothing > 0` raise `UnsupportedError`.
         """
         img = np.asarray(img)
+        from .engine import interpolation_code
+
+        if interpolation == 'smooth':
+            raise _lib.UnsupportedError(
+                "interpolation 'smooth' (PCHIP oversampling, body_xy.py:1704-1853) is not implemented on the GPU path"
+            )
+        interpolation_code(interpolation)  # ValueError for unknown methods (body_xy.py:1630)
+        if interpolation != 'nearest' and spline_smoothing != 0:
+            raise _lib.UnsupportedError('spline_smoothing != 0 (FITPACK smoothing) is not implemented on the GPU path')
         interp = interpolation
-        if interp == 1 or interp == (1, 1):
-            interp = 'linear'
-        if interp not in ('linear', 'nearest'):
-            if interp in ('quadratic', 'cubic', 'smooth') or isinstance(interp, (int, tuple)):
-                raise _lib.UnsupportedError(
-                    f'interpolation {interpolation!r} (FITPACK splines / PCHIP, body_xy.py:1651-1853) '
-                    'is not implemented on the GPU path'
-                )
-            raise ValueError(f'Unknown interpolation method {interpolation!r}')
-        if interp == 'linear' and spline_smoothing != 0:
-            raise _lib.UnsupportedError('spline_smoothing != 0 is not implemented on the GPU path')
         single = img.ndim == 2
         if img.ndim not in (2, 3) or img.shape[-2:] != (self._ny, self._nx):
             raise ValueError(
@@ -589,7 +587,7 @@ class BodyXY:
             )
         x_map = self.get_x_map(**map_kwargs)
         y_map = self.get_y_map(**map_kwargs)
-        if warn_nan and interp == 'linear' and not np.all(np.isfinite(img)):
+        if warn_nan and interp != 'nearest' and not np.all(np.isfinite(img)):
             print('Warning, image contains NaN values which will be corrected')
         out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan)
         return out[0] if single else out

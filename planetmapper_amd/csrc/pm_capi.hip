@@ -22,6 +22,7 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
 void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
 void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
+void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
@@ -48,6 +49,13 @@ struct pm_ctx {
     bool pending = false;
     pm::ReprojectArgs pending_args{};
     int pending_dtype = 0;
+    // spline reprojection: coefficient workspace + per-axis knots / LU (cached per (n, k))
+    double *work = nullptr;
+    size_t work_bytes = 0;
+    struct AxisCache {
+        int n = 0, k = 0;
+        double *t = nullptr, *lu = nullptr;
+    } axis[2];
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
     bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
@@ -205,6 +213,115 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     for (int i = 0; i < PM_NUM_PLANES; i++) p.out[i] = nullptr;
 }
 
+// Knots and banded LU of the B-spline collocation matrix of one axis (n unit-spaced samples,
+// degree k, FITPACK's s = 0 knot placement), uploaded once per (n, k).
+int ensure_axis(pm_ctx *ctx, int which, int n, int k, pm::SplineAxis &out)
+{
+    pm_ctx::AxisCache &ac = ctx->axis[which];
+    if (ac.n != n || ac.k != k) {
+        const int w = 2 * k + 1;
+        std::vector<double> t((size_t)n + k + 1, 0.0), a((size_t)n * w, 0.0);
+        for (int i = 0; i <= k; i++) t[n + i] = (double)(n - 1);
+        const int k3 = k / 2;
+        for (int l = 0; l < n - k - 1; l++) {
+            const int j = k3 + 1 + l;
+            t[k + 1 + l] = (k3 * 2 == k) ? 0.5 * ((double)j + (double)(j - 1)) : (double)j;
+        }
+        for (int i = 0; i < n; i++) {
+            int l = k;
+            while (l < n - 1 && (double)i >= t[l + 1]) l++;
+            double h[6], hh[6];
+            h[0] = 1.0;
+            for (int j = 1; j <= k; j++) {  // fpbspl
+                for (int q = 0; q < j; q++) hh[q] = h[q];
+                h[0] = 0.0;
+                for (int q = 1; q <= j; q++) {
+                    const int li = l + q, lj = li - j;
+                    const double f = hh[q - 1] / (t[li] - t[lj]);
+                    h[q - 1] += f * (t[li] - (double)i);
+                    h[q] = f * ((double)i - t[lj]);
+                }
+            }
+            for (int q = 0; q <= k; q++) {
+                const int j = l - k + q;
+                a[(size_t)i * w + (j - i + k)] = h[q];
+            }
+        }
+        for (int p = 0; p < n; p++) {  // banded LU, no pivoting (totally positive matrix)
+            const double piv = a[(size_t)p * w + k];
+            for (int i = p + 1; i <= p + k && i < n; i++) {
+                const double f = a[(size_t)i * w + (p - i + k)] / piv;
+                if (f == 0.0) continue;
+                a[(size_t)i * w + (p - i + k)] = f;
+                for (int j = p + 1; j <= p + k && j < n; j++) a[(size_t)i * w + (j - i + k)] -= f * a[(size_t)p * w + (j - p + k)];
+            }
+        }
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ac.t) PM_HIP(ctx, hipFree(ac.t));
+        if (ac.lu) PM_HIP(ctx, hipFree(ac.lu));
+        ac = pm_ctx::AxisCache();
+        if (hipMalloc((void **)&ac.t, t.size() * sizeof(double)) != hipSuccess ||
+            hipMalloc((void **)&ac.lu, a.size() * sizeof(double)) != hipSuccess)
+            return fail(ctx, PM_ERR_ALLOC, "hipMalloc of spline factors failed");
+        PM_HIP(ctx, hipMemcpy(ac.t, t.data(), t.size() * sizeof(double), hipMemcpyHostToDevice));
+        PM_HIP(ctx, hipMemcpy(ac.lu, a.data(), a.size() * sizeof(double), hipMemcpyHostToDevice));
+        ac.n = n;
+        ac.k = k;
+    }
+    out.t = ac.t;
+    out.lu = ac.lu;
+    out.n = n;
+    out.k = k;
+    return PM_OK;
+}
+
+int ensure_work(pm_ctx *ctx, size_t bytes)
+{
+    if (bytes <= ctx->work_bytes) return PM_OK;
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->work) PM_HIP(ctx, hipFree(ctx->work));
+    ctx->work = nullptr;
+    ctx->work_bytes = 0;
+    hipError_t e = hipMalloc((void **)&ctx->work, bytes);
+    if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipMalloc(%zu) of the spline workspace failed", bytes);
+    ctx->work_bytes = bytes;
+    return PM_OK;
+}
+
+// Spline reprojection of planes resident on the device (plane chunks bound the workspace).
+int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols)
+{
+    const size_t plane_elems = (size_t)a.ny * a.nx;
+    pm::SplineArgs sa;
+    int rc = ensure_axis(ctx, 0, a.ny, k_rows, sa.rows);
+    if (rc != PM_OK) return rc;
+    rc = ensure_axis(ctx, 1, a.nx, k_cols, sa.cols);
+    if (rc != PM_OK) return rc;
+    size_t chunk = (size_t)(2ull << 30) / (plane_elems * sizeof(double));
+    if (chunk < 1) chunk = 1;
+    if (chunk > (size_t)a.n_planes) chunk = (size_t)a.n_planes;
+    if (chunk > 32768) chunk = 32768;
+    rc = ensure_work(ctx, chunk * plane_elems * sizeof(double));
+    if (rc != PM_OK) return rc;
+    rc = ensure_stats(ctx, chunk);
+    if (rc != PM_OK) return rc;
+    sa.work = ctx->work;
+    for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += chunk) {
+        const int np = (int)std::min(chunk, (size_t)a.n_planes - p0);
+        pm::ReprojectArgs b = a;
+        b.n_planes = np;
+        b.cube = (const char *)a.cube + p0 * plane_elems * dtype_size(dtype);
+        b.out = a.out + p0 * a.n_map;
+        b.plane_stats = ctx->stats;
+        PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)np * sizeof(pm::PlaneStats), ctx->stream));
+        PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)np * 512 * sizeof(unsigned int), ctx->stream));
+        pm_launch_plane_medians(b.cube, dtype, np, plane_elems, ctx->stats, ctx->hist, ctx->stream);
+        pm_launch_spline(b, sa, dtype, ctx->stream);
+    }
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
 // Reproject `a.n_planes` planes that are resident on the device. First pass without plane
 // statistics; if a plane reports that it needs its nanmedian (flags bit 1), the medians are
 // computed and the planes are mapped again. `sync_now`: examine the flags immediately
@@ -348,6 +465,11 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
+    if (ctx->work) (void)hipFree(ctx->work);
+    for (auto &ac : ctx->axis) {
+        if (ac.t) (void)hipFree(ac.t);
+        if (ac.lu) (void)hipFree(ac.lu);
+    }
     if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->hist) (void)hipFree(ctx->hist);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -632,8 +754,19 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     size_t esz = dtype_size(dtype);
     if (esz == 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
     // BodyXY.map_img body_xy.py:1630: ValueError for unknown interpolation
-    if (interpolation != PM_INTERP_NEAREST && interpolation != PM_INTERP_LINEAR)
+    int k_rows = 0, k_cols = 0;
+    if (interpolation & PM_INTERP_SPLINE_FLAG) {
+        k_rows = (interpolation >> 4) & 0xF;
+        k_cols = interpolation & 0xF;
+        if ((interpolation & ~0x1FF) || k_rows < 1 || k_rows > 5 || k_cols < 1 || k_cols > 5)
+            return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Unknown interpolation method %d", interpolation);
+        if (k_rows == 1 && k_cols == 1) {
+            interpolation = PM_INTERP_LINEAR;
+            k_rows = k_cols = 0;
+        }
+    } else if (interpolation != PM_INTERP_NEAREST && interpolation != PM_INTERP_LINEAR) {
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Unknown interpolation method %d", interpolation);
+    }
     const pm_disc &d = ctx->disc;
     if (d.nx <= 0 || d.ny <= 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image size is empty");
     if (n_planes < 0 || n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative shape");
@@ -655,9 +788,19 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     a.interpolation = interpolation;
     a.propagate_nan = propagate_nan ? 1 : 0;
     a.plane_stats = nullptr;
+    a.seq = 0;
     rc = ensure_flags(ctx, (size_t)n_planes);
     if (rc != PM_OK) return rc;
 
+    if (k_rows) {
+        // FITPACK needs more samples than the degree along each axis (scipy raises otherwise)
+        if (d.ny <= k_rows || d.nx <= k_cols)
+            return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image too small for spline degree (%d, %d)", k_rows, k_cols);
+        if (ctx->pending) {
+            rc = pm_synchronize(ctx);
+            if (rc != PM_OK) return rc;
+        }
+    }
     if (mem == PM_MEM_DEVICE) {
         a.cube = cube;
         a.x_map = x_map;
@@ -665,6 +808,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         a.out = out;
         a.plane_flags = ctx->flags;
         a.n_planes = n_planes;
+        if (k_rows) return reproject_spline_resident(ctx, a, dtype, k_rows, k_cols);
         return reproject_resident(ctx, a, dtype, /*sync_now=*/force_sync);
     }
     // host cube: stream it through the device in chunks of planes
@@ -693,7 +837,8 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         b.out = dout;
         b.plane_flags = ctx->flags;
         b.n_planes = (int)np;
-        rc = reproject_resident(ctx, b, dtype, /*sync_now=*/true);
+        rc = k_rows ? reproject_spline_resident(ctx, b, dtype, k_rows, k_cols)
+                    : reproject_resident(ctx, b, dtype, /*sync_now=*/true);
         if (rc != PM_OK) return rc;
         PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
                                    ctx->stream));

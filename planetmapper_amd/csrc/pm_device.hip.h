@@ -123,6 +123,18 @@ struct PlaneStats {
     int pad_;
 };
 
+// Spline (RectBivariateSpline, s = 0) reprojection: per-axis knots + banded LU of the
+// collocation matrix, built on the host (pm_capi.hip), resident in device memory.
+struct SplineAxis {
+    const double *t;   // n + k + 1 knots
+    const double *lu;  // n x (2k + 1) banded LU (unit lower), entry (i, j) at lu[i*(2k+1) + (j-i+k)]
+    int n, k;
+};
+struct SplineArgs {
+    double *work;  // n_planes x ny x nx cleaned image -> B-spline coefficients (in place)
+    SplineAxis rows, cols;  // axis 0 (image y) / axis 1 (image x)
+};
+
 // Arguments of the reprojection kernel (pm_map_cube).
 struct ReprojectArgs {
     const void *cube;     // n_planes x ny x nx elements

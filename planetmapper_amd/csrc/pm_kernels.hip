@@ -748,6 +748,138 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
     o[m] = val;
 }
 
+// ------------------------------------------------------------------ spline reprojection
+// scipy RectBivariateSpline(kx, ky, s=0).ev of BodyXY._do_spline_interpolation
+// (body_xy.py:1651-1702) for 'quadratic', 'cubic' and (k0, k1): interpolating tensor-product
+// B-spline. Pipeline per chunk of planes: k_median_* (plane statistics) -> k_spline_clean
+// (NaN-cleaned float64 copy) -> k_spline_solve axis 0, axis 1 (banded LU substitution, in
+// place: samples -> coefficients) -> k_spline_eval.
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *work, const PlaneStats *stats, int ny, int nx)
+{
+    const size_t npx = (size_t)ny * nx;
+    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const int pl = blockIdx.y;
+    if (i >= npx) return;
+    bool nm = false;
+    work[(size_t)pl * npx + i] = cleaned_at(cube + (size_t)pl * npx, (long)(i / nx), (long)(i % nx), ny, nx, stats[pl].median, nm);
+}
+
+// One lane per (plane, line): solve B c = v along `axis` in place with the banded LU.
+// axis 0: lines are image columns (lanes adjacent in x read one image row per step: coalesced);
+// axis 1: lines are image rows (each lane walks its own row).
+__global__ __launch_bounds__(kBlock) void k_spline_solve(double *work, int n_planes, int ny, int nx, int axis, SplineAxis ax)
+{
+    const size_t npx = (size_t)ny * nx;
+    const int lines = axis == 0 ? nx : ny;
+    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    if (tid >= (size_t)n_planes * lines) return;
+    const int pl = (int)(tid / lines), line = (int)(tid % lines);
+    double *v = work + (size_t)pl * npx + (axis == 0 ? (size_t)line : (size_t)line * nx);
+    const size_t stride = axis == 0 ? (size_t)nx : 1;
+    const int n = ax.n, k = ax.k, w = 2 * k + 1;
+    // forward substitution (unit lower triangle), the last k results kept in registers
+    double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < n; i++) {
+        double s = v[(size_t)i * stride];
+        const double *row = ax.lu + (size_t)i * w;
+#pragma unroll
+        for (int q = 1; q <= 5; q++)
+            if (q <= k && i - q >= 0) s -= row[k - q] * prev[q - 1];
+#pragma unroll
+        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+        prev[0] = s;
+        v[(size_t)i * stride] = s;
+    }
+    // back substitution
+#pragma unroll
+    for (int q = 0; q < 5; q++) prev[q] = 0.0;
+    for (int i = n - 1; i >= 0; i--) {
+        double s = v[(size_t)i * stride];
+        const double *row = ax.lu + (size_t)i * w;
+#pragma unroll
+        for (int q = 1; q <= 5; q++)
+            if (q <= k && i + q < n) s -= row[k + q] * prev[q - 1];
+        s /= row[k];
+#pragma unroll
+        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+        prev[0] = s;
+        v[(size_t)i * stride] = s;
+    }
+}
+
+__device__ __forceinline__ int spline_interval(const SplineAxis &ax, double x)
+{
+    // knots are samples (odd k) or sample midpoints (even k): the span follows from floor(x)
+    int l = ax.k;
+    const int hi = ax.n - 1;
+    // t[k+1+j] = j + k/2 + 1 (odd k) or j + k/2 + 0.5 (even k); find the largest l with t[l] <= x
+    const double off = (ax.k & 1) ? (double)(ax.k / 2 + 1) : (double)(ax.k / 2) + 0.5;
+    int j = (int)floor(x - off) + 1;  // number of interior knots <= x
+    if (j < 0) j = 0;
+    l = ax.k + j;
+    if (l > hi) l = hi;
+    while (l < hi && x >= ax.t[l + 1]) l++;  // guard against rounding at knot values
+    while (l > ax.k && x < ax.t[l]) l--;
+    return l;
+}
+__device__ __forceinline__ void spline_basis(const SplineAxis &ax, double x, int l, double *h)
+{
+    double hh[6];
+    h[0] = 1.0;
+    for (int j = 1; j <= ax.k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 1; i <= j; i++) {
+            const int li = l + i, lj = li - j;
+            const double f = hh[i - 1] / (ax.t[li] - ax.t[lj]);
+            h[i - 1] += f * (ax.t[li] - x);
+            h[i] = f * (x - ax.t[lj]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_spline_eval(const ReprojectArgs a, const SplineArgs sa)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const int pl = blockIdx.y;
+    if (m >= a.n_map) return;
+    const double nan = __builtin_nan("");
+    const int nx = a.nx, ny = a.ny;
+    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
+    const double *c = sa.work + (size_t)pl * ny * nx;
+    double x = a.x_map[m], y = a.y_map[m];
+    double val = nan;
+    bool skip = isnan(x) || a.plane_stats[pl].all_nan;
+    if (!skip && a.propagate_nan) {
+        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
+            skip = true;
+        } else {
+            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
+            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
+            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
+                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
+        }
+    }
+    if (!skip) {
+        const double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
+        double hy[6], hx[6];
+        const int ly = spline_interval(sa.rows, yc), lx = spline_interval(sa.cols, xc);
+        spline_basis(sa.rows, yc, ly, hy);
+        spline_basis(sa.cols, xc, lx, hx);
+        double s = 0.0;
+        for (int p = 0; p <= sa.rows.k; p++) {
+            double r = 0.0;
+            for (int q = 0; q <= sa.cols.k; q++) r += hx[q] * c[(size_t)(ly - sa.rows.k + p) * nx + (lx - sa.cols.k + q)];
+            s += hy[p] * r;
+        }
+        val = s;
+    }
+    a.out[(size_t)pl * a.n_map + m] = val;
+}
+
 // ------------------------------------------------------------------ per-plane nanmedian
 // np.nanmedian of each plane (+-inf treated as NaN, body_xy.py:1882-1890) by an 8-pass
 // radix select over the order-preserving 64-bit key of the doubles. Two ranks are tracked
@@ -926,6 +1058,34 @@ void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)
     case PM_I32: launch_reproject_t<int32_t>(a, s); break;
     case PM_U8: launch_reproject_t<uint8_t>(a, s); break;
     case PM_U16: launch_reproject_t<uint16_t>(a, s); break;
+    }
+}
+
+template <typename T>
+static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, hipStream_t s)
+{
+    const size_t npx = (size_t)a.ny * a.nx;
+    hipLaunchKernelGGL(pm::k_spline_clean<T>, dim3((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes),
+                       dim3(pm::kBlock), 0, s, (const T *)a.cube, sa.work, a.plane_stats, a.ny, a.nx);
+    size_t l0 = (size_t)a.n_planes * a.nx, l1 = (size_t)a.n_planes * a.ny;
+    hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l0 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
+                       sa.work, a.n_planes, a.ny, a.nx, 0, sa.rows);
+    hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l1 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
+                       sa.work, a.n_planes, a.ny, a.nx, 1, sa.cols);
+    hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
+                       0, s, a, sa);
+}
+
+// a.plane_stats must already hold the plane statistics (pm_launch_plane_medians)
+void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_spline_t<double>(a, sa, s); break;
+    case PM_F32: launch_spline_t<float>(a, sa, s); break;
+    case PM_I16: launch_spline_t<int16_t>(a, sa, s); break;
+    case PM_I32: launch_spline_t<int32_t>(a, sa, s); break;
+    case PM_U8: launch_spline_t<uint8_t>(a, sa, s); break;
+    case PM_U16: launch_spline_t<uint16_t>(a, sa, s); break;
     }
 }
 

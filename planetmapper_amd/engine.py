@@ -28,6 +28,31 @@ _DTYPE_CODES = {
 _INTERP_CODES = {'nearest': _lib.PM_INTERP_NEAREST, 'linear': _lib.PM_INTERP_LINEAR, 1: _lib.PM_INTERP_LINEAR}
 
 
+def interpolation_code(interpolation) -> int:
+    """
+    C-ABI code of a `map_img` interpolation (body_xy.py:1598-1630): 'nearest', 'linear',
+    'quadratic', 'cubic', an int degree or a (k_rows, k_cols) tuple of spline degrees.
+    """
+    names = {'linear': 1, 'quadratic': 2, 'cubic': 3}
+    if isinstance(interpolation, str) and interpolation in names:
+        interpolation = names[interpolation]
+    if interpolation == 'nearest':
+        return _lib.PM_INTERP_NEAREST
+    if isinstance(interpolation, bool):
+        raise ValueError(f'Unknown interpolation method {interpolation!r}')
+    if isinstance(interpolation, int):
+        interpolation = (interpolation, interpolation)
+    if (
+        isinstance(interpolation, tuple)
+        and len(interpolation) == 2
+        and all(isinstance(k, int) and 1 <= k <= 5 for k in interpolation)
+    ):
+        if interpolation == (1, 1):
+            return _lib.PM_INTERP_LINEAR
+        return 0x100 | (interpolation[0] << 4) | interpolation[1]
+    raise ValueError(f'Unknown interpolation method {interpolation!r}')
+
+
 def dtype_code(dtype) -> int:
     dt = np.dtype(dtype)
     if dt not in _DTYPE_CODES:
@@ -219,8 +244,7 @@ class Engine:
     # ------------------------------------------------------------------ reprojection
     def map_cube(self, cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True) -> np.ndarray:
         """Reproject host cube (P, ny, nx) [or one (ny, nx) image] -> (P, n0, n1) float64."""
-        if interpolation not in _INTERP_CODES:
-            raise ValueError(f'Unknown interpolation method {interpolation!r}')
+        code = interpolation_code(interpolation)
         cube = np.asarray(cube)
         if cube.dtype.byteorder not in ('=', '|') and cube.dtype.byteorder != ('<' if np.little_endian else '>'):
             cube = cube.astype(cube.dtype.newbyteorder('='))
@@ -242,7 +266,7 @@ class Engine:
         self._check(
             self._lib.pm_map_cube(
                 self._ctx, cube.ctypes.data, dtype_code(cube.dtype), cube.shape[0], xm.ctypes.data,
-                ym.ctypes.data, n0, n1, _INTERP_CODES[interpolation], 1 if propagate_nan else 0,
+                ym.ctypes.data, n0, n1, code, 1 if propagate_nan else 0,
                 out.ctypes.data, _lib.PM_MEM_HOST,
             )
         )
@@ -253,12 +277,10 @@ class Engine:
         interpolation='linear', propagate_nan=True,
     ) -> None:  # fmt: skip
         """Enqueue the reprojection of a device-resident cube into a device output."""
-        if interpolation not in _INTERP_CODES:
-            raise ValueError(f'Unknown interpolation method {interpolation!r}')
         self._check(
             self._lib.pm_map_cube(
                 self._ctx, _ptr(cube), dtype_code(dtype), int(n_planes), _ptr(x_map), _ptr(y_map), int(n0),
-                int(n1), _INTERP_CODES[interpolation], 1 if propagate_nan else 0, _ptr(out), _lib.PM_MEM_DEVICE,
+                int(n1), interpolation_code(interpolation), 1 if propagate_nan else 0, _ptr(out), _lib.PM_MEM_DEVICE,
             )
         )
 

@@ -36,6 +36,9 @@ class OracleEngine:
         return oracle.backplanes_map(self._g, self._d, names, lon, lat, alt=alt)
 
     def map_cube(self, cube, x_map, y_map, interpolation='linear', propagate_nan=True):
+        from planetmapper_amd.engine import interpolation_code
+
+        interpolation_code(interpolation)
         cube = np.asarray(cube)
         if cube.ndim == 2:
             cube = cube[None]

@@ -273,9 +273,26 @@ def test_map_img_kats(body):
         body.map_img(IMAGE[:, :-1], degree_interval=45)
     with pytest.raises(ValueError):
         body.map_img(IMAGE, degree_interval=45, interpolation='<<<test>>>')
-    for interp in ('quadratic', 'cubic', 'smooth', 2, (1, 2)):
-        with pytest.raises(UnsupportedError):
-            body.map_img(IMAGE, degree_interval=45, interpolation=interp)
+    # fmt: off
+    splines = {
+        'quadratic': [[nan, nan, nan, nan, nan, nan, nan, nan], [nan, nan, nan, 47.43961193970507, 780.1933190874719, -11.958641161828965, nan, nan], [nan, nan, nan, -40.33639788223132, 106.33548747800452, nan, nan, nan], [nan, nan, nan, -35.84554405305129, -19.35757229218872, nan, nan, nan]],
+        'cubic': [[nan, nan, nan, nan, nan, nan, nan, nan], [nan, nan, nan, 38.17050096080083, 837.0682797065551, -40.810161294299334, nan, nan], [nan, nan, nan, -77.21287210436617, 103.88323214798433, nan, nan, nan], [nan, nan, nan, -29.994884067130222, -35.81550582449343, nan, nan, nan]],
+        (1, 2): [[nan, nan, nan, nan, nan, nan, nan, nan], [nan, nan, nan, 48.82728713390978, 584.7164003757379, -0.9895987798646678, nan, nan], [nan, nan, nan, -0.625402661173368, 99.24054961575526, nan, nan, nan], [nan, nan, nan, -33.19407454333914, -8.380623602166663, nan, nan, nan]],
+    }
+    # fmt: on
+    for interp, exp in splines.items():
+        got = body.map_img(IMAGE, degree_interval=45, interpolation=interp)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), interp
+    for alias, name in ((2, 'quadratic'), (3, 'cubic'), ((2, 2), 'quadratic'), ((3, 3), 'cubic')):
+        assert np.array_equal(
+            body.map_img(IMAGE, degree_interval=45, interpolation=alias),
+            body.map_img(IMAGE, degree_interval=45, interpolation=name), equal_nan=True,
+        )  # fmt: skip
+    assert np.isnan(body.map_img(IMAGE * nan, degree_interval=45, interpolation='cubic')).all()
+    with pytest.raises(UnsupportedError):
+        body.map_img(IMAGE, degree_interval=45, interpolation='smooth')
+    with pytest.raises(UnsupportedError):
+        body.map_img(IMAGE, degree_interval=45, interpolation='cubic', spline_smoothing=1.0)
 
 
 def test_observation_mapped_data(jupiter):
@@ -288,7 +305,10 @@ def test_observation_mapped_data(jupiter):
     obs = Observation(data=cube, geometry=jupiter, engine=OracleEngine())
     assert obs.get_img_size() == (7, 10)
     obs.set_disc_params(2.5, 3.1, 3.9, 123.456)
-    for interp, name in (('linear', 'map_rectangular_linear'), ('nearest', 'map_rectangular_nearest')):
+    for interp, name in (
+        ('linear', 'map_rectangular_linear'), ('nearest', 'map_rectangular_nearest'),
+        ('quadratic', 'map_rectangular_quadratic'), ('cubic', 'map_rectangular_cubic'),
+    ):  # fmt: skip
         gold = np.load(os.path.join(GOLDEN, f'golden_{name}.npz'))['PRIMARY']
         m = obs.get_mapped_data(interpolation=interp, degree_interval=30)
         assert m.shape == (10, 6, 12)

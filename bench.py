@@ -298,10 +298,18 @@ def main() -> None:
         if i is not None:
             ev1[i].record()
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-        # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only)
-        map_cube_sharded_device(eng, data, np.float64, 1, xm, ym, n0, n1, gathered, rank, 'linear', True)
+        # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only),
+        # left in flight so that it overlaps the next frame's backplane kernel
+        pending[0] = map_cube_sharded_device(
+            eng, data, np.float64, 1, xm, ym, n0, n1, gathered, rank, 'linear', True, async_op=True, previous=pending[0]
+        )
+
+    pending = [None]  # work handle of the all-gather still in flight
 
     def barrier() -> None:
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -196,6 +196,13 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     p.irc = 1.0 / p.radii[2];
     p.inv_c = 1.0 / g.clight;
     p.lat_k = (p.radii[0] / p.radii[2]) * (p.radii[0] / p.radii[2]);
+    for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
+    {
+        double m = std::fmin(p.radii[0], p.radii[2]);
+        double a1 = m / p.radii[0], c1 = m / p.radii[2];
+        p.limb_n[0] = a1 * a1;
+        p.limb_n[1] = c1 * c1;
+    }
     p.nx = d.nx;
     p.ny = d.ny;
     {

@@ -97,6 +97,8 @@ struct Params {
     double ira, irc;  // 1 / radii[0], 1 / radii[2]
     double inv_c;     // 1 / clight
     double lat_k;     // (radii[0] / radii[2])^2
+    double ir[3];     // 1 / radii[i]
+    double limb_n[2]; // surface-normal scalings of recpgr_surface: (m/a)^2, (m/c)^2, m = min(a, c)
     int32_t row_stride;  // row visiting order of the image kernels (coprime with ny)
     int32_t pad_;
 };
@@ -168,6 +170,22 @@ __device__ __forceinline__ void recrad(V3 v, double &ra, double &dec)
     ra = (v.x == 0.0 && v.y == 0.0) ? 0.0 : atan2(v.y, v.x);
     if (ra < 0.0) ra += kTwoPi;
 }
+// radrec / recrad for the all-pixel kernels: same arithmetic, with the range-aware sincos,
+// one-division atan2 and Newton square root of pm_fastmath.hip.h (v must be finite, non-zero)
+__device__ __forceinline__ V3 radrec_f(double ra, double dec)
+{
+    double sr, cr, sd, cd;
+    sincos_auto(ra, sr, cr);
+    sincos_auto(dec, sd, cd);
+    return {cr * cd, sr * cd, sd};
+}
+__device__ __forceinline__ void recrad_f(V3 v, double &ra, double &dec)
+{
+    dec = atan2_fast(v.z, sqrt_fast(fma(v.x, v.x, v.y * v.y)));
+    ra = atan2_fast(v.y, v.x);
+    if (ra < 0.0) ra += kTwoPi;
+}
+__device__ __forceinline__ double norm_f(V3 a) { return sqrt_fast(dot(a, a)); }
 // vsep_c for two UNIT vectors
 __device__ __forceinline__ double vsep_unit(V3 u, V3 v)
 {
@@ -542,6 +560,20 @@ __device__ __forceinline__ void obsvec2angular(const Params &p, V3 ov, double &a
     ay = (dec * kDeg) * 3600.0;
 }
 
+// obsvec2angular for finite non-zero `ov`. RA from recrad is in [0, 2pi], so the reference's
+// `-ra % 360` needs no fmod: one conditional add.
+__device__ __forceinline__ void obsvec2angular_f(const Params &p, V3 ov, double &ax, double &ay)
+{
+    V3 w = mxv(p.g.M, ov);
+    double ra, dec;
+    recrad_f(w, ra, dec);
+    double x = -(ra * kDeg);
+    if (x < 0.0) x += 360.0;
+    if (x > 180.0) x -= 360.0;
+    ax = x * 3600.0;
+    ay = (dec * kDeg) * 3600.0;
+}
+
 // Body._ring_coordinates_from_obsvec(only_visible=False) body.py:2577-2615
 __device__ __forceinline__ void ring_coords(const Params &p, V3 ov, double &radius, double &lon_deg, double &dist)
 {
@@ -588,6 +620,36 @@ __device__ __forceinline__ void limb_coords(const Params &p, V3 ray, double &lon
     lon_deg = lon * kDeg;
     lat_deg = lat * kDeg;
     dist = nd - norm(s);
+}
+
+// limb_coords for a finite ray, every pixel of a frame. The surface point under `tv` is
+// surfpt from the body centre, which reduces to tv / |tv / radii| (Y = 0 in surfpt above), so
+// the quadratic and its branches disappear; the spin angle over the light-time span of a frame
+// is < 1e-3 rad (series sincos, libm otherwise).
+__device__ __forceinline__ void limb_coords_f(const Params &p, V3 ray, double &lon_deg, double &lat_deg, double &dist)
+{
+    V3 T0 = ld3(p.g.T0);
+    double k = div_fast(dot(T0, ray), dot(ray, ray));
+    V3 near = k * ray;
+    double nd = norm_f(near - T0);
+    V3 off = near - ld3(p.g.sub_obsvec);
+    double dd = norm_f(off - ld3(p.g.sub_ray)) - p.g.sub_dist;
+    double t = p.g.sub_et - dd * p.inv_c;
+    M3 R;
+    rot_at<true>(p, t, R);
+    V3 tv = ld3(p.g.sub_sp) + mxv(R, off);
+    V3 X = {tv.x * p.ir[0], tv.y * p.ir[1], tv.z * p.ir[2]};
+    double xx = dot(X, X);
+    double sc = rsqrt_fast(xx);
+    V3 s = sc * tv;
+    double nx = s.x * p.limb_n[0], ny = s.y * p.limb_n[0], nz = s.z * p.limb_n[1];
+    double lat = atan2_fast(nz, sqrt_fast(fma(nx, nx, ny * ny)));
+    double l = atan2_fast(s.y, s.x);
+    if (p.g.west_positive) l = -l;
+    if (l < 0.0) l += kTwoPi;
+    lon_deg = l * kDeg;
+    lat_deg = lat * kDeg;
+    dist = nd - norm_f(s);
 }
 
 // Body.local_solar_time_from_lon body.py:2376-2398 (et2lst_c, truncated to whole seconds)

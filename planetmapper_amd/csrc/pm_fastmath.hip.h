@@ -8,6 +8,7 @@
 //   atan_small(t)   |t| <= tan(pi/8)      10-term odd polynomial, max abs err 1.1e-16
 //   atan2_fast      any finite (y, x) != (0, 0): ONE division + atan_small
 //   sincos_small    |x| <= 0.25           4-term tails, max abs err 1.1e-16
+//   sincos_medium   |x| <= 1e5            3-part pi/2 reduction + 6-term tails, 2.1e-16
 //
 // Coefficients: tools/gen_poly.py (Chebyshev interpolation at 60 digits with mpmath,
 // rounded to binary64 and re-verified in float64 Horner form).
@@ -145,12 +146,46 @@ __device__ __forceinline__ void sincos_small(double x, double &s, double &c)
     c = fma(z * z, qc, fma(-0.5, z, 1.0));
 }
 
+// sin and cos for |x| <= 1e5: Cody-Waite reduction by pi/2 in three parts (k = rint(2x/pi)
+// is exact below 2^20 and k * PIO2_HI, k * PIO2_MID are exact products), then degree-5 tails
+// on |r| <= pi/4 (max abs err 1.1e-16 each) and the quadrant swap. Used for RA/Dec-sized
+// angles; anything larger goes to libm.
+__device__ __forceinline__ void sincos_medium(double x, double &s, double &c)
+{
+    const double kf = rint(x * 0.63661977236758134308);  // 2 / pi
+    // pi/2 = HI + MID + LO with HI, MID carrying 33 bits each (fdlibm's pio2_1, pio2_2, pio2_3)
+    double r = fma(-kf, 1.57079632673412561417e+00, x);
+    r = fma(-kf, 6.07710050630396597660e-11, r);
+    r = fma(-kf, 2.02226624879595063154e-21, r);
+    const double z = r * r;
+    double qs = 1.5918129294866608e-10;
+    qs = fma_c(qs, z, -2.5051131845003624e-08);
+    qs = fma_c(qs, z, 2.755731610255244e-06);
+    qs = fma_c(qs, z, -0.00019841269836758574);
+    qs = fma_c(qs, z, 0.008333333333330948);
+    qs = fma_c(qs, z, -0.16666666666666666);
+    const double sr = fma(r * z, qs, r);
+    double qc = -1.1382632425521717e-11;
+    qc = fma_c(qc, z, 2.08761462684032e-09);
+    qc = fma_c(qc, z, -2.7557317271729793e-07);
+    qc = fma_c(qc, z, 2.480158729876569e-05);
+    qc = fma_c(qc, z, -0.0013888888888887398);
+    qc = fma_c(qc, z, 0.041666666666666664);
+    const double cr = fma(z * z, qc, fma(-0.5, z, 1.0));
+    const int q = (int)kf & 3;
+    const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // sincos with a wave-uniform choice: the short polynomials when every lane of the wave is
 // inside their range (always true for planetary fields of view), libm otherwise.
 __device__ __forceinline__ void sincos_auto(double x, double &s, double &c)
 {
     if (__all(fabs(x) <= 0.25)) {
         sincos_small(x, s, c);
+    } else if (__all(fabs(x) <= 1e5)) {
+        sincos_medium(x, s, c);
     } else {
         sincos(x, &s, &c);
     }

@@ -382,29 +382,38 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
     const int y = blockIdx.y;
     if (x >= p.nx) return;
     const size_t idx = (size_t)y * p.nx + x;
-    V3 ray = xy2ray(p, (double)x, (double)y);
+    // xy2ray with the fast elementary functions (rays are finite for every pixel)
+    const double xd = (double)x, yd = (double)y;
+    const double ax0 = fma(p.A[0], xd, fma(p.A[1], yd, p.A[2]));
+    const double ay0 = fma(p.A[3], xd, fma(p.A[4], yd, p.A[5]));
+    V3 ray = mtxv(p.g.M, radrec_f(-(div_fast(ax0, 3600.0) * kRad), div_fast(ay0, 3600.0) * kRad));
     double ra, dec;
-    recrad(ray, ra, dec);
+    recrad_f(ray, ra, dec);
     double ra_deg = ra * kDeg, dec_deg = dec * kDeg;
     PM_PUT(PM_RA, ra_deg);
     PM_PUT(PM_DEC, dec_deg);
-    PM_PUT(PM_PIXEL_X, (double)x);
-    PM_PUT(PM_PIXEL_Y, (double)y);
+    PM_PUT(PM_PIXEL_X, xd);
+    PM_PUT(PM_PIXEL_Y, yd);
     const bool km = PM_WANT(PM_KM_X) || PM_WANT(PM_KM_Y) || PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y);
     if (km || LIMB) {
-        V3 ray2 = radrec(ra_deg * kRad, dec_deg * kRad);
+        // the reference goes back through degrees (radec2obsvec_norm), so do the same
+        V3 ray2 = radrec_f(ra_deg * kRad, dec_deg * kRad);
         if (km) {
             double ax, ay;
-            obsvec2angular(p, ray2, ax, ay);
+            obsvec2angular_f(p, ray2, ax, ay);
             double kx = fma(p.K[0], ax, p.K[1] * ay), ky = fma(p.K[2], ax, p.K[3] * ay);
             PM_PUT(PM_KM_X, kx);
             PM_PUT(PM_KM_Y, ky);
-            PM_PUT(PM_ANGULAR_X, kx / p.g.km_per_arcsec);
-            PM_PUT(PM_ANGULAR_Y, ky / p.g.km_per_arcsec);
+            if (PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y)) {
+                const double ik = rcp_fast(p.g.km_per_arcsec);
+                const double qx = kx * ik, qy = ky * ik;
+                PM_PUT(PM_ANGULAR_X, fma(fma(-p.g.km_per_arcsec, qx, kx), ik, qx));
+                PM_PUT(PM_ANGULAR_Y, fma(fma(-p.g.km_per_arcsec, qy, ky), ik, qy));
+            }
         }
         if (LIMB) {
             double ll, lb, ld;
-            limb_coords(p, ray2, ll, lb, ld);
+            limb_coords_f(p, ray2, ll, lb, ld);
             PM_PUT(PM_LIMB_LON_GRAPHIC, ll);
             PM_PUT(PM_LIMB_LAT_GRAPHIC, lb);
             PM_PUT(PM_LIMB_DISTANCE, ld);

@@ -91,17 +91,25 @@ def get_mapped_data_sharded(
 
 
 def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_map, n0: int, n1: int,
-                            gathered, rank: int, interpolation='linear', propagate_nan=True, group=None):
+                            gathered, rank: int, interpolation='linear', propagate_nan=True, group=None,
+                            async_op: bool = False, previous=None):
     """
     Device-resident variant used by the benchmark: this rank's `n_planes_local` planes
     (`cube`, a device tensor / pointer) are mapped straight into its slot of `gathered`
     ((world, n_planes_local, n0, n1) float64 cuda tensor) and the slots are exchanged with
-    one in-place RCCL all-gather on the engine's stream. Nothing touches the host.
+    one in-place RCCL all-gather. Nothing touches the host.
+
+    `async_op=True` returns the collective's work handle instead of waiting for it, so the
+    caller can enqueue independent kernels (the next frame's backplanes) while the gather is
+    in flight over xGMI; pass that handle back as `previous` on the next call: it is waited for
+    right before this rank's slot is overwritten.
     """
     import torch.distributed as dist
 
+    if previous is not None:
+        previous.wait()
     mine = gathered[rank]
     engine.map_cube_device(cube, dtype, n_planes_local, x_map, y_map, n0, n1, mine, interpolation, propagate_nan)
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group)
-    return gathered
+        return dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group, async_op=async_op)
+    return None

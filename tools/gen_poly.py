@@ -74,3 +74,8 @@ if __name__ == '__main__':
     for deg in (3, 4):
         fit('sin', tail_sin, mp.mpf('0.0625'), deg, lambda x, t: x + x * (x * x) * t, xs)
         fit('cos', tail_cos, mp.mpf('0.0625'), deg, lambda x, t: 1 - 0.5 * x * x + (x * x) * (x * x) * t, xs)
+    # sincos_medium: |r| <= pi/4 after the Cody-Waite reduction
+    xs = np.linspace(0, float(mp.pi / 4), 20001)
+    for deg in (5,):
+        fit('sin', tail_sin, (mp.pi / 4) ** 2, deg, lambda x, t: x + x * (x * x) * t, xs)
+        fit('cos', tail_cos, (mp.pi / 4) ** 2, deg, lambda x, t: 1 - 0.5 * x * x + (x * x) * (x * x) * t, xs)

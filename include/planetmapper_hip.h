@@ -148,6 +148,10 @@ typedef struct pm_disc {
 typedef enum pm_interpolation {
     PM_INTERP_NEAREST = 0, /* body_xy.py:1633 _do_nearest_interpolation */
     PM_INTERP_LINEAR = 1,  /* body_xy.py:1651 _do_spline_interpolation, kx=ky=1, s=0 */
+    /* 'smooth': PCHIP resampling onto an oversampled grid (rows, then columns; non-finite
+     * pixels are bridged) followed by bilinear sampling, body_xy.py:1704-1853. Options:
+     * pm_set_smooth_options(). */
+    PM_INTERP_SMOOTH = 2,
     /* RectBivariateSpline(kx=k_rows, ky=k_cols, s=0) interpolating splines ('quadratic' =
      * (2, 2), 'cubic' = (3, 3), mixed degrees), body_xy.py:1651-1702:
      * PM_INTERP_SPLINE(k_rows, k_cols); k_rows is the degree along image rows (axis 0),
@@ -276,6 +280,14 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg,
 int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
                 const double *x_map, const double *y_map, int n0, int n1,
                 int interpolation, int propagate_nan, double *out, int mem);
+
+/*
+ * Options of PM_INTERP_SMOOTH: the `smooth_oversample_by` and
+ * `smooth_max_oversampled_img_size` arguments of BodyXY.map_img (body_xy.py:1427-1428,
+ * used at :1724-1741). Defaults 5 and 10000, as in the reference; oversample_by <= 1
+ * samples the PCHIP-cleaned image on the original pixel grid.
+ */
+int pm_set_smooth_options(pm_ctx *ctx, int oversample_by, int max_oversampled_img_size);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,11 @@ def lib() -> ctypes.CDLL:
             ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int,
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp,
         ]
+        _lib.pmo_map_cube_smooth.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp,
+        ]
+        _lib.pmo_pchip.argtypes = [dp, dp, ctypes.c_int, dp, ctypes.c_int, dp]
         _lib.pmo_transform.argtypes = [
             ctypes.POINTER(PMGeometry), ctypes.POINTER(PMDisc), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
             dp, dp, ctypes.c_double, ctypes.c_int, dp, dp,
@@ -172,7 +177,8 @@ def rectangular_grid(g: PMGeometry, degree_interval: float):
     return lon, lat
 
 
-def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True):
+def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True,
+             smooth_oversample_by=5, smooth_max_oversampled_img_size=10_000):
     cube = np.ascontiguousarray(cube)
     if cube.ndim == 2:
         cube = cube[None]
@@ -181,6 +187,14 @@ def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_n
     ym = np.ascontiguousarray(y_map, dtype=np.float64)
     n0, n1 = xm.shape
     out = np.empty((p, n0, n1), dtype=np.float64)
+    if interpolation == 'smooth':
+        rc = lib().pmo_map_cube_smooth(
+            cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym), n0, n1,
+            int(smooth_oversample_by), int(smooth_max_oversampled_img_size), 1 if propagate_nan else 0, _dptr(out),
+        )
+        if rc != 0:
+            raise ValueError(f'oracle error {rc}')
+        return out
     spline = {'quadratic': (2, 2), 'cubic': (3, 3), 2: (2, 2), 3: (3, 3)}.get(interpolation)
     if isinstance(interpolation, tuple):
         spline = interpolation
@@ -197,6 +211,18 @@ def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_n
         cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym),
         n0, n1, interp, 1 if propagate_nan else 0, _dptr(out),
     )
+    if rc != 0:
+        raise ValueError(f'oracle error {rc}')
+    return out
+
+
+def pchip(x, y, xq) -> np.ndarray:
+    """scipy.interpolate.PchipInterpolator(x, y, extrapolate=False)(xq) as restated in the oracle"""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    xq = np.ascontiguousarray(xq, dtype=np.float64)
+    out = np.empty_like(xq)
+    rc = lib().pmo_pchip(_dptr(x), _dptr(y), len(x), _dptr(xq), len(xq), _dptr(out))
     if rc != 0:
         raise ValueError(f'oracle error {rc}')
     return out

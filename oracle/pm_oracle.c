@@ -1179,6 +1179,202 @@ int pmo_map_cube_spline(const void *cube, int dtype, int n_planes, int ny, int n
     return PM_OK;
 }
 
+/* ------------------------------------------------------------------ 'smooth' reprojection */
+/*
+ * BodyXY._do_smooth_interpolation + _pchip_grid_interp2d (body_xy.py:1704-1853): the image is
+ * resampled with PCHIP onto a regular grid `oversample_by` times finer (rows first, then
+ * columns; non-finite samples are left out of each 1-D interpolant, so gaps are bridged), and
+ * the fine image is sampled bilinearly (scipy RegularGridInterpolator, fill NaN).
+ *
+ * pchip_1d restates scipy.interpolate.PchipInterpolator(x, y, extrapolate=False)(xq):
+ * Fritsch-Carlson derivatives (weighted harmonic mean inside, Moler's shape-preserving
+ * three-point rule at the ends, straight line for two points), cubic Hermite pieces in
+ * scipy's power-basis form, NaN outside [x[0], x[n-1]].
+ */
+static double sgn(double v) { return (double)((v > 0.0) - (v < 0.0)); }
+static double pchip_edge(double h0, double h1, double m0, double m1)
+{
+    double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+    if (sgn(d) != sgn(m0)) return 0.0;
+    if (sgn(m0) != sgn(m1) && fabs(d) > 3.0 * fabs(m0)) return 3.0 * m0;
+    return d;
+}
+static void pchip_1d(const double *x, const double *y, int n, const double *xq, int nq, double *out,
+                     size_t out_stride, double *d /* scratch n */)
+{
+    if (n == 2) {
+        d[0] = d[1] = (y[1] - y[0]) / (x[1] - x[0]);
+    } else {
+        for (int k = 1; k < n - 1; k++) {
+            double h0 = x[k] - x[k - 1], h1 = x[k + 1] - x[k];
+            double m0 = (y[k] - y[k - 1]) / h0, m1 = (y[k + 1] - y[k]) / h1;
+            if (sgn(m0) != sgn(m1) || m0 == 0.0 || m1 == 0.0) {
+                d[k] = 0.0;
+            } else {
+                double w1 = 2.0 * h1 + h0, w2 = h1 + 2.0 * h0;
+                d[k] = 1.0 / ((w1 / m0 + w2 / m1) / (w1 + w2));
+            }
+        }
+        double h0 = x[1] - x[0], h1 = x[2] - x[1];
+        d[0] = pchip_edge(h0, h1, (y[1] - y[0]) / h0, (y[2] - y[1]) / h1);
+        h0 = x[n - 1] - x[n - 2];
+        h1 = x[n - 2] - x[n - 3];
+        d[n - 1] = pchip_edge(h0, h1, (y[n - 1] - y[n - 2]) / h0, (y[n - 2] - y[n - 3]) / h1);
+    }
+    int i = 0;
+    for (int q = 0; q < nq; q++) {
+        double v = xq[q];
+        if (!(v >= x[0] && v <= x[n - 1])) { out[q * out_stride] = NAN; continue; }
+        while (i > 0 && v < x[i]) i--;
+        while (i < n - 2 && v >= x[i + 1]) i++;
+        double h = x[i + 1] - x[i], slope = (y[i + 1] - y[i]) / h;
+        double t = (d[i] + d[i + 1] - 2.0 * slope) / h;
+        double c0 = t / h, c1 = (slope - d[i]) / h - t, c2 = d[i], c3 = y[i];
+        double s = v - x[i], z = 1.0, res = 0.0;
+        res += c3 * z; z *= s;
+        res += c2 * z; z *= s;
+        res += c1 * z; z *= s;
+        res += c0 * z;
+        out[q * out_stride] = res;
+    }
+}
+
+/* get_xy_pchip body_xy.py:1724-1741: trimmed original coordinates -> (over)sampled grid,
+ * numpy.linspace arithmetic (i * step + start, last element = stop). Returns the length. */
+static int smooth_axis(int n, double lo, double hi, double pad, int oversample_by, int max_size, int *first,
+                       int *last, double **grid)
+{
+    int a = -1, b = -1;
+    for (int j = 0; j < n; j++)
+        if (j >= lo - pad && j <= hi + pad) { if (a < 0) a = j; b = j; }
+    if (a < 0) return 0;
+    int old = b - a + 1, num = old, found = 0;
+    for (int o = oversample_by; o > 1; o--) {
+        long ns = (long)old * o - (o - 1);
+        if (ns <= max_size) { num = (int)ns; found = 1; break; }
+    }
+    double *g = (double *)malloc((size_t)num * sizeof(double));
+    if (found && num > 1) {
+        double start = a, stop = b, step = (stop - start) / (num - 1);
+        for (int i = 0; i < num; i++) { volatile double t = i * step; g[i] = t + start; }
+        g[num - 1] = stop;
+    } else {
+        for (int i = 0; i < num; i++) g[i] = a + i;
+    }
+    *first = a; *last = b; *grid = g;
+    return num;
+}
+
+static int grid_interval(const double *g, int n, double v)
+{
+    /* find_interval_ascending: g[i] <= v < g[i+1], last interval closed */
+    int lo = 0, hi = n - 2;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) / 2;
+        if (g[mid] <= v) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+int pmo_map_cube_smooth(const void *cube, int dtype, int n_planes, int ny, int nx, const double *x_map,
+                        const double *y_map, int n0, int n1, int oversample_by, int max_size,
+                        int propagate_nan, double *out)
+{
+    const double pad = 5.0; /* limit_padding */
+    size_t npx = (size_t)ny * nx, nmap = (size_t)n0 * n1;
+    size_t esz = dtype_size(dtype);
+    if (esz == 0 || nx <= 0 || ny <= 0) return PM_ERR_INVALID_ARGUMENT;
+    for (size_t m = 0; m < (size_t)n_planes * nmap; m++) out[m] = NAN;
+    double xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    for (size_t m = 0; m < nmap; m++) {
+        if (!isnan(x_map[m])) { xlo = fmin(xlo, x_map[m]); xhi = fmax(xhi, x_map[m]); }
+        if (!isnan(y_map[m])) { ylo = fmin(ylo, y_map[m]); yhi = fmax(yhi, y_map[m]); }
+    }
+    double *img = (double *)malloc(npx * sizeof(double));
+    int any = 0;
+    /* the reference returns before touching the map for an all-NaN plane, and fails
+     * (IndexError) for a map with no visible cell otherwise */
+    int jx0, jx1, jy0, jy1, nxs = 0, nys = 0;
+    double *xs = NULL, *ys = NULL;
+    if (xlo <= xhi && ylo <= yhi) {
+        nxs = smooth_axis(nx, xlo, xhi, pad, oversample_by, max_size, &jx0, &jx1, &xs);
+        nys = smooth_axis(ny, ylo, yhi, pad, oversample_by, max_size, &jy0, &jy1, &ys);
+    }
+    int rc = PM_OK;
+    double *inter = NULL, *fin = NULL, *px = NULL, *pv = NULL, *pd = NULL, *col = NULL;
+    int nmax = nx > ny ? nx : ny;
+    for (int p = 0; p < n_planes && rc == PM_OK; p++) {
+        const char *src = (const char *)cube + (size_t)p * npx * esz;
+        double *o = out + (size_t)p * nmap;
+        int all_nan = 1;
+        for (size_t i = 0; i < npx; i++) {
+            img[i] = load_px(src, dtype, i);
+            if (!isnan(img[i])) all_nan = 0;
+        }
+        if (all_nan) continue;
+        if (nxs < 2 || nys < 2) { rc = PM_ERR_INVALID_ARGUMENT; break; }
+        if (!any) {
+            inter = (double *)malloc((size_t)ny * nxs * sizeof(double));
+            fin = (double *)malloc((size_t)nys * nxs * sizeof(double));
+            px = (double *)malloc(nmax * sizeof(double));
+            pv = (double *)malloc(nmax * sizeof(double));
+            pd = (double *)malloc(nmax * sizeof(double));
+            col = (double *)malloc((size_t)nys * sizeof(double));
+            any = 1;
+        }
+        for (size_t i = 0; i < (size_t)ny * nxs; i++) inter[i] = NAN;
+        for (size_t i = 0; i < (size_t)nys * nxs; i++) fin[i] = NAN;
+        /* along x for every original row near the map's footprint */
+        for (int i = 0; i < ny; i++) {
+            if (i < ylo - pad || i > yhi + pad) continue;
+            int n = 0;
+            for (int j = jx0; j <= jx1; j++)
+                if (isfinite(img[(size_t)i * nx + j])) { px[n] = j; pv[n] = img[(size_t)i * nx + j]; n++; }
+            if (n < 2) continue;
+            pchip_1d(px, pv, n, xs, nxs, inter + (size_t)i * nxs, 1, pd);
+        }
+        /* along y for every fine column */
+        for (int k = 0; k < nxs; k++) {
+            if (xs[k] < xlo - pad || xs[k] > xhi + pad) continue;
+            int n = 0;
+            for (int i = jy0; i <= jy1; i++)
+                if (isfinite(inter[(size_t)i * nxs + k])) { px[n] = i; pv[n] = inter[(size_t)i * nxs + k]; n++; }
+            if (n < 2) continue;
+            pchip_1d(px, pv, n, ys, nys, fin + k, (size_t)nxs, pd);
+        }
+        for (size_t m = 0; m < nmap; m++) {
+            double x = x_map[m], y = y_map[m];
+            if (isnan(x)) continue;
+            if (propagate_nan) {
+                if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) continue;
+                long xa = (long)fmax(floor(x), 0.0), xb = (long)fmin(ceil(x), nx - 1.0);
+                long ya = (long)fmax(floor(y), 0.0), yb = (long)fmin(ceil(y), ny - 1.0);
+                if (isnan(img[ya * nx + xa]) || isnan(img[ya * nx + xb]) || isnan(img[yb * nx + xa]) ||
+                    isnan(img[yb * nx + xb]))
+                    continue;
+            }
+            if (x < xs[0] || x > xs[nxs - 1] || y < ys[0] || y > ys[nys - 1]) continue; /* fill_value */
+            int k = grid_interval(xs, nxs, x), r = grid_interval(ys, nys, y);
+            double fx = (x - xs[k]) / (xs[k + 1] - xs[k]), fy = (y - ys[r]) / (ys[r + 1] - ys[r]);
+            const double *f0 = fin + (size_t)r * nxs + k, *f1 = f0 + nxs;
+            o[m] = f0[0] * (1.0 - fy) * (1.0 - fx) + f0[1] * (1.0 - fy) * fx + f1[0] * fy * (1.0 - fx) +
+                   f1[1] * fy * fx;
+        }
+    }
+    free(img); free(inter); free(fin); free(px); free(pv); free(pd); free(col); free(xs); free(ys);
+    return rc;
+}
+
+/* 1-D entry for the cross-check against scipy.interpolate.PchipInterpolator */
+int pmo_pchip(const double *x, const double *y, int n, const double *xq, int nq, double *out)
+{
+    if (n < 2) return PM_ERR_INVALID_ARGUMENT;
+    double *d = (double *)malloc((size_t)n * sizeof(double));
+    pchip_1d(x, y, n, xq, nq, out, 1, d);
+    free(d);
+    return PM_OK;
+}
+
 /* rectangular map grid: BodyXY.generate_map_coordinates body_xy.py:2899-2907 */
 int pmo_rectangular_grid(const pm_geometry *g, double degree_interval, int n0, int n1,
                          double *lon_deg, double *lat_deg)

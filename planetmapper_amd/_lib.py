@@ -44,6 +44,7 @@ PM_TF_PLANETOCENTRIC = 2
 
 PM_INTERP_NEAREST = 0
 PM_INTERP_LINEAR = 1
+PM_INTERP_SMOOTH = 2
 
 # every symbol declared in include/planetmapper_hip.h
 EXPORTS = (
@@ -51,6 +52,7 @@ EXPORTS = (
     'pm_synchronize', 'pm_stream', 'pm_set_stream', 'pm_device_malloc', 'pm_device_free',
     'pm_memcpy_h2d', 'pm_memcpy_d2h', 'pm_set_geometry', 'pm_set_disc',
     'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube', 'pm_transform',
+    'pm_set_smooth_options',
 )  # fmt: skip
 
 
@@ -118,6 +120,7 @@ def load() -> ctypes.CDLL:
     lib.pm_map_cube.argtypes = [
         vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int,
     ]  # fmt: skip
+    lib.pm_set_smooth_options.argtypes = [vp, c_int, c_int]
     del dp
     if lib.pm_abi_version() != 1:
         raise ImportError('libplanetmapper_hip.so ABI version mismatch')

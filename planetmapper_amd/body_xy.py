@@ -565,18 +565,15 @@ class BodyXY:
         """
         body_xy.py:1414-1631: project an image (ny, nx) - or a cube (P, ny, nx) - onto
         the map grid. `'nearest'`, `'linear'`, `'quadratic'`, `'cubic'`, integer degrees and
-        `(k_rows, k_cols)` tuples (RectBivariateSpline with s=0) run on the GPU; `'smooth'` and
-        `spline_smoothing > 0` raise `UnsupportedError`.
+        `(k_rows, k_cols)` tuples (RectBivariateSpline with s=0) and `'smooth'` (PCHIP
+        oversampling + bilinear, body_xy.py:1704-1853) run on the GPU; `spline_smoothing > 0`
+        raises `UnsupportedError`.
         """
         img = np.asarray(img)
         from .engine import interpolation_code
 
-        if interpolation == 'smooth':
-            raise _lib.UnsupportedError(
-                "interpolation 'smooth' (PCHIP oversampling, body_xy.py:1704-1853) is not implemented on the GPU path"
-            )
         interpolation_code(interpolation)  # ValueError for unknown methods (body_xy.py:1630)
-        if interpolation != 'nearest' and spline_smoothing != 0:
+        if interpolation not in ('nearest', 'smooth') and spline_smoothing != 0:
             raise _lib.UnsupportedError('spline_smoothing != 0 (FITPACK smoothing) is not implemented on the GPU path')
         interp = interpolation
         single = img.ndim == 2
@@ -589,7 +586,17 @@ class BodyXY:
         y_map = self.get_y_map(**map_kwargs)
         if warn_nan and interp != 'nearest' and not np.all(np.isfinite(img)):
             print('Warning, image contains NaN values which will be corrected')
-        out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan)
+        if interp == 'smooth':
+            if np.all(np.isnan(x_map)) and not np.all(np.isnan(img)):
+                # the reference fails here too: `original[0]` of an empty trimmed axis (body_xy.py:1741)
+                raise IndexError('index 0 is out of bounds for axis 0 with size 0')
+            out = self._bind().map_cube(
+                img, x_map, y_map, interp, propagate_nan,
+                smooth_oversample_by=smooth_oversample_by,
+                smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
+            )  # fmt: skip
+        else:
+            out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan)
         return out[0] if single else out
 
     # ------------------------------------------------------------------ backplane registry

@@ -24,6 +24,8 @@ void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hi
 void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
+void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);
+void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
 
@@ -56,6 +58,10 @@ struct pm_ctx {
         int n = 0, k = 0;
         double *t = nullptr, *lu = nullptr;
     } axis[2];
+    // 'smooth' interpolation options (map_img smooth_oversample_by / smooth_max_oversampled_img_size)
+    int smooth_oversample_by = 5;
+    int smooth_max_size = 10000;
+    double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
     bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
@@ -295,6 +301,63 @@ int ensure_work(pm_ctx *ctx, size_t bytes)
     return PM_OK;
 }
 
+// get_xy_pchip body_xy.py:1724-1741: original pixel coordinates within `pad` of the map's
+// footprint [lo, hi], refined by the largest factor <= oversample_by whose grid fits
+// max_size. Returns false if no pixel is in range or the grid has a single point.
+bool smooth_axis(int n, double lo, double hi, int oversample_by, int max_size, pm::SmoothAxis &ax)
+{
+    const double pad = 5.0;  // limit_padding
+    int first = -1, last = -1;
+    for (int j = 0; j < n; j++)
+        if ((double)j >= lo - pad && (double)j <= hi + pad) {
+            if (first < 0) first = j;
+            last = j;
+        }
+    if (first < 0) return false;
+    const long old_size = last - first + 1;
+    ax.first = first;
+    ax.last = last;
+    ax.num = (int)old_size;
+    ax.oversampled = 0;
+    ax.step = 1.0;
+    for (long o = oversample_by; o > 1; o--) {
+        const long num = old_size * o - (o - 1);
+        if (num <= max_size) {
+            if (num > 1) {
+                ax.num = (int)num;
+                ax.oversampled = 1;
+                ax.step = ((double)last - (double)first) / (double)(num - 1);  // numpy.linspace
+            }
+            break;
+        }
+    }
+    return ax.num >= 2;
+}
+
+// 'smooth' reprojection of planes resident on the device. `limits`: nanmin / nanmax of the
+// x and y maps (host values).
+int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype, const double *limits)
+{
+    if (!(limits[0] <= limits[1]) || !(limits[2] <= limits[3])) {
+        // no visible map cell: every output is NaN (the reference only gets this far for
+        // all-NaN planes; for others its own axis trimming fails with an IndexError)
+        std::vector<double> nanrow((size_t)a.n_map, std::nan(""));
+        for (int p = 0; p < a.n_planes; p++)
+            PM_HIP(ctx, hipMemcpyAsync(a.out + (size_t)p * a.n_map, nanrow.data(), (size_t)a.n_map * sizeof(double),
+                                       hipMemcpyHostToDevice, ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PM_OK;
+    }
+    pm::SmoothArgs sm;
+    if (!smooth_axis(a.nx, limits[0], limits[1], ctx->smooth_oversample_by, ctx->smooth_max_size, sm.x) ||
+        !smooth_axis(a.ny, limits[2], limits[3], ctx->smooth_oversample_by, ctx->smooth_max_size, sm.y))
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT,
+                    "smooth interpolation needs at least two image pixels per axis near the mapped region");
+    pm_launch_reproject_smooth(a, sm, dtype, ctx->stream);
+    PM_HIP(ctx, hipGetLastError());
+    return PM_OK;
+}
+
 // Spline reprojection of planes resident on the device (plane chunks bound the workspace).
 int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols)
 {
@@ -473,6 +536,7 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->limits) (void)hipFree(ctx->limits);
     for (auto &ac : ctx->axis) {
         if (ac.t) (void)hipFree(ac.t);
         if (ac.lu) (void)hipFree(ac.lu);
@@ -771,7 +835,8 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
             interpolation = PM_INTERP_LINEAR;
             k_rows = k_cols = 0;
         }
-    } else if (interpolation != PM_INTERP_NEAREST && interpolation != PM_INTERP_LINEAR) {
+    } else if (interpolation != PM_INTERP_NEAREST && interpolation != PM_INTERP_LINEAR &&
+               interpolation != PM_INTERP_SMOOTH) {
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Unknown interpolation method %d", interpolation);
     }
     const pm_disc &d = ctx->disc;
@@ -808,6 +873,26 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
             if (rc != PM_OK) return rc;
         }
     }
+    const bool smooth = interpolation == PM_INTERP_SMOOTH;
+    double limits[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
+    if (smooth && mem == PM_MEM_DEVICE) {
+        // footprint of the map on the image: tiny reduction + 32-byte read-back
+        if (!ctx->limits) PM_HIP(ctx, hipMalloc((void **)&ctx->limits, 4 * sizeof(double)));
+        pm_launch_map_limits(x_map, y_map, (int)nmap, ctx->limits, ctx->stream);
+        PM_HIP(ctx, hipMemcpyAsync(limits, ctx->limits, sizeof(limits), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    } else if (smooth) {
+        for (size_t i = 0; i < nmap; i++) {
+            if (!std::isnan(x_map[i])) {
+                limits[0] = std::fmin(limits[0], x_map[i]);
+                limits[1] = std::fmax(limits[1], x_map[i]);
+            }
+            if (!std::isnan(y_map[i])) {
+                limits[2] = std::fmin(limits[2], y_map[i]);
+                limits[3] = std::fmax(limits[3], y_map[i]);
+            }
+        }
+    }
     if (mem == PM_MEM_DEVICE) {
         a.cube = cube;
         a.x_map = x_map;
@@ -815,6 +900,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         a.out = out;
         a.plane_flags = ctx->flags;
         a.n_planes = n_planes;
+        if (smooth) return reproject_smooth_resident(ctx, a, dtype, limits);
         if (k_rows) return reproject_spline_resident(ctx, a, dtype, k_rows, k_cols);
         return reproject_resident(ctx, a, dtype, /*sync_now=*/force_sync);
     }
@@ -844,13 +930,22 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         b.out = dout;
         b.plane_flags = ctx->flags;
         b.n_planes = (int)np;
-        rc = k_rows ? reproject_spline_resident(ctx, b, dtype, k_rows, k_cols)
-                    : reproject_resident(ctx, b, dtype, /*sync_now=*/true);
+        rc = smooth   ? reproject_smooth_resident(ctx, b, dtype, limits)
+             : k_rows ? reproject_spline_resident(ctx, b, dtype, k_rows, k_cols)
+                      : reproject_resident(ctx, b, dtype, /*sync_now=*/true);
         if (rc != PM_OK) return rc;
         PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
                                    ctx->stream));
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
+    return PM_OK;
+}
+
+int pm_set_smooth_options(pm_ctx *ctx, int oversample_by, int max_oversampled_img_size)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    ctx->smooth_oversample_by = oversample_by;
+    ctx->smooth_max_size = max_oversampled_img_size;
     return PM_OK;
 }
 

@@ -154,6 +154,118 @@ struct ReprojectArgs {
     int propagate_nan;
 };
 
+// One axis of the oversampled grid of 'smooth' interpolation (get_xy_pchip
+// body_xy.py:1724-1741): the original pixel coordinates first..last, optionally refined
+// to `num` points with numpy.linspace arithmetic (i * step + first, last point exact).
+struct SmoothAxis {
+    int first, last;  // trimmed original range [first, last] (pixels within 5 of the map's footprint)
+    int num;          // grid points
+    int oversampled;  // 0: grid = first, first+1, ..., last
+    double step;
+};
+struct SmoothArgs {
+    SmoothAxis x, y;
+};
+__device__ __forceinline__ double smooth_grid(const SmoothAxis &ax, int i)
+{
+    if (!ax.oversampled) return (double)(ax.first + i);
+    if (i == ax.num - 1) return (double)ax.last;
+    return __dadd_rn(__dmul_rn((double)i, ax.step), (double)ax.first);  // no FMA: numpy rounds twice
+}
+// interval i with grid[i] <= v < grid[i+1] (last interval closed), grid[0] <= v <= grid[num-1]
+__device__ __forceinline__ int smooth_interval(const SmoothAxis &ax, double v)
+{
+    int i = ax.oversampled ? (int)floor((v - (double)ax.first) / ax.step) : (int)floor(v) - ax.first;
+    i = i < 0 ? 0 : (i > ax.num - 2 ? ax.num - 2 : i);
+    while (i > 0 && v < smooth_grid(ax, i)) i--;
+    while (i < ax.num - 2 && v >= smooth_grid(ax, i + 1)) i++;
+    return i;
+}
+
+// scipy.interpolate.PchipInterpolator restated piecewise (oracle: pchip_1d): Fritsch-Carlson
+// derivative at an interior sample / Moler's three-point rule at an end sample
+__device__ __forceinline__ double pchip_sign(double v) { return (double)((v > 0.0) - (v < 0.0)); }
+__device__ __forceinline__ double pchip_interior(double h0, double h1, double m0, double m1)
+{
+    if (pchip_sign(m0) != pchip_sign(m1) || m0 == 0.0 || m1 == 0.0) return 0.0;
+    const double w1 = 2.0 * h1 + h0, w2 = h1 + 2.0 * h0;
+    return 1.0 / ((w1 / m0 + w2 / m1) / (w1 + w2));
+}
+__device__ __forceinline__ double pchip_edge(double h0, double h1, double m0, double m1)
+{
+    const double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+    if (pchip_sign(d) != pchip_sign(m0)) return 0.0;
+    if (pchip_sign(m0) != pchip_sign(m1) && fabs(d) > 3.0 * fabs(m0)) return 3.0 * m0;
+    return d;
+}
+// Value at v in [xb, xc] of the PCHIP interpolant whose samples around v are
+// (xa, ya)?, (xb, yb), (xc, yc), (xd, yd)?: the piece on [xb, xc] depends on nothing else.
+__device__ __forceinline__ double pchip_piece(bool has_a, double xa, double ya, double xb, double yb, double xc,
+                                              double yc, bool has_d, double xd, double yd, double v)
+{
+    const double h = xc - xb, slope = (yc - yb) / h;
+    double db = slope, dc = slope;  // two samples in all: straight line
+    if (has_a || has_d) {
+        const double hab = xb - xa, hcd = xd - xc;
+        const double mab = has_a ? (yb - ya) / hab : 0.0, mcd = has_d ? (yd - yc) / hcd : 0.0;
+        db = has_a ? pchip_interior(hab, h, mab, slope) : pchip_edge(h, hcd, slope, mcd);
+        dc = has_d ? pchip_interior(h, hcd, slope, mcd) : pchip_edge(h, hab, slope, mab);
+    }
+    const double t = (db + dc - 2.0 * slope) / h;
+    const double c0 = t / h, c1 = (slope - db) / h - t;
+    const double s = v - xb;
+    double z = s, res = yb;
+    res += db * z;
+    z *= s;
+    res += c1 * z;
+    z *= s;
+    res += c0 * z;
+    return res;
+}
+// PCHIP through the finite samples val(lo..hi) (integer abscissae), evaluated at v;
+// NaN outside the first..last finite sample (extrapolate=False) or with < 2 of them.
+// Only the <= 4 finite samples around v are looked up.
+template <typename F>
+__device__ __forceinline__ double pchip_gappy(F val, int lo, int hi, double v)
+{
+    const double nan = __builtin_nan("");
+    if (!(v >= (double)lo && v <= (double)hi)) return nan;
+    const int fl = (int)floor(v);
+    int ib = fl, ic = fl + 1;
+    double yb = nan, yc = nan;
+    for (;; ib--) {
+        if (ib < lo) return nan;
+        yb = val(ib);
+        if (isfinite(yb)) break;
+    }
+    for (; ic <= hi; ic++) {
+        yc = val(ic);
+        if (isfinite(yc)) break;
+    }
+    if (ic > hi) {
+        // v is at or beyond the last finite sample: the last interval is closed
+        if (v != (double)ib) return nan;
+        ic = ib;
+        yc = yb;
+        for (ib = ic - 1;; ib--) {
+            if (ib < lo) return nan;
+            yb = val(ib);
+            if (isfinite(yb)) break;
+        }
+    }
+    int ia = ib - 1, id = ic + 1;
+    double ya = nan, yd = nan;
+    for (; ia >= lo; ia--) {
+        ya = val(ia);
+        if (isfinite(ya)) break;
+    }
+    for (; id <= hi; id++) {
+        yd = val(id);
+        if (isfinite(yd)) break;
+    }
+    return pchip_piece(ia >= lo, (double)ia, ya, (double)ib, yb, (double)ic, yc, id <= hi, (double)id, yd, v);
+}
+
 // ------------------------------------------------------------------ CSPICE basics
 // radrec_c
 __device__ __forceinline__ V3 radrec(double ra, double dec)

@@ -6,6 +6,7 @@
 //                   (RA/Dec, pixel x/y, km, angular, limb)
 //   k_map           map-space planes + x_map/y_map for a lon/lat grid
 //   k_reproject<T>  bilinear / nearest reprojection of a cube onto the map grid
+//   k_reproject_smooth<T>  'smooth' (PCHIP-oversampled) reprojection, evaluated on the fly
 //
 // Launch geometry of the image kernels: one lane per pixel, a wave covers 64
 // consecutive x of one row, so every plane store is one 512-byte fully coalesced
@@ -764,6 +765,90 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 // (NaN-cleaned float64 copy) -> k_spline_solve axis 0, axis 1 (banded LU substitution, in
 // place: samples -> coefficients) -> k_spline_eval.
 
+// 'smooth' interpolation (BodyXY._do_smooth_interpolation / _pchip_grid_interp2d
+// body_xy.py:1704-1853). The reference materialises the whole oversampled image (up to
+// 10000 x 10000 per plane) and then samples it bilinearly at the map cells. PCHIP is local
+// (a piece depends on four samples), so here each (cell, plane) lane evaluates just the four
+// fine-grid nodes around its sample: node (r, k) = column PCHIP at ys[r] over the rows whose
+// row PCHIP at xs[k] is finite, each of those a PCHIP over the finite pixels of the row.
+// Work scales with the map, not with the oversampled image, and nothing is staged in HBM.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reproject_smooth(const ReprojectArgs a, const SmoothArgs sm)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const int pl = blockIdx.y;
+    if (m >= a.n_map) return;
+    const double nan = __builtin_nan("");
+    const int nx = a.nx, ny = a.ny;
+    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
+    const double x = a.x_map[m], y = a.y_map[m];
+    double val = nan;
+    bool skip = isnan(x);
+    if (!skip && a.propagate_nan) {
+        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
+            skip = true;
+        } else {
+            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
+            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
+            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
+                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
+        }
+    }
+    // RegularGridInterpolator(bounds_error=False, fill_value=nan)
+    const double x_lo = (double)sm.x.first, x_hi = (double)sm.x.last;
+    const double y_lo = (double)sm.y.first, y_hi = (double)sm.y.last;
+    if (!skip && x >= x_lo && x <= x_hi && y >= y_lo && y <= y_hi) {
+        const int k = smooth_interval(sm.x, x), r = smooth_interval(sm.y, y);
+        const double xk0 = smooth_grid(sm.x, k), xk1 = smooth_grid(sm.x, k + 1);
+        const double yr0 = smooth_grid(sm.y, r), yr1 = smooth_grid(sm.y, r + 1);
+        auto node = [&](double xq, double yq) {
+            auto column = [&](int i) {
+                auto row = [&](int j) { return load_as_f64(img, (size_t)i * nx + j); };
+                return pchip_gappy(row, sm.x.first, sm.x.last, xq);
+            };
+            return pchip_gappy(column, sm.y.first, sm.y.last, yq);
+        };
+        const double f00 = node(xk0, yr0), f01 = node(xk1, yr0), f10 = node(xk0, yr1), f11 = node(xk1, yr1);
+        const double fx = (x - xk0) / (xk1 - xk0), fy = (y - yr0) / (yr1 - yr0);
+        val = f00 * (1.0 - fy) * (1.0 - fx) + f01 * (1.0 - fy) * fx + f10 * fy * (1.0 - fx) + f11 * fy * fx;
+    }
+    a.out[(size_t)pl * a.n_map + m] = val;
+}
+
+// nanmin / nanmax of the x and y maps (one block): limits[0..3] = xmin, xmax, ymin, ymax;
+// +inf / -inf when no cell is visible.
+__global__ __launch_bounds__(kBlock) void k_map_limits(const double *x_map, const double *y_map, int n, double *limits)
+{
+    __shared__ double sh[4][kBlock];
+    double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+        const double x = x_map[i], y = y_map[i];
+        if (!isnan(x)) {
+            xmin = fmin(xmin, x);
+            xmax = fmax(xmax, x);
+        }
+        if (!isnan(y)) {
+            ymin = fmin(ymin, y);
+            ymax = fmax(ymax, y);
+        }
+    }
+    sh[0][threadIdx.x] = xmin;
+    sh[1][threadIdx.x] = xmax;
+    sh[2][threadIdx.x] = ymin;
+    sh[3][threadIdx.x] = ymax;
+    __syncthreads();
+    for (int st = kBlock / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) {
+            sh[0][threadIdx.x] = fmin(sh[0][threadIdx.x], sh[0][threadIdx.x + st]);
+            sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + st]);
+            sh[2][threadIdx.x] = fmin(sh[2][threadIdx.x], sh[2][threadIdx.x + st]);
+            sh[3][threadIdx.x] = fmax(sh[3][threadIdx.x], sh[3][threadIdx.x + st]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) limits[threadIdx.x] = sh[threadIdx.x][0];
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *work, const PlaneStats *stats, int ny, int nx)
 {
@@ -1056,6 +1141,30 @@ static void launch_median_t(const void *cube, int n_planes, size_t plane_elems, 
                            plane_elems, shift, stats, hist);
         hipLaunchKernelGGL(pm::k_median_pick, dim3(n_planes), dim3(pm::kBlock), 0, s, shift, plane_elems, stats, hist);
     }
+}
+
+template <typename T>
+static void launch_smooth_t(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, hipStream_t s)
+{
+    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes);
+    hipLaunchKernelGGL(pm::k_reproject_smooth<T>, grid, dim3(pm::kBlock), 0, s, a, sm);
+}
+
+void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_smooth_t<double>(a, sm, s); break;
+    case PM_F32: launch_smooth_t<float>(a, sm, s); break;
+    case PM_I16: launch_smooth_t<int16_t>(a, sm, s); break;
+    case PM_I32: launch_smooth_t<int32_t>(a, sm, s); break;
+    case PM_U8: launch_smooth_t<uint8_t>(a, sm, s); break;
+    case PM_U16: launch_smooth_t<uint16_t>(a, sm, s); break;
+    }
+}
+
+void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_map_limits, dim3(1), dim3(pm::kBlock), 0, s, x_map, y_map, n, limits);
 }
 
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)

@@ -31,13 +31,15 @@ _INTERP_CODES = {'nearest': _lib.PM_INTERP_NEAREST, 'linear': _lib.PM_INTERP_LIN
 def interpolation_code(interpolation) -> int:
     """
     C-ABI code of a `map_img` interpolation (body_xy.py:1598-1630): 'nearest', 'linear',
-    'quadratic', 'cubic', an int degree or a (k_rows, k_cols) tuple of spline degrees.
+    'quadratic', 'cubic', 'smooth', an int degree or a (k_rows, k_cols) tuple of spline degrees.
     """
     names = {'linear': 1, 'quadratic': 2, 'cubic': 3}
     if isinstance(interpolation, str) and interpolation in names:
         interpolation = names[interpolation]
     if interpolation == 'nearest':
         return _lib.PM_INTERP_NEAREST
+    if interpolation == 'smooth':
+        return _lib.PM_INTERP_SMOOTH
     if isinstance(interpolation, bool):
         raise ValueError(f'Unknown interpolation method {interpolation!r}')
     if isinstance(interpolation, int):
@@ -242,9 +244,17 @@ class Engine:
         return oa.reshape(shape), ob.reshape(shape)
 
     # ------------------------------------------------------------------ reprojection
-    def map_cube(self, cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True) -> np.ndarray:
+    def set_smooth_options(self, oversample_by: int = 5, max_oversampled_img_size: int = 10_000) -> None:
+        """`smooth_oversample_by` / `smooth_max_oversampled_img_size` of map_img (body_xy.py:1427-1428)"""
+        clip = lambda v: int(max(-(2**31), min(2**31 - 1, int(v))))  # noqa: E731
+        self._check(self._lib.pm_set_smooth_options(self._ctx, clip(oversample_by), clip(max_oversampled_img_size)))
+
+    def map_cube(self, cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True, *,
+                 smooth_oversample_by: int = 5, smooth_max_oversampled_img_size: int = 10_000) -> np.ndarray:
         """Reproject host cube (P, ny, nx) [or one (ny, nx) image] -> (P, n0, n1) float64."""
         code = interpolation_code(interpolation)
+        if code == _lib.PM_INTERP_SMOOTH:
+            self.set_smooth_options(smooth_oversample_by, smooth_max_oversampled_img_size)
         cube = np.asarray(cube)
         if cube.dtype.byteorder not in ('=', '|') and cube.dtype.byteorder != ('<' if np.little_endian else '>'):
             cube = cube.astype(cube.dtype.newbyteorder('='))

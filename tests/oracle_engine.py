@@ -35,7 +35,7 @@ class OracleEngine:
         self.calls.append(('map', tuple(names), alt))
         return oracle.backplanes_map(self._g, self._d, names, lon, lat, alt=alt)
 
-    def map_cube(self, cube, x_map, y_map, interpolation='linear', propagate_nan=True):
+    def map_cube(self, cube, x_map, y_map, interpolation='linear', propagate_nan=True, **smooth):
         from planetmapper_amd.engine import interpolation_code
 
         interpolation_code(interpolation)
@@ -45,7 +45,7 @@ class OracleEngine:
         if cube.dtype not in oracle.DTYPES:
             cube = cube.astype(np.float64)
         self.calls.append(('cube', cube.shape, interpolation))
-        return oracle.map_cube(cube, x_map, y_map, interpolation, propagate_nan)
+        return oracle.map_cube(cube, x_map, y_map, interpolation, propagate_nan, **smooth)
 
     def transform(self, src, dst, a, b, *, alt=0.0, not_visible_nan=False, planetocentric=False):
         self.calls.append(('transform', src, dst))

@@ -290,9 +290,54 @@ def test_map_img_kats(body):
         )  # fmt: skip
     assert np.isnan(body.map_img(IMAGE * nan, degree_interval=45, interpolation='cubic')).all()
     with pytest.raises(UnsupportedError):
-        body.map_img(IMAGE, degree_interval=45, interpolation='smooth')
-    with pytest.raises(UnsupportedError):
         body.map_img(IMAGE, degree_interval=45, interpolation='cubic', spline_smoothing=1.0)
+
+
+def _smooth_kats(name):
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_map_img_smooth.json'), encoding='utf-8') as f:
+        kats = json.load(f)[name]
+    return [(k['kwargs'], np.array(k['expected'], dtype=float)) for k in kats]  # null -> NaN
+
+
+def smooth_test_image():
+    """the 90 x 120 input of tests/test_body_xy.py:1329-1348 (recipe: sin x cos pattern, every
+    other row scaled, two spikes, a NaN pixel, a NaN column and a constant row)"""
+    xs = np.linspace(0, 1, 90)
+    ys = np.linspace(0, 1, 120)
+    image = np.sin(xs[None, :] * 10 * np.pi) * np.cos(ys[:, None] * 5 * np.pi)
+    image[::2, :] *= 1.5
+    image[50, 30] = 3
+    image[60, 40] = -2
+    image[45, 35] = np.nan
+    image[:, 22] = np.nan
+    image[40, :] = 1
+    return image
+
+
+def test_map_img_smooth_kats(body):
+    """'smooth' interpolation against the reference's own expected values
+    (tests/test_body_xy.py:1290-1327 and 1329-1372)"""
+    body.set_img_size(6, 5)
+    body.set_disc_params(2.75, 1.3, 2.3, 45.678)
+    for kw, exp in _smooth_kats('map_img_6x5'):
+        got = body.map_img(IMAGE, degree_interval=45, interpolation='smooth', **kw)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), kw
+    # oversampling off == bilinear on the original grid
+    assert np.allclose(
+        body.map_img(IMAGE, degree_interval=45, interpolation='smooth', smooth_oversample_by=1),
+        body.map_img(IMAGE, degree_interval=45, interpolation='linear'), equal_nan=True,
+    )  # fmt: skip
+    assert np.isnan(body.map_img(IMAGE * nan, degree_interval=45, interpolation='smooth')).all()
+
+    body.set_img_size(90, 120)
+    body.set_disc_params(32.1, 50, 12, 98.76)
+    image = smooth_test_image()
+    for kw, exp in _smooth_kats('map_img_90x120'):
+        got = body.map_img(image, degree_interval=45, interpolation='smooth', **kw)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), kw
 
 
 def test_observation_mapped_data(jupiter):
@@ -308,6 +353,7 @@ def test_observation_mapped_data(jupiter):
     for interp, name in (
         ('linear', 'map_rectangular_linear'), ('nearest', 'map_rectangular_nearest'),
         ('quadratic', 'map_rectangular_quadratic'), ('cubic', 'map_rectangular_cubic'),
+        ('smooth', 'map_rectangular_smooth'),
     ):  # fmt: skip
         gold = np.load(os.path.join(GOLDEN, f'golden_{name}.npz'))['PRIMARY']
         m = obs.get_mapped_data(interpolation=interp, degree_interval=30)

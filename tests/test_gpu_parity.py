@@ -412,3 +412,90 @@ def test_spline_interpolation_vs_oracle_and_goldens(engine, oracle, jupiter):
         engine.map_cube(cube, xm, ym, (0, 1), True)
     with pytest.raises(ValueError):
         engine.map_cube(cube, xm, ym, 'bicubic', True)
+
+
+def test_smooth_interpolation_vs_oracle_kats_and_golden(engine, oracle, jupiter):
+    """
+    'smooth' map_img (PCHIP oversampling + bilinear, body_xy.py:1704-1853): the reference's
+    own expected values (tests/test_body_xy.py:1290-1372), its golden FITS
+    map_rectangular-smooth, and the oracle (whose PCHIP equals scipy's bit for bit) on a
+    larger cube with NaN pixels / blocks / rows / columns, +-inf, integer and f32 planes.
+    The GPU evaluates only the four fine-grid nodes around each sample, the oracle builds
+    the whole oversampled image like the reference: agreement to 1e-9 relative.
+    """
+    from planetmapper_amd import BodyXY, Observation
+    from test_api_host import IMAGE, _smooth_kats, smooth_test_image
+
+    body = BodyXY('Jupiter', geometry=jupiter, engine=engine)
+    body.set_img_size(6, 5)
+    body.set_disc_params(2.75, 1.3, 2.3, 45.678)
+    for kw, exp in _smooth_kats('map_img_6x5'):
+        got = body.map_img(IMAGE, degree_interval=45, interpolation='smooth', **kw)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), kw
+    assert np.isnan(body.map_img(IMAGE * np.nan, degree_interval=45, interpolation='smooth')).all()
+    body.set_img_size(90, 120)
+    body.set_disc_params(32.1, 50, 12, 98.76)
+    image = smooth_test_image()
+    for kw, exp in _smooth_kats('map_img_90x120'):
+        got = body.map_img(image, degree_interval=45, interpolation='smooth', **kw)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), kw
+
+    cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
+    obs = Observation(data=cube, geometry=jupiter, engine=engine)
+    obs.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    gold = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_smooth.npz'))['PRIMARY']
+    got = obs.get_mapped_data('smooth', degree_interval=30)
+    assert np.array_equal(np.isnan(got), np.isnan(gold))
+    assert np.allclose(got, gold, rtol=1e-5, atol=1e-6, equal_nan=True)
+
+    sz = 200
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, 0.7 * x0, 0.2, sz + 13, sz, True)
+    d = oracle.make_disc(x0, y0, 0.7 * x0, 0.0, sz + 13, sz)
+    d.rotation_rad = 0.2
+    lon, lat = oracle.rectangular_grid(jupiter, 3.0)
+    xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+    rng = np.random.default_rng(11)
+    cube = rng.standard_normal((7, sz, sz + 13)) * 5
+    cube[0][rng.random((sz, sz + 13)) < 0.02] = np.nan
+    cube[1][50:90, 60:120] = np.nan
+    cube[2][:] = np.nan
+    cube[3][rng.random((sz, sz + 13)) < 0.01] = np.inf
+    cube[4][100, :] = np.nan
+    cube[4][:, 77] = np.nan
+    cube[5][:, :] = np.nan
+    cube[5][60:140:7, 40:180:5] = rng.standard_normal(cube[5][60:140:7, 40:180:5].shape)  # sparse samples
+    for kw in ({}, dict(smooth_oversample_by=1), dict(smooth_oversample_by=3),
+               dict(smooth_oversample_by=10, smooth_max_oversampled_img_size=700)):  # fmt: skip
+        for prop in (True, False):
+            a = engine.map_cube(cube, xm, ym, 'smooth', prop, **kw)
+            b = oracle.map_cube(cube, xm, ym, 'smooth', prop, **kw)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (kw, prop)
+            assert np.isfinite(b).sum() > 1000
+            fin = np.isfinite(b)
+            scale = np.maximum(1.0, np.abs(b[fin]))
+            assert np.max(np.abs(a[fin] - b[fin]) / scale) <= 1e-9, (kw, prop)
+    for dt in (np.float32, np.int16, np.uint8):
+        c = (np.nan_to_num(cube[0]) * 10).astype(dt) if dt is not np.float32 else cube[0].astype(dt)
+        a = engine.map_cube(c, xm, ym, 'smooth', True)
+        b = oracle.map_cube(c, xm, ym, 'smooth', True)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), dt
+        assert np.nanmax(np.abs(a - b) / np.maximum(1.0, np.abs(b))) <= 1e-9, dt
+    # a map with no visible cell: all-NaN output (the Python layer raises like the reference)
+    a = engine.map_cube(cube[:2], xm * np.nan, ym * np.nan, 'smooth', True)
+    assert np.isnan(a).all()
+    with pytest.raises(IndexError):
+        body.map_img(image, projection='manual', lon_coords=np.full((2, 2), np.nan), lat_coords=np.full((2, 2), np.nan),
+                     interpolation='smooth')  # fmt: skip
+    # device-resident call (the body above re-bound its own disc to the shared engine)
+    import torch
+
+    engine.set_disc(x0, y0, 0.7 * x0, 0.2, sz + 13, sz, True)
+    dc = torch.from_numpy(cube).cuda()
+    dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+    dout = torch.empty((cube.shape[0],) + xm.shape, dtype=torch.float64, device='cuda')
+    engine.set_smooth_options(5, 10_000)
+    engine.map_cube_device(dc, np.float64, cube.shape[0], dx, dy, xm.shape[0], xm.shape[1], dout, 'smooth', True)
+    engine.synchronize()
+    assert np.array_equal(dout.cpu().numpy(), engine.map_cube(cube, xm, ym, 'smooth', True), equal_nan=True)

@@ -211,3 +211,29 @@ def test_empty_image_is_value_error(jupiter):
     d = oracle.make_disc(0, 0, 1, 0, 0, 0)
     with pytest.raises(ValueError):
         oracle.backplanes_img(jupiter, d, ['LON-GRAPHIC'])
+
+
+def test_oracle_pchip_equals_scipy():
+    """
+    The 1-D building block of 'smooth' interpolation: the oracle's PCHIP against
+    scipy.interpolate.PchipInterpolator(extrapolate=False) - the third-party routine the
+    reference calls (body_xy.py:1807-1830) - on gappy integer abscissae: 2, 3, 4 and many
+    samples, flat runs, queries on / between / outside the samples.
+    """
+    from scipy.interpolate import PchipInterpolator
+
+    from oracle import oracle
+
+    rng = np.random.default_rng(0)
+    for n in (2, 3, 4, 7, 50):
+        for t in range(20):
+            x = np.sort(rng.choice(np.arange(200), n, replace=False)).astype(float)
+            y = rng.standard_normal(n)
+            if t % 5 == 0:
+                y[::2] = y[0]
+            xq = np.linspace(x[0] - 3, x[-1] + 3, 301)
+            xq[10], xq[20], xq[30] = x[0], x[-1], x[n // 2]
+            got = oracle.pchip(x, y, xq)
+            ref = PchipInterpolator(x, y, extrapolate=False)(xq)
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            assert np.nanmax(np.abs(got - ref)) <= 1e-14

@@ -19,6 +19,7 @@ management, pyproj projections) is out of scope for this path.
 
 from __future__ import annotations
 
+import datetime
 import math
 from typing import Any, Callable, Iterable, NamedTuple
 
@@ -135,8 +136,16 @@ class BodyXY:
                 )
         self._geometry = geometry.copy()
         self.target = None if target is None else str(target).strip().upper()
-        self.utc = utc
-        self.observer = observer
+        self.observer = observer.strip().upper() if isinstance(observer, str) else observer
+        # base.py:818-829: `utc` is normalised to a UTC string made from the epoch itself
+        from .timeconv import et2utc
+
+        try:
+            self.dtm = et2utc(geometry.et).replace(tzinfo=datetime.timezone.utc)
+            self.utc = self.dtm.strftime('%Y-%m-%dT%H:%M:%S.%f')
+        except (ValueError, OverflowError):
+            self.dtm = None
+            self.utc = utc
         self._optimize_speed = bool(optimize_speed)
         self._engine = engine if engine is not None else _shared_engine(device)
 
@@ -154,6 +163,27 @@ class BodyXY:
         self.positive_longitude_direction = 'W' if g.west_positive else 'E'
         self.subpoint_distance = g.sub_dist
         self._alt_adjustment = 0.0
+        # metadata of Body (body.py:501-606) that ends up in saved FITS headers
+        from .geometry import GeometryBuilder
+        from .kernels import body_id
+
+        d = GeometryBuilder.describe(g)
+        self.target_ra = d['target_ra']
+        self.target_dec = d['target_dec']
+        self.subpoint_lon = d['subpoint_lon']
+        self.subpoint_lat = d['subpoint_lat']
+        self.subsol_lon = d['subsol_lon']
+        self.subsol_lat = d['subsol_lat']
+        try:
+            self.target_body_id = body_id(self.target) if self.target is not None else None
+        except (KeyError, ValueError):
+            self.target_body_id = None
+        self.target_frame = None if self.target is None else 'IAU_' + self.target
+        self.observer_frame = 'J2000'
+        self.illumination_source = 'SUN'
+        self.aberration_correction = 'CN'
+        self.subpoint_method = 'INTERCEPT/ELLIPSOID'
+        self.surface_method = 'ELLIPSOID'
 
         self._cache: dict = {}  # cleared when the disc parameters change (base.py:58-88)
         self._stable_cache: dict = {}  # map-space results (base.py:91-112)
@@ -167,6 +197,19 @@ class BodyXY:
         self.backplanes: dict[str, Backplane] = {}
         self._register_default_backplanes()
         self.reset_disc_params()
+
+    def north_pole_angle(self) -> float:
+        """
+        Angle of the north pole on the sky, degrees in (-180, 180], clockwise from +Dec
+        (body.py:2985-3005): from the angular coordinates of the pole (lon 0, lat 90, at the
+        current altitude adjustment) and of the target centre.
+        """
+        if self._alt_adjustment == 0.0:
+            return float(np.rad2deg(self._geometry.np_angle_rad))
+        np_x, np_y = self._transform('lonlat', 'angular', 0.0, 90.0, alt=self._alt_adjustment)
+        t_x, t_y = self._transform('radec', 'angular', self.target_ra, self.target_dec)
+        theta = float(np.rad2deg(-np.arctan2(t_x - np_x, np_y - t_y))) % 360.0
+        return theta - 360.0 if theta > 180 else theta
 
     @property
     def geometry(self) -> PMGeometry:
@@ -749,10 +792,19 @@ class _AltitudeContext:
             if body._alt_adjustment != 0.0:
                 raise ValueError('Cannot nest _AdjustedSurfaceAltitude context managers with alt != 0')
 
+    def _set_radii(self, alt: float) -> None:
+        b = self.body
+        b.radii = np.array(b._geometry.radii[:]) + alt  # body.py:196-214: all three radii, then
+        b.r_eq = float(b.radii[0])  # the derived attributes
+        b.r_polar = float(b.radii[2])
+        b.flattening = (b.r_eq - b.r_polar) / b.r_eq
+
     def __enter__(self) -> None:
         if self.do:
             self.body._alt_adjustment = self.alt
+            self._set_radii(self.alt)
 
     def __exit__(self, *exc) -> None:
         if self.do:
             self.body._alt_adjustment = 0.0
+            self._set_radii(0.0)

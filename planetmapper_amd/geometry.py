@@ -418,7 +418,35 @@ class GeometryBuilder:
             lon = -lon
         lon %= 2 * math.pi
         lat = math.atan2(sp[2] / (1 - f) ** 2, math.hypot(sp[0], sp[1]))
+
+        # sub-solar point, spice.subslr('INTERCEPT/ELLIPSOID', ..., 'CN') (body.py:553-560):
+        # where the centre -> Sun line leaves the surface, body orientation and Sun direction
+        # taken at et - (light time from the observer to that surface point)
+        R0 = np.array(g.R0[:]).reshape(3, 3)
+        VT, AT = np.array(g.VT[:]), np.array(g.AT[:])
+        S0, VS, AS = np.array(g.S0[:]), np.array(g.VS[:]), np.array(g.AS[:])
+        t0 = g.et - g.lt_c
+        lt = g.lt_c
+        ssp = np.zeros(3)
+        for _ in range(4):
+            d = (g.et - lt) - t0
+            ang = g.wdot * d
+            cz, sz = math.cos(ang), math.sin(ang)
+            R = np.array([[cz, sz, 0.0], [-sz, cz, 0.0], [0.0, 0.0, 1.0]]) @ R0
+            moved = VT * d + 0.5 * AT * d * d  # target centre since t0 (SSB)
+            sun = S0 + VS * d + 0.5 * AS * d * d - moved  # Sun wrt target centre, same light-time lag
+            u = R @ sun
+            u /= np.linalg.norm(u)
+            ssp = u / math.sqrt((u[0] / radii[0]) ** 2 + (u[1] / radii[1]) ** 2 + (u[2] / radii[2]) ** 2)
+            lt = float(np.linalg.norm(T0 + moved + R.T @ ssp)) / g.clight
+        slon = math.atan2(ssp[1], ssp[0])
+        if g.west_positive:
+            slon = -slon
+        slon %= 2 * math.pi
+        slat = math.atan2(ssp[2] / (1 - f) ** 2, math.hypot(ssp[0], ssp[1]))
         return {
+            'subsol_lon': float(np.rad2deg(slon)),
+            'subsol_lat': float(np.rad2deg(slat)),
             'target_ra': float(np.rad2deg(ra)),
             'target_dec': float(np.rad2deg(dec)),
             'target_distance': g.lt_c * g.clight,

@@ -87,3 +87,25 @@ def utc2et(utc, leap_seconds=None) -> float:
         ecc_anom = mean_anom + EB * math.sin(mean_anom)
         et = tai + DELTA_T_A + K * math.sin(ecc_anom)
     return et
+
+
+def et2utc(et: float, leap_seconds=None) -> datetime.datetime:
+    """UTC datetime of a TDB epoch (`spice.et2datetime` of base.py:826); microsecond resolution."""
+    table = LEAP_SECONDS if leap_seconds is None else leap_seconds
+    mean_anom = M0 + M1 * et
+    ecc_anom = mean_anom + EB * math.sin(mean_anom)
+    tai = et - DELTA_T_A - K * math.sin(ecc_anom)
+    delta_at = table[-1][0]
+    for _ in range(3):  # the leap-second count depends on the UTC date it produces
+        t = _J2000 + datetime.timedelta(seconds=tai - delta_at)
+        new = 0
+        for n, (y, m, d) in table:
+            if t >= datetime.datetime(y, m, d):
+                new = n
+        if new == 0:
+            raise ValueError('epochs before 1972-01-01 are not supported')
+        if new == delta_at:
+            break
+        delta_at = new
+    us = round((tai - delta_at) * 1e6)
+    return _J2000 + datetime.timedelta(microseconds=us)

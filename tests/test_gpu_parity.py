@@ -499,3 +499,37 @@ def test_smooth_interpolation_vs_oracle_kats_and_golden(engine, oracle, jupiter)
     engine.map_cube_device(dc, np.float64, cube.shape[0], dx, dy, xm.shape[0], xm.shape[1], dout, 'smooth', True)
     engine.synchronize()
     assert np.array_equal(dout.cpu().numpy(), engine.map_cube(cube, xm, ym, 'smooth', True), equal_nan=True)
+
+
+def test_save_observation_and_map_on_gpu(engine, oracle, jupiter, tmp_path):
+    """
+    The callers that want every plane (observation.py:1184-1474) on the real engine: a 257 x 193
+    frame written with all 26 backplanes and its 5 deg map, read back and compared with the oracle.
+    """
+    from planetmapper_amd import Observation, fits_io
+
+    rng = np.random.default_rng(8)
+    cube = rng.standard_normal((3, 193, 257)).astype(np.float32)
+    obs = Observation(data=cube, target='jupiter', geometry=jupiter, engine=engine)
+    obs.set_disc_params(120.3, 99.1, 80.5, 33.0)
+    out = os.path.join(tmp_path, 'nav.fits')
+    obs.save_observation(out, print_info=False)
+    hdus = fits_io.read(out)
+    assert [h.name for h in hdus[1:]] == list(obs.backplanes)
+    assert hdus[0].data.dtype == np.float32 and np.array_equal(hdus[0].data, cube)
+    d = oracle.make_disc(120.3, 99.1, 80.5, 33.0, 257, 193)
+    ref = oracle.backplanes_img(jupiter, d, oracle.PLANE_NAMES)
+    _compare({h.name: h.data for h in hdus[1:]}, ref, oracle.PLANE_NAMES, jupiter, r0=80.5)
+    out = os.path.join(tmp_path, 'map.fits')
+    obs.save_mapped_observation(out, degree_interval=5, print_info=False)
+    hdus = fits_io.read(out)
+    lon, lat = oracle.rectangular_grid(jupiter, 5.0)
+    xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+    # white noise has unit gradients per pixel: the 1e-10 px differences of the x/y maps near
+    # the limb show up at that level in the samples
+    assert np.array_equal(np.isnan(hdus[0].data), np.isnan(oracle.map_cube(cube, xm, ym)))
+    assert np.allclose(hdus[0].data, oracle.map_cube(cube, xm, ym), rtol=1e-7, atol=1e-7, equal_nan=True)
+    gx, gy = obs.get_x_map(degree_interval=5), obs.get_y_map(degree_interval=5)
+    assert np.allclose(hdus[0].data, oracle.map_cube(cube, gx, gy), rtol=1e-12, atol=1e-12, equal_nan=True)
+    assert hdus[0].header['PLANMAP MAP DEGREE-INTERVAL'] == 5 and hdus[0].header['CDELT1'] == -5.0
+    assert [h.name for h in hdus[1:]] == list(obs.backplanes)

@@ -631,6 +631,9 @@ int pm_set_disc(pm_ctx *ctx, const pm_disc *disc)
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "disc parameters must be finite");
     if (!(disc->r0 > 0.0)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "r0 must be greater than zero");
     if (disc->nx < 0 || disc->ny < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "nx and ny must be non-negative");
+    // the image kernels address a row with a 32-bit byte offset and put rows on gridDim.y
+    if (disc->nx > (1 << 28) || disc->ny > 65535)
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image size is limited to nx <= 2^28, ny <= 65535");
     ctx->disc = *disc;
     ctx->have_disc = true;
     return PM_OK;

@@ -32,6 +32,14 @@ enum DiscFlags : int {
         if (PM_WANT(pl)) p.out[pl][idx] = (val);   \
     } while (0)
 
+// Store through a wave-uniform row pointer (SGPR pair) + 32-bit lane offset: the
+// global_store saddr form, one address dword per lane instead of a 64-bit VGPR pointer.
+#define PM_PUT_ROW(pl, val)                                               \
+    do {                                                                  \
+        if (PM_WANT(pl))                                                  \
+            *reinterpret_cast<double *>(reinterpret_cast<char *>(p.out[pl] + row_base) + lane_off) = (val); \
+    } while (0)
+
 // Reference loops fused here: BodyXY._get_targvec_img body_xy.py:3195, _get_lonlat_img
 // :3281, _get_lonlat_centric_img :3346, _get_illumination_gie_img :3658,
 // get_azimuth_angle_img :3742, get_local_solar_time_img :3787, _get_state_imgs :3830,
@@ -43,7 +51,8 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
     const int x = blockIdx.x * kBlock + threadIdx.x;
     const int y = blockIdx.y;
     const bool inside = x < p.nx;
-    const size_t idx = (size_t)y * p.nx + (inside ? x : 0);
+    const size_t row_base = (size_t)y * p.nx;  // wave-uniform: stores use the saddr form
+    const unsigned lane_off = (unsigned)x * 8u;
     const double nan = __builtin_nan("");
 
     // radius pre-mask of _get_targvec_img (only with optimize_speed)
@@ -77,8 +86,8 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
         lat_deg = lat * kDeg;
     }
     if (inside) {
-        PM_PUT(PM_LON_GRAPHIC, lon_deg);
-        PM_PUT(PM_LAT_GRAPHIC, lat_deg);
+        PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
+        PM_PUT_ROW(PM_LAT_GRAPHIC, lat_deg);
     }
     if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
         double lc = nan, bc = nan;
@@ -88,13 +97,13 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
             lc = ((sp.x == 0.0 && sp.y == 0.0) ? 0.0 : atan2(sp.y, sp.x)) * kDeg;
         }
         if (inside) {
-            PM_PUT(PM_LON_CENTRIC, lc);
-            PM_PUT(PM_LAT_CENTRIC, bc);
+            PM_PUT_ROW(PM_LON_CENTRIC, lc);
+            PM_PUT_ROW(PM_LAT_CENTRIC, bc);
         }
     }
     if (PM_WANT(PM_LOCAL_SOLAR_TIME)) {
         double v = local_solar_time(p, lon_deg);
-        if (inside) PM_PUT(PM_LOCAL_SOLAR_TIME, v);
+        if (inside) PM_PUT_ROW(PM_LOCAL_SOLAR_TIME, v);
     }
 
     double surf_dist = nan;
@@ -122,15 +131,15 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
         }
         if (inside) {
             if (FLAGS & DF_ILLUM) {
-                PM_PUT(PM_PHASE, ph);
-                PM_PUT(PM_INCIDENCE, in);
-                PM_PUT(PM_EMISSION, em);
-                PM_PUT(PM_AZIMUTH, az);
+                PM_PUT_ROW(PM_PHASE, ph);
+                PM_PUT_ROW(PM_INCIDENCE, in);
+                PM_PUT_ROW(PM_EMISSION, em);
+                PM_PUT_ROW(PM_AZIMUTH, az);
             }
             if (FLAGS & DF_STATE) {
-                PM_PUT(PM_DISTANCE, surf_dist);
-                PM_PUT(PM_RADIAL_VELOCITY, rv);
-                PM_PUT(PM_DOPPLER, dop);
+                PM_PUT_ROW(PM_DISTANCE, surf_dist);
+                PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);
+                PM_PUT_ROW(PM_DOPPLER, dop);
             }
         }
     }
@@ -141,9 +150,9 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
         // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
         if (rd > surf_dist) rr = rl = rd = nan;
         if (inside) {
-            PM_PUT(PM_RING_RADIUS, rr);
-            PM_PUT(PM_RING_LON_GRAPHIC, rl);
-            PM_PUT(PM_RING_DISTANCE, rd);
+            PM_PUT_ROW(PM_RING_RADIUS, rr);
+            PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
+            PM_PUT_ROW(PM_RING_DISTANCE, rd);
         }
     }
 }
@@ -184,7 +193,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     // chip at the same time: HBM writes of the former overlap the VALU work of the latter.
     const int y = (int)(((long long)blockIdx.y * p.row_stride) % p.ny);
     const bool inside = x < p.nx;
-    const size_t idx = (size_t)y * p.nx + (inside ? x : 0);
+    const size_t row_base = (size_t)y * p.nx;  // wave-uniform
+    const unsigned lane_off = (unsigned)x * 8u;  // byte offset in the row (< 4 GiB, checked by the host)
     const double nan = __builtin_nan("");
 
     const double dx = (double)x - p.x0, dy = (double)y - p.y0;
@@ -350,25 +360,25 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 
     if (inside) {
         if (FLAGS & DF_RING) {
-            PM_PUT(PM_RING_RADIUS, rr);
-            PM_PUT(PM_RING_LON_GRAPHIC, rl);
-            PM_PUT(PM_RING_DISTANCE, rd);
+            PM_PUT_ROW(PM_RING_RADIUS, rr);
+            PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
+            PM_PUT_ROW(PM_RING_DISTANCE, rd);
         }
-        PM_PUT(PM_LON_GRAPHIC, lon_deg);
-        PM_PUT(PM_LAT_GRAPHIC, lat_deg);
-        PM_PUT(PM_LON_CENTRIC, lc_deg);
-        PM_PUT(PM_LAT_CENTRIC, bc_deg);
-        if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
+        PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
+        PM_PUT_ROW(PM_LAT_GRAPHIC, lat_deg);
+        PM_PUT_ROW(PM_LON_CENTRIC, lc_deg);
+        PM_PUT_ROW(PM_LAT_CENTRIC, bc_deg);
+        if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT_ROW(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
         if (FLAGS & DF_ILLUM) {
-            PM_PUT(PM_PHASE, ph);
-            PM_PUT(PM_INCIDENCE, in);
-            PM_PUT(PM_EMISSION, em);
-            PM_PUT(PM_AZIMUTH, az);
+            PM_PUT_ROW(PM_PHASE, ph);
+            PM_PUT_ROW(PM_INCIDENCE, in);
+            PM_PUT_ROW(PM_EMISSION, em);
+            PM_PUT_ROW(PM_AZIMUTH, az);
         }
         if (FLAGS & DF_STATE) {
-            PM_PUT(PM_DISTANCE, dist);
-            PM_PUT(PM_RADIAL_VELOCITY, rv);
-            PM_PUT(PM_DOPPLER, dop);
+            PM_PUT_ROW(PM_DISTANCE, dist);
+            PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);
+            PM_PUT_ROW(PM_DOPPLER, dop);
         }
     }
 }
@@ -382,7 +392,8 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
     const int x = blockIdx.x * kBlock + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= p.nx) return;
-    const size_t idx = (size_t)y * p.nx + x;
+    const size_t row_base = (size_t)y * p.nx;  // wave-uniform: stores use the saddr form
+    const unsigned lane_off = (unsigned)x * 8u;
     // xy2ray with the fast elementary functions (rays are finite for every pixel)
     const double xd = (double)x, yd = (double)y;
     const double ax0 = fma(p.A[0], xd, fma(p.A[1], yd, p.A[2]));
@@ -391,10 +402,10 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
     double ra, dec;
     recrad_f(ray, ra, dec);
     double ra_deg = ra * kDeg, dec_deg = dec * kDeg;
-    PM_PUT(PM_RA, ra_deg);
-    PM_PUT(PM_DEC, dec_deg);
-    PM_PUT(PM_PIXEL_X, xd);
-    PM_PUT(PM_PIXEL_Y, yd);
+    PM_PUT_ROW(PM_RA, ra_deg);
+    PM_PUT_ROW(PM_DEC, dec_deg);
+    PM_PUT_ROW(PM_PIXEL_X, xd);
+    PM_PUT_ROW(PM_PIXEL_Y, yd);
     const bool km = PM_WANT(PM_KM_X) || PM_WANT(PM_KM_Y) || PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y);
     if (km || LIMB) {
         // the reference goes back through degrees (radec2obsvec_norm), so do the same
@@ -403,21 +414,21 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
             double ax, ay;
             obsvec2angular_f(p, ray2, ax, ay);
             double kx = fma(p.K[0], ax, p.K[1] * ay), ky = fma(p.K[2], ax, p.K[3] * ay);
-            PM_PUT(PM_KM_X, kx);
-            PM_PUT(PM_KM_Y, ky);
+            PM_PUT_ROW(PM_KM_X, kx);
+            PM_PUT_ROW(PM_KM_Y, ky);
             if (PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y)) {
                 const double ik = rcp_fast(p.g.km_per_arcsec);
                 const double qx = kx * ik, qy = ky * ik;
-                PM_PUT(PM_ANGULAR_X, fma(fma(-p.g.km_per_arcsec, qx, kx), ik, qx));
-                PM_PUT(PM_ANGULAR_Y, fma(fma(-p.g.km_per_arcsec, qy, ky), ik, qy));
+                PM_PUT_ROW(PM_ANGULAR_X, fma(fma(-p.g.km_per_arcsec, qx, kx), ik, qx));
+                PM_PUT_ROW(PM_ANGULAR_Y, fma(fma(-p.g.km_per_arcsec, qy, ky), ik, qy));
             }
         }
         if (LIMB) {
             double ll, lb, ld;
             limb_coords_f(p, ray2, ll, lb, ld);
-            PM_PUT(PM_LIMB_LON_GRAPHIC, ll);
-            PM_PUT(PM_LIMB_LAT_GRAPHIC, lb);
-            PM_PUT(PM_LIMB_DISTANCE, ld);
+            PM_PUT_ROW(PM_LIMB_LON_GRAPHIC, ll);
+            PM_PUT_ROW(PM_LIMB_LAT_GRAPHIC, lb);
+            PM_PUT_ROW(PM_LIMB_DISTANCE, ld);
         }
     }
 }

@@ -47,6 +47,14 @@ class OracleEngine:
         self.calls.append(('cube', cube.shape, interpolation))
         return oracle.map_cube(cube, x_map, y_map, interpolation, propagate_nan, **smooth)
 
+    def map_cube_device(self, cube, dtype, n_planes, x_map, y_map, n0, n1, out, interpolation='linear',
+                        propagate_nan=True):
+        """stand-in for the device-resident call: CPU torch tensors in, result written into `out`"""
+        import torch
+
+        res = self.map_cube(cube.numpy()[:n_planes], x_map.numpy(), y_map.numpy(), interpolation, propagate_nan)
+        out.reshape(n_planes, n0, n1).copy_(torch.from_numpy(res))
+
     def transform(self, src, dst, a, b, *, alt=0.0, not_visible_nan=False, planetocentric=False):
         self.calls.append(('transform', src, dst))
         return oracle.transform(self._g, self._d, src, dst, a, b, alt=alt, not_visible_nan=not_visible_nan,

@@ -79,3 +79,56 @@ def test_sharded_mapping_world_size_2(tmp_path, n_planes):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_planes, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def _pipeline_worker(rank: int, world: int, port: int, tmpdir: str) -> None:
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import torch
+
+        from oracle import oracle
+        from oracle_engine import OracleEngine
+        from planetmapper_amd.distributed import map_cube_sharded_device
+        from planetmapper_amd.scenarios import load_scenario
+
+        g = load_scenario('jupiter_hst_2005')
+        eng = OracleEngine()
+        eng.set_geometry(g)
+        eng.set_disc(9.5, 12.0, 8.0, 0.5, 20, 24, True)
+        lon, lat = oracle.rectangular_grid(g, 15.0)
+        out = eng.backplanes_map(['PIXEL-X', 'PIXEL-Y'], lon, lat)
+        xm, ym = torch.from_numpy(out['PIXEL-X'].copy()), torch.from_numpy(out['PIXEL-Y'].copy())
+        n0, n1 = lon.shape
+        gathered = torch.full((world, 2, n0, n1), float('nan'), dtype=torch.float64)
+        pending = None
+        # what bench.py does per step: map this rank's planes into its slot, all-gather the slots
+        # asynchronously, hand the work handle to the next step
+        for step in range(3):
+            rng = np.random.default_rng(100 * step)  # same stream on every rank
+            frames = rng.standard_normal((world, 2, 24, 20))
+            mine = torch.from_numpy(frames[rank].copy())
+            pending = map_cube_sharded_device(eng, mine, np.float64, 2, xm, ym, n0, n1, gathered, rank,
+                                              'linear', True, async_op=True, previous=pending)  # fmt: skip
+            assert pending is not None
+        pending.wait()
+        expect = np.stack([oracle.map_cube(frames[r], xm.numpy(), ym.numpy()) for r in range(world)])
+        assert np.array_equal(gathered.numpy(), expect, equal_nan=True)
+        # synchronous form returns the finished handle / None for a single rank
+        h = map_cube_sharded_device(eng, mine, np.float64, 2, xm, ym, n0, n1, gathered, rank)
+        assert h is None or h.is_completed()
+        open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_device_all_gather_world_size_2(tmp_path):
+    """bench.py's N > 1 step (slot write + in-place all-gather with the handle carried over)"""
+    world = 2
+    mp.spawn(_pipeline_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))

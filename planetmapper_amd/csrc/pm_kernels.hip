@@ -724,7 +724,9 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
             long xi = (long)rint(x), yi = (long)rint(y);
             if (xi < 0) xi += nx;
             if (yi < 0) yi += ny;
-            val = load_as_f64(img, (size_t)yi * nx + xi);
+            // maps made by pm_xy_map are always inside the frame; a caller-supplied map that is
+            // not (the reference raises IndexError there) must not read outside the plane
+            if (xi >= 0 && xi < nx && yi >= 0 && yi < ny && !isnan(y)) val = load_as_f64(img, (size_t)yi * nx + xi);
         } else {
             const bool have_stats = a.plane_stats != nullptr;
             bool skip = have_stats && a.plane_stats[pl].all_nan;  // body_xy.py:1668-1670

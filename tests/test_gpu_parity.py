@@ -183,6 +183,18 @@ def test_error_behaviour(engine, jupiter):
         engine.map_cube(np.zeros((7, 8)), np.zeros((2, 2)), np.zeros((2, 2)), 'linear')
     with pytest.raises(ValueError):
         engine.set_disc(0, 0, -1, 0, 8, 8, True)
+    # caller-supplied maps that leave the frame (or have a NaN y for a finite x) never read
+    # outside the plane: such cells come back NaN for every interpolation
+    img = np.arange(64.0).reshape(8, 8)
+    xm = np.array([[3.2, 1e9, -1e9, 2.0, np.inf, 7.49], [-0.4, 3.0, 8.6, 1e300, -7.6, np.nan]])
+    ym = np.array([[2.1, 3.0, 3.0, np.nan, 2.0, 7.49], [-0.4, -1e12, 2.0, 2.0, 1.0, 1.0]])
+    for interp in ('nearest', 'linear', 'cubic', 'smooth'):
+        for prop in (True, False):
+            out = engine.map_cube(img, xm, ym, interp, prop)[0]
+            assert np.isfinite(out[0, 0]) and np.isnan(out[1, 5]), (interp, prop)
+            if interp == 'nearest':
+                assert out[0, 0] == img[2, 3] and out[0, 5] == img[7, 7] and out[1, 0] == img[0, 0]
+                assert np.isnan(out[0, 1:5]).all() and np.isnan(out[1, 1:4]).all()
 
 
 def test_headline_frame_4096_vs_oracle_and_round_trip(engine, oracle, jupiter):

@@ -102,6 +102,7 @@ def lib() -> ctypes.CDLL:
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp,
         ]
         _lib.pmo_pchip.argtypes = [dp, dp, ctypes.c_int, dp, ctypes.c_int, dp]
+        _lib.pmo_clean_nans.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp]
         _lib.pmo_transform.argtypes = [
             ctypes.POINTER(PMGeometry), ctypes.POINTER(PMDisc), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
             dp, dp, ctypes.c_double, ctypes.c_int, dp, dp,
@@ -211,6 +212,16 @@ def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_n
         cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym),
         n0, n1, interp, 1 if propagate_nan else 0, _dptr(out),
     )
+    if rc != 0:
+        raise ValueError(f'oracle error {rc}')
+    return out
+
+
+def clean_nans(img) -> np.ndarray:
+    """BodyXY._replace_nans_with_interpolated_values (body_xy.py:1871-1904)"""
+    img = np.ascontiguousarray(img, dtype=np.float64)
+    out = np.empty_like(img)
+    rc = lib().pmo_clean_nans(_dptr(img), img.shape[0], img.shape[1], _dptr(out))
     if rc != 0:
         raise ValueError(f'oracle error {rc}')
     return out

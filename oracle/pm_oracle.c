@@ -961,6 +961,15 @@ static void clean_nans(const double *img, int ny, int nx, double *cleaned)
         }
 }
 
+/* test entry: the NaN pre-clean on its own (reference KAT table of
+ * tests/test_body_xy.py:1479-1536) */
+int pmo_clean_nans(const double *img, int ny, int nx, double *cleaned)
+{
+    if (ny <= 0 || nx <= 0) return PM_ERR_INVALID_ARGUMENT;
+    clean_nans(img, ny, nx, cleaned);
+    return PM_OK;
+}
+
 /*
  * BodyXY.map_img body_xy.py:1414-1631 per plane, over all planes like
  * Observation._get_mapped_data observation.py:876-905.

@@ -2,8 +2,8 @@
 """
 Known-answer vectors for `map_img(..., interpolation='smooth')`, lifted from the expected-value
 tables of the reference's own tests (tests/test_body_xy.py: `test_map_img` 'smooth' subtest and
-`test_map_img_smooth_interpolation`). Only the (keyword arguments -> expected map) pairs are
-taken - data, not code; the inputs are rebuilt in tests/test_api_host.py from the recipe the
+`test_map_img_smooth_interpolation`). Also the (image -> NaN-cleaned image) table of
+`test_replace_nans_with_interpolated_values`. Only value tables are taken - data, not code; the inputs are rebuilt in tests/test_api_host.py from the recipe the
 reference documents.
 
     python tests/golden/make_kat_fixtures.py [/root/reference]
@@ -32,8 +32,32 @@ def tables(text: str) -> list[list]:
     return out
 
 
+def literal_after(text: str, marker: str):
+    """the Python list literal that follows `marker` (bracket matching; nan / inf allowed)"""
+    i = text.index(marker) + len(marker)
+    i = text.index('[', i)
+    depth, j = 0, i
+    while True:
+        depth += {'[': 1, ']': -1}.get(text[j], 0)
+        j += 1
+        if depth == 0:
+            break
+    return eval(text[i:j], {}, {'nan': float('nan'), 'inf': float('inf')})
+
+
 def main(ref: str) -> None:
     text = open(os.path.join(ref, 'tests', 'test_body_xy.py'), encoding='utf-8').read()
+    # (image, cleaned image) pairs of test_replace_nans_with_interpolated_values
+    pairs = literal_after(text, 'images: list[tuple[list, list]] =')
+    with open(os.path.join(HERE, 'kat_replace_nans.json'), 'w', encoding='utf-8') as f:
+        json.dump(
+            {
+                'source': 'tests/test_body_xy.py test_replace_nans_with_interpolated_values value table',
+                'cases': [{'image': a, 'cleaned': b} for a, b in pairs],
+            },
+            f,
+        )
+    print('replace_nans cases', len(pairs))
     found = [t for t in tables(text) if any('smooth_oversample_by' in e['kwargs'] for e in t)]
     assert len(found) == 2, len(found)
     fixture = {

@@ -605,3 +605,33 @@ def test_other_body_shapes_and_longitude_conventions(engine, oracle, jupiter, ca
         # (recpgr / pgrrec work on the spheroid (a, f): for a triaxial body the round trip is
         # not the identity in the reference either)
         assert np.nanmax(np.hypot(bx - px[fin], by - py[fin])) < 5e-3  # the reference's own round-trip error
+
+
+def test_nan_preclean_reference_kats_on_gpu(engine, jupiter):
+    """
+    The reference's value table for `_replace_nans_with_interpolated_values`
+    (tests/test_body_xy.py:1479-1536) through the GPU: with `propagate_nan=False` a bilinear
+    sample at an integer pixel position returns that pixel's cleaned value, so an identity map
+    reads the whole cleaned image back (window means evaluated on the fly in `k_reproject`,
+    plane nanmedian by the radix-select kernels). The all-NaN image is the exception: `map_img`
+    returns an all-NaN map before cleaning (body_xy.py:1668-1670).
+    """
+    import json
+
+    with open(os.path.join(GOLDEN, 'kat_replace_nans.json'), encoding='utf-8') as f:
+        cases = json.load(f)['cases']
+    engine.set_geometry(jupiter)
+    for c in cases:
+        img = np.array(c['image'], dtype=float)
+        exp = np.array(c['cleaned'], dtype=float)
+        ny, nx = img.shape
+        engine.set_disc(1.0, 1.0, 1.0, 0.0, nx, ny, True)
+        xm, ym = np.meshgrid(np.arange(nx, dtype=float), np.arange(ny, dtype=float))
+        got = engine.map_cube(img, xm, ym, 'linear', False)[0]
+        if np.isnan(img).all():
+            assert np.isnan(got).all()
+        else:
+            assert np.allclose(got, exp, rtol=1e-12, atol=0), c['image']
+        for dt in (np.float32,):
+            if np.isfinite(img).all():
+                assert np.allclose(engine.map_cube(img.astype(dt), xm, ym, 'linear', False)[0], exp)

@@ -237,3 +237,20 @@ def test_oracle_pchip_equals_scipy():
             ref = PchipInterpolator(x, y, extrapolate=False)(xq)
             assert np.array_equal(np.isnan(got), np.isnan(ref))
             assert np.nanmax(np.abs(got - ref)) <= 1e-14
+
+
+def test_oracle_nan_preclean_kats():
+    """the reference's own value table for _replace_nans_with_interpolated_values
+    (tests/test_body_xy.py:1479-1536; tests/golden/kat_replace_nans.json)"""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from oracle import oracle
+
+    with open(os.path.join(GOLDEN, 'kat_replace_nans.json'), encoding='utf-8') as f:
+        cases = json.load(f)['cases']
+    assert len(cases) == 6
+    for c in cases:
+        got = oracle.clean_nans(np.array(c['image'], dtype=float))
+        assert np.allclose(got, np.array(c['cleaned'], dtype=float), rtol=1e-12, atol=0), c['image']

@@ -635,3 +635,52 @@ def test_nan_preclean_reference_kats_on_gpu(engine, jupiter):
         for dt in (np.float32,):
             if np.isfinite(img).all():
                 assert np.allclose(engine.map_cube(img.astype(dt), xm, ym, 'linear', False)[0], exp)
+
+
+def _near_field_geometry(distance_km):
+    """Jupiter seen from `distance_km` (an observer like the reference's 'amalthea' test case,
+    tests/test_body_xy.py:2592-2607), built by the package's own host geometry provider"""
+    from planetmapper_amd.ephem import Ephemeris, RotationModel
+    from planetmapper_amd.geometry import CLIGHT, GeometryBuilder
+    from planetmapper_amd.scenarios import _load_json
+
+    d = _load_json('jupiter_hst_2005')
+    gb = GeometryBuilder(Ephemeris.from_json(d['ephemeris']), RotationModel.from_json(d['pck']), d['target_id'])
+    h = d['header']
+    return gb.build(
+        d['et'] + 3 * 3600.0,
+        observer_velocity=[-10.0, 28.0, 3.0],
+        target_ra_dec_dist_lt=(h['PLANMAP TARGET RA'] + 40.0, h['PLANMAP TARGET DEC'] + 20.0, distance_km,
+                               distance_km / CLIGHT),  # fmt: skip
+    )
+
+
+@pytest.mark.parametrize('distance_km', [181_000.0, 1.2e6])
+def test_near_field_observer(engine, oracle, distance_km):
+    """
+    A close observer: the disc subtends tens of degrees, so the small-angle shortcuts of the
+    fast path (series sincos of the view angles, spin angle over the light-time span) are
+    outside their range for part of the frame and the wave-uniform fallbacks take over;
+    parallax makes the visible cap much smaller than a hemisphere. All planes + map chain vs
+    the oracle (no reference golden for this geometry: "parity unpinned").
+    """
+    g = _near_field_geometry(distance_km)
+    assert g.diameter_arcsec > 5 * 3600
+    nx, ny = 261, 197
+    x0, y0, r0, rot = 128.0, 101.5, 70.0, 200.0
+    engine.set_geometry(g)
+    engine.set_disc(x0, y0, r0, float(np.deg2rad(rot)), nx, ny, True)
+    d = oracle.make_disc(x0, y0, r0, rot, nx, ny)
+    d.rotation_rad = float(np.deg2rad(rot))
+    out = engine.backplanes_img(oracle.PLANE_NAMES)
+    ref = oracle.backplanes_img(g, d, oracle.PLANE_NAMES)
+    _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)
+    assert 0.1 < np.isfinite(out['LON-GRAPHIC']).mean() < 0.6
+    lon, lat = oracle.rectangular_grid(g, 5.0)
+    om = engine.backplanes_map(oracle.PLANE_NAMES, lon, lat)
+    rm = oracle.backplanes_map(g, d, oracle.PLANE_NAMES, lon, lat)
+    _compare(om, rm, oracle.PLANE_NAMES, g, r0=r0)
+    # test_mapping_visible_areas: a cell is mapped exactly where its emission angle is <= 90 deg
+    vis = om['EMISSION'] <= 90
+    assert np.isfinite(om['RA'][vis]).all() and np.isnan(om['RA'][~vis]).all()
+    assert 0.02 < vis.mean() < 0.5

@@ -227,6 +227,15 @@ int pm_set_disc(pm_ctx *ctx, const pm_disc *disc);
 int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt,
                       double *const *out, int mem);
 
+/*
+ * Row block of pm_backplanes_img: image rows [row_begin, row_begin + n_rows) only, out[p] ->
+ * n_rows*nx doubles (output row r = image row row_begin + r). Pixels are independent
+ * (body_xy.py:3155-3164 iterates them one by one), so a frame shards over GPUs by row blocks
+ * with no halo; planetmapper_amd.distributed.backplanes_img_sharded all-gathers the blocks.
+ */
+int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row_begin,
+                           int n_rows, double *const *out, int mem);
+
 /* Point transforms --------------------------------------------------------------- */
 /*
  * replaces the array-valued coordinate transforms built on

@@ -90,6 +90,17 @@ int fail(pm_ctx *ctx, int code, const char *fmt, ...)
                         __FILE__, __LINE__);                                                  \
     } while (0)
 
+// golden-ratio row stride, made coprime with the row count so the row map is a bijection
+int32_t golden_stride(int rows)
+{
+    auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
+    const long n = rows > 0 ? rows : 1;
+    long s = (long)(0.6180339887498949 * n);
+    if (s < 1) s = 1;
+    while (gcd(s, n) != 1) s++;
+    return (int32_t)s;
+}
+
 int ensure_scratch(pm_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->scratch_bytes) return PM_OK;
@@ -211,15 +222,10 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     }
     p.nx = d.nx;
     p.ny = d.ny;
-    {
-        // golden-ratio row stride, made coprime with ny so the row map is a bijection
-        auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
-        long s = (long)(0.6180339887498949 * d.ny);
-        if (s < 1) s = 1;
-        while (gcd(s, d.ny > 0 ? d.ny : 1) != 1) s++;
-        p.row_stride = (int32_t)s;
-        p.pad_ = 0;
-    }
+    p.y_off = 0;
+    p.rows = d.ny;
+    p.row_stride = golden_stride(d.ny);
+    p.pad_ = 0;
     p.optimize_speed = d.optimize_speed;
     p.n0 = p.n1 = 0;
     p.mask = 0;
@@ -641,6 +647,13 @@ int pm_set_disc(pm_ctx *ctx, const pm_disc *disc)
 
 int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *const *out, int mem)
 {
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    return pm_backplanes_img_rows(ctx, plane_mask, alt, 0, ctx->disc.ny, out, mem);
+}
+
+int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row_begin, int n_rows,
+                           double *const *out, int mem)
+{
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
     if (!out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "out is NULL");
@@ -650,15 +663,21 @@ int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *cons
     // BodyXY._make_empty_img body_xy.py:3166-3168
     if (d.nx <= 0 || d.ny <= 0)
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "nx and ny must be positive to create a backplane image");
-    if (plane_mask == 0) return PM_OK;
+    if (row_begin < 0 || n_rows < 0 || row_begin > d.ny - n_rows)
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "rows [%d, %d) are outside the image (ny = %d)", row_begin,
+                    row_begin + n_rows, d.ny);
+    if (plane_mask == 0 || n_rows == 0) return PM_OK;
     for (int i = 0; i < 3; i++)
         if (!(ctx->geometry.radii[i] + alt > 0.0))
             return fail(ctx, PM_ERR_INVALID_ARGUMENT, "radii + alt must be positive");
-    size_t npx = (size_t)d.nx * d.ny;
+    size_t npx = (size_t)d.nx * n_rows;
 
     pm::Params p;
     fill_params(ctx, alt, p);
     p.mask = plane_mask;
+    p.y_off = row_begin;
+    p.rows = n_rows;
+    p.row_stride = golden_stride(n_rows);
     int nreq = 0;
     for (int i = 0; i < PM_NUM_PLANES; i++)
         if ((plane_mask >> i) & 1) {

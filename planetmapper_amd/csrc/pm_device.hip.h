@@ -99,7 +99,9 @@ struct Params {
     double lat_k;     // (radii[0] / radii[2])^2
     double ir[3];     // 1 / radii[i]
     double limb_n[2]; // surface-normal scalings of recpgr_surface: (m/a)^2, (m/c)^2, m = min(a, c)
-    int32_t row_stride;  // row visiting order of the image kernels (coprime with ny)
+    int32_t row_stride;  // row visiting order of the image kernels (coprime with `rows`)
+    int32_t y_off;       // first image row of this launch (row-block sharding), normally 0
+    int32_t rows;        // rows computed by this launch (<= ny); output row r holds image row y_off + r
     int32_t pad_;
 };
 

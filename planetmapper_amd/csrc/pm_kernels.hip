@@ -49,9 +49,9 @@ template <int FLAGS>
 __global__ __launch_bounds__(kBlock) void k_disc(const Params p)
 {
     const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y = p.y_off + (int)blockIdx.y;
     const bool inside = x < p.nx;
-    const size_t row_base = (size_t)y * p.nx;  // wave-uniform: stores use the saddr form
+    const size_t row_base = (size_t)blockIdx.y * p.nx;  // wave-uniform: stores use the saddr form
     const unsigned lane_off = (unsigned)x * 8u;
     const double nan = __builtin_nan("");
 
@@ -191,9 +191,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     // Rows are visited in a golden-ratio stride order (a bijection: gcd(row_stride, ny) = 1)
     // so that store-only rows off the disc and FP64-heavy rows through it are resident on the
     // chip at the same time: HBM writes of the former overlap the VALU work of the latter.
-    const int y = (int)(((long long)blockIdx.y * p.row_stride) % p.ny);
+    const int yl = (int)(((long long)blockIdx.y * p.row_stride) % p.rows);  // row within this launch
+    const int y = p.y_off + yl;
     const bool inside = x < p.nx;
-    const size_t row_base = (size_t)y * p.nx;  // wave-uniform
+    const size_t row_base = (size_t)yl * p.nx;  // wave-uniform
     const unsigned lane_off = (unsigned)x * 8u;  // byte offset in the row (< 4 GiB, checked by the host)
     const double nan = __builtin_nan("");
 
@@ -390,9 +391,9 @@ template <bool LIMB>
 __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
 {
     const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int y = blockIdx.y;
+    const int y = p.y_off + (int)blockIdx.y;
     if (x >= p.nx) return;
-    const size_t row_base = (size_t)y * p.nx;  // wave-uniform: stores use the saddr form
+    const size_t row_base = (size_t)blockIdx.y * p.nx;  // wave-uniform: stores use the saddr form
     const unsigned lane_off = (unsigned)x * 8u;
     // xy2ray with the fast elementary functions (rays are finite for every pixel)
     const double xd = (double)x, yd = (double)y;
@@ -1082,7 +1083,7 @@ extern "C++" {
 
 void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
 {
-    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.ny);
+    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.rows);
     dim3 block(pm::kBlock);
     switch (flags & 7) {
     case 0: hipLaunchKernelGGL(pm::k_disc<0>, grid, block, 0, s, p); break;
@@ -1098,7 +1099,7 @@ void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
 
 void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 {
-    dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.ny);
+    dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
     dim3 block(pm::kSphBlock);
     switch (flags & 7) {
     case 0: hipLaunchKernelGGL(pm::k_disc_sph<0>, grid, block, 0, s, p); break;
@@ -1114,7 +1115,7 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s)
 {
-    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.ny);
+    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.rows);
     dim3 block(pm::kBlock);
     if (limb)
         hipLaunchKernelGGL(pm::k_sky<true>, grid, block, 0, s, p);

@@ -1,5 +1,6 @@
 """
-Wavelength-plane sharding of `Observation.get_mapped_data` over the GPUs of one node.
+Sharding of the path over the GPUs of one node: wavelength planes of
+`Observation.get_mapped_data`, and row blocks of a frame's backplane images.
 
 The planes of a cube are independent in the reference (`observation.py:892-904` maps
 them one after another with the same x/y map), so the path shards with no halo and no
@@ -88,6 +89,37 @@ def get_mapped_data_sharded(
     if n_planes == 0:
         return np.empty((0, n0, n1))
     return all_gather_planes(local, n_planes, group)
+
+
+def backplanes_img_sharded(engine, names, ny: int, nx: int, *, alt: float = 0.0, group=None) -> dict[str, np.ndarray]:
+    """
+    One frame's image backplanes with the ROWS sharded over the ranks of `group`: rank r computes
+    the contiguous block of ceil(ny / world) rows `shard_bounds(ny, world, r)` on its GPU
+    (`pm_backplanes_img_rows`; pixels are independent in the reference, body_xy.py:3155-3164, so
+    there is no halo) and one all-gather assembles the (ny, nx) planes on every rank.
+    `engine` must already hold the geometry and disc of the full frame on every rank.
+    """
+    import torch
+    import torch.distributed as dist
+
+    names = list(names)
+    if not dist.is_initialized():
+        return engine.backplanes_img_rows(names, 0, ny, alt=alt)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    start, stop, per_rank = shard_bounds(ny, world, rank)
+    local = np.full((len(names), per_rank, nx), np.nan)
+    if stop > start:
+        block = engine.backplanes_img_rows(names, start, stop - start, alt=alt)
+        for i, n in enumerate(names):
+            local[i, : stop - start] = block[n]
+    dev = _group_device(group)
+    t_local = torch.from_numpy(local).to(dev)
+    out = torch.empty((world,) + tuple(t_local.shape), dtype=t_local.dtype, device=dev)
+    dist.all_gather_into_tensor(out.view(-1), t_local.view(-1), group=group)
+    full = out.permute(1, 0, 2, 3).reshape(len(names), world * per_rank, nx)[:, :ny]
+    full = full.cpu().numpy()
+    return {n: np.ascontiguousarray(full[i]) for i, n in enumerate(names)}
 
 
 def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_map, n0: int, n1: int,

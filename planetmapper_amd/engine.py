@@ -188,6 +188,35 @@ class Engine:
             self._lib.pm_backplanes_img(self._ctx, plane_mask(outs.keys()), float(alt), ptrs, _lib.PM_MEM_DEVICE)
         )
 
+    def backplanes_img_rows(self, names: Iterable[str], row_begin: int, n_rows: int, alt: float = 0.0):
+        """Rows [row_begin, row_begin + n_rows) of the image backplanes: arrays of shape (n_rows, nx)."""
+        names = list(names)
+        assert self._disc is not None
+        if self._disc.ny <= 0 or self._disc.nx <= 0:
+            raise ValueError('nx and ny must be positive to create a backplane image')
+        outs = {n: np.empty((int(n_rows), self._disc.nx), dtype=np.float64) for n in names}
+        ptrs = (ctypes.c_void_p * NUM_PLANES)()
+        for n, a in outs.items():
+            ptrs[PLANE_INDEX[n]] = a.ctypes.data
+        self._check(
+            self._lib.pm_backplanes_img_rows(
+                self._ctx, plane_mask(names), float(alt), int(row_begin), int(n_rows), ptrs, _lib.PM_MEM_HOST
+            )
+        )
+        return outs
+
+    def backplanes_img_rows_device(self, outs: Mapping[str, object], row_begin: int, n_rows: int,
+                                   alt: float = 0.0) -> None:
+        """Enqueue a row block of the image backplanes into device buffers of n_rows * nx doubles."""
+        ptrs = (ctypes.c_void_p * NUM_PLANES)()
+        for n, a in outs.items():
+            ptrs[PLANE_INDEX[n]] = _ptr(a)
+        self._check(
+            self._lib.pm_backplanes_img_rows(
+                self._ctx, plane_mask(outs.keys()), float(alt), int(row_begin), int(n_rows), ptrs, _lib.PM_MEM_DEVICE
+            )
+        )
+
     # ------------------------------------------------------------------ map space
     def backplanes_map(self, names, lon_deg, lat_deg, alt: float = 0.0) -> dict[str, np.ndarray]:
         names = list(names)

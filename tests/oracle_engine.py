@@ -30,6 +30,11 @@ class OracleEngine:
         self.calls.append(('img', tuple(names), alt))
         return oracle.backplanes_img(self._g, self._d, names, alt=alt)
 
+    def backplanes_img_rows(self, names, row_begin, n_rows, alt=0.0):
+        self.calls.append(('rows', tuple(names), row_begin, n_rows))
+        full = oracle.backplanes_img(self._g, self._d, list(names), alt=alt)
+        return {n: np.ascontiguousarray(a[row_begin : row_begin + n_rows]) for n, a in full.items()}
+
     def backplanes_map(self, names, lon, lat, alt=0.0):
         names = list(names)
         self.calls.append(('map', tuple(names), alt))

@@ -132,3 +132,46 @@ def test_pipelined_device_all_gather_world_size_2(tmp_path):
     world = 2
     mp.spawn(_pipeline_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def _rows_worker(rank: int, world: int, port: int, ny: int, tmpdir: str) -> None:
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from oracle_engine import OracleEngine
+        from planetmapper_amd.distributed import backplanes_img_sharded
+        from planetmapper_amd.scenarios import load_scenario
+
+        g = load_scenario('jupiter_hst_2005')
+        eng = OracleEngine()
+        eng.set_geometry(g)
+        nx = 23
+        eng.set_disc(11.0, ny / 2, 0.4 * ny, 0.3, nx, ny, True)
+        names = ['LON-GRAPHIC', 'EMISSION', 'RA', 'RING-RADIUS']
+        got = backplanes_img_sharded(eng, names, ny, nx)
+        d = oracle.make_disc(11.0, ny / 2, 0.4 * ny, 0.0, nx, ny)
+        d.rotation_rad = 0.3
+        ref = oracle.backplanes_img(g, d, names)
+        for n in names:
+            assert got[n].shape == (ny, nx)
+            assert np.array_equal(got[n], ref[n], equal_nan=True), n
+        a, b, _ = shard_bounds(ny, world, rank)
+        rows = [c for c in eng.calls if c[0] == 'rows']
+        assert [(c[2], c[3]) for c in rows] == ([(a, b - a)] if b > a else [])
+        open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('ny', [20, 17, 1])
+def test_row_block_sharded_backplanes_world_size_2(tmp_path, ny):
+    """a frame's rows split over two ranks and all-gathered (SURVEY 8e partition 2)"""
+    world = 2
+    mp.spawn(_rows_worker, args=(world, _free_port(), ny, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))

@@ -684,3 +684,32 @@ def test_near_field_observer(engine, oracle, distance_km):
     vis = om['EMISSION'] <= 90
     assert np.isfinite(om['RA'][vis]).all() and np.isnan(om['RA'][~vis]).all()
     assert 0.02 < vis.mean() < 0.5
+
+
+@pytest.mark.parametrize('force_names', [None, ['LON-GRAPHIC', 'EMISSION', 'RING-RADIUS', 'RA', 'LIMB-DISTANCE', 'PIXEL-Y']])
+def test_row_blocks_equal_the_full_frame(engine, oracle, jupiter, saturn, force_names):
+    """
+    pm_backplanes_img_rows (the unit of row-block sharding over GPUs): any row block is
+    bit-identical to the same rows of the full-frame launch, for the spheroid fast path, the
+    ring path, the sky planes and ragged blocks; invalid windows are rejected.
+    """
+    names = force_names or oracle.PLANE_NAMES
+    for g, (nx, ny) in ((jupiter, (203, 157)), (saturn, (130, 95))):
+        engine.set_geometry(g)
+        engine.set_disc(nx / 2.1, ny / 1.9, 0.3 * nx, 0.7, nx, ny, True)
+        full = engine.backplanes_img(names)
+        for a, n in ((0, ny), (0, 1), (ny - 1, 1), (ny // 4, ny // 2 + 1), (5, ny - 6), (ny, 0)):
+            block = engine.backplanes_img_rows(names, a, n)
+            for k in names:
+                assert block[k].shape == (n, nx)
+                assert np.array_equal(block[k], full[k][a : a + n], equal_nan=True), (k, a, n)
+        for a, n in ((-1, 3), (ny - 2, 3), (0, -1)):
+            with pytest.raises(ValueError):
+                engine.backplanes_img_rows(names, a, n)
+    import torch
+
+    dev = {k: torch.empty((64, 130), dtype=torch.float64, device='cuda') for k in names}
+    engine.backplanes_img_rows_device(dev, 20, 64)
+    engine.synchronize()
+    for k in names:
+        assert np.array_equal(dev[k].cpu().numpy(), full[k][20:84], equal_nan=True), k

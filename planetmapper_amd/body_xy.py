@@ -328,6 +328,63 @@ class BodyXY:
     def get_img_size(self) -> tuple[int, int]:
         return (self._nx, self._ny)
 
+    def rotate_north_to_top(self) -> None:
+        """body_xy.py:892-902"""
+        self.set_rotation(-self.north_pole_angle())
+        self.set_disc_method('rotate_north_to_top')
+
+    def scale_img_size(self, factor: float, *, allow_rounding: bool = False) -> None:
+        """body_xy.py:973-1023: multiply nx, ny by `factor`, keeping the disc where it is"""
+        if factor <= 0:
+            raise ValueError('Scaling factor must be greater than zero')
+        nx, ny = self.get_img_size()
+        nx_f, ny_f = nx * factor, ny * factor
+        nx_c, ny_c = math.ceil(nx_f), math.ceil(ny_f)
+        if not allow_rounding and (nx_c != nx_f or ny_c != ny_f):
+            raise ValueError(
+                f'Image size ({nx}, {ny}) cannot be exactly scaled by {factor} to an integer number of '
+                f'pixels: new size would be ({nx_f}, {ny_f}). Use `allow_rounding=True` to allow rounding '
+                'of the image size.'
+            )
+        self.set_img_size(nx_c, ny_c)
+        self.set_r0(self.get_r0() * factor)
+        offset = (factor - 1) / 2  # the pixel grid runs from -0.5 to n - 0.5
+        self.set_x0(self.get_x0() * factor + offset)
+        self.set_y0(self.get_y0() * factor + offset)
+
+    def add_img_border(self, border: int) -> None:
+        """body_xy.py:1025-1058: grow (or crop, if negative) the frame by `border` pixels per side"""
+        border = int(border)
+        nx, ny = self.get_img_size()
+        self.set_img_size(nx + 2 * border, ny + 2 * border)
+        self.set_x0(self.get_x0() + border)
+        self.set_y0(self.get_y0() + border)
+
+    def add_arcsec_offset(self, dra_arcsec: float = 0, ddec_arcsec: float = 0) -> None:
+        """body_xy.py:1088-1103: shift (x0, y0) by an offset given in RA/Dec arcseconds"""
+        ra0, dec0 = self.xy2radec(0, 0)
+        dx, dy = self.radec2xy(ra0 + dra_arcsec / 3600, dec0 + ddec_arcsec / 3600)
+        self.adjust_disc_params(dx=dx, dy=dy)
+
+    def _get_img_limits(self, func):
+        """body_xy.py:1106-1120: extremes over the four outer pixel corners"""
+        corners = [(-0.5, -0.5), (-0.5, self._ny - 0.5), (self._nx - 0.5, -0.5), (self._nx - 0.5, self._ny - 0.5)]
+        pts = [func(x, y) for x, y in corners]
+        return (min(p[0] for p in pts), max(p[0] for p in pts)), (min(p[1] for p in pts), max(p[1] for p in pts))
+
+    def get_img_limits_radec(self):
+        xlim, ylim = self._get_img_limits(self.xy2radec)
+        return (xlim[1], xlim[0]), ylim  # RA increases to the left
+
+    def get_img_limits_km(self):
+        return self._get_img_limits(self.xy2km)
+
+    def get_img_limits_angular(self):
+        return self._get_img_limits(self.xy2angular)
+
+    def get_img_limits_xy(self):
+        return self._get_img_limits(lambda x, y: (x, y))
+
     def set_disc_method(self, method: str) -> None:
         self._disc_method = method
 

@@ -473,3 +473,52 @@ def test_azimuthal_equal_area_grid(body):
     lons, lats, xx, yy, _, _ = body.generate_map_coordinates('azimuthal equal area', size=41, lat=30, lon=100)
     assert np.isnan(lons[0, 0]) and np.isfinite(lons[20, 20])
     assert lats[20, 20] == pytest.approx(30.0) and (lons[20, 20] % 360) == pytest.approx(100.0)
+
+
+def test_disc_helpers_kats(jupiter):
+    """tests/test_body_xy.py:588-595, 637-763: rotate_north_to_top, scale_img_size, add_img_border,
+    add_arcsec_offset and the image limits, with the reference's expected values"""
+    body = BodyXY('Jupiter', geometry=jupiter, nx=15, ny=10, engine=OracleEngine())
+    body.set_disc_params(0, 0, 1, 0)
+    body.rotate_north_to_top()
+    assert body.get_rotation() == pytest.approx(24.15516987997688, abs=1e-7)
+    assert body.get_disc_method() == 'rotate_north_to_top'
+
+    def fresh():
+        b = BodyXY('Jupiter', geometry=jupiter, nx=16, ny=10, engine=OracleEngine())
+        b.set_disc_params(3, 4, 5, 6)
+        return b
+
+    for factor, size, disc in (
+        (1, (16, 10), (3.0, 4.0, 5.0, 6.0)), (2, (32, 20), (6.5, 8.5, 10.0, 6.0)),
+        (1.5, (24, 15), (4.75, 6.25, 7.5, 6.0)), (0.5, (8, 5), (1.25, 1.75, 2.5, 6.0)),
+    ):  # fmt: skip
+        b = fresh()
+        b.scale_img_size(factor)
+        assert b.get_img_size() == size and np.allclose(b.get_disc_params(), disc)
+    with pytest.raises(ValueError):
+        fresh().scale_img_size(0.25)
+    with pytest.raises(ValueError):
+        fresh().scale_img_size(-1)
+    b = fresh()
+    b.scale_img_size(0.25, allow_rounding=True)
+    assert b.get_img_size() == (4, 3) and np.allclose(b.get_disc_params(), (0.375, 0.625, 1.25, 6.0))
+    for border, size, disc in ((0, (16, 10), (3, 4, 5, 6)), (2, (20, 14), (5, 6, 5, 6)), (-1, (14, 8), (2, 3, 5, 6))):
+        b = fresh()
+        b.add_img_border(border)
+        assert b.get_img_size() == size and np.allclose(b.get_disc_params(), disc)
+
+    body = BodyXY('Jupiter', geometry=jupiter, nx=15, ny=10, engine=OracleEngine())
+    body.set_disc_params(0, 0, 1, 0)
+    body.add_arcsec_offset(0, 0)
+    assert np.allclose(body.get_disc_params(), (0, 0, 1, 0))
+    body.add_arcsec_offset(1, 2)
+    assert np.allclose(body.get_disc_params(), (-0.05532064212457044, 0.11116537556358708, 1.0, 0.0))
+    body.set_disc_params(7.5, 5.0, 4.5, 0.0)
+    assert body.get_img_limits_xy() == ((-0.5, 14.5), (-0.5, 9.5))
+    assert np.allclose(body.get_img_limits_radec(),
+                       ((196.38091225891438, 196.36417481895663), (-5.571901975157448, -5.560796287842726)))  # fmt: skip
+    assert np.allclose(body.get_img_limits_km(),
+                       ((-151724.69753899056, 130727.50016257458), (-125236.31445765976, 117241.42226096484)))  # fmt: skip
+    assert np.allclose(body.get_img_limits_angular(),
+                       ((-31.984379466325663, 27.98633203326517), (-21.98926088314898, 17.99121344984992)))  # fmt: skip

@@ -186,6 +186,9 @@ def other_workloads(args) -> None:
         )
         alg = n0 * n1 * (16 + 40 * per_rank)
         scaling = 'strong'
+    for _ in range(min(args.preheat_steps, 200)):  # untimed clock ramp (see main)
+        step()
+    barrier()
     for _ in range(args.warmup):
         step()
     barrier()

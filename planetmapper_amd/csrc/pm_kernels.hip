@@ -400,17 +400,20 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
     const double ax0 = fma(p.A[0], xd, fma(p.A[1], yd, p.A[2]));
     const double ay0 = fma(p.A[3], xd, fma(p.A[4], yd, p.A[5]));
     V3 ray = mtxv(p.g.M, radrec_f(-(div_fast(ax0, 3600.0) * kRad), div_fast(ay0, 3600.0) * kRad));
-    double ra, dec;
-    recrad_f(ray, ra, dec);
-    double ra_deg = ra * kDeg, dec_deg = dec * kDeg;
-    PM_PUT_ROW(PM_RA, ra_deg);
-    PM_PUT_ROW(PM_DEC, dec_deg);
+    if (PM_WANT(PM_RA) || PM_WANT(PM_DEC)) {
+        double ra, dec;
+        recrad_f(ray, ra, dec);
+        PM_PUT_ROW(PM_RA, ra * kDeg);
+        PM_PUT_ROW(PM_DEC, dec * kDeg);
+    }
     PM_PUT_ROW(PM_PIXEL_X, xd);
     PM_PUT_ROW(PM_PIXEL_Y, yd);
     const bool km = PM_WANT(PM_KM_X) || PM_WANT(PM_KM_Y) || PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y);
     if (km || LIMB) {
-        // the reference goes back through degrees (radec2obsvec_norm), so do the same
-        V3 ray2 = radrec_f(ra_deg * kRad, dec_deg * kRad);
+        // The reference rebuilds the ray from RA/Dec in degrees (radec2obsvec_norm, body_xy.py:3262);
+        // that round trip moves it by < 1 ulp - below the rounding of the ray itself, 1e4 times
+        // below the parity bar after the D/R amplification - and is not replayed.
+        const V3 ray2 = ray;
         if (km) {
             double ax, ay;
             obsvec2angular_f(p, ray2, ax, ay);

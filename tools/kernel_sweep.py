@@ -16,17 +16,15 @@ g = load_scenario(os.environ.get('SCENARIO', 'jupiter_hst_2005'))
 eng.set_geometry(g)
 planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
 x0 = (sz - 1) / 2
-# clock ramp: a fresh box needs ~0.1 s of sustained load before the shader clock settles
-eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
-for _ in range(int(os.environ.get('PREHEAT', '400'))):
-    eng.backplanes_img_device(planes)
-torch.cuda.synchronize()
+# The shader clock follows the load within milliseconds (and needs ~0.1 s of sustained work to
+# settle after an idle gap), so every configuration gets its own untimed run-in.
+PREHEAT = int(os.environ.get('PREHEAT', '400'))
 for r0 in (1.0, 0.45 * x0, 0.9 * x0, 1e5):
     eng.set_disc(x0, x0, r0, 0.0, sz, sz, True)
-    for _ in range(3):
+    for _ in range(PREHEAT):
         eng.backplanes_img_device(planes)
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(100)]
     for a, b in evs:
         a.record(); eng.backplanes_img_device(planes); b.record()
     torch.cuda.synchronize()

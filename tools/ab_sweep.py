@@ -2,7 +2,7 @@
 """
 A/B timing of two builds of libplanetmapper_hip.so in ONE process on ONE GPU (clock and
 device variance between gpurun sessions is ~10 %, larger than most kernel tweaks).
-usage: python tools/ab_sweep.py libA.so libB.so [planes] ; interleaved, median of 30.
+usage: python tools/ab_sweep.py libA.so libB.so [planes] ; alternating blocks of back-to-back launches.
 """
 import ctypes, json, os, sys
 import numpy as np
@@ -25,18 +25,24 @@ for path in sys.argv[1:3]:
     e.set_geometry(g)
     engines.append(e)
 x0 = (sz - 1) / 2
+BLOCK, ROUNDS = 60, 6
 for r0 in (0.9 * x0, 1e5):
     res = [[], []]
     for e in engines:
         e.set_disc(x0, x0, r0, 0.0, sz, sz, True)
-        for _ in range(3):
+    # run-in: the shader clock needs ~0.1 s of sustained load to settle (and drops again within
+    # milliseconds of idling), so launches are issued back to back without host syncs
+    for _ in range(200):
+        for e in engines:
             e.backplanes_img_device(planes)
     torch.cuda.synchronize()
-    for rep in range(30):
-        for i, e in enumerate(engines):
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record(); e.backplanes_img_device(planes); b.record()
+    for rep in range(ROUNDS):
+        for i, e in enumerate(engines if rep % 2 == 0 else engines[::-1]):
+            i = i if rep % 2 == 0 else 1 - i
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(BLOCK)]
+            for a, b in evs:
+                a.record(); e.backplanes_img_device(planes); b.record()
             torch.cuda.synchronize()
-            res[i].append(a.elapsed_time(b))
-    print(json.dumps({'r0': r0, 'A_ms': round(float(np.median(res[0])), 4), 'B_ms': round(float(np.median(res[1])), 4),
-                      'B/A': round(float(np.median(res[1]) / np.median(res[0])), 4)}))
+            res[i] += [a.elapsed_time(b) for a, b in evs[10:]]  # the first launches after a switch settle
+    print(json.dumps({'r0': r0, 'A_ms': round(float(np.mean(res[0])), 4), 'B_ms': round(float(np.mean(res[1])), 4),
+                      'B/A': round(float(np.mean(res[1]) / np.mean(res[0])), 4)}))

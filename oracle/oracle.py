@@ -102,6 +102,14 @@ def lib() -> ctypes.CDLL:
             ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp,
         ]
         _lib.pmo_pchip.argtypes = [dp, dp, ctypes.c_int, dp, ctypes.c_int, dp]
+        ip = ctypes.POINTER(ctypes.c_int)
+        _lib.pmo_regrid_smooth.argtypes = [
+            dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, dp, ip, dp, ip, dp,
+        ]
+        _lib.pmo_map_cube_spline_smooth.argtypes = [
+            ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, dp, dp, ctypes.c_int,
+            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, dp,
+        ]
         _lib.pmo_clean_nans.argtypes = [dp, ctypes.c_int, ctypes.c_int, dp]
         _lib.pmo_transform.argtypes = [
             ctypes.POINTER(PMGeometry), ctypes.POINTER(PMDisc), ctypes.c_int, ctypes.c_int, ctypes.c_size_t,
@@ -178,8 +186,24 @@ def rectangular_grid(g: PMGeometry, degree_interval: float):
     return lon, lat
 
 
+def regrid_smooth(z, kx: int, ky: int, s: float):
+    """FITPACK regrid smoothing spline of z on (arange, arange): (tx, ty, c) like
+    scipy.interpolate.RectBivariateSpline(..., s=s).get_knots() / get_coeffs()"""
+    z = np.ascontiguousarray(z, dtype=np.float64)
+    mx, my = z.shape
+    tx, ty = np.empty(mx + kx + 1), np.empty(my + ky + 1)
+    c = np.empty((mx + 1) * (my + 1))
+    nx, ny = ctypes.c_int(0), ctypes.c_int(0)
+    rc = lib().pmo_regrid_smooth(_dptr(z), mx, my, kx, ky, float(s), _dptr(tx), ctypes.byref(nx), _dptr(ty),
+                                 ctypes.byref(ny), _dptr(c))
+    if rc != 0:
+        raise ValueError(f'oracle error {rc}')
+    tx, ty = tx[: nx.value].copy(), ty[: ny.value].copy()
+    return tx, ty, c[: (nx.value - kx - 1) * (ny.value - ky - 1)].reshape(nx.value - kx - 1, ny.value - ky - 1).copy()
+
+
 def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True,
-             smooth_oversample_by=5, smooth_max_oversampled_img_size=10_000):
+             smooth_oversample_by=5, smooth_max_oversampled_img_size=10_000, spline_smoothing=0.0):
     cube = np.ascontiguousarray(cube)
     if cube.ndim == 2:
         cube = cube[None]
@@ -199,6 +223,16 @@ def map_cube(cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_n
     spline = {'quadratic': (2, 2), 'cubic': (3, 3), 2: (2, 2), 3: (3, 3)}.get(interpolation)
     if isinstance(interpolation, tuple):
         spline = interpolation
+    if spline_smoothing and interpolation != 'nearest':
+        if spline is None:
+            spline = (1, 1)
+        rc = lib().pmo_map_cube_spline_smooth(
+            cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym), n0, n1,
+            int(spline[0]), int(spline[1]), float(spline_smoothing), 1 if propagate_nan else 0, _dptr(out),
+        )
+        if rc != 0:
+            raise ValueError(f'oracle error {rc}')
+        return out
     if spline is not None and spline != (1, 1):
         rc = lib().pmo_map_cube_spline(
             cube.ctypes.data_as(ctypes.c_void_p), DTYPES[cube.dtype], p, ny, nx, _dptr(xm), _dptr(ym), n0, n1,

@@ -1188,6 +1188,395 @@ int pmo_map_cube_spline(const void *cube, int dtype, int n_planes, int ny, int n
     return PM_OK;
 }
 
+/* ------------------------------------------------------------------ smoothing splines */
+/*
+ * RectBivariateSpline(arange(ny), arange(nx), img, kx, ky, s > 0) as used by
+ * BodyXY._do_spline_interpolation for `spline_smoothing > 0` (body_xy.py:1673-1680):
+ * FITPACK `regrid` (Dierckx) restated. Part 1 grows the knot sets from the least-squares
+ * polynomial, adding knots at data points in the interval with the largest residual sum, in
+ * x or y according to the reduction each direction achieved last time, until the
+ * least-squares spline has fp <= s. Part 2 finds the smoothing parameter p with
+ * F(p) = fp(p) - s = 0 by rational interpolation, where fp(p) belongs to the least-squares
+ * solution of
+ *        (ax) C (ay)' = q,   ax = [spx; bx / p], ay = [spy; by / p], q = [z 0; 0 0]
+ * (spx, spy: B-spline collocation; bx, by: jumps of the k-th derivative at the interior knots).
+ * Constants tol = 0.001, maxit = 20, con1 = 0.1, con9 = 0.9, con4 = 0.04 as in FITPACK.
+ * The separable system is solved direction by direction with banded Givens rotations.
+ */
+typedef struct sm_axis {
+    int m, k;       /* samples 0..m-1, degree */
+    int n;          /* number of knots */
+    double *t;      /* knots, capacity m + k + 1 */
+    double *fpint;  /* residual sum per knot interval */
+    int *nrdata;    /* data points strictly inside each interval */
+    int nplus;      /* knots added the last time this direction was refined */
+} sm_axis;
+
+static int sm_axis_init(sm_axis *a, int m, int k)
+{
+    a->m = m; a->k = k; a->n = 2 * (k + 1); a->nplus = 0;
+    a->t = (double *)calloc((size_t)m + k + 2, sizeof(double));
+    a->fpint = (double *)calloc((size_t)m + 1, sizeof(double));
+    a->nrdata = (int *)calloc((size_t)m + 1, sizeof(int));
+    if (!a->t || !a->fpint || !a->nrdata) return 0;
+    for (int i = 0; i <= k; i++) { a->t[i] = 0.0; a->t[k + 1 + i] = (double)(m - 1); }
+    a->nrdata[0] = m - 2;
+    return 1;
+}
+static void sm_axis_free(sm_axis *a) { free(a->t); free(a->fpint); free(a->nrdata); }
+
+/* fpknot: a new knot at the middle data point of the interval with the largest residual sum */
+static void sm_add_knot(sm_axis *a)
+{
+    int k = a->k, nrint = a->n - 2 * k - 1;
+    double fpmax = 0.0;
+    int number = -1, maxpt = 0, maxbeg = 0, jbegin = 1;
+    for (int j = 0; j < nrint; j++) {
+        int jp = a->nrdata[j];
+        if (!(fpmax >= a->fpint[j] || jp == 0)) { fpmax = a->fpint[j]; number = j; maxpt = jp; maxbeg = jbegin; }
+        jbegin += jp + 1;
+    }
+    if (number < 0) return;
+    int ihalf = maxpt / 2 + 1, nrx = maxbeg + ihalf; /* 1-based index of the data point: abscissa nrx - 1 */
+    for (int j = nrint - 1; j > number; j--) { a->fpint[j + 1] = a->fpint[j]; a->nrdata[j + 1] = a->nrdata[j]; }
+    for (int j = a->n - 1; j >= number + k + 1; j--) a->t[j + 1] = a->t[j];
+    a->nrdata[number] = ihalf - 1;
+    a->nrdata[number + 1] = maxpt - ihalf;
+    a->fpint[number] = fpmax * (double)a->nrdata[number] / (double)maxpt;
+    a->fpint[number + 1] = fpmax * (double)a->nrdata[number + 1] / (double)maxpt;
+    a->t[number + k + 1] = (double)(nrx - 1);
+    a->n += 1;
+}
+
+/* fpdisc: jumps of the k-th derivative of the B-splines at the interior knots, FITPACK
+ * scaling; row r (interior knot t[k+1+r]) has k+2 entries for columns r .. r+k+1 */
+static void sm_disc(const double *t, int n, int k, double *b)
+{
+    int nrint = n - 2 * k - 1;
+    double fac = (double)nrint / (t[n - k - 1] - t[k]);
+    for (int r = 0; r < nrint - 1; r++) {
+        int l = r + k + 1; /* knot index */
+        for (int j = 0; j < k + 2; j++) {
+            int i = r + j; /* column = B-spline index */
+            double prod = 1.0;
+            int first = 1;
+            for (int q = 0; q < k + 2; q++) {
+                if (i + q == l) continue;
+                double h = t[l] - t[i + q];
+                prod = first ? h : prod * h * fac;
+                first = 0;
+            }
+            b[(size_t)r * (k + 2) + j] = (t[i + k + 1] - t[i]) / prod;
+        }
+    }
+}
+
+/* Least squares  A X = RHS  for a banded A given row by row (Givens rotations into an upper
+ * triangular band of width k + 2), all right-hand sides at once. rows: nd data rows with k+1
+ * B-spline values (+ nb = nrint-1 rows of the jump matrix divided by p when p > 0).
+ * rhs(i, q) for data row i; X (nc x nrhs) is returned in `x`. */
+typedef double (*sm_rhs_fn)(const void *ctx, int i, int q);
+static void sm_lsq(const sm_axis *a, double p, int nrhs, sm_rhs_fn rhs, const void *ctx, double *x)
+{
+    const int k = a->k, n = a->n, nc = n - k - 1, band = k + 2, nrint = n - 2 * k - 1;
+    double *R = (double *)calloc((size_t)nc * band, sizeof(double));
+    double *row = (double *)malloc((size_t)nrhs * sizeof(double));
+    double *bj = (double *)malloc((size_t)(nrint > 1 ? nrint - 1 : 1) * band * sizeof(double));
+    for (size_t i = 0; i < (size_t)nc * nrhs; i++) x[i] = 0.0;
+    if (p > 0.0 && nrint > 1) sm_disc(a->t, n, k, bj);
+    const int nrows = a->m + ((p > 0.0) ? nrint - 1 : 0);
+    int l = k;
+    for (int i = 0; i < nrows; i++) {
+        double h[8];
+        int j0, w;
+        if (i < a->m) {
+            double xv = (double)i;
+            while (l < n - k - 2 && xv >= a->t[l + 1]) l++;
+            bspl_basis(a->t, k, xv, l, h);
+            j0 = l - k; w = k + 1;
+            for (int q = 0; q < nrhs; q++) row[q] = rhs(ctx, i, q);
+        } else {
+            int r = i - a->m;
+            for (int j = 0; j < band; j++) h[j] = bj[(size_t)r * band + j] / p;
+            j0 = r; w = band;
+            for (int q = 0; q < nrhs; q++) row[q] = 0.0;
+        }
+        for (int e = w; e < 8; e++) h[e] = 0.0;
+        /* the row slides down the triangle: eliminating its leading entry against R(j, :)
+         * fills in up to band - 1 entries to the right (jump rows travel to the last column) */
+        for (int j = j0; j < nc; j++) {
+            double piv = h[0];
+            if (piv != 0.0) {
+                /* fpgivs */
+                double ww = R[(size_t)j * band], store = fabs(piv), dd;
+                if (store >= ww) dd = store * sqrt(1.0 + (ww / piv) * (ww / piv));
+                else dd = ww * sqrt(1.0 + (piv / ww) * (piv / ww));
+                double c = ww / dd, sn = piv / dd;
+                R[(size_t)j * band] = dd;
+                double *xj = x + (size_t)j * nrhs;
+                for (int q = 0; q < nrhs; q++) { /* fprota on the right-hand sides */
+                    double s1 = row[q], s2 = xj[q];
+                    xj[q] = c * s2 + sn * s1;
+                    row[q] = c * s1 - sn * s2;
+                }
+                for (int b = 1; b < band; b++) {
+                    double s1 = h[b], s2 = R[(size_t)j * band + b];
+                    R[(size_t)j * band + b] = c * s2 + sn * s1;
+                    h[b] = c * s1 - sn * s2;
+                }
+            }
+            int any = 0;
+            for (int b = 0; b < band - 1; b++) { h[b] = h[b + 1]; any |= (h[b] != 0.0); }
+            h[band - 1] = 0.0;
+            if (!any) break;
+        }
+    }
+    for (int j = nc - 1; j >= 0; j--) { /* fpback */
+        double *xj = x + (size_t)j * nrhs;
+        for (int b = 1; b < band && j + b < nc; b++) {
+            double r = R[(size_t)j * band + b];
+            if (r == 0.0) continue;
+            const double *xb = x + (size_t)(j + b) * nrhs;
+            for (int q = 0; q < nrhs; q++) xj[q] -= r * xb[q];
+        }
+        double d = R[(size_t)j * band];
+        for (int q = 0; q < nrhs; q++) xj[q] /= d;
+    }
+    free(R); free(row); free(bj);
+}
+
+typedef struct sm_ctx { const double *a; size_t s0, s1; } sm_ctx; /* element (i, q) = a[i*s0 + q*s1] */
+static double sm_get(const void *ctx, int i, int q)
+{
+    const sm_ctx *c = (const sm_ctx *)ctx;
+    return c->a[(size_t)i * c->s0 + (size_t)q * c->s1];
+}
+
+/* coefficients c (ncx x ncy, row-major) of the least-squares (p <= 0) / smoothing (p > 0)
+ * spline for the current knots; fp and the per-interval residual sums are updated */
+static double sm_fit(const double *z, sm_axis *ax, sm_axis *ay, double p, double *c, double *u, double *ct)
+{
+    const int mx = ax->m, my = ay->m, ncx = ax->n - ax->k - 1, ncy = ay->n - ay->k - 1;
+    sm_ctx cz = {z, (size_t)my, 1};
+    sm_lsq(ax, p, my, sm_get, &cz, u);                  /* u: ncx x my */
+    sm_ctx cu = {u, 1, (size_t)my};                     /* rows of ay see u transposed */
+    sm_lsq(ay, p, ncx, sm_get, &cu, ct);                /* ct: ncy x ncx */
+    for (int i = 0; i < ncx; i++)
+        for (int j = 0; j < ncy; j++) c[(size_t)i * ncy + j] = ct[(size_t)j * ncx + i];
+    /* residuals (fpgrre): points on a knot give half to each neighbouring interval */
+    int nrx = ax->n - 2 * ax->k - 1, nry = ay->n - 2 * ay->k - 1;
+    for (int i = 0; i < nrx; i++) ax->fpint[i] = 0.0;
+    for (int j = 0; j < nry; j++) ay->fpint[j] = 0.0;
+    double fp = 0.0;
+    int lx = ax->k, oldx = 0;
+    double *hy = (double *)malloc((size_t)my * 8 * sizeof(double));
+    int *ly = (int *)malloc((size_t)my * sizeof(int));
+    {
+        int l = ay->k;
+        for (int j = 0; j < my; j++) {
+            while (l < ay->n - ay->k - 2 && (double)j >= ay->t[l + 1]) l++;
+            ly[j] = l;
+            bspl_basis(ay->t, ay->k, (double)j, l, hy + (size_t)j * 8);
+        }
+    }
+    for (int i = 0; i < mx; i++) {
+        double hx[8];
+        while (lx < ax->n - ax->k - 2 && (double)i >= ax->t[lx + 1]) lx++;
+        bspl_basis(ax->t, ax->k, (double)i, lx, hx);
+        int numx = lx - ax->k, oldy = 0;
+        for (int j = 0; j < my; j++) {
+            int numy = ly[j] - ay->k;
+            double sv = 0.0;
+            for (int a = 0; a <= ax->k; a++) {
+                double r = 0.0;
+                for (int b = 0; b <= ay->k; b++) r += hy[(size_t)j * 8 + b] * c[(size_t)(numx + a) * ncy + (numy + b)];
+                sv += hx[a] * r;
+            }
+            double term = (z[(size_t)i * my + j] - sv) * (z[(size_t)i * my + j] - sv);
+            fp += term;
+            ax->fpint[numx] += term;
+            ay->fpint[numy] += term;
+            double fac = 0.5 * term;
+            if (numy != oldy) { ay->fpint[numy] -= fac; ay->fpint[numy - 1] += fac; }
+            oldy = numy;
+            if (numx != oldx) { ax->fpint[numx] -= fac; ax->fpint[numx - 1] += fac; }
+        }
+        oldx = numx;
+    }
+    free(hy); free(ly);
+    return fp;
+}
+
+/* fits the smoothing spline of `z` (mx x my, finite); on return ax / ay hold the knots and
+ * `c` the coefficients ((ax->n - kx - 1) x (ay->n - ky - 1)) */
+static int sm_regrid(const double *z, int mx, int my, int kx, int ky, double s, sm_axis *ax, sm_axis *ay, double *c)
+{
+    const double tol = 0.001, con1 = 0.1, con9 = 0.9, con4 = 0.04;
+    const int maxit = 20;
+    const double acc = tol * s;
+    if (!sm_axis_init(ax, mx, kx) || !sm_axis_init(ay, my, ky)) return PM_ERR_ALLOC;
+    const int nminx = 2 * (kx + 1), nminy = 2 * (ky + 1), nmaxx = mx + kx + 1, nmaxy = my + ky + 1;
+    double *u = (double *)malloc((size_t)(mx + 1) * my * sizeof(double));
+    double *ct = (double *)malloc((size_t)(mx + 1) * (my + 1) * sizeof(double));
+    if (!u || !ct) { free(u); free(ct); return PM_ERR_ALLOC; }
+    int lastdi = 0, poly = 0;
+    double fp = 0.0, fp0 = 0.0, fpold = 0.0, reducx = 0.0, reducy = 0.0, fpms = 0.0;
+    int done = 0;
+    for (int iter = 0; iter < mx + my; iter++) {
+        poly = (ax->n == nminx && ay->n == nminy);
+        fp = sm_fit(z, ax, ay, -1.0, c, u, ct);
+        if (poly) fp0 = fp;
+        fpms = fp - s;
+        if (fabs(fpms) < acc) { done = 1; break; }
+        if (fpms < 0.0) break;
+        if (ax->n == nmaxx && ay->n == nmaxy) { done = 1; break; } /* interpolating spline */
+        if (lastdi < 0) reducx = fpold - fp;
+        else if (lastdi > 0) reducy = fpold - fp;
+        fpold = fp;
+        int nplx = 1, nply = 1;
+        if (ax->n != nminx) {
+            int npl1 = ax->nplus * 2;
+            if (reducx > acc) npl1 = (int)((double)ax->nplus * fpms / reducx);
+            int mxv = npl1 > ax->nplus / 2 ? npl1 : ax->nplus / 2;
+            if (mxv < 1) mxv = 1;
+            nplx = ax->nplus * 2 < mxv ? ax->nplus * 2 : mxv;
+        }
+        if (ay->n != nminy) {
+            int npl1 = ay->nplus * 2;
+            if (reducy > acc) npl1 = (int)((double)ay->nplus * fpms / reducy);
+            int mxv = npl1 > ay->nplus / 2 ? npl1 : ay->nplus / 2;
+            if (mxv < 1) mxv = 1;
+            nply = ay->nplus * 2 < mxv ? ay->nplus * 2 : mxv;
+        }
+        int go_x = (nplx < nply) || (nplx == nply && lastdi >= 0);
+        if (go_x && ax->n == nmaxx) go_x = 0;
+        if (!go_x && ay->n == nmaxy) go_x = 1;
+        sm_axis *a = go_x ? ax : ay;
+        lastdi = go_x ? -1 : 1;
+        a->nplus = go_x ? nplx : nply;
+        int nmax = go_x ? nmaxx : nmaxy;
+        for (int l = 0; l < a->nplus; l++) {
+            sm_add_knot(a);
+            if (a->n == nmax) break;
+        }
+    }
+    if (!done && !poly) {
+        /* part 2: the smoothing spline, f(p) = s by rational interpolation */
+        double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms, p = 1.0;
+        int ich1 = 0, ich3 = 0;
+        for (int iter = 0; iter < maxit; iter++) {
+            fp = sm_fit(z, ax, ay, p, c, u, ct);
+            fpms = fp - s;
+            if (fabs(fpms) < acc) break;
+            if (iter == maxit - 1) break;
+            double p2 = p, f2 = fpms;
+            if (!ich3) {
+                if ((f2 - f3) <= acc) { /* initial p too large */
+                    p3 = p2; f3 = f2;
+                    p = p * con4;
+                    if (p <= p1) p = p1 * con9 + p2 * con1;
+                    continue;
+                }
+                if (f2 < 0.0) ich3 = 1;
+            }
+            if (!ich1) {
+                if ((f1 - f2) <= acc) { /* initial p too small */
+                    p1 = p2; f1 = f2;
+                    p = p / con4;
+                    if (p3 >= 0.0 && p >= p3) p = p2 * con1 + p3 * con9;
+                    continue;
+                }
+                if (f2 > 0.0) ich1 = 1;
+            }
+            if (f2 >= f1 || f2 <= f3) break;
+            /* fprati */
+            if (p3 > 0.0) {
+                double h1 = f1 * (f2 - f3), h2 = f2 * (f3 - f1), h3 = f3 * (f1 - f2);
+                p = -(p1 * p2 * h3 + p2 * p3 * h1 + p3 * p1 * h2) / (p1 * h1 + p2 * h2 + p3 * h3);
+            } else {
+                p = (p1 * (f1 - f3) * f2 - p2 * (f2 - f3) * f1) / ((f1 - f2) * f3);
+            }
+            if (f2 < 0.0) { p3 = p2; f3 = f2; } else { p1 = p2; f1 = f2; }
+        }
+    }
+    free(u); free(ct);
+    return PM_OK;
+}
+
+/* test entry: knots / coefficients / residual of the fit (compared with scipy in tests) */
+int pmo_regrid_smooth(const double *z, int mx, int my, int kx, int ky, double s, double *tx, int *nx_out,
+                      double *ty, int *ny_out, double *c)
+{
+    if (mx <= kx || my <= ky || kx < 1 || kx > 5 || ky < 1 || ky > 5 || !(s > 0.0)) return PM_ERR_INVALID_ARGUMENT;
+    sm_axis ax, ay;
+    int rc = sm_regrid(z, mx, my, kx, ky, s, &ax, &ay, c);
+    if (rc == PM_OK) {
+        for (int i = 0; i < ax.n; i++) tx[i] = ax.t[i];
+        for (int i = 0; i < ay.n; i++) ty[i] = ay.t[i];
+        *nx_out = ax.n; *ny_out = ay.n;
+    }
+    sm_axis_free(&ax); sm_axis_free(&ay);
+    return rc;
+}
+
+int pmo_map_cube_spline_smooth(const void *cube, int dtype, int n_planes, int ny, int nx, const double *x_map,
+                               const double *y_map, int n0, int n1, int k_rows, int k_cols, double s,
+                               int propagate_nan, double *out)
+{
+    size_t npx = (size_t)ny * nx, nmap = (size_t)n0 * n1;
+    size_t esz = dtype_size(dtype);
+    if (esz == 0 || k_rows < 1 || k_rows > 5 || k_cols < 1 || k_cols > 5 || !(s > 0.0)) return PM_ERR_INVALID_ARGUMENT;
+    if (ny <= k_rows || nx <= k_cols) return PM_ERR_INVALID_ARGUMENT;
+    double *img = (double *)malloc(npx * sizeof(double));
+    double *cl = (double *)malloc(npx * sizeof(double));
+    double *c = (double *)malloc((size_t)(ny + 1) * (nx + 1) * sizeof(double));
+    int rc = PM_OK;
+    for (int p = 0; p < n_planes && rc == PM_OK; p++) {
+        const char *src = (const char *)cube + (size_t)p * npx * esz;
+        double *o = out + (size_t)p * nmap;
+        int all_nan = 1;
+        for (size_t i = 0; i < npx; i++) {
+            img[i] = load_px(src, dtype, i);
+            if (!isnan(img[i])) all_nan = 0;
+        }
+        for (size_t m = 0; m < nmap; m++) o[m] = NAN;
+        if (all_nan) continue;
+        clean_nans(img, ny, nx, cl);
+        sm_axis ay, ax; /* ay: image rows (axis 0, the reference's "x"), ax: image columns */
+        rc = sm_regrid(cl, ny, nx, k_rows, k_cols, s, &ay, &ax, c);
+        if (rc != PM_OK) break;
+        int ncx = ax.n - k_cols - 1;
+        pmo_axis ey = {ay.n - k_rows - 1, k_rows, ay.t, NULL}, ex = {ncx, k_cols, ax.t, NULL};
+        for (size_t m = 0; m < nmap; m++) {
+            double x = x_map[m], y = y_map[m];
+            if (isnan(x)) continue;
+            if (propagate_nan) {
+                if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) continue;
+                long xa = (long)fmax(floor(x), 0.0), xb = (long)fmin(ceil(x), nx - 1.0);
+                long ya = (long)fmax(floor(y), 0.0), yb = (long)fmin(ceil(y), ny - 1.0);
+                if (isnan(img[ya * nx + xa]) || isnan(img[ya * nx + xb]) || isnan(img[yb * nx + xa]) ||
+                    isnan(img[yb * nx + xb]))
+                    continue;
+            }
+            double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
+            double hy[6], hx[6];
+            int ly = find_interval(&ey, yc), lx = find_interval(&ex, xc);
+            bspl_basis(ey.t, k_rows, yc, ly, hy);
+            bspl_basis(ex.t, k_cols, xc, lx, hx);
+            double sv = 0.0;
+            for (int a = 0; a <= k_rows; a++) {
+                double r = 0.0;
+                for (int b = 0; b <= k_cols; b++) r += hx[b] * c[(size_t)(ly - k_rows + a) * ncx + (lx - k_cols + b)];
+                sv += hy[a] * r;
+            }
+            o[m] = sv;
+        }
+        sm_axis_free(&ay); sm_axis_free(&ax);
+    }
+    free(img); free(cl); free(c);
+    return rc;
+}
+
 /* ------------------------------------------------------------------ 'smooth' reprojection */
 /*
  * BodyXY._do_smooth_interpolation + _pchip_grid_interp2d (body_xy.py:1704-1853): the image is

@@ -666,15 +666,15 @@ class BodyXY:
         body_xy.py:1414-1631: project an image (ny, nx) - or a cube (P, ny, nx) - onto
         the map grid. `'nearest'`, `'linear'`, `'quadratic'`, `'cubic'`, integer degrees and
         `(k_rows, k_cols)` tuples (RectBivariateSpline with s=0) and `'smooth'` (PCHIP
-        oversampling + bilinear, body_xy.py:1704-1853) run on the GPU; `spline_smoothing > 0`
-        raises `UnsupportedError`.
+        oversampling + bilinear, body_xy.py:1704-1853) run on the GPU, and so do the FITPACK
+        smoothing splines of `spline_smoothing > 0`.
         """
         img = np.asarray(img)
         from .engine import interpolation_code
 
         interpolation_code(interpolation)  # ValueError for unknown methods (body_xy.py:1630)
-        if interpolation not in ('nearest', 'smooth') and spline_smoothing != 0:
-            raise _lib.UnsupportedError('spline_smoothing != 0 (FITPACK smoothing) is not implemented on the GPU path')
+        if spline_smoothing < 0:
+            raise ValueError('s should be s >= 0.0')  # scipy's message (RectBivariateSpline)
         interp = interpolation
         single = img.ndim == 2
         if img.ndim not in (2, 3) or img.shape[-2:] != (self._ny, self._nx):
@@ -695,6 +695,8 @@ class BodyXY:
                 smooth_oversample_by=smooth_oversample_by,
                 smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
             )  # fmt: skip
+        elif interp != 'nearest' and spline_smoothing != 0:
+            out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan, spline_smoothing=spline_smoothing)
         else:
             out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan)
         return out[0] if single else out

@@ -137,6 +137,7 @@ def main(ref: str) -> None:
         'map_orthographic-1', 'map_orthographic-2', 'map_orthographic-3',
         'map_azimuthal-1', 'map_azimuthal-2', 'map_azimuthal-3',
         'map_rectangular-quadratic', 'map_rectangular-cubic', 'map_rectangular-smooth',
+        'map_rectangular-interpolation',
     ]:  # fmt: skip
         hdr = fits_to_npz(
             os.path.join(odir, name + '.fits'),

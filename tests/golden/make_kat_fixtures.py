@@ -58,6 +58,19 @@ def main(ref: str) -> None:
             f,
         )
     print('replace_nans cases', len(pairs))
+    # {spline_smoothing: expected map} table of test_map_img (linear interpolation, 45 deg map)
+    i = text.index('expected_smoothings: dict[float, list] =')
+    j = text.index('}', i)
+    table = eval(text[text.index('{', i) : j + 1], {}, {'nan': None})
+    with open(os.path.join(HERE, 'kat_map_img_smoothing.json'), 'w', encoding='utf-8') as f:
+        json.dump(
+            {
+                'source': 'tests/test_body_xy.py test_map_img expected_smoothings value table',
+                'cases': [{'smoothing': k, 'expected': v} for k, v in table.items()],
+            },
+            f,
+        )
+    print('smoothing cases', len(table))
     found = [t for t in tables(text) if any('smooth_oversample_by' in e['kwargs'] for e in t)]
     assert len(found) == 2, len(found)
     fixture = {

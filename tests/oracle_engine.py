@@ -40,7 +40,7 @@ class OracleEngine:
         self.calls.append(('map', tuple(names), alt))
         return oracle.backplanes_map(self._g, self._d, names, lon, lat, alt=alt)
 
-    def map_cube(self, cube, x_map, y_map, interpolation='linear', propagate_nan=True, **smooth):
+    def map_cube(self, cube, x_map, y_map, interpolation='linear', propagate_nan=True, **smooth):  # incl. spline_smoothing
         from planetmapper_amd.engine import interpolation_code
 
         interpolation_code(interpolation)

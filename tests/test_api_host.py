@@ -289,8 +289,34 @@ def test_map_img_kats(body):
             body.map_img(IMAGE, degree_interval=45, interpolation=name), equal_nan=True,
         )  # fmt: skip
     assert np.isnan(body.map_img(IMAGE * nan, degree_interval=45, interpolation='cubic')).all()
-    with pytest.raises(UnsupportedError):
-        body.map_img(IMAGE, degree_interval=45, interpolation='cubic', spline_smoothing=1.0)
+    # spline_smoothing > 0: FITPACK smoothing splines (tests/test_body_xy.py:1194-1231)
+    # fmt: off
+    smoothings = {
+        0: [[nan, nan, nan, nan, nan, nan, nan, nan], [nan, nan, nan, 61.591824124152424, 488.0893412811879, 4.181692402514696, nan, nan], [nan, nan, nan, 3.678385742930187, 94.03788871233297, nan, nan, nan], [nan, nan, nan, -25.28910210942658, -1.6502703714050462, nan, nan, nan]],
+        1: [[nan, nan, nan, nan, nan, nan, nan, nan], [nan, nan, nan, 61.78601266274162, 487.8146612006081, 4.182606695966389, nan, nan], [nan, nan, nan, 3.7096818751834397, 94.00272821072134, nan, nan, nan], [nan, nan, nan, -25.261262121302103, -1.6266437752937738, nan, nan, nan]],
+    }
+    # fmt: on
+    for sm, exp in smoothings.items():
+        got = body.map_img(IMAGE, interpolation='linear', degree_interval=45, spline_smoothing=sm)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), sm
+    for sm, exp in _smoothing_kats():
+        got = body.map_img(IMAGE, interpolation='linear', degree_interval=45, spline_smoothing=sm)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), sm
+    factors = [1, 2.345, -10, 3456.789, np.nan]
+    kwargs = dict(interpolation='cubic', degree_interval=45, spline_smoothing=1)
+    mapped = body.map_img([IMAGE * f for f in factors], **kwargs)
+    for f, m in zip(factors, mapped):
+        assert np.array_equal(m, body.map_img(IMAGE * f, **kwargs), equal_nan=True), f
+    with pytest.raises(ValueError):
+        body.map_img(IMAGE, degree_interval=45, interpolation='cubic', spline_smoothing=-1.0)
+
+
+def _smoothing_kats():
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), 'golden', 'kat_map_img_smoothing.json'), encoding='utf-8') as f:
+        return [(k['smoothing'], np.array(k['expected'], dtype=float)) for k in json.load(f)['cases']]
 
 
 def _smooth_kats(name):
@@ -361,6 +387,15 @@ def test_observation_mapped_data(jupiter):
         assert np.allclose(m, gold, rtol=1e-5, atol=1e-6, equal_nan=True)
         m[:] = 0  # a copy: the cache is untouched (observation.py:864-872)
         assert np.allclose(obs.get_mapped_data(interpolation=interp, degree_interval=30), gold, equal_nan=True)
+    # map_rectangular-interpolation.fits: interpolation=(1, 3), spline_smoothing=2.34 (FITPACK
+    # smoothing); planes 6 and 7 are the ones the reference itself compares loosely because the
+    # smoothing of extreme data differs between scipy versions (tests/test_observation.py:1162-1170)
+    gold = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_interpolation.npz'))['PRIMARY']
+    m = obs.get_mapped_data(interpolation=(1, 3), spline_smoothing=2.34, degree_interval=30)
+    assert np.array_equal(np.isnan(m), np.isnan(gold))
+    for pl in range(10):
+        rtol, atol = {6: (1e-1, 1e-1), 7: (10, 1)}.get(pl, (1e-6, 1e-5))
+        assert np.allclose(m[pl], gold[pl], rtol=rtol, atol=atol, equal_nan=True), pl
     n = len(obs._engine.calls)
     obs.get_mapped_data(degree_interval=30)
     assert len(obs._engine.calls) == n  # cached

@@ -254,3 +254,33 @@ def test_oracle_nan_preclean_kats():
     for c in cases:
         got = oracle.clean_nans(np.array(c['image'], dtype=float))
         assert np.allclose(got, np.array(c['cleaned'], dtype=float), rtol=1e-12, atol=0), c['image']
+
+
+def test_oracle_smoothing_spline_equals_scipy():
+    """
+    `spline_smoothing > 0`: the oracle's restatement of FITPACK `regrid` against
+    scipy.interpolate.RectBivariateSpline(s > 0) - the third-party routine the reference calls
+    (body_xy.py:1673-1680): identical knot sets (the knot-placement strategy) and coefficients
+    to 1e-9 (the rational-interpolation search for the smoothing parameter), degrees 1..5,
+    least-squares-polynomial, knot-limited and p-limited regimes.
+    """
+    from scipy.interpolate import RectBivariateSpline
+
+    from oracle import oracle
+
+    rng = np.random.default_rng(0)
+    cases = []
+    for n0, n1, kx, ky, s in (
+        (12, 9, 3, 3, 5.0), (30, 40, 3, 3, 400.0), (30, 40, 1, 3, 900.0), (25, 31, 2, 2, 100.0),
+        (64, 48, 3, 3, 2500.0), (40, 40, 5, 4, 1000.0), (120, 90, 1, 1, 3000.0), (7, 6, 5, 5, 0.5),
+        (50, 50, 4, 2, 1e-3), (33, 35, 2, 3, 1e4), (33, 35, 2, 3, 1e7),
+    ):  # fmt: skip
+        yy, xx = np.mgrid[0:n0, 0:n1]
+        cases.append((np.sin(xx / 5.0) * np.cos(yy / 7.0) * 3 + rng.standard_normal((n0, n1)), kx, ky, s))
+    for z, kx, ky, s in cases:
+        ref = RectBivariateSpline(np.arange(z.shape[0]), np.arange(z.shape[1]), z, kx=kx, ky=ky, s=s)
+        rtx, rty = ref.get_knots()
+        tx, ty, c = oracle.regrid_smooth(z, kx, ky, s)
+        assert np.array_equal(tx, rtx) and np.array_equal(ty, rty), (z.shape, kx, ky, s)
+        cref = ref.get_coeffs().reshape(c.shape)
+        assert np.abs(c - cref).max() <= 1e-9 * np.abs(cref).max(), (z.shape, kx, ky, s)

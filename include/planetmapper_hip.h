@@ -298,6 +298,16 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
  */
 int pm_set_smooth_options(pm_ctx *ctx, int oversample_by, int max_oversampled_img_size);
 
+/*
+ * `spline_smoothing` of BodyXY.map_img (body_xy.py:1420, used at :1673-1680 as the `s` of
+ * scipy's RectBivariateSpline = FITPACK regrid). 0 (default): interpolating splines. s > 0:
+ * smoothing splines for PM_INTERP_LINEAR and PM_INTERP_SPLINE(kr, kc) - knots are added where
+ * the residuals are largest until the least-squares spline reaches a residual sum <= s, then
+ * the smoothing parameter is found by FITPACK's rational interpolation; fits run per plane on
+ * the GPU (calls with s > 0 complete synchronously).
+ */
+int pm_set_spline_smoothing(pm_ctx *ctx, double s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -5,6 +5,7 @@
 // compute path here: without a gfx950 device pm_create() fails.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -26,6 +27,13 @@ void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int 
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
+void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
+void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
+                        double *c, hipStream_t s);
+void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s);
+void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
+                        double *rowsum, double *colsum, hipStream_t s);
+void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, int dtype, hipStream_t s);
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
 
@@ -62,6 +70,9 @@ struct pm_ctx {
     int smooth_oversample_by = 5;
     int smooth_max_size = 10000;
     double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
+    double spline_smoothing = 0.0;  // map_img spline_smoothing (FITPACK s), 0 = interpolating splines
+    void *sm_arena = nullptr;       // device workspace of the smoothing-spline fit
+    size_t sm_arena_bytes = 0;
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
     bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
@@ -364,6 +375,386 @@ int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype
     return PM_OK;
 }
 
+
+// ------------------------------------------------------------------ smoothing splines (spline_smoothing > 0)
+// BodyXY._do_spline_interpolation with s > 0 (body_xy.py:1673-1680) is FITPACK's `regrid`
+// (Dierckx): grow the knot sets from the least-squares polynomial until the least-squares
+// spline has a residual sum fp <= s, then find the smoothing parameter p with fp(p) = s by
+// rational interpolation. The control flow (a few dozen scalar decisions per plane) and the
+// QR factors of the two small banded design matrices stay on the host; every fit - two
+// directional least-squares solves over all image columns / coefficient rows and the residual
+// sums over all pixels - runs on the GPU.
+struct SmAxis {
+    int m = 0, k = 0, n = 0, nplus = 0;
+    std::vector<double> t, fpint;
+    std::vector<int> nrdata;
+    std::vector<double> hb, R, Bp;  // tables for the current knots / p
+    std::vector<int> lb, span;
+    bool knots_changed = true;
+    int nc() const { return n - k - 1; }
+    int nrint() const { return n - 2 * k - 1; }
+
+    void init(int m_, int k_)
+    {
+        m = m_; k = k_; n = 2 * (k + 1); nplus = 0;
+        t.assign((size_t)m + k + 2, 0.0);
+        for (int i = 0; i <= k; i++) t[k + 1 + i] = (double)(m - 1);
+        fpint.assign((size_t)m + 1, 0.0);
+        nrdata.assign((size_t)m + 1, 0);
+        nrdata[0] = m - 2;
+        knots_changed = true;
+    }
+    // fpknot: new knot at the middle data point of the interval with the largest residual sum
+    void add_knot()
+    {
+        const int nri = nrint();
+        double fpmax = 0.0;
+        int number = -1, maxpt = 0, maxbeg = 0, jbegin = 1;
+        for (int j = 0; j < nri; j++) {
+            const int jp = nrdata[j];
+            if (!(fpmax >= fpint[j] || jp == 0)) { fpmax = fpint[j]; number = j; maxpt = jp; maxbeg = jbegin; }
+            jbegin += jp + 1;
+        }
+        if (number < 0) return;
+        const int ihalf = maxpt / 2 + 1, nrx = maxbeg + ihalf;  // 1-based data index: abscissa nrx - 1
+        for (int j = nri - 1; j > number; j--) { fpint[j + 1] = fpint[j]; nrdata[j + 1] = nrdata[j]; }
+        for (int j = n - 1; j >= number + k + 1; j--) t[j + 1] = t[j];
+        nrdata[number] = ihalf - 1;
+        nrdata[number + 1] = maxpt - ihalf;
+        fpint[number] = fpmax * (double)nrdata[number] / (double)maxpt;
+        fpint[number + 1] = fpmax * (double)nrdata[number + 1] / (double)maxpt;
+        t[number + k + 1] = (double)(nrx - 1);
+        n += 1;
+        knots_changed = true;
+    }
+    static void bspl(const double *t, int k, double x, int l, double *h)
+    {
+        double hh[6];
+        h[0] = 1.0;
+        for (int j = 1; j <= k; j++) {  // fpbspl
+            for (int q = 0; q < j; q++) hh[q] = h[q];
+            h[0] = 0.0;
+            for (int q = 1; q <= j; q++) {
+                const int li = l + q, lj = li - j;
+                const double f = hh[q - 1] / (t[li] - t[lj]);
+                h[q - 1] += f * (t[li] - x);
+                h[q] = f * (x - t[lj]);
+            }
+        }
+    }
+    // B-spline values of every sample + knot interval of every integer abscissa
+    void build_tables()
+    {
+        hb.assign((size_t)m * 6, 0.0);
+        lb.assign((size_t)m, 0);
+        span.assign((size_t)m, 0);
+        int l = k;
+        for (int i = 0; i < m; i++) {
+            while (l < n - k - 2 && (double)i >= t[l + 1]) l++;
+            bspl(t.data(), k, (double)i, l, &hb[(size_t)i * 6]);
+            lb[i] = l - k;
+            span[i] = l;
+        }
+    }
+    // triangular band of the QR factor of [A; B / p] (Givens rotations, fpgivs / fprota), and
+    // the scaled jump rows B / p themselves (fpdisc) for the refinement step on the device
+    void factor(double p)
+    {
+        const int ncf = nc(), band = k + 2, nri = nrint();
+        const int nb = (p > 0.0 && nri > 1) ? nri - 1 : 0;
+        R.assign((size_t)ncf * pm::kSmBand, 0.0);
+        Bp.assign((size_t)(nb > 0 ? nb : 1) * pm::kSmBand, 0.0);
+        if (nb) {
+            const double fac = (double)nri / (t[n - k - 1] - t[k]);
+            for (int r = 0; r < nb; r++) {
+                const int l = r + k + 1;
+                for (int j = 0; j < band; j++) {
+                    const int i = r + j;
+                    double prod = 1.0;
+                    bool first = true;
+                    for (int q = 0; q < band; q++) {
+                        if (i + q == l) continue;
+                        const double h = t[l] - t[i + q];
+                        prod = first ? h : prod * h * fac;
+                        first = false;
+                    }
+                    Bp[(size_t)r * pm::kSmBand + j] = (t[i + k + 1] - t[i]) / prod / p;
+                }
+            }
+        }
+        for (int i = 0; i < m + nb; i++) {
+            double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int j0;
+            if (i < m) {
+                for (int e = 0; e <= k; e++) h[e] = hb[(size_t)i * 6 + e];
+                j0 = lb[i];
+            } else {
+                const int r = i - m;
+                for (int e = 0; e < band; e++) h[e] = Bp[(size_t)r * pm::kSmBand + e];
+                j0 = r;
+            }
+            for (int j = j0; j < ncf; j++) {
+                const double piv = h[0];
+                if (piv != 0.0) {
+                    double *Rj = &R[(size_t)j * pm::kSmBand];
+                    const double ww = Rj[0], store = std::fabs(piv);
+                    const double dd = (store >= ww) ? store * std::sqrt(1.0 + (ww / piv) * (ww / piv))
+                                                    : ww * std::sqrt(1.0 + (piv / ww) * (piv / ww));
+                    const double cs = ww / dd, sn = piv / dd;
+                    Rj[0] = dd;
+                    for (int b = 1; b < band; b++) {
+                        const double s1 = h[b], s2 = Rj[b];
+                        Rj[b] = cs * s2 + sn * s1;
+                        h[b] = cs * s1 - sn * s2;
+                    }
+                }
+                bool any = false;
+                for (int b = 0; b < band - 1; b++) { h[b] = h[b + 1]; any |= (h[b] != 0.0); }
+                h[band - 1] = 0.0;
+                if (!any) break;
+            }
+        }
+    }
+    // per-interval residual sums from per-sample sums: a sample on a knot gives half to each side
+    void account(const double *sums)
+    {
+        const int nri = nrint();
+        for (int j = 0; j < nri; j++) fpint[j] = 0.0;
+        int old = 0;
+        for (int i = 0; i < m; i++) {
+            const int num = lb[i];
+            fpint[num] += sums[i];
+            if (num != old) { fpint[num] -= 0.5 * sums[i]; fpint[num - 1] += 0.5 * sums[i]; }
+            old = num;
+        }
+    }
+};
+
+struct SmDevice {  // carve-up of ctx->sm_arena for one (ny, nx) plane
+    double *U, *UT, *G, *CT, *hb_y, *hb_x, *R_y, *R_x, *Bp_y, *Bp_x, *rowsum, *colsum, *t_y, *t_x;
+    int *lb_y, *lb_x, *span_y, *span_x;
+};
+
+int ensure_sm_arena(pm_ctx *ctx, int ny, int nx, SmDevice &d)
+{
+    const size_t npx = (size_t)ny * nx, mx = (size_t)std::max(ny, nx) + 8;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t oU = take(npx * 8), oUT = take(npx * 8), oG = take(npx * 8), oCT = take(npx * 8);
+    const size_t ohy = take(mx * 6 * 8), ohx = take(mx * 6 * 8), oRy = take(mx * pm::kSmBand * 8), oRx = take(mx * pm::kSmBand * 8);
+    const size_t oBy = take(mx * pm::kSmBand * 8), oBx = take(mx * pm::kSmBand * 8), ors = take(mx * 8), ocs = take(mx * 8);
+    const size_t oty = take(mx * 8), otx = take(mx * 8), oly = take(mx * 4), olx = take(mx * 4), osy = take(mx * 4), osx = take(mx * 4);
+    if (off > ctx->sm_arena_bytes) {
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->sm_arena) PM_HIP(ctx, hipFree(ctx->sm_arena));
+        ctx->sm_arena = nullptr;
+        ctx->sm_arena_bytes = 0;
+        if (hipMalloc(&ctx->sm_arena, off) != hipSuccess)
+            return fail(ctx, PM_ERR_ALLOC, "hipMalloc(%zu) of the smoothing-spline workspace failed", off);
+        ctx->sm_arena_bytes = off;
+    }
+    char *b = (char *)ctx->sm_arena;
+    d.U = (double *)(b + oU); d.UT = (double *)(b + oUT); d.G = (double *)(b + oG); d.CT = (double *)(b + oCT);
+    d.hb_y = (double *)(b + ohy); d.hb_x = (double *)(b + ohx); d.R_y = (double *)(b + oRy); d.R_x = (double *)(b + oRx);
+    d.Bp_y = (double *)(b + oBy); d.Bp_x = (double *)(b + oBx); d.rowsum = (double *)(b + ors); d.colsum = (double *)(b + ocs);
+    d.t_y = (double *)(b + oty); d.t_x = (double *)(b + otx);
+    d.lb_y = (int *)(b + oly); d.lb_x = (int *)(b + olx); d.span_y = (int *)(b + osy); d.span_x = (int *)(b + osx);
+    return PM_OK;
+}
+
+// one fit for the current knots and p (p <= 0: least-squares spline); returns fp and updates
+// the per-interval residual sums of both axes. z: cleaned plane on the device.
+int sm_fit(pm_ctx *ctx, const double *z, SmAxis &ay, SmAxis &ax, double p, const SmDevice &d, double &fp,
+           std::vector<double> &sums)
+{
+    hipStream_t s = ctx->stream;
+    // the host vectors below are reused by the next fit: every upload is followed by a stream
+    // synchronisation before they change (the D2H of the residual sums at the end of this fit)
+    if (ay.knots_changed) {
+        ay.build_tables();
+        PM_HIP(ctx, hipMemcpyAsync(d.hb_y, ay.hb.data(), ay.hb.size() * 8, hipMemcpyHostToDevice, s));
+        PM_HIP(ctx, hipMemcpyAsync(d.lb_y, ay.lb.data(), ay.lb.size() * 4, hipMemcpyHostToDevice, s));
+        ay.knots_changed = false;
+    }
+    if (ax.knots_changed) {
+        ax.build_tables();
+        PM_HIP(ctx, hipMemcpyAsync(d.hb_x, ax.hb.data(), ax.hb.size() * 8, hipMemcpyHostToDevice, s));
+        PM_HIP(ctx, hipMemcpyAsync(d.lb_x, ax.lb.data(), ax.lb.size() * 4, hipMemcpyHostToDevice, s));
+        ax.knots_changed = false;
+    }
+    ay.factor(p);
+    ax.factor(p);
+    PM_HIP(ctx, hipMemcpyAsync(d.R_y, ay.R.data(), ay.R.size() * 8, hipMemcpyHostToDevice, s));
+    PM_HIP(ctx, hipMemcpyAsync(d.R_x, ax.R.data(), ax.R.size() * 8, hipMemcpyHostToDevice, s));
+    PM_HIP(ctx, hipMemcpyAsync(d.Bp_y, ay.Bp.data(), ay.Bp.size() * 8, hipMemcpyHostToDevice, s));
+    PM_HIP(ctx, hipMemcpyAsync(d.Bp_x, ax.Bp.data(), ax.Bp.size() * 8, hipMemcpyHostToDevice, s));
+    const int nby = (p > 0.0 && ay.nrint() > 1) ? ay.nrint() - 1 : 0, nbx = (p > 0.0 && ax.nrint() > 1) ? ax.nrint() - 1 : 0;
+    pm::SmoothFitAxis fy = {d.hb_y, d.lb_y, d.R_y, d.Bp_y, ay.m, ay.k, ay.nc(), nby};
+    pm::SmoothFitAxis fx = {d.hb_x, d.lb_x, d.R_x, d.Bp_x, ax.m, ax.k, ax.nc(), nbx};
+    const int ny = ay.m, nx = ax.m, nr = ay.nc(), ncx = ax.nc();
+    // along image rows for every image column: U (nr x nx)
+    pm_launch_sm_solve(fy, z, (size_t)nx, 1, nx, d.G, d.U, s);
+    // U' (nx x nr), then along image columns for every row coefficient: CT (ncx x nr)
+    pm_launch_transpose(d.U, d.UT, nr, nx, s);
+    pm_launch_sm_solve(fx, d.UT, (size_t)nr, 1, nr, d.G, d.CT, s);
+    PM_HIP(ctx, hipMemsetAsync(d.rowsum, 0, (size_t)ny * 8, s));
+    PM_HIP(ctx, hipMemsetAsync(d.colsum, 0, (size_t)nx * 8, s));
+    pm_launch_sm_resid(fy, fx, z, d.CT, d.rowsum, d.colsum, s);
+    PM_HIP(ctx, hipGetLastError());
+    sums.resize((size_t)ny + nx);
+    PM_HIP(ctx, hipMemcpyAsync(sums.data(), d.rowsum, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
+    PM_HIP(ctx, hipMemcpyAsync(sums.data() + ny, d.colsum, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+    PM_HIP(ctx, hipStreamSynchronize(s));
+    (void)ncx;
+    fp = 0.0;
+    for (int i = 0; i < ny; i++) fp += sums[i];
+    if (std::getenv("PM_SM_DEBUG"))  // trace of the knot / smoothing-parameter search
+        std::fprintf(stderr, "sm_fit ny=%d nx=%d knots=(%d,%d) p=%g fp=%.17g\n", ny, nx, ay.n, ax.n, p, fp);
+    ay.account(sums.data());
+    ax.account(sums.data() + ny);
+    return PM_OK;
+}
+
+// FITPACK fpregr for one cleaned plane: on return ay / ax hold the knots and d.CT the coefficients
+int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_cols, double s, SmAxis &ay, SmAxis &ax,
+              const SmDevice &d)
+{
+    const double tol = 0.001, con1 = 0.1, con9 = 0.9, con4 = 0.04;
+    const int maxit = 20;
+    const double acc = tol * s;
+    ay.init(ny, k_rows);
+    ax.init(nx, k_cols);
+    const int nminy = 2 * (k_rows + 1), nminx = 2 * (k_cols + 1), nmaxy = ny + k_rows + 1, nmaxx = nx + k_cols + 1;
+    std::vector<double> sums;
+    int lastdi = 0, rc;
+    bool poly = false, done = false;
+    double fp = 0.0, fp0 = 0.0, fpold = 0.0, reducy = 0.0, reducx = 0.0, fpms = 0.0;
+    // (FITPACK's "x" is the first array axis = image rows, "y" the image columns)
+    for (int iter = 0; iter < ny + nx; iter++) {
+        poly = (ay.n == nminy && ax.n == nminx);
+        rc = sm_fit(ctx, z, ay, ax, -1.0, d, fp, sums);
+        if (rc != PM_OK) return rc;
+        if (poly) fp0 = fp;
+        fpms = fp - s;
+        if (std::fabs(fpms) < acc) { done = true; break; }
+        if (fpms < 0.0) break;
+        if (ay.n == nmaxy && ax.n == nmaxx) { done = true; break; }  // interpolating spline
+        if (lastdi < 0) reducy = fpold - fp;
+        else if (lastdi > 0) reducx = fpold - fp;
+        fpold = fp;
+        auto nplus = [&](const SmAxis &a, int nmin, double reduc) {
+            if (a.n == nmin) return 1;
+            int npl1 = a.nplus * 2;
+            if (reduc > acc) npl1 = (int)((double)a.nplus * fpms / reduc);
+            return std::min(a.nplus * 2, std::max(std::max(npl1, a.nplus / 2), 1));
+        };
+        const int nply = nplus(ay, nminy, reducy), nplx = nplus(ax, nminx, reducx);
+        bool first_axis = (nply < nplx) || (nply == nplx && lastdi >= 0);
+        if (first_axis && ay.n == nmaxy) first_axis = false;
+        if (!first_axis && ax.n == nmaxx) first_axis = true;
+        SmAxis &a = first_axis ? ay : ax;
+        lastdi = first_axis ? -1 : 1;
+        a.nplus = first_axis ? nply : nplx;
+        const int nmax = first_axis ? nmaxy : nmaxx;
+        for (int l = 0; l < a.nplus; l++) {
+            a.add_knot();
+            if (a.n == nmax) break;
+        }
+    }
+    if (!done && !poly) {
+        double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms, p = 1.0;
+        bool ich1 = false, ich3 = false;
+        for (int iter = 0; iter < maxit; iter++) {
+            rc = sm_fit(ctx, z, ay, ax, p, d, fp, sums);
+            if (rc != PM_OK) return rc;
+            fpms = fp - s;
+            if (std::fabs(fpms) < acc || iter == maxit - 1) break;
+            const double p2 = p, f2 = fpms;
+            if (!ich3) {
+                if ((f2 - f3) <= acc) {  // initial p too large
+                    p3 = p2; f3 = f2;
+                    p *= con4;
+                    if (p <= p1) p = p1 * con9 + p2 * con1;
+                    continue;
+                }
+                if (f2 < 0.0) ich3 = true;
+            }
+            if (!ich1) {
+                if ((f1 - f2) <= acc) {  // initial p too small
+                    p1 = p2; f1 = f2;
+                    p /= con4;
+                    if (p3 >= 0.0 && p >= p3) p = p2 * con1 + p3 * con9;
+                    continue;
+                }
+                if (f2 > 0.0) ich1 = true;
+            }
+            if (f2 >= f1 || f2 <= f3) break;
+            if (p3 > 0.0) {  // fprati
+                const double h1 = f1 * (f2 - f3), h2 = f2 * (f3 - f1), h3 = f3 * (f1 - f2);
+                p = -(p1 * p2 * h3 + p2 * p3 * h1 + p3 * p1 * h2) / (p1 * h1 + p2 * h2 + p3 * h3);
+            } else {
+                p = (p1 * (f1 - f3) * f2 - p2 * (f2 - f3) * f1) / ((f1 - f2) * f3);
+            }
+            if (f2 < 0.0) { p3 = p2; f3 = f2; } else { p1 = p2; f1 = f2; }
+        }
+    }
+    return PM_OK;
+}
+
+// smoothing-spline reprojection of planes resident on the device
+int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols, double s)
+{
+    const size_t plane_elems = (size_t)a.ny * a.nx;
+    SmDevice d;
+    int rc = ensure_sm_arena(ctx, a.ny, a.nx, d);
+    if (rc != PM_OK) return rc;
+    size_t chunk = (size_t)(1ull << 30) / (plane_elems * sizeof(double));
+    chunk = std::max<size_t>(1, std::min<size_t>(chunk, (size_t)a.n_planes));
+    if (chunk > 32768) chunk = 32768;
+    rc = ensure_work(ctx, chunk * plane_elems * sizeof(double));
+    if (rc != PM_OK) return rc;
+    rc = ensure_stats(ctx, chunk);
+    if (rc != PM_OK) return rc;
+    std::vector<pm::PlaneStats> stats(chunk);
+    std::vector<double> nan_row((size_t)a.n_map, std::nan(""));
+    SmAxis ay, ax;
+    for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += chunk) {
+        const int np = (int)std::min(chunk, (size_t)a.n_planes - p0);
+        pm::ReprojectArgs b = a;
+        b.n_planes = np;
+        b.cube = (const char *)a.cube + p0 * plane_elems * dtype_size(dtype);
+        b.out = a.out + p0 * a.n_map;
+        b.plane_stats = ctx->stats;
+        PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)np * sizeof(pm::PlaneStats), ctx->stream));
+        PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)np * 512 * sizeof(unsigned int), ctx->stream));
+        pm_launch_plane_medians(b.cube, dtype, np, plane_elems, ctx->stats, ctx->hist, ctx->stream);
+        pm_launch_clean(b, ctx->work, dtype, ctx->stream);
+        PM_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->stats, (size_t)np * sizeof(pm::PlaneStats), hipMemcpyDeviceToHost,
+                                   ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int pl = 0; pl < np; pl++) {
+            if (stats[pl].all_nan) {  // body_xy.py:1668-1670: the map of an all-NaN image is all NaN
+                PM_HIP(ctx, hipMemcpyAsync(b.out + (size_t)pl * a.n_map, nan_row.data(), (size_t)a.n_map * 8,
+                                           hipMemcpyHostToDevice, ctx->stream));
+                continue;
+            }
+            const double *z = ctx->work + (size_t)pl * plane_elems;
+            rc = sm_regrid(ctx, z, a.ny, a.nx, k_rows, k_cols, s, ay, ax, d);
+            if (rc != PM_OK) return rc;
+            PM_HIP(ctx, hipMemcpyAsync(d.t_y, ay.t.data(), (size_t)ay.n * 8, hipMemcpyHostToDevice, ctx->stream));
+            PM_HIP(ctx, hipMemcpyAsync(d.t_x, ax.t.data(), (size_t)ax.n * 8, hipMemcpyHostToDevice, ctx->stream));
+            PM_HIP(ctx, hipMemcpyAsync(d.span_y, ay.span.data(), (size_t)a.ny * 4, hipMemcpyHostToDevice, ctx->stream));
+            PM_HIP(ctx, hipMemcpyAsync(d.span_x, ax.span.data(), (size_t)a.nx * 4, hipMemcpyHostToDevice, ctx->stream));
+            pm::SmoothEvalArgs e = {d.CT, d.t_y, d.t_x, d.span_y, d.span_x, ay.nc(), ax.nc(), k_rows, k_cols, pl};
+            pm_launch_sm_eval(b, e, dtype, ctx->stream);
+            PM_HIP(ctx, hipGetLastError());
+            PM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // knots / spans are reused by the next plane
+        }
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PM_OK;
+}
+
 // Spline reprojection of planes resident on the device (plane chunks bound the workspace).
 int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols)
 {
@@ -543,6 +934,7 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->limits) (void)hipFree(ctx->limits);
+    if (ctx->sm_arena) (void)hipFree(ctx->sm_arena);
     for (auto &ac : ctx->axis) {
         if (ac.t) (void)hipFree(ac.t);
         if (ac.lu) (void)hipFree(ac.lu);
@@ -895,6 +1287,18 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
             if (rc != PM_OK) return rc;
         }
     }
+    // spline_smoothing > 0 (FITPACK smoothing) applies to 'linear' and every spline degree
+    const double smoothing = (interpolation == PM_INTERP_NEAREST || interpolation == PM_INTERP_SMOOTH)
+                                 ? 0.0 : ctx->spline_smoothing;
+    if (smoothing > 0.0) {
+        if (!k_rows) k_rows = k_cols = 1;
+        if (d.ny <= k_rows || d.nx <= k_cols)
+            return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image too small for spline degree (%d, %d)", k_rows, k_cols);
+        if (ctx->pending) {
+            rc = pm_synchronize(ctx);
+            if (rc != PM_OK) return rc;
+        }
+    }
     const bool smooth = interpolation == PM_INTERP_SMOOTH;
     double limits[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
     if (smooth && mem == PM_MEM_DEVICE) {
@@ -923,6 +1327,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         a.plane_flags = ctx->flags;
         a.n_planes = n_planes;
         if (smooth) return reproject_smooth_resident(ctx, a, dtype, limits);
+        if (smoothing > 0.0) return reproject_smoothing_resident(ctx, a, dtype, k_rows, k_cols, smoothing);
         if (k_rows) return reproject_spline_resident(ctx, a, dtype, k_rows, k_cols);
         return reproject_resident(ctx, a, dtype, /*sync_now=*/force_sync);
     }
@@ -952,8 +1357,9 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         b.out = dout;
         b.plane_flags = ctx->flags;
         b.n_planes = (int)np;
-        rc = smooth   ? reproject_smooth_resident(ctx, b, dtype, limits)
-             : k_rows ? reproject_spline_resident(ctx, b, dtype, k_rows, k_cols)
+        rc = smooth            ? reproject_smooth_resident(ctx, b, dtype, limits)
+             : smoothing > 0.0 ? reproject_smoothing_resident(ctx, b, dtype, k_rows, k_cols, smoothing)
+             : k_rows          ? reproject_spline_resident(ctx, b, dtype, k_rows, k_cols)
                       : reproject_resident(ctx, b, dtype, /*sync_now=*/true);
         if (rc != PM_OK) return rc;
         PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
@@ -968,6 +1374,14 @@ int pm_set_smooth_options(pm_ctx *ctx, int oversample_by, int max_oversampled_im
     if (!ctx) return PM_ERR_INVALID_ARGUMENT;
     ctx->smooth_oversample_by = oversample_by;
     ctx->smooth_max_size = max_oversampled_img_size;
+    return PM_OK;
+}
+
+int pm_set_spline_smoothing(pm_ctx *ctx, double s)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    if (!(s >= 0.0) || !std::isfinite(s)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "s should be s >= 0.0");
+    ctx->spline_smoothing = s;
     return PM_OK;
 }
 

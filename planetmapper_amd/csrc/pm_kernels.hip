@@ -1007,6 +1007,155 @@ __device__ __forceinline__ double key_to_double(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
+// ------------------------------------------------------------------ smoothing splines
+// Least squares  [A; B/p] c = [d; 0]  for every right-hand side q of one direction (one lane
+// each) by the corrected semi-normal equations: R'R c = A'd with the host's QR factor R, then
+// one refinement step with the residual (restores the accuracy the normal equations lose:
+// error ~ cond(A) eps instead of cond(A)^2 eps). d(i, q) = in[i * si + q * sq]; g and c are
+// nc x nrhs work / result arrays (coalesced over q); the substitutions keep their band of
+// previous values in registers.
+__global__ __launch_bounds__(kBlock) void k_sm_solve(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
+                                                     size_t sq, int nrhs, double *__restrict__ g,
+                                                     double *__restrict__ c)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nrhs) return;
+    const int band = a.k + 2, nc = a.nc;
+    const size_t st = (size_t)nrhs;
+    for (int pass = 0; pass < 2; pass++) {
+        for (int j = 0; j < nc; j++) g[j * st + q] = 0.0;
+        // g = A' r, r = d (first pass) or d - A c (refinement)
+        for (int i = 0; i < a.m; i++) {
+            const int l0 = a.lb[i];
+            const double *h = a.hb + (size_t)i * 6;
+            double r = in[i * si + q * sq];
+            if (pass)
+                for (int e = 0; e <= a.k; e++) r -= h[e] * c[(l0 + e) * st + q];
+            for (int e = 0; e <= a.k; e++) g[(l0 + e) * st + q] += h[e] * r;
+        }
+        if (pass)  // ... minus (B/p)' (B/p) c: the jump rows have a zero right-hand side
+            for (int r = 0; r < a.nb; r++) {
+                const double *b = a.Bp + (size_t)r * kSmBand;
+                double v = 0.0;
+                for (int e = 0; e < band; e++) v += b[e] * c[(r + e) * st + q];
+                for (int e = 0; e < band; e++) g[(r + e) * st + q] -= b[e] * v;
+            }
+        // forward substitution R' w = g (w overwrites g)
+        double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0;  // w[j-1] .. w[j-6]
+        for (int j = 0; j < nc; j++) {
+            double sv = g[j * st + q];
+            const double *Rj = a.R + (size_t)j * kSmBand;
+            if (j >= 1) sv -= (Rj - 1 * kSmBand)[1] * w1;
+            if (band > 2 && j >= 2) sv -= (Rj - 2 * kSmBand)[2] * w2;
+            if (band > 3 && j >= 3) sv -= (Rj - 3 * kSmBand)[3] * w3;
+            if (band > 4 && j >= 4) sv -= (Rj - 4 * kSmBand)[4] * w4;
+            if (band > 5 && j >= 5) sv -= (Rj - 5 * kSmBand)[5] * w5;
+            if (band > 6 && j >= 6) sv -= (Rj - 6 * kSmBand)[6] * w6;
+            sv /= Rj[0];
+            g[j * st + q] = sv;
+            w6 = w5; w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = sv;
+        }
+        // back substitution R x = w, then c = x (first pass) or c += x
+        double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0, x5 = 0.0, x6 = 0.0;  // x[j+1] .. x[j+6]
+        for (int j = nc - 1; j >= 0; j--) {
+            double sv = g[j * st + q];
+            const double *Rj = a.R + (size_t)j * kSmBand;
+            sv -= Rj[1] * x1;  // (entries beyond the matrix are stored as zeros)
+            if (band > 2) sv -= Rj[2] * x2;
+            if (band > 3) sv -= Rj[3] * x3;
+            if (band > 4) sv -= Rj[4] * x4;
+            if (band > 5) sv -= Rj[5] * x5;
+            if (band > 6) sv -= Rj[6] * x6;
+            sv /= Rj[0];
+            x6 = x5; x5 = x4; x4 = x3; x3 = x2; x2 = x1; x1 = sv;
+            c[j * st + q] = pass ? c[j * st + q] + sv : sv;
+        }
+    }
+}
+
+// out[j * rows + i] = in[i * cols + j] (LDS-tiled)
+__global__ __launch_bounds__(kBlock) void k_transpose(const double *__restrict__ in, double *__restrict__ out, int rows,
+                                                     int cols)
+{
+    __shared__ double tile[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
+    if (i < rows && j < cols) tile[ty][tx] = in[(size_t)i * cols + j];
+    __syncthreads();
+    i = blockIdx.y * 16 + tx;
+    j = blockIdx.x * 16 + ty;
+    if (i < rows && j < cols) out[(size_t)j * rows + i] = tile[tx][ty];
+}
+
+// Squared residuals of the fitted spline at the image pixels, summed per image row and per
+// image column (the host turns them into fp and the per-knot-interval sums of FITPACK).
+__global__ __launch_bounds__(kBlock) void k_sm_resid(const SmoothFitAxis ay, const SmoothFitAxis ax,
+                                                     const double *__restrict__ z, const double *__restrict__ ct,
+                                                     double *__restrict__ rowsum, double *__restrict__ colsum)
+{
+    const int j = blockIdx.x * kBlock + threadIdx.x;  // image column
+    const int i = blockIdx.y;                         // image row
+    double term = 0.0;
+    if (j < ax.m) {
+        const int la = ay.lb[i], lb = ax.lb[j], nr = ay.nc;
+        const double *hy = ay.hb + (size_t)i * 6, *hx = ax.hb + (size_t)j * 6;
+        double sv = 0.0;
+        for (int b = 0; b <= ax.k; b++) {
+            double r = 0.0;
+            for (int e = 0; e <= ay.k; e++) r += hy[e] * ct[(size_t)(lb + b) * nr + (la + e)];
+            sv += hx[b] * r;
+        }
+        const double d = z[(size_t)i * ax.m + j] - sv;
+        term = d * d;
+        atomicAdd(&colsum[j], term);
+    }
+    // one atomic per wave for the row
+    double rs = term;
+    for (int off = 32; off > 0; off >>= 1) rs += __shfl_down(rs, off, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&rowsum[i], rs);
+}
+
+// bispev of a fitted smoothing spline at the map cells of one plane
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_sm_eval(const ReprojectArgs a, const SmoothEvalArgs e)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= a.n_map) return;
+    const double nan = __builtin_nan("");
+    const int nx = a.nx, ny = a.ny;
+    const T *img = (const T *)a.cube + (size_t)e.plane * ny * nx;
+    const double x = a.x_map[m], y = a.y_map[m];
+    double val = nan;
+    bool skip = isnan(x) || isnan(y);
+    if (!skip && a.propagate_nan) {
+        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
+            skip = true;
+        } else {
+            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
+            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
+            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
+                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
+        }
+    }
+    if (!skip) {
+        const double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
+        // the knots are integer abscissae: the span of x is the span of floor(x)
+        const int ly = e.span_rows[(int)yc], lx = e.span_cols[(int)xc];
+        double hy[6], hx[6];
+        SplineAxis ry = {e.t_rows, nullptr, e.nr, e.k_rows}, rx = {e.t_cols, nullptr, e.nc, e.k_cols};
+        spline_basis(ry, yc, ly, hy);
+        spline_basis(rx, xc, lx, hx);
+        double sv = 0.0;
+        for (int q = 0; q <= e.k_cols; q++) {
+            double r = 0.0;
+            for (int p = 0; p <= e.k_rows; p++) r += hy[p] * e.ct[(size_t)(lx - e.k_cols + q) * e.nr + (ly - e.k_rows + p)];
+            sv += hx[q] * r;
+        }
+        val = sv;
+    }
+    a.out[(size_t)e.plane * a.n_map + m] = val;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_median_hist(const T *cube, size_t plane_elems, int shift, PlaneStats *stats,
                                                         unsigned int *hist /* [P][2][256] */)
@@ -1209,6 +1358,56 @@ static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa
                        sa.work, a.n_planes, a.ny, a.nx, 1, sa.cols);
     hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
                        0, s, a, sa);
+}
+
+template <typename T>
+static void launch_clean_t(const pm::ReprojectArgs &a, double *work, hipStream_t s)
+{
+    const size_t npx = (size_t)a.ny * a.nx;
+    hipLaunchKernelGGL(pm::k_spline_clean<T>, dim3((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes),
+                       dim3(pm::kBlock), 0, s, (const T *)a.cube, work, a.plane_stats, a.ny, a.nx);
+}
+// NaN-cleaned f64 copy of a.n_planes planes into `work` (a.plane_stats must hold the medians)
+void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_clean_t<double>(a, work, s); break;
+    case PM_F32: launch_clean_t<float>(a, work, s); break;
+    case PM_I16: launch_clean_t<int16_t>(a, work, s); break;
+    case PM_I32: launch_clean_t<int32_t>(a, work, s); break;
+    case PM_U8: launch_clean_t<uint8_t>(a, work, s); break;
+    case PM_U16: launch_clean_t<uint16_t>(a, work, s); break;
+    }
+}
+
+void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
+                        double *c, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_sm_solve, dim3((nrhs + pm::kBlock - 1) / pm::kBlock), dim3(pm::kBlock), 0, s, ax, in, si, sq,
+                       nrhs, g, c);
+}
+void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_transpose, dim3((cols + 15) / 16, (rows + 15) / 16), dim3(pm::kBlock), 0, s, in, out, rows,
+                       cols);
+}
+void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
+                        double *rowsum, double *colsum, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_sm_resid, dim3((ax.m + pm::kBlock - 1) / pm::kBlock, ay.m), dim3(pm::kBlock), 0, s, ay, ax, z,
+                       ct, rowsum, colsum);
+}
+void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, int dtype, hipStream_t s)
+{
+    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock), block(pm::kBlock);
+    switch (dtype) {
+    case PM_F64: hipLaunchKernelGGL(pm::k_sm_eval<double>, grid, block, 0, s, a, e); break;
+    case PM_F32: hipLaunchKernelGGL(pm::k_sm_eval<float>, grid, block, 0, s, a, e); break;
+    case PM_I16: hipLaunchKernelGGL(pm::k_sm_eval<int16_t>, grid, block, 0, s, a, e); break;
+    case PM_I32: hipLaunchKernelGGL(pm::k_sm_eval<int32_t>, grid, block, 0, s, a, e); break;
+    case PM_U8: hipLaunchKernelGGL(pm::k_sm_eval<uint8_t>, grid, block, 0, s, a, e); break;
+    case PM_U16: hipLaunchKernelGGL(pm::k_sm_eval<uint16_t>, grid, block, 0, s, a, e); break;
+    }
 }
 
 // a.plane_stats must already hold the plane statistics (pm_launch_plane_medians)

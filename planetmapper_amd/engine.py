@@ -278,10 +278,16 @@ class Engine:
         clip = lambda v: int(max(-(2**31), min(2**31 - 1, int(v))))  # noqa: E731
         self._check(self._lib.pm_set_smooth_options(self._ctx, clip(oversample_by), clip(max_oversampled_img_size)))
 
+    def set_spline_smoothing(self, s: float = 0.0) -> None:
+        """`spline_smoothing` of map_img (FITPACK `s`), used by 'linear' and the spline degrees"""
+        self._check(self._lib.pm_set_spline_smoothing(self._ctx, float(s)))
+
     def map_cube(self, cube: np.ndarray, x_map, y_map, interpolation='linear', propagate_nan=True, *,
-                 smooth_oversample_by: int = 5, smooth_max_oversampled_img_size: int = 10_000) -> np.ndarray:
+                 smooth_oversample_by: int = 5, smooth_max_oversampled_img_size: int = 10_000,
+                 spline_smoothing: float = 0.0) -> np.ndarray:
         """Reproject host cube (P, ny, nx) [or one (ny, nx) image] -> (P, n0, n1) float64."""
         code = interpolation_code(interpolation)
+        self.set_spline_smoothing(spline_smoothing)
         if code == _lib.PM_INTERP_SMOOTH:
             self.set_smooth_options(smooth_oversample_by, smooth_max_oversampled_img_size)
         cube = np.asarray(cube)
@@ -313,9 +319,10 @@ class Engine:
 
     def map_cube_device(
         self, cube, dtype, n_planes: int, x_map, y_map, n0: int, n1: int, out,
-        interpolation='linear', propagate_nan=True,
+        interpolation='linear', propagate_nan=True, spline_smoothing: float = 0.0,
     ) -> None:  # fmt: skip
         """Enqueue the reprojection of a device-resident cube into a device output."""
+        self.set_spline_smoothing(spline_smoothing)
         self._check(
             self._lib.pm_map_cube(
                 self._ctx, _ptr(cube), dtype_code(dtype), int(n_planes), _ptr(x_map), _ptr(y_map), int(n0),

@@ -713,3 +713,74 @@ def test_row_blocks_equal_the_full_frame(engine, oracle, jupiter, saturn, force_
     engine.synchronize()
     for k in names:
         assert np.array_equal(dev[k].cpu().numpy(), full[k][20:84], equal_nan=True), k
+
+
+def test_smoothing_splines_vs_oracle_kats_and_golden(engine, oracle, jupiter):
+    """
+    `spline_smoothing > 0` (FITPACK regrid smoothing, body_xy.py:1673-1680): the reference's
+    own expected values (tests/test_body_xy.py:1194-1231), its golden FITS
+    map_rectangular-interpolation ((1, 3), s = 2.34; planes 6 and 7 loosely, as the reference
+    compares them) and the oracle - whose knots and coefficients equal scipy's - on a larger
+    cube: the fits run on the GPU (corrected semi-normal equations against the host's band QR),
+    so agreement is to 1e-7 of the data scale rather than to the last digits.
+    """
+    from planetmapper_amd import BodyXY, Observation
+    from test_api_host import IMAGE, _smoothing_kats
+
+    body = BodyXY('Jupiter', geometry=jupiter, engine=engine)
+    body.set_img_size(6, 5)
+    body.set_disc_params(2.75, 1.3, 2.3, 45.678)
+    for sm, exp in _smoothing_kats():
+        got = body.map_img(IMAGE, interpolation='linear', degree_interval=45, spline_smoothing=sm)
+        assert np.allclose(got, exp, rtol=1e-5, atol=1e-8, equal_nan=True), sm
+    factors = [1, 2.345, -10, 3456.789, np.nan]
+    kwargs = dict(interpolation='cubic', degree_interval=45, spline_smoothing=1)
+    mapped = body.map_img([IMAGE * f for f in factors], **kwargs)
+    for f, m in zip(factors, mapped):
+        assert np.allclose(m, body.map_img(IMAGE * f, **kwargs), rtol=1e-9, atol=1e-9, equal_nan=True), f
+
+    cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
+    obs = Observation(data=cube, geometry=jupiter, engine=engine)
+    obs.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    gold = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_interpolation.npz'))['PRIMARY']
+    m = obs.get_mapped_data(interpolation=(1, 3), spline_smoothing=2.34, degree_interval=30)
+    assert np.array_equal(np.isnan(m), np.isnan(gold))
+    for pl in range(10):
+        rtol, atol = {6: (1e-1, 1e-1), 7: (10, 1)}.get(pl, (1e-6, 1e-5))
+        assert np.allclose(m[pl], gold[pl], rtol=rtol, atol=atol, equal_nan=True), pl
+
+    sz = 150
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, 0.7 * x0, 0.2, sz + 13, sz, True)
+    d = oracle.make_disc(x0, y0, 0.7 * x0, 0.0, sz + 13, sz)
+    d.rotation_rad = 0.2
+    lon, lat = oracle.rectangular_grid(jupiter, 3.0)
+    xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+    rng = np.random.default_rng(21)
+    yy, xx = np.mgrid[0:sz, 0 : sz + 13]
+    base = np.sin(xx / 9.0) * np.cos(yy / 13.0) * 4
+    cube = base[None] + rng.standard_normal((4, sz, sz + 13))
+    cube[0][rng.random((sz, sz + 13)) < 0.01] = np.nan
+    cube[1][40:60, 50:90] = np.nan
+    cube[2][:] = np.nan
+    npx = sz * (sz + 13)
+    # (s is kept at or above the noise level n_pixels * sigma^2: far below it FITPACK itself runs
+    #  into numerically singular knot sets and scipy returns coefficients of 1e120)
+    for interp, s in (('linear', 0.9 * npx), ('cubic', 1.0 * npx), ('cubic', 0.93 * npx), ((2, 3), 1.05 * npx), ('quadratic', 30.0 * npx), (5, 1e3 * npx)):
+        for prop in (True, False):
+            a = engine.map_cube(cube, xm, ym, interp, prop, spline_smoothing=s)
+            b = oracle.map_cube(cube, xm, ym, (interp, interp) if isinstance(interp, int) else interp, prop,
+                                spline_smoothing=s)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (interp, s, prop)
+            fin = np.isfinite(b)
+            assert fin.sum() > 1000
+            assert np.max(np.abs(a[fin] - b[fin])) <= 1e-7 * max(1.0, np.abs(b[fin]).max()), (interp, s, prop)
+    a = engine.map_cube(cube[0].astype(np.float32), xm, ym, 'cubic', True, spline_smoothing=npx)
+    b = oracle.map_cube(cube[0].astype(np.float32), xm, ym, 'cubic', True, spline_smoothing=npx)
+    assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) <= 1e-6
+    with pytest.raises(ValueError):
+        engine.map_cube(cube, xm, ym, 'cubic', True, spline_smoothing=-1.0)
+    # s = 0 afterwards is the interpolating spline again
+    assert np.array_equal(engine.map_cube(cube[:1], xm, ym, 'cubic', True),
+                          engine.map_cube(cube[:1], xm, ym, 'cubic', True, spline_smoothing=0.0), equal_nan=True)

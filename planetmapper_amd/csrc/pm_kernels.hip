@@ -890,36 +890,65 @@ __global__ __launch_bounds__(kBlock) void k_spline_solve(double *work, int n_pla
     double *v = work + (size_t)pl * npx + (axis == 0 ? (size_t)line : (size_t)line * nx);
     const size_t stride = axis == 0 ? (size_t)nx : 1;
     const int n = ax.n, k = ax.k, w = 2 * k + 1;
-    // forward substitution (unit lower triangle), the last k results kept in registers
+    // forward substitution (unit lower triangle), the last k results kept in registers. Samples
+    // and LU rows are fetched eight at a time so that their load latencies overlap (a line along
+    // image rows then also uses every 64-byte sector it touches in full).
     double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < n; i++) {
-        double s = v[(size_t)i * stride];
-        const double *row = ax.lu + (size_t)i * w;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        double vb[8], lb[8][5];
 #pragma unroll
-        for (int q = 1; q <= 5; q++)
-            if (q <= k && i - q >= 0) s -= row[k - q] * prev[q - 1];
+        for (int u = 0; u < 8; u++) {
+            const int i = (i0 + u < n) ? i0 + u : n - 1;
+            vb[u] = v[(size_t)i * stride];
+            const double *row = ax.lu + (size_t)i * w;
 #pragma unroll
-        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-        prev[0] = s;
-        v[(size_t)i * stride] = s;
+            for (int q = 1; q <= 5; q++) lb[u][q - 1] = (q <= k) ? row[k - q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u;
+            if (i < n) {
+                double s = vb[u];
+#pragma unroll
+                for (int q = 1; q <= 5; q++)
+                    if (q <= k && i - q >= 0) s -= lb[u][q - 1] * prev[q - 1];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[(size_t)i * stride] = s;
+            }
+        }
     }
     // back substitution
 #pragma unroll
     for (int q = 0; q < 5; q++) prev[q] = 0.0;
-    for (int i = n - 1; i >= 0; i--) {
-        double s = v[(size_t)i * stride];
-        const double *row = ax.lu + (size_t)i * w;
+    for (int i0 = n - 1; i0 >= 0; i0 -= 8) {
+        double vb[8], ub[8][6];
 #pragma unroll
-        for (int q = 1; q <= 5; q++)
-            if (q <= k && i + q < n) s -= row[k + q] * prev[q - 1];
-        s /= row[k];
+        for (int u = 0; u < 8; u++) {
+            const int i = (i0 - u >= 0) ? i0 - u : 0;
+            vb[u] = v[(size_t)i * stride];
+            const double *row = ax.lu + (size_t)i * w;
 #pragma unroll
-        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-        prev[0] = s;
-        v[(size_t)i * stride] = s;
+            for (int q = 0; q <= 5; q++) ub[u][q] = (q <= k) ? row[k + q] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 - u;
+            if (i >= 0) {
+                double s = vb[u];
+#pragma unroll
+                for (int q = 1; q <= 5; q++)
+                    if (q <= k && i + q < n) s -= ub[u][q] * prev[q - 1];
+                s /= ub[u][0];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[(size_t)i * stride] = s;
+            }
+        }
     }
 }
-
 __device__ __forceinline__ int spline_interval(const SplineAxis &ax, double x)
 {
     // knots are samples (odd k) or sample midpoints (even k): the span follows from floor(x)
@@ -950,7 +979,6 @@ __device__ __forceinline__ void spline_basis(const SplineAxis &ax, double x, int
         }
     }
 }
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_spline_eval(const ReprojectArgs a, const SplineArgs sa)
 {

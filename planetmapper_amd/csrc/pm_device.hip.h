@@ -564,8 +564,8 @@ __device__ __forceinline__ V3 pgrrec_alt(const Params &p, const double *radii, d
     double a = radii[0], b = radii[2];
     double le = p.g.west_positive ? -lon : lon;
     double sl, cl, so, co;
-    sincos(lat, &sl, &cl);
-    sincos(le, &so, &co);
+    sincos_auto(lat, sl, cl);  // degree-sized angles: pi/2-reduced polynomials, libm beyond 1e5 / NaN
+    sincos_auto(le, so, co);
     double big = fmax(fabs(a * cl), fabs(b * sl));
     double x = a * cl / big, y = b * sl / big;
     double scale = 1.0 / (big * sqrt(fma(x, x, y * y)));
@@ -579,8 +579,8 @@ __device__ __forceinline__ V3 pgrrec_surface(const Params &p, double lon, double
     double a = p.radii[0], b = p.radii[2];
     double le = p.g.west_positive ? -lon : lon;
     double sl, cl, so, co;
-    sincos(lat, &sl, &cl);
-    sincos(le, &so, &co);
+    sincos_auto(lat, sl, cl);  // degree-sized angles: pi/2-reduced polynomials, libm beyond 1e5 / NaN
+    sincos_auto(le, so, co);
     double big = fmax(fabs(a * cl), fabs(b * sl));
     double x = a * cl / big, y = b * sl / big;
     double scale = 1.0 / (big * sqrt(fma(x, x, y * y)));
@@ -633,6 +633,17 @@ __device__ __forceinline__ void illum_angles(const Params &p, V3 sp, double lt, 
     phase = vsep_unit(sunb, ob);
     inc = vsep_unit(n, sunb);
     emi = vsep_unit(n, ob);
+}
+
+// emission angle alone (the `visibl` flag of illumf_c: emission < 90 deg), for callers that
+// need no Sun geometry: same operations as in illum_angles
+__device__ __forceinline__ double emission_angle(const Params &p, V3 sp, V3 pos, const M3 &R)
+{
+    V3 ob = unit(neg(mxv(R, pos)));
+    double m = fmin(p.radii[0], fmin(p.radii[1], p.radii[2]));
+    double a1 = m / p.radii[0], b1 = m / p.radii[1], c1 = m / p.radii[2];
+    V3 n = unit(v3(sp.x * (a1 * a1), sp.y * (b1 * b1), sp.z * (c1 * c1)));
+    return vsep_unit(n, ob);
 }
 
 // Body._azimuth_angle_from_gie_radians body.py:2319 on degree images (body_xy.py:3742)

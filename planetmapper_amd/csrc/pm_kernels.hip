@@ -440,6 +440,10 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
 // Map-space chain: BodyXY._get_targvec_map body_xy.py:3227, _get_illumf_map :3667,
 // _get_obsvec_map :3273, _get_radec_map :3419, _get_xy_map :3478 and the get_*_map
 // planes. One lane per map location; lon/lat grids are read coalesced.
+// SUN: phase / incidence / azimuth or the `lit` gate of the limb / ring planes are wanted;
+// STATE: distance / radial velocity / doppler. The x/y-map request of a reprojection needs
+// neither: only the emission angle (visibility) is evaluated then.
+template <bool SUN, bool STATE>
 __global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__restrict__ lon_in,
                                                 const double *__restrict__ lat_in)
 {
@@ -462,16 +466,22 @@ __global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__
         V3 pos;
         M3 R;
         point_lt<3>(p, tv, lt, pos, R);
-        illum_angles(p, tv, lt, pos, R, ph, in, em);
+        if (SUN) {
+            illum_angles(p, tv, lt, pos, R, ph, in, em);
+            lit = in < kHalfPi;
+        } else {
+            em = emission_angle(p, tv, pos, R);
+        }
         vis = em < kHalfPi;
-        lit = in < kHalfPi;
         ph *= kDeg;
         in *= kDeg;
         em *= kDeg;
         surf_dist = lt * p.g.clight;
-        rv = radial_velocity(p, tv, lt, pos, R);
-        double beta = rv / p.g.clight;
-        dop = sqrt((1.0 + beta) / (1.0 - beta));
+        if (STATE) {
+            rv = radial_velocity(p, tv, lt, pos, R);
+            double beta = rv / p.g.clight;
+            dop = sqrt((1.0 + beta) / (1.0 - beta));
+        }
     }
     PM_PUT(PM_PHASE, ph);
     PM_PUT(PM_INCIDENCE, in);
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__
     double ra_deg = nan, dec_deg = nan;
     if (have && vis) {
         double ra, dec;
-        recrad(ov, ra, dec);
+        recrad_f(ov, ra, dec);  // (ov is finite and non-zero here)
         ra_deg = ra * kDeg;
         dec_deg = dec * kDeg;
     }
@@ -505,9 +515,9 @@ __global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__
 
     double px = nan, py = nan, kx = nan, ky = nan;
     if (!isnan(ra_deg)) {
-        V3 u = radrec(ra_deg * kRad, dec_deg * kRad);
+        V3 u = radrec_f(ra_deg * kRad, dec_deg * kRad);
         double ax, ay;
-        obsvec2angular(p, u, ax, ay);
+        obsvec2angular_f(p, u, ax, ay);
         double xx = fma(p.Ai[0], ax, fma(p.Ai[1], ay, p.Ai[2]));
         double yy = fma(p.Ai[3], ax, fma(p.Ai[4], ay, p.Ai[5]));
         // BodyXY._xy_in_image_frame body_xy.py:1868
@@ -1382,7 +1392,16 @@ void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hi
 {
     size_t n = (size_t)p.n0 * p.n1;
     dim3 grid((unsigned)((n + pm::kBlock - 1) / pm::kBlock));
-    hipLaunchKernelGGL(pm::k_map, grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+    const uint64_t sun_bits = PM_PLANE_BIT(PM_PHASE) | PM_PLANE_BIT(PM_INCIDENCE) | PM_PLANE_BIT(PM_AZIMUTH) |
+                              PM_PLANE_BIT(PM_LIMB_LON_GRAPHIC) | PM_PLANE_BIT(PM_LIMB_LAT_GRAPHIC) |
+                              PM_PLANE_BIT(PM_LIMB_DISTANCE) | PM_PLANE_BIT(PM_RING_RADIUS) |
+                              PM_PLANE_BIT(PM_RING_LON_GRAPHIC) | PM_PLANE_BIT(PM_RING_DISTANCE);
+    const uint64_t state_bits = PM_PLANE_BIT(PM_RADIAL_VELOCITY) | PM_PLANE_BIT(PM_DOPPLER);
+    const bool sun = (p.mask & sun_bits) != 0, state = (p.mask & state_bits) != 0;
+    if (sun && state) hipLaunchKernelGGL((pm::k_map<true, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+    else if (sun) hipLaunchKernelGGL((pm::k_map<true, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+    else if (state) hipLaunchKernelGGL((pm::k_map<false, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+    else hipLaunchKernelGGL((pm::k_map<false, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
 }
 
 template <typename T>

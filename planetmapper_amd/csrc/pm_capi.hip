@@ -1100,7 +1100,18 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         // coordinates); anything else, e.g. a lander, goes through the general kernel
         double y2 = 0.0;
         for (int i = 0; i < 3; i++) y2 += (pd.O0[i] / pd.radii[i]) * (pd.O0[i] / pd.radii[i]);
-        const bool spheroid = pd.radii[0] == pd.radii[1] && y2 > 4.0 && !ctx->force_general;
+        // ... and it does not carry the target's / Sun's acceleration over the light-time span of a
+        // disc intercept (|d| <= R / c): fine while A (R/c)^2 / 2 is below 1e-12 of the smallest
+        // radius (Jupiter: 6e-9 km of 66 854 km; the ray itself is rounded at 1e-7 km)
+        const double rmax = std::fmax(pd.radii[0], pd.radii[2]), rmin = std::fmin(pd.radii[0], pd.radii[2]);
+        const double span = rmax / ctx->geometry.clight;
+        double acc2 = 0.0, accs2 = 0.0;
+        for (int i = 0; i < 3; i++) {
+            acc2 += ctx->geometry.AT[i] * ctx->geometry.AT[i];
+            accs2 += ctx->geometry.AS[i] * ctx->geometry.AS[i];
+        }
+        const bool slow = 0.5 * std::sqrt(std::fmax(acc2, accs2)) * span * span < 1e-12 * rmin;
+        const bool spheroid = pd.radii[0] == pd.radii[1] && y2 > 4.0 && slow && !ctx->force_general;
         if (spheroid)
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else

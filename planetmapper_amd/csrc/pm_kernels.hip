@@ -238,9 +238,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // wave-uniform exit once no lane is still iterating
             const double te = p.g.et - lt;
             d = te - p.t0;
-            const double h = 0.5 * d * d;
-            const V3 obs = {fma(-p.AB[0], h, fma(-p.VB[0], d, p.O0[0])), fma(-p.AB[1], h, fma(-p.VB[1], d, p.O0[1])),
-                            fma(-p.AB[2], h, fma(-p.VB[2], d, p.O0[2]))};
+            // (the target's acceleration moves it by A d^2 / 2 < 1e-8 km over the |d| <= R / c of a
+            //  disc intercept, 10x below the rounding of the ray itself: not carried here)
+            const V3 obs = {fma(-p.VB[0], d, p.O0[0]), fma(-p.VB[1], d, p.O0[1]), fma(-p.VB[2], d, p.O0[2])};
             const V3 Y = {obs.x * p.ira, obs.y * p.ira, obs.z * p.irc};
             const double yx = dot(Y, X);
             k = yx * ixx;
@@ -283,9 +283,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             }
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
-                const double h = 0.5 * d * d;
-                const V3 q = {fma(p.AB[0], h, fma(p.VB[0], d, sp.x)), fma(p.AB[1], h, fma(p.VB[1], d, sp.y)),
-                              fma(p.AB[2], h, fma(p.VB[2], d, sp.z))};
+                const V3 q = {fma(p.VB[0], d, sp.x), fma(p.VB[1], d, sp.y), fma(p.VB[2], d, sp.z)};
                 const double te = p.g.et - lt;
                 // Sun light time (spkcpo_c 'CN'): at lts0 = te - ts0 the Sun sits at S0 exactly;
                 // one correction pass leaves |d lts| ~ (v_sun / c) * 0.25 s = 1e-8 s, i.e. 1e-10 km
@@ -293,10 +291,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 const double s2 = dot(sv, sv);
                 const double lts = s2 * rsqrt_fast(s2) * p.inv_c;
                 const double ds = (te - lts) - p.g.ts0;
-                const double hs = 0.5 * ds * ds;
-                sv = v3(fma(p.ASB[0], hs, fma(p.VSB[0], ds, p.SB0[0])) - q.x,
-                        fma(p.ASB[1], hs, fma(p.VSB[1], ds, p.SB0[1])) - q.y,
-                        fma(p.ASB[2], hs, fma(p.VSB[2], ds, p.SB0[2])) - q.z);
+                sv = v3(fma(p.VSB[0], ds, p.SB0[0]) - q.x, fma(p.VSB[1], ds, p.SB0[1]) - q.y,
+                        fma(p.VSB[2], ds, p.SB0[2]) - q.z);
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
                 const double ia2 = p.ira * p.ira, ic2 = p.irc * p.irc;

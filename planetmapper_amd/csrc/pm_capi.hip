@@ -1094,8 +1094,8 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         if (plane_mask & kRingBits) flags |= 4;
         pm::Params pd = p;
         pd.mask = plane_mask & kDiscBits;
-        // spheroids (every planet in pck00010) take the rotation-free fast path; triaxial
-        // bodies use the general kernel
+        // spheroids (every planet in pck00010) take the rotation-free fast path, triaxial bodies
+        // (most moons) its variant with one small rotation per light-time evaluation
         // the fast path assumes an observer well outside the body (|O0| > 2 radii in scaled
         // coordinates); anything else, e.g. a lander, goes through the general kernel
         double y2 = 0.0;
@@ -1103,7 +1103,8 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         // ... and it does not carry the target's / Sun's acceleration over the light-time span of a
         // disc intercept (|d| <= R / c): fine while A (R/c)^2 / 2 is below 1e-12 of the smallest
         // radius (Jupiter: 6e-9 km of 66 854 km; the ray itself is rounded at 1e-7 km)
-        const double rmax = std::fmax(pd.radii[0], pd.radii[2]), rmin = std::fmin(pd.radii[0], pd.radii[2]);
+        const double rmax = std::fmax(pd.radii[0], std::fmax(pd.radii[1], pd.radii[2]));
+        const double rmin = std::fmin(pd.radii[0], std::fmin(pd.radii[1], pd.radii[2]));
         const double span = rmax / ctx->geometry.clight;
         double acc2 = 0.0, accs2 = 0.0;
         for (int i = 0; i < 3; i++) {
@@ -1111,7 +1112,9 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
             accs2 += ctx->geometry.AS[i] * ctx->geometry.AS[i];
         }
         const bool slow = 0.5 * std::sqrt(std::fmax(acc2, accs2)) * span * span < 1e-12 * rmin;
-        const bool spheroid = pd.radii[0] == pd.radii[1] && y2 > 4.0 && slow && !ctx->force_general;
+        // a triaxial body is turned by its spin angle per light-time evaluation with a short series
+        const bool small_spin = std::fabs(ctx->geometry.wdot) * span < 1e-3;
+        const bool spheroid = y2 > 4.0 && slow && small_spin && !ctx->force_general;
         if (spheroid)
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else

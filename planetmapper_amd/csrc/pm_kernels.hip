@@ -180,7 +180,11 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
     return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
 }
 
-template <int FLAGS>
+// TRI: triaxial ellipsoid (a != b). The shape is no longer invariant under the spin, so each
+// light-time evaluation first turns ray and observer by the spin angle of its epoch (a few
+// 1e-5 rad: series) into the body-fixed frame and rescales the ray; the intercept is then
+// body-fixed, and is turned back to B0 for the illumination geometry.
+template <int FLAGS, bool TRI>
 __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 {
     // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8); with a row-major grid
@@ -223,9 +227,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     if (any_cand) {
         const V3 u = mxv(p.C, va);  // ray in B0
 
-        // surfpt_c in scaled coordinates; X and 1/(X.X) are fixed for the pixel
-        const V3 X = {u.x * p.ira, u.y * p.ira, u.z * p.irc};
-        const double ixx = rcp_fast(dot(X, X));
+        // surfpt_c in scaled coordinates; for a spheroid X and 1/(X.X) are fixed for the pixel
+        V3 X = {u.x * p.ir[0], u.y * p.ir[1], u.z * p.ir[2]};
+        double ixx = rcp_fast(dot(X, X));
+        double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
         // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
@@ -241,7 +246,18 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // (the target's acceleration moves it by A d^2 / 2 < 1e-8 km over the |d| <= R / c of a
             //  disc intercept, 10x below the rounding of the ray itself: not carried here)
             const V3 obs = {fma(-p.VB[0], d, p.O0[0]), fma(-p.VB[1], d, p.O0[1]), fma(-p.VB[2], d, p.O0[2])};
-            const V3 Y = {obs.x * p.ira, obs.y * p.ira, obs.z * p.irc};
+            V3 Y;
+            if (TRI) {
+                const double dl = p.g.wdot * d, d2 = dl * dl;  // |dl| < 1e-3 (host check)
+                cz = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+                sz = dl * fma(d2, -1.0 / 6.0, 1.0);
+                const V3 ub = {fma(cz, u.x, sz * u.y), fma(cz, u.y, -sz * u.x), u.z};
+                X = {ub.x * p.ir[0], ub.y * p.ir[1], ub.z * p.ir[2]};
+                ixx = rcp_fast(dot(X, X));
+                Y = {fma(cz, obs.x, sz * obs.y) * p.ir[0], fma(cz, obs.y, -sz * obs.x) * p.ir[1], obs.z * p.ir[2]};
+            } else {
+                Y = {obs.x * p.ir[0], obs.y * p.ir[1], obs.z * p.ir[2]};
+            }
             const double yx = dot(Y, X);
             k = yx * ixx;
             P = {fma(-k, X.x, Y.x), fma(-k, X.y, Y.y), fma(-k, X.z, Y.z)};
@@ -262,8 +278,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double tau = -k - root;  // distance observer -> point along the ray
             if (FLAGS & (DF_RING | DF_STATE)) dist_lt = lt * p.g.clight;
             const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
-            const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[0], Xf.z * p.radii[2]};
-            const double delta = p.g.wdot * d;
+            // body-fixed at te for TRI, B0 otherwise (body-fixed = Rz_frame(delta) * B0)
+            const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[1], Xf.z * p.radii[2]};
+            const double delta = TRI ? 0.0 : p.g.wdot * d;
             const double rho = sqrt_fast(fma(sp.x, sp.x, sp.y * sp.y));
             const bool polar = (sp.x == 0.0 && sp.y == 0.0);
             // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - delta
@@ -281,9 +298,11 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 lc_deg = lc * kDeg;
                 bc_deg = ((polar && sp.z == 0.0) ? 0.0 : atan2_fast(sp.z, rho)) * kDeg;
             }
+            // the point in B0 (for the Sun / observer geometry, which lives there)
+            const V3 sp0 = TRI ? v3(fma(cz, sp.x, -sz * sp.y), fma(sz, sp.x, cz * sp.y), sp.z) : sp;
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
-                const V3 q = {fma(p.VB[0], d, sp.x), fma(p.VB[1], d, sp.y), fma(p.VB[2], d, sp.z)};
+                const V3 q = {fma(p.VB[0], d, sp0.x), fma(p.VB[1], d, sp0.y), fma(p.VB[2], d, sp0.z)};
                 const double te = p.g.et - lt;
                 // Sun light time (spkcpo_c 'CN'): at lts0 = te - ts0 the Sun sits at S0 exactly;
                 // one correction pass leaves |d lts| ~ (v_sun / c) * 0.25 s = 1e-8 s, i.e. 1e-10 km
@@ -295,8 +314,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                         fma(p.VSB[2], ds, p.SB0[2]) - q.z);
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
-                const double ia2 = p.ira * p.ira, ic2 = p.irc * p.irc;
-                V3 n = {sp.x * ia2, sp.y * ia2, sp.z * ic2};  // surfnm_c
+                V3 n = {sp.x * (p.ir[0] * p.ir[0]), sp.y * (p.ir[1] * p.ir[1]), sp.z * (p.ir[2] * p.ir[2])};  // surfnm_c
+                if (TRI) n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
                 n = rsqrt_fast(dot(n, n)) * n;
                 ph = vsep_fast(sunb, ob) * kDeg;
                 in = vsep_fast(n, sunb) * kDeg;
@@ -306,7 +325,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
                 dist = dist_lt;
-                const V3 vp = {fma(p.AB[0], d, p.VB[0]) - p.g.wdot * sp.y, fma(p.AB[1], d, p.VB[1]) + p.g.wdot * sp.x,
+                const V3 vp = {fma(p.AB[0], d, p.VB[0]) - p.g.wdot * sp0.y, fma(p.AB[1], d, p.VB[1]) + p.g.wdot * sp0.x,
                                fma(p.AB[2], d, p.VB[2])};
                 const V3 vo = ld3(p.VOB);
                 const double dlt = (dot(u, vp - vo) * p.inv_c) / (1.0 + dot(u, vp) * p.inv_c);
@@ -1356,16 +1375,23 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 {
     dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
     dim3 block(pm::kSphBlock);
+    const bool tri = p.radii[0] != p.radii[1];
+#define PM_SPH_CASE(F)                                                                  \
+    case F:                                                                             \
+        if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, true>), grid, block, 0, s, p);   \
+        else hipLaunchKernelGGL((pm::k_disc_sph<F, false>), grid, block, 0, s, p);      \
+        break;
     switch (flags & 7) {
-    case 0: hipLaunchKernelGGL(pm::k_disc_sph<0>, grid, block, 0, s, p); break;
-    case 1: hipLaunchKernelGGL(pm::k_disc_sph<1>, grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL(pm::k_disc_sph<2>, grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(pm::k_disc_sph<3>, grid, block, 0, s, p); break;
-    case 4: hipLaunchKernelGGL(pm::k_disc_sph<4>, grid, block, 0, s, p); break;
-    case 5: hipLaunchKernelGGL(pm::k_disc_sph<5>, grid, block, 0, s, p); break;
-    case 6: hipLaunchKernelGGL(pm::k_disc_sph<6>, grid, block, 0, s, p); break;
-    case 7: hipLaunchKernelGGL(pm::k_disc_sph<7>, grid, block, 0, s, p); break;
+        PM_SPH_CASE(0)
+        PM_SPH_CASE(1)
+        PM_SPH_CASE(2)
+        PM_SPH_CASE(3)
+        PM_SPH_CASE(4)
+        PM_SPH_CASE(5)
+        PM_SPH_CASE(6)
+        PM_SPH_CASE(7)
     }
+#undef PM_SPH_CASE
 }
 
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s)

@@ -13,6 +13,8 @@ dev = torch.device('cuda', 0)
 eng = Engine(0)
 eng.set_stream(torch.cuda.current_stream().cuda_stream)
 g = load_scenario(os.environ.get('SCENARIO', 'jupiter_hst_2005'))
+if os.environ.get('TRIAXIAL'):
+    g.radii[1] = g.radii[0] * 0.97  # a triaxial body: the TRI variant of the fast kernel
 eng.set_geometry(g)
 planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
 x0 = (sz - 1) / 2

@@ -290,8 +290,15 @@ def _read_header(buf: bytes, pos: int) -> tuple[Header, int]:
 
 def read(path: str | os.PathLike) -> list[HDU]:
     """All HDUs of a FITS file (data of non-image extensions is None)."""
-    with open(os.fspath(path), 'rb') as f:
-        buf = f.read()
+    path = os.fspath(path)
+    if path.lower().endswith('.gz'):
+        import gzip
+
+        with gzip.open(path, 'rb') as f:
+            buf = f.read()
+    else:
+        with open(path, 'rb') as f:
+            buf = f.read()
     pos = 0
     hdus: list[HDU] = []
     while pos < len(buf):

@@ -145,6 +145,31 @@ class Observation(BodyXY):
                     pass
             _try_get_header_value(kw, header, 'utc', ['DATE-OBS', 'DATE-BEG', 'DATE-END', 'MJD-BEG', 'MJD-END'])
 
+    def disc_from_header(self) -> None:
+        """observation.py:399-425: take x0, y0, r0, rotation from the `HIERARCH PLANMAP DISC ...`
+        cards written by a previous `save_observation`"""
+        mk = self._make_fits_kw
+        if mk('MAP PROJECTION') in self.header or mk('DEGREE-INTERVAL') in self.header:
+            raise ValueError('FITS header refers to mapped data')
+        try:
+            self.set_disc_params(
+                x0=self.header[mk('DISC X0')], y0=self.header[mk('DISC Y0')],
+                r0=self.header[mk('DISC R0')], rotation=self.header[mk('DISC ROT')],
+            )  # fmt: skip
+            self.set_disc_method('header')
+        except KeyError as exc:
+            raise ValueError('No disc parameters found in FITS header') from exc
+
+    def to_body_xy(self) -> BodyXY:
+        """observation.py:183-195: a `BodyXY` with the same geometry, image size and disc parameters"""
+        new = BodyXY(
+            self.target, self.utc, self.observer, nx=self._nx, ny=self._ny, geometry=self._geometry,
+            optimize_speed=self._optimize_speed, engine=self._engine,
+        )  # fmt: skip
+        new.set_disc_params(*self.get_disc_params())
+        new.set_disc_method(self.get_disc_method())
+        return new
+
     # ------------------------------------------------------------------ header metadata
     def append_to_header(
         self, keyword: str, value, comment: str | None = None, *, hierarch_keyword: bool = True,

@@ -784,3 +784,113 @@ def test_smoothing_splines_vs_oracle_kats_and_golden(engine, oracle, jupiter):
     # s = 0 afterwards is the interpolating spline again
     assert np.array_equal(engine.map_cube(cube[:1], xm, ym, 'cubic', True),
                           engine.map_cube(cube[:1], xm, ym, 'cubic', True, spline_smoothing=0.0), equal_nan=True)
+
+
+def test_config4_saturn_rings_full_size(engine, oracle, saturn):
+    """
+    BASELINE config 4 at its full size: Saturn + rings, 4096^2, r0 = 800 px, rotation 20 deg,
+    8 planes. NaN masks (disc limb, ring-plane hits, rings hidden behind the disc) bit-exact and
+    the conditioned tolerances against the OpenMP oracle ("parity unpinned" by reference goldens).
+    """
+    sz = 4096
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(saturn)
+    engine.set_disc(x0, y0, 800.0, float(np.deg2rad(20.0)), sz, sz, True)
+    names = HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']
+    out = engine.backplanes_img(names)
+    oracle.set_num_threads(16)
+    ref = oracle.backplanes_img(saturn, oracle.make_disc(x0, y0, 800.0, 20.0, sz, sz), names)
+    for n in names:
+        assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), n
+    stats = _compare(out, ref, names, saturn, r0=800.0)
+    print('\nconfig 4 (4096^2 Saturn + rings) HIP vs oracle:', stats)
+    assert 0.1 < np.isfinite(out['LON-GRAPHIC']).mean() < 0.14  # pi * 800^2 * (1 - f) / 4096^2
+    assert np.isfinite(out['RING-RADIUS']).mean() > 0.5
+
+
+def test_config3_cube_2048_full_size(engine, oracle, jupiter):
+    """
+    BASELINE config 3 at its full size (SURVEY 8d recipe): P = 8 planes of 2048^2 f64 - limb-darkened
+    disc + 0.05 sigma noise from default_rng(20050101), 0.1 % NaN per plane, one full NaN row in
+    plane 3 - disc (1023.5, 1023.5, 921.15), 1 deg map, bilinear, propagate_nan. x/y maps against
+    the oracle, mapped cube against the oracle on the GPU's own maps to 1e-12.
+    """
+    sz, P = 2048, 8
+    x0 = y0 = (sz - 1) / 2
+    r0 = 0.9 * x0
+    rng = np.random.default_rng(20050101)
+    yy, xx = np.mgrid[0:sz, 0:sz]
+    mu = np.sqrt(np.clip(1 - ((xx - x0) ** 2 + (yy - y0) ** 2) / r0**2, 0, None))
+    cube = mu[None] + 0.05 * rng.standard_normal((P, sz, sz))
+    cube[rng.random((P, sz, sz)) < 1e-3] = np.nan
+    cube[3, 1000, :] = np.nan
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, r0, 0.0, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 1.0)
+    assert lon.shape == (180, 360) and lon[0, 0] == 359.5 and lon[0, -1] == 0.5
+    xm, ym = engine.xy_map(lon, lat)
+    d = oracle.make_disc(x0, y0, r0, 0.0, sz, sz)
+    ox, oy = oracle.xy_map(jupiter, d, lon, lat)
+    assert np.array_equal(np.isnan(xm), np.isnan(ox))
+    # the 1e-9 deg bar is 1e-9 * 3600 / plate scale = 1.8e-4 px here (x 1 / cos(emission) towards
+    # the limb); measured: 100x below it at the limb, 1e-9 px in the median
+    assert np.nanmax(np.abs(xm - ox)) < 2e-6 and np.nanmax(np.abs(ym - oy)) < 2e-6
+    assert np.nanmedian(np.abs(xm - ox)) < 1e-8
+    got = engine.map_cube(cube, xm, ym, 'linear', True)
+    ref = oracle.map_cube(cube, xm, ym, 'linear', True)
+    assert got.shape == (P, 180, 360)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    assert np.nanmax(np.abs(got - ref)) <= 1e-12
+    assert 0.3 < np.isfinite(got[0]).mean() < 0.5 and np.isfinite(got[3]).sum() < np.isfinite(got[2]).sum()
+
+
+def test_config5_cube_512_planes_properties(engine, oracle, jupiter):
+    """
+    BASELINE config 5 at its full size, device-resident: 512 planes of 1024^2 f64 (4 GiB in HBM)
+    mapped in one call. Size-independent properties: (1) linearity - plane p holds
+    a_p * base + b_p, so on every finite cell mapped[p] = a_p * mapped_base + b_p; (2) NaN masks of
+    all planes equal the base plane's; (3) planes chosen at random equal the oracle's map of
+    that plane bit-for-bit-close (1e-12); (4) a checksum over planes is invariant to the order in
+    which they are mapped (plane blocks as the multi-GPU shards would see them).
+    """
+    import torch
+
+    sz, P = 1024, 512
+    x0 = y0 = (sz - 1) / 2
+    r0 = 0.9 * x0
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, r0, 0.0, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 1.0)
+    xm, ym = engine.xy_map(lon, lat)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    base = torch.randn((sz, sz), generator=gen, device='cuda', dtype=torch.float64)
+    base[torch.rand((sz, sz), generator=gen, device='cuda') < 1e-3] = float('nan')
+    a = torch.linspace(-3.0, 3.0, P, device='cuda', dtype=torch.float64)
+    a[a.abs() < 0.01] = 0.5
+    b = torch.linspace(100.0, -100.0, P, device='cuda', dtype=torch.float64)
+    cube = a[:, None, None] * base[None] + b[:, None, None]  # 4 GiB
+    dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+    out = torch.empty((P, 180, 360), dtype=torch.float64, device='cuda')
+    engine.map_cube_device(cube, np.float64, P, dx, dy, 180, 360, out)
+    engine.synchronize()
+    mb = torch.empty((1, 180, 360), dtype=torch.float64, device='cuda')
+    engine.map_cube_device(base, np.float64, 1, dx, dy, 180, 360, mb)
+    engine.synchronize()
+    fin = torch.isfinite(mb[0])
+    assert 20000 < int(fin.sum()) < 32400
+    assert bool((torch.isfinite(out) == fin[None]).all())  # (2)
+    lin = a[:, None, None] * mb + b[:, None, None]
+    err = (out - lin)[:, fin].abs().max()
+    assert float(err) < 1e-11, float(err)  # (1): bilinear weights sum to 1 within rounding
+    host_base = base.cpu().numpy()
+    for p in (0, 77, 300, 511):  # (3)
+        plane = float(a[p]) * host_base + float(b[p])
+        ref = oracle.map_cube(plane, xm, ym, 'linear', True)[0]
+        got = out[p].cpu().numpy()
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) <= 1e-11, p
+    out2 = torch.empty_like(out)  # (4): 8 blocks of 64 planes, last block first
+    for blk in reversed(range(8)):
+        s = slice(64 * blk, 64 * blk + 64)
+        engine.map_cube_device(cube[s], np.float64, 64, dx, dy, 180, 360, out2[s])
+    engine.synchronize()
+    assert torch.equal(torch.nan_to_num(out2), torch.nan_to_num(out))

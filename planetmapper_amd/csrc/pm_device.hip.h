@@ -105,6 +105,11 @@ struct Params {
     int32_t pad_;
 };
 
+constexpr int kBlock = 256;
+// the spheroid image kernel runs one wave per workgroup: finer-grained dispatch mixes the
+// cheap and the expensive row segments better (measured 0.269 vs 0.275 ms at 256, 0.291 at 512)
+constexpr int kSphBlock = 64;
+
 // Arguments of the point-transform kernel (pm_transform).
 struct TransformArgs {
     const double *a, *b;

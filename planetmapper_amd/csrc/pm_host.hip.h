@@ -1,0 +1,106 @@
+// pm_host.hip.h -- declarations shared by the host-side sources of libplanetmapper_hip.so
+// (pm_capi.hip: context + C ABI; pm_reproject.hip: the host logic of pm_map_cube).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "pm_device.hip.h"
+
+
+
+void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s);
+void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s);
+void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
+void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
+void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
+void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
+void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
+void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);
+void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
+void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
+void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
+                        double *c, hipStream_t s);
+void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s);
+void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
+                        double *rowsum, double *colsum, hipStream_t s);
+void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, int dtype, hipStream_t s);
+void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
+                             unsigned int *hist, hipStream_t s);
+
+struct pm_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    bool have_geometry = false;
+    bool have_disc = false;
+    pm_geometry geometry{};
+    pm_disc disc{};
+    std::string error;
+    // grow-only device scratch for host-buffer callers
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int *flags = nullptr;  // per-plane flags of pm_map_cube
+    size_t flags_count = 0;
+    pm::PlaneStats *stats = nullptr;  // per-plane nanmedian state (NaN pre-clean)
+    unsigned int *hist = nullptr;
+    size_t stats_count = 0;
+    // device-mode pm_map_cube is asynchronous: planes that turn out to need the nanmedian
+    // are finished by pm_synchronize(), which replays the call with the statistics
+    bool pending = false;
+    pm::ReprojectArgs pending_args{};
+    int pending_dtype = 0;
+    // spline reprojection: coefficient workspace + per-axis knots / LU (cached per (n, k))
+    double *work = nullptr;
+    size_t work_bytes = 0;
+    struct AxisCache {
+        int n = 0, k = 0;
+        double *t = nullptr, *lu = nullptr;
+    } axis[2];
+    // 'smooth' interpolation options (map_img smooth_oversample_by / smooth_max_oversampled_img_size)
+    int smooth_oversample_by = 5;
+    int smooth_max_size = 10000;
+    double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
+    double spline_smoothing = 0.0;  // map_img spline_smoothing (FITPACK s), 0 = interpolating splines
+    void *sm_arena = nullptr;       // device workspace of the smoothing-spline fit
+    size_t sm_arena_bytes = 0;
+    int map_seq = 0;        // sequence number of the latest pm_map_cube call
+    int checked_seq = 0;    // calls up to this number have had their flags examined
+    bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
+};
+
+namespace pmh {
+
+// records the message in the context and returns `code`
+int fail(pm_ctx *ctx, int code, const char *fmt, ...);
+
+#define PM_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return pmh::fail(ctx, PM_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                             __FILE__, __LINE__);                                             \
+    } while (0)
+
+size_t dtype_size(int dtype);
+int ensure_scratch(pm_ctx *ctx, size_t bytes);  // grow-only device buffers of the context
+int ensure_flags(pm_ctx *ctx, size_t count);
+int ensure_stats(pm_ctx *ctx, size_t count);
+
+// pm_reproject.hip: reprojection of planes resident on the device
+int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_now);
+int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype);
+int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols);
+int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype, const double *limits);
+int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols, double s);
+
+}  // namespace pmh

@@ -5,8 +5,8 @@
 //   k_sky<LIMB>     image-space planes defined for every pixel
 //                   (RA/Dec, pixel x/y, km, angular, limb)
 //   k_map           map-space planes + x_map/y_map for a lon/lat grid
-//   k_reproject<T>  bilinear / nearest reprojection of a cube onto the map grid
-//   k_reproject_smooth<T>  'smooth' (PCHIP-oversampled) reprojection, evaluated on the fly
+//   k_transform     array-valued coordinate transforms
+// (reprojection kernels: pm_kernels_reproject.hip)
 //
 // Launch geometry of the image kernels: one lane per pixel, a wave covers 64
 // consecutive x of one row, so every plane store is one 512-byte fully coalesced
@@ -15,10 +15,6 @@
 
 namespace pm {
 
-constexpr int kBlock = 256;
-// the spheroid image kernel runs one wave per workgroup: finer-grained dispatch mixes the
-// cheap and the expensive row segments better (measured 0.269 vs 0.275 ms at 256, 0.291 at 512)
-constexpr int kSphBlock = 64;
 
 enum DiscFlags : int {
     DF_ILLUM = 1,  // PHASE / INCIDENCE / EMISSION / AZIMUTH
@@ -692,664 +688,6 @@ __global__ __launch_bounds__(kBlock) void k_transform(const Params p, const Tran
     t.ob[i] = rb_out;
 }
 
-// ------------------------------------------------------------------ reprojection
-template <typename T>
-__device__ __forceinline__ double load_as_f64(const T *p, size_t i)
-{
-    return (double)p[i];
-}
-
-// Value the reference would interpolate from at pixel (i, j): the pixel itself if finite,
-// else the mean of the finite pixels of its clipped 3x3 window, else the plane's nanmedian
-// (BodyXY._replace_nans_with_interpolated_values body_xy.py:1871-1904; the reflect-mode
-// `uniform_filter(bad, size=3)` test there is equivalent to "the clipped window holds no
-// finite pixel" because reflection only repeats pixels of the window).
-template <typename T>
-__device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int ny, int nx, double median,
-                                             bool &needs_median)
-{
-    const double v = load_as_f64(img, (size_t)i * nx + j);
-    if (isfinite(v)) return v;
-    double sum = 0.0;
-    int cnt = 0;
-    for (long ii = (i > 0 ? i - 1 : 0); ii <= i + 1 && ii < ny; ii++)
-        for (long jj = (j > 0 ? j - 1 : 0); jj <= j + 1 && jj < nx; jj++) {
-            const double w = load_as_f64(img, (size_t)ii * nx + jj);
-            if (isfinite(w)) {
-                sum += w;
-                cnt++;
-            }
-        }
-    if (cnt > 0) return sum / (double)cnt;
-    needs_median = true;
-    return median;
-}
-
-// One lane per (map location, plane): BodyXY.map_img body_xy.py:1414 for every plane of
-// Observation._get_mapped_data observation.py:876. blockIdx.y = plane, so the 64 lanes
-// of a wave gather from one plane around neighbouring (x, y) -> the 4-point footprints
-// overlap in L2; the store is coalesced along the map row.
-//
-// The reference interpolates a NaN-cleaned copy of each plane; here the cleaned value of a
-// non-finite corner is computed on the fly from its 3x3 window. Only a corner whose whole
-// window is non-finite needs the plane's nanmedian: with plane_stats == NULL (first pass)
-// such a plane is flagged (plane_flags[pl] = call sequence number) and the host reruns it
-// after k_median_*.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
-{
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
-    if (m >= a.n_map) return;
-    const double nan = __builtin_nan("");
-    const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
-    double *o = a.out + (size_t)pl * a.n_map;
-    double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    if (!isnan(x)) {
-        if (a.interpolation == PM_INTERP_NEAREST) {
-            // _do_nearest_interpolation body_xy.py:1633: np.round = half to even
-            long xi = (long)rint(x), yi = (long)rint(y);
-            if (xi < 0) xi += nx;
-            if (yi < 0) yi += ny;
-            // maps made by pm_xy_map are always inside the frame; a caller-supplied map that is
-            // not (the reference raises IndexError there) must not read outside the plane
-            if (xi >= 0 && xi < nx && yi >= 0 && yi < ny && !isnan(y)) val = load_as_f64(img, (size_t)yi * nx + xi);
-        } else {
-            const bool have_stats = a.plane_stats != nullptr;
-            bool skip = have_stats && a.plane_stats[pl].all_nan;  // body_xy.py:1668-1670
-            if (a.propagate_nan && !skip) {
-                // _should_propagate_nan_to_map body_xy.py:1855-1866
-                if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-                    skip = true;
-                } else {
-                    long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-                    long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-                    double t0 = load_as_f64(img, (size_t)ja * nx + ia), t1 = load_as_f64(img, (size_t)ja * nx + ib);
-                    double t2 = load_as_f64(img, (size_t)jb * nx + ia), t3 = load_as_f64(img, (size_t)jb * nx + ib);
-                    skip = isnan(t0) || isnan(t1) || isnan(t2) || isnan(t3);
-                }
-            }
-            if (!skip) {
-                // RectBivariateSpline(kx=ky=1, s=0).ev == bilinear; FITPACK clamps the
-                // evaluation point to the knot range.
-                double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
-                long x0 = (long)floor(xc), y0 = (long)floor(yc);
-                if (x0 > nx - 2) x0 = nx - 2;
-                if (y0 > ny - 2) y0 = ny - 2;
-                if (x0 < 0) x0 = 0;
-                if (y0 < 0) y0 = 0;
-                long x1 = x0 + 1 < nx ? x0 + 1 : x0, y1 = y0 + 1 < ny ? y0 + 1 : y0;
-                double fx = xc - (double)x0, fy = yc - (double)y0;
-                const double med = have_stats ? a.plane_stats[pl].median : 0.0;
-                bool nm = false;
-                // corners with zero weight contribute exactly 0 in the reference (their cleaned
-                // value is finite), so they are not evaluated at all
-                const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
-                const double v00 = (fx != 1.0 && fy != 1.0) ? cleaned_at(img, y0, x0, ny, nx, med, nm) : 0.0;
-                const double v01 = (fx != 0.0 && fy != 1.0) ? cleaned_at(img, y0, x1, ny, nx, med, nm) : 0.0;
-                const double v10 = (fx != 1.0 && fy != 0.0) ? cleaned_at(img, y1, x0, ny, nx, med, nm) : 0.0;
-                const double v11 = (fx != 0.0 && fy != 0.0) ? cleaned_at(img, y1, x1, ny, nx, med, nm) : 0.0;
-                (void)w00; (void)w01; (void)w10; (void)w11;
-                val = (1.0 - fy) * ((1.0 - fx) * v00 + fx * v01) + fy * ((1.0 - fx) * v10 + fx * v11);
-                if (nm && !have_stats) atomicMax(&a.plane_flags[pl], a.seq);
-            }
-        }
-    }
-    o[m] = val;
-}
-
-// ------------------------------------------------------------------ spline reprojection
-// scipy RectBivariateSpline(kx, ky, s=0).ev of BodyXY._do_spline_interpolation
-// (body_xy.py:1651-1702) for 'quadratic', 'cubic' and (k0, k1): interpolating tensor-product
-// B-spline. Pipeline per chunk of planes: k_median_* (plane statistics) -> k_spline_clean
-// (NaN-cleaned float64 copy) -> k_spline_solve axis 0, axis 1 (banded LU substitution, in
-// place: samples -> coefficients) -> k_spline_eval.
-
-// 'smooth' interpolation (BodyXY._do_smooth_interpolation / _pchip_grid_interp2d
-// body_xy.py:1704-1853). The reference materialises the whole oversampled image (up to
-// 10000 x 10000 per plane) and then samples it bilinearly at the map cells. PCHIP is local
-// (a piece depends on four samples), so here each (cell, plane) lane evaluates just the four
-// fine-grid nodes around its sample: node (r, k) = column PCHIP at ys[r] over the rows whose
-// row PCHIP at xs[k] is finite, each of those a PCHIP over the finite pixels of the row.
-// Work scales with the map, not with the oversampled image, and nothing is staged in HBM.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reproject_smooth(const ReprojectArgs a, const SmoothArgs sm)
-{
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
-    if (m >= a.n_map) return;
-    const double nan = __builtin_nan("");
-    const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
-    const double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    bool skip = isnan(x);
-    if (!skip && a.propagate_nan) {
-        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-            skip = true;
-        } else {
-            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
-                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
-        }
-    }
-    // RegularGridInterpolator(bounds_error=False, fill_value=nan)
-    const double x_lo = (double)sm.x.first, x_hi = (double)sm.x.last;
-    const double y_lo = (double)sm.y.first, y_hi = (double)sm.y.last;
-    if (!skip && x >= x_lo && x <= x_hi && y >= y_lo && y <= y_hi) {
-        const int k = smooth_interval(sm.x, x), r = smooth_interval(sm.y, y);
-        const double xk0 = smooth_grid(sm.x, k), xk1 = smooth_grid(sm.x, k + 1);
-        const double yr0 = smooth_grid(sm.y, r), yr1 = smooth_grid(sm.y, r + 1);
-        auto node = [&](double xq, double yq) {
-            auto column = [&](int i) {
-                auto row = [&](int j) { return load_as_f64(img, (size_t)i * nx + j); };
-                return pchip_gappy(row, sm.x.first, sm.x.last, xq);
-            };
-            return pchip_gappy(column, sm.y.first, sm.y.last, yq);
-        };
-        const double f00 = node(xk0, yr0), f01 = node(xk1, yr0), f10 = node(xk0, yr1), f11 = node(xk1, yr1);
-        const double fx = (x - xk0) / (xk1 - xk0), fy = (y - yr0) / (yr1 - yr0);
-        val = f00 * (1.0 - fy) * (1.0 - fx) + f01 * (1.0 - fy) * fx + f10 * fy * (1.0 - fx) + f11 * fy * fx;
-    }
-    a.out[(size_t)pl * a.n_map + m] = val;
-}
-
-// nanmin / nanmax of the x and y maps (one block): limits[0..3] = xmin, xmax, ymin, ymax;
-// +inf / -inf when no cell is visible.
-__global__ __launch_bounds__(kBlock) void k_map_limits(const double *x_map, const double *y_map, int n, double *limits)
-{
-    __shared__ double sh[4][kBlock];
-    double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-        const double x = x_map[i], y = y_map[i];
-        if (!isnan(x)) {
-            xmin = fmin(xmin, x);
-            xmax = fmax(xmax, x);
-        }
-        if (!isnan(y)) {
-            ymin = fmin(ymin, y);
-            ymax = fmax(ymax, y);
-        }
-    }
-    sh[0][threadIdx.x] = xmin;
-    sh[1][threadIdx.x] = xmax;
-    sh[2][threadIdx.x] = ymin;
-    sh[3][threadIdx.x] = ymax;
-    __syncthreads();
-    for (int st = kBlock / 2; st > 0; st >>= 1) {
-        if ((int)threadIdx.x < st) {
-            sh[0][threadIdx.x] = fmin(sh[0][threadIdx.x], sh[0][threadIdx.x + st]);
-            sh[1][threadIdx.x] = fmax(sh[1][threadIdx.x], sh[1][threadIdx.x + st]);
-            sh[2][threadIdx.x] = fmin(sh[2][threadIdx.x], sh[2][threadIdx.x + st]);
-            sh[3][threadIdx.x] = fmax(sh[3][threadIdx.x], sh[3][threadIdx.x + st]);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 4) limits[threadIdx.x] = sh[threadIdx.x][0];
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *work, const PlaneStats *stats, int ny, int nx)
-{
-    const size_t npx = (size_t)ny * nx;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
-    if (i >= npx) return;
-    bool nm = false;
-    work[(size_t)pl * npx + i] = cleaned_at(cube + (size_t)pl * npx, (long)(i / nx), (long)(i % nx), ny, nx, stats[pl].median, nm);
-}
-
-// One lane per (plane, line): solve B c = v along `axis` in place with the banded LU.
-// axis 0: lines are image columns (lanes adjacent in x read one image row per step: coalesced);
-// axis 1: lines are image rows (each lane walks its own row).
-__global__ __launch_bounds__(kBlock) void k_spline_solve(double *work, int n_planes, int ny, int nx, int axis, SplineAxis ax)
-{
-    const size_t npx = (size_t)ny * nx;
-    const int lines = axis == 0 ? nx : ny;
-    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (tid >= (size_t)n_planes * lines) return;
-    const int pl = (int)(tid / lines), line = (int)(tid % lines);
-    double *v = work + (size_t)pl * npx + (axis == 0 ? (size_t)line : (size_t)line * nx);
-    const size_t stride = axis == 0 ? (size_t)nx : 1;
-    const int n = ax.n, k = ax.k, w = 2 * k + 1;
-    // forward substitution (unit lower triangle), the last k results kept in registers. Samples
-    // and LU rows are fetched eight at a time so that their load latencies overlap (a line along
-    // image rows then also uses every 64-byte sector it touches in full).
-    double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int i0 = 0; i0 < n; i0 += 8) {
-        double vb[8], lb[8][5];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = (i0 + u < n) ? i0 + u : n - 1;
-            vb[u] = v[(size_t)i * stride];
-            const double *row = ax.lu + (size_t)i * w;
-#pragma unroll
-            for (int q = 1; q <= 5; q++) lb[u][q - 1] = (q <= k) ? row[k - q] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + u;
-            if (i < n) {
-                double s = vb[u];
-#pragma unroll
-                for (int q = 1; q <= 5; q++)
-                    if (q <= k && i - q >= 0) s -= lb[u][q - 1] * prev[q - 1];
-#pragma unroll
-                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-                prev[0] = s;
-                v[(size_t)i * stride] = s;
-            }
-        }
-    }
-    // back substitution
-#pragma unroll
-    for (int q = 0; q < 5; q++) prev[q] = 0.0;
-    for (int i0 = n - 1; i0 >= 0; i0 -= 8) {
-        double vb[8], ub[8][6];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = (i0 - u >= 0) ? i0 - u : 0;
-            vb[u] = v[(size_t)i * stride];
-            const double *row = ax.lu + (size_t)i * w;
-#pragma unroll
-            for (int q = 0; q <= 5; q++) ub[u][q] = (q <= k) ? row[k + q] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 - u;
-            if (i >= 0) {
-                double s = vb[u];
-#pragma unroll
-                for (int q = 1; q <= 5; q++)
-                    if (q <= k && i + q < n) s -= ub[u][q] * prev[q - 1];
-                s /= ub[u][0];
-#pragma unroll
-                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-                prev[0] = s;
-                v[(size_t)i * stride] = s;
-            }
-        }
-    }
-}
-__device__ __forceinline__ int spline_interval(const SplineAxis &ax, double x)
-{
-    // knots are samples (odd k) or sample midpoints (even k): the span follows from floor(x)
-    int l = ax.k;
-    const int hi = ax.n - 1;
-    // t[k+1+j] = j + k/2 + 1 (odd k) or j + k/2 + 0.5 (even k); find the largest l with t[l] <= x
-    const double off = (ax.k & 1) ? (double)(ax.k / 2 + 1) : (double)(ax.k / 2) + 0.5;
-    int j = (int)floor(x - off) + 1;  // number of interior knots <= x
-    if (j < 0) j = 0;
-    l = ax.k + j;
-    if (l > hi) l = hi;
-    while (l < hi && x >= ax.t[l + 1]) l++;  // guard against rounding at knot values
-    while (l > ax.k && x < ax.t[l]) l--;
-    return l;
-}
-__device__ __forceinline__ void spline_basis(const SplineAxis &ax, double x, int l, double *h)
-{
-    double hh[6];
-    h[0] = 1.0;
-    for (int j = 1; j <= ax.k; j++) {
-        for (int i = 0; i < j; i++) hh[i] = h[i];
-        h[0] = 0.0;
-        for (int i = 1; i <= j; i++) {
-            const int li = l + i, lj = li - j;
-            const double f = hh[i - 1] / (ax.t[li] - ax.t[lj]);
-            h[i - 1] += f * (ax.t[li] - x);
-            h[i] = f * (x - ax.t[lj]);
-        }
-    }
-}
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_spline_eval(const ReprojectArgs a, const SplineArgs sa)
-{
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
-    if (m >= a.n_map) return;
-    const double nan = __builtin_nan("");
-    const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
-    const double *c = sa.work + (size_t)pl * ny * nx;
-    double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    bool skip = isnan(x) || a.plane_stats[pl].all_nan;
-    if (!skip && a.propagate_nan) {
-        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-            skip = true;
-        } else {
-            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
-                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
-        }
-    }
-    if (!skip) {
-        const double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
-        double hy[6], hx[6];
-        const int ly = spline_interval(sa.rows, yc), lx = spline_interval(sa.cols, xc);
-        spline_basis(sa.rows, yc, ly, hy);
-        spline_basis(sa.cols, xc, lx, hx);
-        double s = 0.0;
-        for (int p = 0; p <= sa.rows.k; p++) {
-            double r = 0.0;
-            for (int q = 0; q <= sa.cols.k; q++) r += hx[q] * c[(size_t)(ly - sa.rows.k + p) * nx + (lx - sa.cols.k + q)];
-            s += hy[p] * r;
-        }
-        val = s;
-    }
-    a.out[(size_t)pl * a.n_map + m] = val;
-}
-
-// ------------------------------------------------------------------ per-plane nanmedian
-// np.nanmedian of each plane (+-inf treated as NaN, body_xy.py:1882-1890) by an 8-pass
-// radix select over the order-preserving 64-bit key of the doubles. Two ranks are tracked
-// at once (the two middle elements of an even count). All planes are processed by the
-// same launches; one pass = one streaming read of the cube.
-__device__ __forceinline__ unsigned long long sortable_key(double v)
-{
-    unsigned long long b = (unsigned long long)__double_as_longlong(v);
-    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_to_double(unsigned long long k)
-{
-    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)b);
-}
-
-// ------------------------------------------------------------------ smoothing splines
-// Least squares  [A; B/p] c = [d; 0]  for every right-hand side q of one direction (one lane
-// each) by the corrected semi-normal equations: R'R c = A'd with the host's QR factor R, then
-// one refinement step with the residual (restores the accuracy the normal equations lose:
-// error ~ cond(A) eps instead of cond(A)^2 eps). d(i, q) = in[i * si + q * sq]; g and c are
-// nc x nrhs work / result arrays (coalesced over q); the substitutions keep their band of
-// previous values in registers.
-__global__ __launch_bounds__(kBlock) void k_sm_solve(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
-                                                     size_t sq, int nrhs, double *__restrict__ g_glob,
-                                                     double *__restrict__ c_glob, int use_lds)
-{
-    extern __shared__ double sm_lds[];
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nrhs) return;
-    const int band = a.k + 2, nc = a.nc;
-    // work vectors g, c of this right-hand side: element j at v[j * st + o]. With few knots (the
-    // usual outcome of smoothing) both live in LDS, lane-contiguous and conflict-free: the
-    // substitutions are chains of dependent read-modify-writes, i.e. latency-bound in HBM.
-    double *g = use_lds ? sm_lds : g_glob;
-    double *c = use_lds ? sm_lds + (size_t)nc * blockDim.x : c_glob;
-    const size_t st = use_lds ? (size_t)blockDim.x : (size_t)nrhs;
-    const size_t o = use_lds ? (size_t)threadIdx.x : (size_t)q;
-    for (int pass = 0; pass < 2; pass++) {
-        // g = A' r, r = d (first pass) or d - A c (refinement). Consecutive samples share their
-        // k + 1 B-splines or move on by one: the partial sums (and the coefficients they need)
-        // sit in a register window that slides with the knot interval, and the samples are
-        // fetched eight at a time so that their load latencies overlap.
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0, c5 = 0.0;
-        int cur = 0;
-        if (pass) {
-            c0 = c[0 * st + o];
-            c1 = c[1 * st + o];
-            if (a.k >= 2) c2 = c[2 * st + o];
-            if (a.k >= 3) c3 = c[3 * st + o];
-            if (a.k >= 4) c4 = c[4 * st + o];
-            if (a.k >= 5) c5 = c[5 * st + o];
-        }
-        for (int i0 = 0; i0 < a.m; i0 += 8) {
-            double buf[8], hv[8][6];
-            int lv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {  // all loads of the batch are issued before any is used
-                const int i = (i0 + u < a.m) ? i0 + u : a.m - 1;
-                buf[u] = in[(size_t)i * si + q * sq];
-                lv[u] = a.lb[i];
-#pragma unroll
-                for (int e = 0; e < 6; e++) hv[u][e] = a.hb[(size_t)i * 6 + e];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = i0 + u;
-                if (i < a.m) {
-                    const int l0 = lv[u];
-                    while (cur < l0) {  // slide the window: retire the leading partial sum
-                        g[cur * st + o] = s0;
-                        s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0.0;
-                        cur++;
-                        if (pass) {
-                            c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5;
-                            const double nv = c[(cur + a.k) * st + o];
-                            if (a.k == 1) c1 = nv;
-                            else if (a.k == 2) c2 = nv;
-                            else if (a.k == 3) c3 = nv;
-                            else if (a.k == 4) c4 = nv;
-                            else c5 = nv;
-                        }
-                    }
-                    const double *h = hv[u];
-                    double r = buf[u];
-                    if (pass) {
-                        r -= h[0] * c0 + h[1] * c1;
-                        if (a.k >= 2) r -= h[2] * c2;
-                        if (a.k >= 3) r -= h[3] * c3;
-                        if (a.k >= 4) r -= h[4] * c4;
-                        if (a.k >= 5) r -= h[5] * c5;
-                    }
-                    s0 += h[0] * r;
-                    s1 += h[1] * r;
-                    if (a.k >= 2) s2 += h[2] * r;
-                    if (a.k >= 3) s3 += h[3] * r;
-                    if (a.k >= 4) s4 += h[4] * r;
-                    if (a.k >= 5) s5 += h[5] * r;
-                }
-            }
-        }
-        // flush the last window (it ends at coefficient nc - 1)
-        g[cur * st + o] = s0;
-        g[(cur + 1) * st + o] = s1;
-        if (a.k >= 2) g[(cur + 2) * st + o] = s2;
-        if (a.k >= 3) g[(cur + 3) * st + o] = s3;
-        if (a.k >= 4) g[(cur + 4) * st + o] = s4;
-        if (a.k >= 5) g[(cur + 5) * st + o] = s5;
-        if (pass)  // ... minus (B/p)' (B/p) c: the jump rows have a zero right-hand side
-            for (int r = 0; r < a.nb; r++) {
-                const double *b = a.Bp + (size_t)r * kSmBand;
-                double v = 0.0;
-                for (int e = 0; e < band; e++) v += b[e] * c[(r + e) * st + o];
-                for (int e = 0; e < band; e++) g[(r + e) * st + o] -= b[e] * v;
-            }
-        // forward substitution R' w = g (w overwrites g)
-        double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0;  // w[j-1] .. w[j-6]
-        for (int j = 0; j < nc; j++) {
-            double sv = g[j * st + o];
-            const double *Rj = a.R + (size_t)j * kSmBand;
-            if (j >= 1) sv -= (Rj - 1 * kSmBand)[1] * w1;
-            if (band > 2 && j >= 2) sv -= (Rj - 2 * kSmBand)[2] * w2;
-            if (band > 3 && j >= 3) sv -= (Rj - 3 * kSmBand)[3] * w3;
-            if (band > 4 && j >= 4) sv -= (Rj - 4 * kSmBand)[4] * w4;
-            if (band > 5 && j >= 5) sv -= (Rj - 5 * kSmBand)[5] * w5;
-            if (band > 6 && j >= 6) sv -= (Rj - 6 * kSmBand)[6] * w6;
-            sv /= Rj[0];
-            g[j * st + o] = sv;
-            w6 = w5; w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = sv;
-        }
-        // back substitution R x = w, then c = x (first pass) or c += x
-        double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0, x5 = 0.0, x6 = 0.0;  // x[j+1] .. x[j+6]
-        for (int j = nc - 1; j >= 0; j--) {
-            double sv = g[j * st + o];
-            const double *Rj = a.R + (size_t)j * kSmBand;
-            sv -= Rj[1] * x1;  // (entries beyond the matrix are stored as zeros)
-            if (band > 2) sv -= Rj[2] * x2;
-            if (band > 3) sv -= Rj[3] * x3;
-            if (band > 4) sv -= Rj[4] * x4;
-            if (band > 5) sv -= Rj[5] * x5;
-            if (band > 6) sv -= Rj[6] * x6;
-            sv /= Rj[0];
-            x6 = x5; x5 = x4; x4 = x3; x3 = x2; x2 = x1; x1 = sv;
-            c[j * st + o] = pass ? c[j * st + o] + sv : sv;
-        }
-    }
-    if (use_lds)
-        for (int j = 0; j < nc; j++) c_glob[(size_t)j * nrhs + q] = c[j * st + o];
-}
-
-// out[j * rows + i] = in[i * cols + j] (LDS-tiled)
-__global__ __launch_bounds__(kBlock) void k_transpose(const double *__restrict__ in, double *__restrict__ out, int rows,
-                                                     int cols)
-{
-    __shared__ double tile[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
-    if (i < rows && j < cols) tile[ty][tx] = in[(size_t)i * cols + j];
-    __syncthreads();
-    i = blockIdx.y * 16 + tx;
-    j = blockIdx.x * 16 + ty;
-    if (i < rows && j < cols) out[(size_t)j * rows + i] = tile[tx][ty];
-}
-
-// Squared residuals of the fitted spline at the image pixels, summed per image row and per
-// image column (the host turns them into fp and the per-knot-interval sums of FITPACK).
-__global__ __launch_bounds__(kBlock) void k_sm_resid(const SmoothFitAxis ay, const SmoothFitAxis ax,
-                                                     const double *__restrict__ z, const double *__restrict__ ct,
-                                                     double *__restrict__ rowsum, double *__restrict__ colsum)
-{
-    const int j = blockIdx.x * kBlock + threadIdx.x;  // image column
-    const int i = blockIdx.y;                         // image row
-    double term = 0.0;
-    if (j < ax.m) {
-        const int la = ay.lb[i], lb = ax.lb[j], nr = ay.nc;
-        const double *hy = ay.hb + (size_t)i * 6, *hx = ax.hb + (size_t)j * 6;
-        double sv = 0.0;
-        for (int b = 0; b <= ax.k; b++) {
-            double r = 0.0;
-            for (int e = 0; e <= ay.k; e++) r += hy[e] * ct[(size_t)(lb + b) * nr + (la + e)];
-            sv += hx[b] * r;
-        }
-        const double d = z[(size_t)i * ax.m + j] - sv;
-        term = d * d;
-        atomicAdd(&colsum[j], term);
-    }
-    // one atomic per wave for the row
-    double rs = term;
-    for (int off = 32; off > 0; off >>= 1) rs += __shfl_down(rs, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&rowsum[i], rs);
-}
-
-// bispev of a fitted smoothing spline at the map cells of one plane
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_sm_eval(const ReprojectArgs a, const SmoothEvalArgs e)
-{
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    if (m >= a.n_map) return;
-    const double nan = __builtin_nan("");
-    const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)e.plane * ny * nx;
-    const double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    bool skip = isnan(x) || isnan(y);
-    if (!skip && a.propagate_nan) {
-        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-            skip = true;
-        } else {
-            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
-                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
-        }
-    }
-    if (!skip) {
-        const double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
-        // the knots are integer abscissae: the span of x is the span of floor(x)
-        const int ly = e.span_rows[(int)yc], lx = e.span_cols[(int)xc];
-        double hy[6], hx[6];
-        SplineAxis ry = {e.t_rows, nullptr, e.nr, e.k_rows}, rx = {e.t_cols, nullptr, e.nc, e.k_cols};
-        spline_basis(ry, yc, ly, hy);
-        spline_basis(rx, xc, lx, hx);
-        double sv = 0.0;
-        for (int q = 0; q <= e.k_cols; q++) {
-            double r = 0.0;
-            for (int p = 0; p <= e.k_rows; p++) r += hy[p] * e.ct[(size_t)(lx - e.k_cols + q) * e.nr + (ly - e.k_rows + p)];
-            sv += hx[q] * r;
-        }
-        val = sv;
-    }
-    a.out[(size_t)e.plane * a.n_map + m] = val;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_median_hist(const T *cube, size_t plane_elems, int shift, PlaneStats *stats,
-                                                        unsigned int *hist /* [P][2][256] */)
-{
-    __shared__ unsigned int h[2][256];
-    const int pl = blockIdx.y;
-    h[0][threadIdx.x] = 0;
-    h[1][threadIdx.x] = 0;
-    __syncthreads();
-    const T *img = cube + (size_t)pl * plane_elems;
-    const unsigned long long mask = (shift == 56) ? 0ull : (~0ull << (shift + 8));
-    const unsigned long long pa = stats[pl].prefix[0], pb = stats[pl].prefix[1];
-    unsigned int n_nan = 0;
-    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < plane_elems; i += (size_t)gridDim.x * kBlock) {
-        const double v = (double)img[i];
-        if (!isfinite(v)) {
-            n_nan += isnan(v) ? 1u : 0u;
-            continue;
-        }
-        const unsigned long long key = sortable_key(v);
-        const unsigned int bin = (unsigned int)(key >> shift) & 255u;
-        if ((key & mask) == pa) atomicAdd(&h[0][bin], 1u);
-        if ((key & mask) == pb) atomicAdd(&h[1][bin], 1u);
-    }
-    __syncthreads();
-    unsigned int *g = hist + (size_t)pl * 512;
-    if (h[0][threadIdx.x]) atomicAdd(&g[threadIdx.x], h[0][threadIdx.x]);
-    if (h[1][threadIdx.x]) atomicAdd(&g[256 + threadIdx.x], h[1][threadIdx.x]);
-    if (shift == 56 && n_nan) atomicAdd(&stats[pl].n_nan, (unsigned long long)n_nan);
-}
-
-// one 256-thread block per plane: pick the bin holding each tracked rank, extend the prefix
-__global__ __launch_bounds__(kBlock) void k_median_pick(int shift, size_t plane_elems, PlaneStats *stats, unsigned int *hist)
-{
-    const int pl = blockIdx.x;
-    unsigned int *g = hist + (size_t)pl * 512;
-    __shared__ unsigned long long cum[2][256];
-    cum[0][threadIdx.x] = g[threadIdx.x];
-    cum[1][threadIdx.x] = g[256 + threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        const int s = threadIdx.x;
-        PlaneStats &st = stats[pl];
-        if (shift == 56) {
-            unsigned long long n = 0;
-            for (int b = 0; b < 256; b++) n += cum[s][b];
-            st.n_finite = n;
-            st.rank[s] = (n == 0) ? 0 : (s == 0 ? (n - 1) / 2 : n / 2);
-        }
-        unsigned long long k = st.rank[s], acc = 0;
-        int bin = 0;
-        for (int b = 0; b < 256; b++) {
-            if (acc + cum[s][b] > k) {
-                bin = b;
-                break;
-            }
-            acc += cum[s][b];
-        }
-        st.rank[s] = k - acc;
-        st.prefix[s] |= ((unsigned long long)bin) << shift;
-    }
-    __syncthreads();
-    g[threadIdx.x] = 0;
-    g[256 + threadIdx.x] = 0;
-    if (shift == 0 && threadIdx.x == 0) {
-        PlaneStats &st = stats[pl];
-        // np.nanmedian: mean of the two middle values; 0.0 if nothing is finite (:1887-1890)
-        st.median = st.n_finite ? 0.5 * (key_to_double(st.prefix[0]) + key_to_double(st.prefix[1])) : 0.0;
-        st.all_nan = (st.n_nan == (unsigned long long)plane_elems) ? 1 : 0;
-    }
-}
-
 }  // namespace pm
 
 // ------------------------------------------------------------------ launchers (called from pm_capi.hip)
@@ -1424,167 +762,5 @@ void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hi
     else if (sun) hipLaunchKernelGGL((pm::k_map<true, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
     else if (state) hipLaunchKernelGGL((pm::k_map<false, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
     else hipLaunchKernelGGL((pm::k_map<false, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
-}
-
-template <typename T>
-static void launch_reproject_t(const pm::ReprojectArgs &a, hipStream_t s)
-{
-    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes);
-    hipLaunchKernelGGL(pm::k_reproject<T>, grid, dim3(pm::kBlock), 0, s, a);
-}
-
-template <typename T>
-static void launch_median_t(const void *cube, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
-                            unsigned int *hist, hipStream_t s)
-{
-    unsigned gx = (unsigned)((plane_elems + pm::kBlock * 16 - 1) / (pm::kBlock * 16));
-    if (gx < 1) gx = 1;
-    if (gx > 256) gx = 256;
-    for (int shift = 56; shift >= 0; shift -= 8) {
-        hipLaunchKernelGGL(pm::k_median_hist<T>, dim3(gx, n_planes), dim3(pm::kBlock), 0, s, (const T *)cube,
-                           plane_elems, shift, stats, hist);
-        hipLaunchKernelGGL(pm::k_median_pick, dim3(n_planes), dim3(pm::kBlock), 0, s, shift, plane_elems, stats, hist);
-    }
-}
-
-template <typename T>
-static void launch_smooth_t(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, hipStream_t s)
-{
-    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes);
-    hipLaunchKernelGGL(pm::k_reproject_smooth<T>, grid, dim3(pm::kBlock), 0, s, a, sm);
-}
-
-void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s)
-{
-    switch (dtype) {
-    case PM_F64: launch_smooth_t<double>(a, sm, s); break;
-    case PM_F32: launch_smooth_t<float>(a, sm, s); break;
-    case PM_I16: launch_smooth_t<int16_t>(a, sm, s); break;
-    case PM_I32: launch_smooth_t<int32_t>(a, sm, s); break;
-    case PM_U8: launch_smooth_t<uint8_t>(a, sm, s); break;
-    case PM_U16: launch_smooth_t<uint16_t>(a, sm, s); break;
-    }
-}
-
-void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s)
-{
-    hipLaunchKernelGGL(pm::k_map_limits, dim3(1), dim3(pm::kBlock), 0, s, x_map, y_map, n, limits);
-}
-
-void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)
-{
-    switch (dtype) {
-    case PM_F64: launch_reproject_t<double>(a, s); break;
-    case PM_F32: launch_reproject_t<float>(a, s); break;
-    case PM_I16: launch_reproject_t<int16_t>(a, s); break;
-    case PM_I32: launch_reproject_t<int32_t>(a, s); break;
-    case PM_U8: launch_reproject_t<uint8_t>(a, s); break;
-    case PM_U16: launch_reproject_t<uint16_t>(a, s); break;
-    }
-}
-
-template <typename T>
-static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, hipStream_t s)
-{
-    const size_t npx = (size_t)a.ny * a.nx;
-    hipLaunchKernelGGL(pm::k_spline_clean<T>, dim3((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes),
-                       dim3(pm::kBlock), 0, s, (const T *)a.cube, sa.work, a.plane_stats, a.ny, a.nx);
-    size_t l0 = (size_t)a.n_planes * a.nx, l1 = (size_t)a.n_planes * a.ny;
-    hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l0 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
-                       sa.work, a.n_planes, a.ny, a.nx, 0, sa.rows);
-    hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l1 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
-                       sa.work, a.n_planes, a.ny, a.nx, 1, sa.cols);
-    hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
-                       0, s, a, sa);
-}
-
-template <typename T>
-static void launch_clean_t(const pm::ReprojectArgs &a, double *work, hipStream_t s)
-{
-    const size_t npx = (size_t)a.ny * a.nx;
-    hipLaunchKernelGGL(pm::k_spline_clean<T>, dim3((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes),
-                       dim3(pm::kBlock), 0, s, (const T *)a.cube, work, a.plane_stats, a.ny, a.nx);
-}
-// NaN-cleaned f64 copy of a.n_planes planes into `work` (a.plane_stats must hold the medians)
-void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s)
-{
-    switch (dtype) {
-    case PM_F64: launch_clean_t<double>(a, work, s); break;
-    case PM_F32: launch_clean_t<float>(a, work, s); break;
-    case PM_I16: launch_clean_t<int16_t>(a, work, s); break;
-    case PM_I32: launch_clean_t<int32_t>(a, work, s); break;
-    case PM_U8: launch_clean_t<uint8_t>(a, work, s); break;
-    case PM_U16: launch_clean_t<uint16_t>(a, work, s); break;
-    }
-}
-
-void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
-                        double *c, hipStream_t s)
-{
-    // both work vectors of a 64-lane workgroup in LDS when they fit (nc <= 146 of the 160 KB;
-    // more than 64 KB of dynamic LDS has to be enabled per kernel)
-    static const size_t lds_limit = [] {
-        const int want = 150 * 1024;
-        return hipFuncSetAttribute((const void *)pm::k_sm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, want) ==
-                       hipSuccess
-                   ? (size_t)want
-                   : (size_t)(64 * 1024);
-    }();
-    const size_t lds = (size_t)2 * ax.nc * 64 * sizeof(double);
-    if (lds <= lds_limit)
-        hipLaunchKernelGGL(pm::k_sm_solve, dim3((nrhs + 63) / 64), dim3(64), lds, s, ax, in, si, sq, nrhs, g, c, 1);
-    else
-        hipLaunchKernelGGL(pm::k_sm_solve, dim3((nrhs + pm::kBlock - 1) / pm::kBlock), dim3(pm::kBlock), 0, s, ax, in, si,
-                           sq, nrhs, g, c, 0);
-}
-void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s)
-{
-    hipLaunchKernelGGL(pm::k_transpose, dim3((cols + 15) / 16, (rows + 15) / 16), dim3(pm::kBlock), 0, s, in, out, rows,
-                       cols);
-}
-void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
-                        double *rowsum, double *colsum, hipStream_t s)
-{
-    hipLaunchKernelGGL(pm::k_sm_resid, dim3((ax.m + pm::kBlock - 1) / pm::kBlock, ay.m), dim3(pm::kBlock), 0, s, ay, ax, z,
-                       ct, rowsum, colsum);
-}
-void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, int dtype, hipStream_t s)
-{
-    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock), block(pm::kBlock);
-    switch (dtype) {
-    case PM_F64: hipLaunchKernelGGL(pm::k_sm_eval<double>, grid, block, 0, s, a, e); break;
-    case PM_F32: hipLaunchKernelGGL(pm::k_sm_eval<float>, grid, block, 0, s, a, e); break;
-    case PM_I16: hipLaunchKernelGGL(pm::k_sm_eval<int16_t>, grid, block, 0, s, a, e); break;
-    case PM_I32: hipLaunchKernelGGL(pm::k_sm_eval<int32_t>, grid, block, 0, s, a, e); break;
-    case PM_U8: hipLaunchKernelGGL(pm::k_sm_eval<uint8_t>, grid, block, 0, s, a, e); break;
-    case PM_U16: hipLaunchKernelGGL(pm::k_sm_eval<uint16_t>, grid, block, 0, s, a, e); break;
-    }
-}
-
-// a.plane_stats must already hold the plane statistics (pm_launch_plane_medians)
-void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s)
-{
-    switch (dtype) {
-    case PM_F64: launch_spline_t<double>(a, sa, s); break;
-    case PM_F32: launch_spline_t<float>(a, sa, s); break;
-    case PM_I16: launch_spline_t<int16_t>(a, sa, s); break;
-    case PM_I32: launch_spline_t<int32_t>(a, sa, s); break;
-    case PM_U8: launch_spline_t<uint8_t>(a, sa, s); break;
-    case PM_U16: launch_spline_t<uint16_t>(a, sa, s); break;
-    }
-}
-
-// stats / hist must be zero-filled by the caller (hipMemsetAsync) before this call
-void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
-                             unsigned int *hist, hipStream_t s)
-{
-    switch (dtype) {
-    case PM_F64: launch_median_t<double>(cube, n_planes, plane_elems, stats, hist, s); break;
-    case PM_F32: launch_median_t<float>(cube, n_planes, plane_elems, stats, hist, s); break;
-    case PM_I16: launch_median_t<int16_t>(cube, n_planes, plane_elems, stats, hist, s); break;
-    case PM_I32: launch_median_t<int32_t>(cube, n_planes, plane_elems, stats, hist, s); break;
-    case PM_U8: launch_median_t<uint8_t>(cube, n_planes, plane_elems, stats, hist, s); break;
-    case PM_U16: launch_median_t<uint16_t>(cube, n_planes, plane_elems, stats, hist, s); break;
-    }
 }
 }

@@ -259,6 +259,7 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->limits) (void)hipFree(ctx->limits);
     if (ctx->sm_arena) (void)hipFree(ctx->sm_arena);
+    if (ctx->sm_tables_host) (void)hipHostFree(ctx->sm_tables_host);
     for (auto &ac : ctx->axis) {
         if (ac.t) (void)hipFree(ac.t);
         if (ac.lu) (void)hipFree(ac.lu);

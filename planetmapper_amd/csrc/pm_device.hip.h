@@ -152,6 +152,8 @@ constexpr int kSmBand = 7;  // degree <= 5: band = k + 2
 struct SmoothFitAxis {
     const double *hb;  // m x 6: the k + 1 non-zero B-splines at sample i
     const int *lb;     // m: index of the first of them
+    const int *first;  // nc: first / last sample whose B-splines include coefficient j
+    const int *last;
     const double *R;   // nc x kSmBand: R(j, j + b) at R[j * kSmBand + b]
     const double *Bp;  // nb x kSmBand: jump rows / p, row r covers coefficients r .. r + k + 1
     int m, k, nc, nb;

@@ -29,7 +29,7 @@ void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
 void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
 void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
-                        double *c, hipStream_t s);
+                        double *c, double *r, hipStream_t s);
 void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s);
 void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
                         double *rowsum, double *colsum, hipStream_t s);
@@ -72,6 +72,7 @@ struct pm_ctx {
     double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
     double spline_smoothing = 0.0;  // map_img spline_smoothing (FITPACK s), 0 = interpolating splines
     void *sm_arena = nullptr;       // device workspace of the smoothing-spline fit
+    void *sm_tables_host = nullptr; // pinned mirror of its table block
     size_t sm_arena_bytes = 0;
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined

@@ -382,138 +382,128 @@ __device__ __forceinline__ double key_to_double(unsigned long long k)
 }
 
 // ------------------------------------------------------------------ smoothing splines
-// Least squares  [A; B/p] c = [d; 0]  for every right-hand side q of one direction (one lane
-// each) by the corrected semi-normal equations: R'R c = A'd with the host's QR factor R, then
-// one refinement step with the residual (restores the accuracy the normal equations lose:
-// error ~ cond(A) eps instead of cond(A)^2 eps). d(i, q) = in[i * si + q * sq]; g and c are
-// nc x nrhs work / result arrays (coalesced over q); the substitutions keep their band of
-// previous values in registers.
-__global__ __launch_bounds__(kBlock) void k_sm_solve(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
-                                                     size_t sq, int nrhs, double *__restrict__ g_glob,
-                                                     double *__restrict__ c_glob, int use_lds)
+// Least squares  [A; B/p] c = [d; 0]  for every right-hand side q of one direction by the
+// corrected semi-normal equations: R'R c = A'd with the host's QR factor R, then one refinement
+// step with the residual (restores the accuracy the normal equations lose: error ~ cond(A) eps
+// instead of cond(A)^2 eps). Three kernels, all coalesced over the right-hand sides q:
+//   k_sm_atr    g = A' r     one lane per (coefficient, q): a banded transposed product, fully parallel
+//   k_sm_subst  R'R x = g    one lane per q: two banded substitutions (the only sequential part,
+//                            nc steps), work vector in LDS when it fits
+//   k_sm_res    r = d - A c  one lane per (sample, q)
+constexpr int kSmChunk = 32;  // samples per lane of k_sm_atr
+__global__ __launch_bounds__(kBlock) void k_sm_atr(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
+                                                   size_t sq, int nrhs, double *__restrict__ g)
+{
+    // One lane per (right-hand side q, chunk of 32 consecutive samples). Consecutive samples
+    // share their k + 1 B-splines or move on by one: the partial sums sit in a register window
+    // that slides with the knot interval and are retired into g (zeroed by the caller) with
+    // atomic adds - a handful per lane whatever the number of knots, so the early fits with
+    // very few coefficients are as parallel as the late ones.
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nrhs) return;
+    const int i0 = blockIdx.y * kSmChunk, i1 = min(i0 + kSmChunk, a.m);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
+    int cur = a.lb[i0];
+    for (int ib = i0; ib < i1; ib += 8) {
+        double buf[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) buf[u] = in[(size_t)min(ib + u, i1 - 1) * si + q * sq];  // loads in flight together
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = ib + u;
+            if (i < i1) {
+                const int l0 = a.lb[i];
+                while (cur < l0) {  // retire the leading partial sum
+                    atomicAdd(&g[(size_t)cur * nrhs + q], s0);
+                    s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0.0;
+                    cur++;
+                }
+                const double *h = a.hb + (size_t)i * 6;
+                const double r = buf[u];
+                s0 += h[0] * r;
+                s1 += h[1] * r;
+                if (a.k >= 2) s2 += h[2] * r;
+                if (a.k >= 3) s3 += h[3] * r;
+                if (a.k >= 4) s4 += h[4] * r;
+                if (a.k >= 5) s5 += h[5] * r;
+            }
+        }
+    }
+    atomicAdd(&g[(size_t)cur * nrhs + q], s0);
+    atomicAdd(&g[(size_t)(cur + 1) * nrhs + q], s1);
+    if (a.k >= 2) atomicAdd(&g[(size_t)(cur + 2) * nrhs + q], s2);
+    if (a.k >= 3) atomicAdd(&g[(size_t)(cur + 3) * nrhs + q], s3);
+    if (a.k >= 4) atomicAdd(&g[(size_t)(cur + 4) * nrhs + q], s4);
+    if (a.k >= 5) atomicAdd(&g[(size_t)(cur + 5) * nrhs + q], s5);
+}
+
+__global__ __launch_bounds__(kBlock) void k_sm_res(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
+                                                   size_t sq, int nrhs, const double *__restrict__ c,
+                                                   double *__restrict__ r)
+{
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    const int i = blockIdx.y;
+    if (q >= nrhs) return;
+    const int l0 = a.lb[i];
+    const double *h = a.hb + (size_t)i * 6;
+    double v = in[(size_t)i * si + q * sq];
+    for (int e = 0; e <= a.k; e++) v -= h[e] * c[(size_t)(l0 + e) * nrhs + q];
+    r[(size_t)i * nrhs + q] = v;
+}
+
+// pass 0: c = (R'R)^-1 g; pass 1: c += (R'R)^-1 (g - (B/p)'(B/p) c)   (g = A'(d - A c) then)
+__global__ __launch_bounds__(kBlock) void k_sm_subst(const SmoothFitAxis a, int nrhs, double *__restrict__ g_glob,
+                                                     double *__restrict__ c_glob, int pass, int use_lds)
 {
     extern __shared__ double sm_lds[];
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nrhs) return;
     const int band = a.k + 2, nc = a.nc;
-    // work vectors g, c of this right-hand side: element j at v[j * st + o]. With few knots (the
-    // usual outcome of smoothing) both live in LDS, lane-contiguous and conflict-free: the
-    // substitutions are chains of dependent read-modify-writes, i.e. latency-bound in HBM.
+    // the work vector of this right-hand side: element j at g[j * st + o]; in LDS (lane-contiguous,
+    // conflict-free) when it fits - the substitutions are chains of dependent updates
     double *g = use_lds ? sm_lds : g_glob;
-    double *c = use_lds ? sm_lds + (size_t)nc * blockDim.x : c_glob;
     const size_t st = use_lds ? (size_t)blockDim.x : (size_t)nrhs;
     const size_t o = use_lds ? (size_t)threadIdx.x : (size_t)q;
-    for (int pass = 0; pass < 2; pass++) {
-        // g = A' r, r = d (first pass) or d - A c (refinement). Consecutive samples share their
-        // k + 1 B-splines or move on by one: the partial sums (and the coefficients they need)
-        // sit in a register window that slides with the knot interval, and the samples are
-        // fetched eight at a time so that their load latencies overlap.
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
-        double c0 = 0.0, c1 = 0.0, c2 = 0.0, c3 = 0.0, c4 = 0.0, c5 = 0.0;
-        int cur = 0;
-        if (pass) {
-            c0 = c[0 * st + o];
-            c1 = c[1 * st + o];
-            if (a.k >= 2) c2 = c[2 * st + o];
-            if (a.k >= 3) c3 = c[3 * st + o];
-            if (a.k >= 4) c4 = c[4 * st + o];
-            if (a.k >= 5) c5 = c[5 * st + o];
-        }
-        for (int i0 = 0; i0 < a.m; i0 += 8) {
-            double buf[8], hv[8][6];
-            int lv[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) {  // all loads of the batch are issued before any is used
-                const int i = (i0 + u < a.m) ? i0 + u : a.m - 1;
-                buf[u] = in[(size_t)i * si + q * sq];
-                lv[u] = a.lb[i];
-#pragma unroll
-                for (int e = 0; e < 6; e++) hv[u][e] = a.hb[(size_t)i * 6 + e];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int i = i0 + u;
-                if (i < a.m) {
-                    const int l0 = lv[u];
-                    while (cur < l0) {  // slide the window: retire the leading partial sum
-                        g[cur * st + o] = s0;
-                        s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0.0;
-                        cur++;
-                        if (pass) {
-                            c0 = c1; c1 = c2; c2 = c3; c3 = c4; c4 = c5;
-                            const double nv = c[(cur + a.k) * st + o];
-                            if (a.k == 1) c1 = nv;
-                            else if (a.k == 2) c2 = nv;
-                            else if (a.k == 3) c3 = nv;
-                            else if (a.k == 4) c4 = nv;
-                            else c5 = nv;
-                        }
-                    }
-                    const double *h = hv[u];
-                    double r = buf[u];
-                    if (pass) {
-                        r -= h[0] * c0 + h[1] * c1;
-                        if (a.k >= 2) r -= h[2] * c2;
-                        if (a.k >= 3) r -= h[3] * c3;
-                        if (a.k >= 4) r -= h[4] * c4;
-                        if (a.k >= 5) r -= h[5] * c5;
-                    }
-                    s0 += h[0] * r;
-                    s1 += h[1] * r;
-                    if (a.k >= 2) s2 += h[2] * r;
-                    if (a.k >= 3) s3 += h[3] * r;
-                    if (a.k >= 4) s4 += h[4] * r;
-                    if (a.k >= 5) s5 += h[5] * r;
-                }
-            }
-        }
-        // flush the last window (it ends at coefficient nc - 1)
-        g[cur * st + o] = s0;
-        g[(cur + 1) * st + o] = s1;
-        if (a.k >= 2) g[(cur + 2) * st + o] = s2;
-        if (a.k >= 3) g[(cur + 3) * st + o] = s3;
-        if (a.k >= 4) g[(cur + 4) * st + o] = s4;
-        if (a.k >= 5) g[(cur + 5) * st + o] = s5;
-        if (pass)  // ... minus (B/p)' (B/p) c: the jump rows have a zero right-hand side
-            for (int r = 0; r < a.nb; r++) {
-                const double *b = a.Bp + (size_t)r * kSmBand;
-                double v = 0.0;
-                for (int e = 0; e < band; e++) v += b[e] * c[(r + e) * st + o];
-                for (int e = 0; e < band; e++) g[(r + e) * st + o] -= b[e] * v;
-            }
-        // forward substitution R' w = g (w overwrites g)
-        double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0;  // w[j-1] .. w[j-6]
-        for (int j = 0; j < nc; j++) {
-            double sv = g[j * st + o];
-            const double *Rj = a.R + (size_t)j * kSmBand;
-            if (j >= 1) sv -= (Rj - 1 * kSmBand)[1] * w1;
-            if (band > 2 && j >= 2) sv -= (Rj - 2 * kSmBand)[2] * w2;
-            if (band > 3 && j >= 3) sv -= (Rj - 3 * kSmBand)[3] * w3;
-            if (band > 4 && j >= 4) sv -= (Rj - 4 * kSmBand)[4] * w4;
-            if (band > 5 && j >= 5) sv -= (Rj - 5 * kSmBand)[5] * w5;
-            if (band > 6 && j >= 6) sv -= (Rj - 6 * kSmBand)[6] * w6;
-            sv /= Rj[0];
-            g[j * st + o] = sv;
-            w6 = w5; w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = sv;
-        }
-        // back substitution R x = w, then c = x (first pass) or c += x
-        double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0, x5 = 0.0, x6 = 0.0;  // x[j+1] .. x[j+6]
-        for (int j = nc - 1; j >= 0; j--) {
-            double sv = g[j * st + o];
-            const double *Rj = a.R + (size_t)j * kSmBand;
-            sv -= Rj[1] * x1;  // (entries beyond the matrix are stored as zeros)
-            if (band > 2) sv -= Rj[2] * x2;
-            if (band > 3) sv -= Rj[3] * x3;
-            if (band > 4) sv -= Rj[4] * x4;
-            if (band > 5) sv -= Rj[5] * x5;
-            if (band > 6) sv -= Rj[6] * x6;
-            sv /= Rj[0];
-            x6 = x5; x5 = x4; x4 = x3; x3 = x2; x2 = x1; x1 = sv;
-            c[j * st + o] = pass ? c[j * st + o] + sv : sv;
-        }
-    }
     if (use_lds)
-        for (int j = 0; j < nc; j++) c_glob[(size_t)j * nrhs + q] = c[j * st + o];
+        for (int j = 0; j < nc; j++) g[j * st + o] = g_glob[(size_t)j * nrhs + q];
+    if (pass)  // the jump rows have a zero right-hand side: their residual is -(B/p) c
+        for (int r = 0; r < a.nb; r++) {
+            const double *b = a.Bp + (size_t)r * kSmBand;
+            double v = 0.0;
+            for (int e = 0; e < band; e++) v += b[e] * c_glob[(size_t)(r + e) * nrhs + q];
+            for (int e = 0; e < band; e++) g[(r + e) * st + o] -= b[e] * v;
+        }
+    // forward substitution R' w = g (w overwrites g), the band of previous values in registers
+    double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0;  // w[j-1] .. w[j-6]
+    for (int j = 0; j < nc; j++) {
+        double sv = g[j * st + o];
+        const double *Rj = a.R + (size_t)j * kSmBand;
+        if (j >= 1) sv -= (Rj - 1 * kSmBand)[1] * w1;
+        if (band > 2 && j >= 2) sv -= (Rj - 2 * kSmBand)[2] * w2;
+        if (band > 3 && j >= 3) sv -= (Rj - 3 * kSmBand)[3] * w3;
+        if (band > 4 && j >= 4) sv -= (Rj - 4 * kSmBand)[4] * w4;
+        if (band > 5 && j >= 5) sv -= (Rj - 5 * kSmBand)[5] * w5;
+        if (band > 6 && j >= 6) sv -= (Rj - 6 * kSmBand)[6] * w6;
+        sv /= Rj[0];
+        g[j * st + o] = sv;
+        w6 = w5; w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = sv;
+    }
+    // back substitution R x = w, then c = x (first pass) or c += x
+    double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0, x5 = 0.0, x6 = 0.0;  // x[j+1] .. x[j+6]
+    for (int j = nc - 1; j >= 0; j--) {
+        double sv = g[j * st + o];
+        const double *Rj = a.R + (size_t)j * kSmBand;
+        sv -= Rj[1] * x1;  // (entries beyond the matrix are stored as zeros)
+        if (band > 2) sv -= Rj[2] * x2;
+        if (band > 3) sv -= Rj[3] * x3;
+        if (band > 4) sv -= Rj[4] * x4;
+        if (band > 5) sv -= Rj[5] * x5;
+        if (band > 6) sv -= Rj[6] * x6;
+        sv /= Rj[0];
+        x6 = x5; x5 = x4; x4 = x3; x3 = x2; x2 = x1; x1 = sv;
+        const size_t ci = (size_t)j * nrhs + q;
+        c_glob[ci] = pass ? c_glob[ci] + sv : sv;
+    }
 }
 
 // out[j * rows + i] = in[i * cols + j] (LDS-tiled)
@@ -767,24 +757,38 @@ void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStr
     }
 }
 
+// c (nc x nrhs) = least-squares solution for all right-hand sides d(i, q) = in[i * si + q * sq];
+// g (nc x nrhs) and r (m x nrhs) are work arrays
 void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
-                        double *c, hipStream_t s)
+                        double *c, double *r, hipStream_t s)
 {
-    // both work vectors of a 64-lane workgroup in LDS when they fit (nc <= 146 of the 160 KB;
-    // more than 64 KB of dynamic LDS has to be enabled per kernel)
+    // the work vector of a 64-lane workgroup in LDS when it fits (more than 64 KB of dynamic LDS
+    // has to be enabled per kernel)
     static const size_t lds_limit = [] {
         const int want = 150 * 1024;
-        return hipFuncSetAttribute((const void *)pm::k_sm_solve, hipFuncAttributeMaxDynamicSharedMemorySize, want) ==
+        return hipFuncSetAttribute((const void *)pm::k_sm_subst, hipFuncAttributeMaxDynamicSharedMemorySize, want) ==
                        hipSuccess
                    ? (size_t)want
                    : (size_t)(64 * 1024);
     }();
-    const size_t lds = (size_t)2 * ax.nc * 64 * sizeof(double);
-    if (lds <= lds_limit)
-        hipLaunchKernelGGL(pm::k_sm_solve, dim3((nrhs + 63) / 64), dim3(64), lds, s, ax, in, si, sq, nrhs, g, c, 1);
-    else
-        hipLaunchKernelGGL(pm::k_sm_solve, dim3((nrhs + pm::kBlock - 1) / pm::kBlock), dim3(pm::kBlock), 0, s, ax, in, si,
-                           sq, nrhs, g, c, 0);
+    const size_t lds = (size_t)ax.nc * 64 * sizeof(double);
+    const bool use_lds = lds <= lds_limit;
+    const dim3 gq((nrhs + pm::kBlock - 1) / pm::kBlock);
+    auto subst = [&](int pass) {
+        if (use_lds)
+            hipLaunchKernelGGL(pm::k_sm_subst, dim3((nrhs + 63) / 64), dim3(64), lds, s, ax, nrhs, g, c, pass, 1);
+        else
+            hipLaunchKernelGGL(pm::k_sm_subst, gq, dim3(pm::kBlock), 0, s, ax, nrhs, g, c, pass, 0);
+    };
+    const dim3 ga(gq.x, (ax.m + pm::kSmChunk - 1) / pm::kSmChunk);
+    const size_t gbytes = (size_t)ax.nc * nrhs * sizeof(double);
+    (void)hipMemsetAsync(g, 0, gbytes, s);
+    hipLaunchKernelGGL(pm::k_sm_atr, ga, dim3(pm::kBlock), 0, s, ax, in, si, sq, nrhs, g);
+    subst(0);
+    hipLaunchKernelGGL(pm::k_sm_res, dim3(gq.x, ax.m), dim3(pm::kBlock), 0, s, ax, in, si, sq, nrhs, c, r);
+    (void)hipMemsetAsync(g, 0, gbytes, s);
+    hipLaunchKernelGGL(pm::k_sm_atr, ga, dim3(pm::kBlock), 0, s, ax, r, (size_t)nrhs, (size_t)1, nrhs, g);
+    subst(1);
 }
 void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s)
 {

@@ -153,7 +153,7 @@ struct SmAxis {
     std::vector<double> t, fpint;
     std::vector<int> nrdata;
     std::vector<double> hb, R, Bp;  // tables for the current knots / p
-    std::vector<int> lb, span;
+    std::vector<int> lb, span, first, last;
     bool knots_changed = true;
     int nc() const { return n - k - 1; }
     int nrint() const { return n - 2 * k - 1; }
@@ -219,6 +219,14 @@ struct SmAxis {
             lb[i] = l - k;
             span[i] = l;
         }
+        // samples whose k + 1 B-splines include coefficient j: lb[i] in [j - k, j]
+        first.assign((size_t)nc(), m);
+        last.assign((size_t)nc(), -1);
+        for (int i = 0; i < m; i++)
+            for (int e = 0; e <= k; e++) {
+                first[lb[i] + e] = std::min(first[lb[i] + e], i);
+                last[lb[i] + e] = std::max(last[lb[i] + e], i);
+            }
     }
     // triangular band of the QR factor of [A; B / p] (Givens rotations, fpgivs / fprota), and
     // the scaled jump rows B / p themselves (fpdisc) for the refinement step on the device
@@ -294,9 +302,19 @@ struct SmAxis {
     }
 };
 
-struct SmDevice {  // carve-up of ctx->sm_arena for one (ny, nx) plane
-    double *U, *UT, *G, *CT, *hb_y, *hb_x, *R_y, *R_x, *Bp_y, *Bp_x, *rowsum, *colsum, *t_y, *t_x;
-    int *lb_y, *lb_x, *span_y, *span_x;
+// Device workspace of the fits of one (ny, nx) plane (ctx->sm_arena). The small per-fit tables
+// form ONE contiguous block with a pinned host mirror of the same layout (ctx->sm_tables_host):
+// a fit uploads them with a single asynchronous copy and reads its residual sums back with another.
+struct SmTables {  // byte offsets inside the table block
+    size_t hb_y, hb_x, R_y, R_x, Bp_y, Bp_x, t_y, t_x, lb_y, lb_x, fl_y, fl_x, span_y, span_x, sums, bytes;
+};
+struct SmDevice {
+    double *U, *UT, *G, *CT, *RB;
+    char *tables;       // device table block
+    char *tables_host;  // pinned mirror
+    SmTables o;
+    template <typename T> T *dev(size_t off) const { return (T *)(tables + off); }
+    template <typename T> T *host(size_t off) const { return (T *)(tables_host + off); }
 };
 
 int ensure_sm_arena(pm_ctx *ctx, int ny, int nx, SmDevice &d)
@@ -304,78 +322,96 @@ int ensure_sm_arena(pm_ctx *ctx, int ny, int nx, SmDevice &d)
     const size_t npx = (size_t)ny * nx, mx = (size_t)std::max(ny, nx) + 8;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t oU = take(npx * 8), oUT = take(npx * 8), oG = take(npx * 8), oCT = take(npx * 8);
-    const size_t ohy = take(mx * 6 * 8), ohx = take(mx * 6 * 8), oRy = take(mx * pm::kSmBand * 8), oRx = take(mx * pm::kSmBand * 8);
-    const size_t oBy = take(mx * pm::kSmBand * 8), oBx = take(mx * pm::kSmBand * 8), ors = take(mx * 8), ocs = take(mx * 8);
-    const size_t oty = take(mx * 8), otx = take(mx * 8), oly = take(mx * 4), olx = take(mx * 4), osy = take(mx * 4), osx = take(mx * 4);
+    SmTables &t = d.o;
+    t.hb_y = take(mx * 6 * 8); t.hb_x = take(mx * 6 * 8);
+    t.R_y = take(mx * pm::kSmBand * 8); t.R_x = take(mx * pm::kSmBand * 8);
+    t.Bp_y = take(mx * pm::kSmBand * 8); t.Bp_x = take(mx * pm::kSmBand * 8);
+    t.t_y = take(mx * 8); t.t_x = take(mx * 8);
+    t.lb_y = take(mx * 4); t.lb_x = take(mx * 4);
+    t.fl_y = take(mx * 8); t.fl_x = take(mx * 8);  // first[nc] then last[nc]
+    t.span_y = take(mx * 4); t.span_x = take(mx * 4);
+    t.bytes = off;               // ... everything above is uploaded per fit
+    t.sums = take(2 * mx * 8);   // row sums then column sums, read back per fit
+    const size_t table_bytes = off;
+    const size_t oU = take(npx * 8), oUT = take(npx * 8), oG = take(npx * 8), oCT = take(npx * 8), oRB = take(npx * 8);
     if (off > ctx->sm_arena_bytes) {
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ctx->sm_arena) PM_HIP(ctx, hipFree(ctx->sm_arena));
+        if (ctx->sm_tables_host) PM_HIP(ctx, hipHostFree(ctx->sm_tables_host));
         ctx->sm_arena = nullptr;
+        ctx->sm_tables_host = nullptr;
         ctx->sm_arena_bytes = 0;
-        if (hipMalloc(&ctx->sm_arena, off) != hipSuccess)
-            return fail(ctx, PM_ERR_ALLOC, "hipMalloc(%zu) of the smoothing-spline workspace failed", off);
+        if (hipMalloc(&ctx->sm_arena, off) != hipSuccess || hipHostMalloc(&ctx->sm_tables_host, table_bytes) != hipSuccess)
+            return fail(ctx, PM_ERR_ALLOC, "allocation of the smoothing-spline workspace (%zu bytes) failed", off);
         ctx->sm_arena_bytes = off;
     }
     char *b = (char *)ctx->sm_arena;
+    d.tables = b;
+    d.tables_host = (char *)ctx->sm_tables_host;
     d.U = (double *)(b + oU); d.UT = (double *)(b + oUT); d.G = (double *)(b + oG); d.CT = (double *)(b + oCT);
-    d.hb_y = (double *)(b + ohy); d.hb_x = (double *)(b + ohx); d.R_y = (double *)(b + oRy); d.R_x = (double *)(b + oRx);
-    d.Bp_y = (double *)(b + oBy); d.Bp_x = (double *)(b + oBx); d.rowsum = (double *)(b + ors); d.colsum = (double *)(b + ocs);
-    d.t_y = (double *)(b + oty); d.t_x = (double *)(b + otx);
-    d.lb_y = (int *)(b + oly); d.lb_x = (int *)(b + olx); d.span_y = (int *)(b + osy); d.span_x = (int *)(b + osx);
+    d.RB = (double *)(b + oRB);
     return PM_OK;
 }
 
 // one fit for the current knots and p (p <= 0: least-squares spline); returns fp and updates
 // the per-interval residual sums of both axes. z: cleaned plane on the device.
-int sm_fit(pm_ctx *ctx, const double *z, SmAxis &ay, SmAxis &ax, double p, const SmDevice &d, double &fp,
-           std::vector<double> &sums)
+int sm_fit(pm_ctx *ctx, const double *z, SmAxis &ay, SmAxis &ax, double p, const SmDevice &d, double &fp)
 {
     hipStream_t s = ctx->stream;
-    // the host vectors below are reused by the next fit: every upload is followed by a stream
-    // synchronisation before they change (the D2H of the residual sums at the end of this fit)
+    const SmTables &t = d.o;
+    auto put = [&](size_t off, const void *src, size_t bytes) { std::memcpy(d.tables_host + off, src, bytes); };
+    // (the mirror is rewritten only after the previous fit's read-back has synchronised the stream)
     if (ay.knots_changed) {
         ay.build_tables();
-        PM_HIP(ctx, hipMemcpyAsync(d.hb_y, ay.hb.data(), ay.hb.size() * 8, hipMemcpyHostToDevice, s));
-        PM_HIP(ctx, hipMemcpyAsync(d.lb_y, ay.lb.data(), ay.lb.size() * 4, hipMemcpyHostToDevice, s));
+        put(t.hb_y, ay.hb.data(), ay.hb.size() * 8);
+        put(t.lb_y, ay.lb.data(), ay.lb.size() * 4);
+        put(t.fl_y, ay.first.data(), ay.first.size() * 4);
+        put(t.fl_y + (size_t)ay.nc() * 4, ay.last.data(), ay.last.size() * 4);
+        put(t.t_y, ay.t.data(), (size_t)ay.n * 8);
+        put(t.span_y, ay.span.data(), ay.span.size() * 4);
         ay.knots_changed = false;
     }
     if (ax.knots_changed) {
         ax.build_tables();
-        PM_HIP(ctx, hipMemcpyAsync(d.hb_x, ax.hb.data(), ax.hb.size() * 8, hipMemcpyHostToDevice, s));
-        PM_HIP(ctx, hipMemcpyAsync(d.lb_x, ax.lb.data(), ax.lb.size() * 4, hipMemcpyHostToDevice, s));
+        put(t.hb_x, ax.hb.data(), ax.hb.size() * 8);
+        put(t.lb_x, ax.lb.data(), ax.lb.size() * 4);
+        put(t.fl_x, ax.first.data(), ax.first.size() * 4);
+        put(t.fl_x + (size_t)ax.nc() * 4, ax.last.data(), ax.last.size() * 4);
+        put(t.t_x, ax.t.data(), (size_t)ax.n * 8);
+        put(t.span_x, ax.span.data(), ax.span.size() * 4);
         ax.knots_changed = false;
     }
     ay.factor(p);
     ax.factor(p);
-    PM_HIP(ctx, hipMemcpyAsync(d.R_y, ay.R.data(), ay.R.size() * 8, hipMemcpyHostToDevice, s));
-    PM_HIP(ctx, hipMemcpyAsync(d.R_x, ax.R.data(), ax.R.size() * 8, hipMemcpyHostToDevice, s));
-    PM_HIP(ctx, hipMemcpyAsync(d.Bp_y, ay.Bp.data(), ay.Bp.size() * 8, hipMemcpyHostToDevice, s));
-    PM_HIP(ctx, hipMemcpyAsync(d.Bp_x, ax.Bp.data(), ax.Bp.size() * 8, hipMemcpyHostToDevice, s));
+    put(t.R_y, ay.R.data(), ay.R.size() * 8);
+    put(t.R_x, ax.R.data(), ax.R.size() * 8);
+    put(t.Bp_y, ay.Bp.data(), ay.Bp.size() * 8);
+    put(t.Bp_x, ax.Bp.data(), ax.Bp.size() * 8);
+    PM_HIP(ctx, hipMemcpyAsync(d.tables, d.tables_host, t.bytes, hipMemcpyHostToDevice, s));
     const int nby = (p > 0.0 && ay.nrint() > 1) ? ay.nrint() - 1 : 0, nbx = (p > 0.0 && ax.nrint() > 1) ? ax.nrint() - 1 : 0;
-    pm::SmoothFitAxis fy = {d.hb_y, d.lb_y, d.R_y, d.Bp_y, ay.m, ay.k, ay.nc(), nby};
-    pm::SmoothFitAxis fx = {d.hb_x, d.lb_x, d.R_x, d.Bp_x, ax.m, ax.k, ax.nc(), nbx};
-    const int ny = ay.m, nx = ax.m, nr = ay.nc(), ncx = ax.nc();
+    pm::SmoothFitAxis fy = {d.dev<double>(t.hb_y), d.dev<int>(t.lb_y), d.dev<int>(t.fl_y), d.dev<int>(t.fl_y) + ay.nc(),
+                            d.dev<double>(t.R_y), d.dev<double>(t.Bp_y), ay.m, ay.k, ay.nc(), nby};
+    pm::SmoothFitAxis fx = {d.dev<double>(t.hb_x), d.dev<int>(t.lb_x), d.dev<int>(t.fl_x), d.dev<int>(t.fl_x) + ax.nc(),
+                            d.dev<double>(t.R_x), d.dev<double>(t.Bp_x), ax.m, ax.k, ax.nc(), nbx};
+    const int ny = ay.m, nx = ax.m, nr = ay.nc();
+    double *rowsum = d.dev<double>(t.sums), *colsum = rowsum + ny;
     // along image rows for every image column: U (nr x nx)
-    pm_launch_sm_solve(fy, z, (size_t)nx, 1, nx, d.G, d.U, s);
+    pm_launch_sm_solve(fy, z, (size_t)nx, 1, nx, d.G, d.U, d.RB, s);
     // U' (nx x nr), then along image columns for every row coefficient: CT (ncx x nr)
     pm_launch_transpose(d.U, d.UT, nr, nx, s);
-    pm_launch_sm_solve(fx, d.UT, (size_t)nr, 1, nr, d.G, d.CT, s);
-    PM_HIP(ctx, hipMemsetAsync(d.rowsum, 0, (size_t)ny * 8, s));
-    PM_HIP(ctx, hipMemsetAsync(d.colsum, 0, (size_t)nx * 8, s));
-    pm_launch_sm_resid(fy, fx, z, d.CT, d.rowsum, d.colsum, s);
+    pm_launch_sm_solve(fx, d.UT, (size_t)nr, 1, nr, d.G, d.CT, d.RB, s);
+    PM_HIP(ctx, hipMemsetAsync(rowsum, 0, (size_t)(ny + nx) * 8, s));
+    pm_launch_sm_resid(fy, fx, z, d.CT, rowsum, colsum, s);
     PM_HIP(ctx, hipGetLastError());
-    sums.resize((size_t)ny + nx);
-    PM_HIP(ctx, hipMemcpyAsync(sums.data(), d.rowsum, (size_t)ny * 8, hipMemcpyDeviceToHost, s));
-    PM_HIP(ctx, hipMemcpyAsync(sums.data() + ny, d.colsum, (size_t)nx * 8, hipMemcpyDeviceToHost, s));
+    double *sums = d.host<double>(t.sums);
+    PM_HIP(ctx, hipMemcpyAsync(sums, rowsum, (size_t)(ny + nx) * 8, hipMemcpyDeviceToHost, s));
     PM_HIP(ctx, hipStreamSynchronize(s));
-    (void)ncx;
     fp = 0.0;
     for (int i = 0; i < ny; i++) fp += sums[i];
     if (std::getenv("PM_SM_DEBUG"))  // trace of the knot / smoothing-parameter search
         std::fprintf(stderr, "sm_fit ny=%d nx=%d knots=(%d,%d) p=%g fp=%.17g\n", ny, nx, ay.n, ax.n, p, fp);
-    ay.account(sums.data());
-    ax.account(sums.data() + ny);
+    ay.account(sums);
+    ax.account(sums + ny);
     return PM_OK;
 }
 
@@ -389,14 +425,13 @@ int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_co
     ay.init(ny, k_rows);
     ax.init(nx, k_cols);
     const int nminy = 2 * (k_rows + 1), nminx = 2 * (k_cols + 1), nmaxy = ny + k_rows + 1, nmaxx = nx + k_cols + 1;
-    std::vector<double> sums;
     int lastdi = 0, rc;
     bool poly = false, done = false;
     double fp = 0.0, fp0 = 0.0, fpold = 0.0, reducy = 0.0, reducx = 0.0, fpms = 0.0;
     // (FITPACK's "x" is the first array axis = image rows, "y" the image columns)
     for (int iter = 0; iter < ny + nx; iter++) {
         poly = (ay.n == nminy && ax.n == nminx);
-        rc = sm_fit(ctx, z, ay, ax, -1.0, d, fp, sums);
+        rc = sm_fit(ctx, z, ay, ax, -1.0, d, fp);
         if (rc != PM_OK) return rc;
         if (poly) fp0 = fp;
         fpms = fp - s;
@@ -429,7 +464,7 @@ int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_co
         double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms, p = 1.0;
         bool ich1 = false, ich3 = false;
         for (int iter = 0; iter < maxit; iter++) {
-            rc = sm_fit(ctx, z, ay, ax, p, d, fp, sums);
+            rc = sm_fit(ctx, z, ay, ax, p, d, fp);
             if (rc != PM_OK) return rc;
             fpms = fp - s;
             if (std::fabs(fpms) < acc || iter == maxit - 1) break;
@@ -505,11 +540,9 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
             const double *z = ctx->work + (size_t)pl * plane_elems;
             rc = sm_regrid(ctx, z, a.ny, a.nx, k_rows, k_cols, s, ay, ax, d);
             if (rc != PM_OK) return rc;
-            PM_HIP(ctx, hipMemcpyAsync(d.t_y, ay.t.data(), (size_t)ay.n * 8, hipMemcpyHostToDevice, ctx->stream));
-            PM_HIP(ctx, hipMemcpyAsync(d.t_x, ax.t.data(), (size_t)ax.n * 8, hipMemcpyHostToDevice, ctx->stream));
-            PM_HIP(ctx, hipMemcpyAsync(d.span_y, ay.span.data(), (size_t)a.ny * 4, hipMemcpyHostToDevice, ctx->stream));
-            PM_HIP(ctx, hipMemcpyAsync(d.span_x, ax.span.data(), (size_t)a.nx * 4, hipMemcpyHostToDevice, ctx->stream));
-            pm::SmoothEvalArgs e = {d.CT, d.t_y, d.t_x, d.span_y, d.span_x, ay.nc(), ax.nc(), k_rows, k_cols, pl};
+            // (knots and spans of the final fit are already in the device table block)
+            pm::SmoothEvalArgs e = {d.CT, d.dev<double>(d.o.t_y), d.dev<double>(d.o.t_x), d.dev<int>(d.o.span_y),
+                                    d.dev<int>(d.o.span_x), ay.nc(), ax.nc(), k_rows, k_cols, pl};
             pm_launch_sm_eval(b, e, dtype, ctx->stream);
             PM_HIP(ctx, hipGetLastError());
             PM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // knots / spans are reused by the next plane

@@ -370,13 +370,13 @@ def main() -> None:
                 'preheat_steps': args.preheat_steps,
             },
             'roofline': {
-                'kernel': 'pm::k_disc_sph<1> (DF_ILLUM)',
+                'kernel': 'pm::k_disc_sph<1, false> (DF_ILLUM, spheroid)',
                 'bound': 'hbm',
                 'achieved': round(achieved, 2),
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                'traffic': measured_traffic('pm::k_disc_sph<1>') if sz == 4096 else None,
+                'traffic': measured_traffic('pm::k_disc_sph<1,') if sz == 4096 else None,
                 'kernel_ms': round(kernel_ms, 4),
                 'algorithmic_bytes': alg,
             },

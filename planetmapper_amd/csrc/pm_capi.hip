@@ -156,6 +156,11 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     p.irc = 1.0 / p.radii[2];
     p.inv_c = 1.0 / g.clight;
     p.lat_k = (p.radii[0] / p.radii[2]) * (p.radii[0] / p.radii[2]);
+    {
+        const double sb = std::sqrt(p.SB0[0] * p.SB0[0] + p.SB0[1] * p.SB0[1] + p.SB0[2] * p.SB0[2]);
+        p.sun_ds0 = (p.t0 - g.ts0) - sb / g.clight;
+        p.sun_k = 1.0 / (sb * g.clight);
+    }
     for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
     {
         double m = std::fmin(p.radii[0], p.radii[2]);

@@ -97,6 +97,8 @@ struct Params {
     double ira, irc;  // 1 / radii[0], 1 / radii[2]
     double inv_c;     // 1 / clight
     double lat_k;     // (radii[0] / radii[2])^2
+    double sun_ds0;   // Sun emission epoch of a surface point q (wrt P_T(t0), B0), linearised in q:
+    double sun_k;     //   ds = d + sun_ds0 + (SB0 . q) sun_k,  sun_k = 1 / (|SB0| c); see k_disc_sph
     double ir[3];     // 1 / radii[i]
     double limb_n[2]; // surface-normal scalings of recpgr_surface: (m/a)^2, (m/c)^2, m = min(a, c)
     int32_t row_stride;  // row visiting order of the image kernels (coprime with `rows`)

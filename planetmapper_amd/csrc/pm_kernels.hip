@@ -299,14 +299,13 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
                 const V3 q = {fma(p.VB[0], d, sp0.x), fma(p.VB[1], d, sp0.y), fma(p.VB[2], d, sp0.z)};
-                const double te = p.g.et - lt;
-                // Sun light time (spkcpo_c 'CN'): at lts0 = te - ts0 the Sun sits at S0 exactly;
-                // one correction pass leaves |d lts| ~ (v_sun / c) * 0.25 s = 1e-8 s, i.e. 1e-10 km
-                V3 sv = ld3(p.SB0) - q;
-                const double s2 = dot(sv, sv);
-                const double lts = s2 * rsqrt_fast(s2) * p.inv_c;
-                const double ds = (te - lts) - p.g.ts0;
-                sv = v3(fma(p.VSB[0], ds, p.SB0[0]) - q.x, fma(p.VSB[1], ds, p.SB0[1]) - q.y,
+                // Sun light time (spkcpo_c 'CN'): the Sun is taken at te - |S - q| / c. Its epoch
+                // offset from ts0 is d + (lts0 - |SB0 - q| / c), and |SB0 - q| = |SB0| - s0.q up to
+                // q^2 / (2 |SB0|) ~ 3 km, i.e. 1e-5 s of a Sun that moves 0.013 km/s = 1e-7 km at
+                // 8e8 km (2e-16 rad): the square root of the exact form buys nothing, the linear
+                // form is one dot product.
+                const double ds = d + fma(dot(ld3(p.SB0), q), p.sun_k, p.sun_ds0);
+                V3 sv = v3(fma(p.VSB[0], ds, p.SB0[0]) - q.x, fma(p.VSB[1], ds, p.SB0[1]) - q.y,
                         fma(p.VSB[2], ds, p.SB0[2]) - q.z);
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)

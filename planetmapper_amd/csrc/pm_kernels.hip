@@ -309,7 +309,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                         fma(p.VSB[2], ds, p.SB0[2]) - q.z);
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
-                V3 n = {sp.x * (p.ir[0] * p.ir[0]), sp.y * (p.ir[1] * p.ir[1]), sp.z * (p.ir[2] * p.ir[2])};  // surfnm_c
+                V3 n = {Xf.x * p.ir[0], Xf.y * p.ir[1], Xf.z * p.ir[2]};  // surfnm_c: sp / radii^2 = Xf / radii
                 if (TRI) n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
                 n = rsqrt_fast(dot(n, n)) * n;
                 ph = vsep_fast(sunb, ob) * kDeg;

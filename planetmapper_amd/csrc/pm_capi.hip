@@ -156,6 +156,11 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     p.irc = 1.0 / p.radii[2];
     p.inv_c = 1.0 / g.clight;
     p.lat_k = (p.radii[0] / p.radii[2]) * (p.radii[0] / p.radii[2]);
+    p.a_over_c = p.radii[0] / p.radii[2];
+    for (int i = 0; i < 3; i++) {
+        p.O0s[i] = p.O0[i] / p.radii[i];
+        p.VBs[i] = p.VB[i] / p.radii[i];
+    }
     {
         const double sb = std::sqrt(p.SB0[0] * p.SB0[0] + p.SB0[1] * p.SB0[1] + p.SB0[2] * p.SB0[2]);
         p.sun_ds0 = (p.t0 - g.ts0) - sb / g.clight;

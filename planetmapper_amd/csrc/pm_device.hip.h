@@ -97,6 +97,9 @@ struct Params {
     double ira, irc;  // 1 / radii[0], 1 / radii[2]
     double inv_c;     // 1 / clight
     double lat_k;     // (radii[0] / radii[2])^2
+    double O0s[3];    // O0 / radii, VB / radii: the observer in the scaled frame of surfpt_c is
+    double VBs[3];    //   Y(d) = O0s - VBs d (spheroid fast path)
+    double a_over_c;  // radii[0] / radii[2]
     double sun_ds0;   // Sun emission epoch of a surface point q (wrt P_T(t0), B0), linearised in q:
     double sun_k;     //   ds = d + sun_ds0 + (SB0 . q) sun_k,  sun_k = 1 / (|SB0| c); see k_disc_sph
     double ir[3];     // 1 / radii[i]

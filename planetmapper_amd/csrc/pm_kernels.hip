@@ -241,9 +241,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             d = te - p.t0;
             // (the target's acceleration moves it by A d^2 / 2 < 1e-8 km over the |d| <= R / c of a
             //  disc intercept, 10x below the rounding of the ray itself: not carried here)
-            const V3 obs = {fma(-p.VB[0], d, p.O0[0]), fma(-p.VB[1], d, p.O0[1]), fma(-p.VB[2], d, p.O0[2])};
             V3 Y;
             if (TRI) {
+                const V3 obs = {fma(-p.VB[0], d, p.O0[0]), fma(-p.VB[1], d, p.O0[1]), fma(-p.VB[2], d, p.O0[2])};
                 const double dl = p.g.wdot * d, d2 = dl * dl;  // |dl| < 1e-3 (host check)
                 cz = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
                 sz = dl * fma(d2, -1.0 / 6.0, 1.0);
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 ixx = rcp_fast(dot(X, X));
                 Y = {fma(cz, obs.x, sz * obs.y) * p.ir[0], fma(cz, obs.y, -sz * obs.x) * p.ir[1], obs.z * p.ir[2]};
             } else {
-                Y = {obs.x * p.ir[0], obs.y * p.ir[1], obs.z * p.ir[2]};
+                Y = {fma(-p.VBs[0], d, p.O0s[0]), fma(-p.VBs[1], d, p.O0s[1]), fma(-p.VBs[2], d, p.O0s[2])};
             }
             const double yx = dot(Y, X);
             k = yx * ixx;
@@ -277,28 +277,33 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // body-fixed at te for TRI, B0 otherwise (body-fixed = Rz_frame(delta) * B0)
             const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[1], Xf.z * p.radii[2]};
             const double delta = TRI ? 0.0 : p.g.wdot * d;
-            const double rho = sqrt_fast(fma(sp.x, sp.x, sp.y * sp.y));
-            const bool polar = (sp.x == 0.0 && sp.y == 0.0);
+            // (for a spheroid x and y share their radius: longitude and latitude follow from the
+            //  scaled intercept Xf directly, sp / rho are only needed by the triaxial variant)
+            const V3 ll = TRI ? sp : Xf;
+            const double rho = sqrt_fast(fma(ll.x, ll.x, ll.y * ll.y));
+            const bool polar = (ll.x == 0.0 && ll.y == 0.0);
             // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - delta
-            const double le = polar ? 0.0 : atan2_fast(sp.y, sp.x) - delta;
+            const double le = polar ? 0.0 : atan2_fast(ll.y, ll.x) - delta;
             double l = p.g.west_positive ? -le : le;
             if (l < 0.0) l += kTwoPi;
             if (l >= kTwoPi) l -= kTwoPi;
             lon_deg = l * kDeg;
-            lat_deg = ((polar && sp.z == 0.0) ? kHalfPi : atan2_fast(sp.z * p.lat_k, rho)) * kDeg;
+            lat_deg = ((polar && sp.z == 0.0) ? kHalfPi : atan2_fast(TRI ? sp.z * p.lat_k : Xf.z * p.a_over_c, rho)) * kDeg;
             if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
                 // reclat_c body.py:2905: east-positive, (-pi, pi]
                 double lc = le;
                 if (lc <= -kPi) lc += kTwoPi;
                 if (lc > kPi) lc -= kTwoPi;
                 lc_deg = lc * kDeg;
-                bc_deg = ((polar && sp.z == 0.0) ? 0.0 : atan2_fast(sp.z, rho)) * kDeg;
+                bc_deg = ((polar && sp.z == 0.0) ? 0.0 : atan2_fast(TRI ? sp.z : Xf.z / p.a_over_c, rho)) * kDeg;
             }
             // the point in B0 (for the Sun / observer geometry, which lives there)
             const V3 sp0 = TRI ? v3(fma(cz, sp.x, -sz * sp.y), fma(sz, sp.x, cz * sp.y), sp.z) : sp;
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
-                const V3 q = {fma(p.VB[0], d, sp0.x), fma(p.VB[1], d, sp0.y), fma(p.VB[2], d, sp0.z)};
+                const V3 q = TRI ? v3(fma(p.VB[0], d, sp0.x), fma(p.VB[1], d, sp0.y), fma(p.VB[2], d, sp0.z))
+                                 : v3(fma(p.VBs[0], d, Xf.x) * p.radii[0], fma(p.VBs[1], d, Xf.y) * p.radii[1],
+                                      fma(p.VBs[2], d, Xf.z) * p.radii[2]);
                 // Sun light time (spkcpo_c 'CN'): the Sun is taken at te - |S - q| / c. Its epoch
                 // offset from ts0 is d + (lts0 - |SB0 - q| / c), and |SB0 - q| = |SB0| - s0.q up to
                 // q^2 / (2 |SB0|) ~ 3 km, i.e. 1e-5 s of a Sun that moves 0.013 km/s = 1e-7 km at

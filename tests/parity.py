@@ -108,7 +108,9 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
         tol['RING-RADIUS'] = 1e-3
         tol['RING-LON-GRAPHIC'] = 1e-7
     if 'RING-DISTANCE' in ref:
-        tol['RING-DISTANCE'] = 2e-4 + 1e-11 * np.abs(ref['RING-DISTANCE'] - np.nanmin(ref['RING-DISTANCE']))
+        rd = ref['RING-DISTANCE']
+        rd_min = np.nanmin(rd) if np.isfinite(rd).any() else 0.0
+        tol['RING-DISTANCE'] = 2e-4 + 1e-11 * np.abs(rd - rd_min)
     else:
         tol['RING-DISTANCE'] = 1e-3
     return tol

@@ -894,3 +894,31 @@ def test_config5_cube_512_planes_properties(engine, oracle, jupiter):
         engine.map_cube_device(cube[s], np.float64, 64, dx, dy, 180, 360, out2[s])
     engine.synchronize()
     assert torch.equal(torch.nan_to_num(out2), torch.nan_to_num(out))
+
+
+def test_random_discs_and_frames_fuzz(engine, oracle, jupiter, saturn):
+    """
+    Seeded sweep over frame shapes (1 x 1 up to ragged 200-pixel sides), disc positions inside,
+    on the edge of and outside the frame, radii from sub-pixel to frame-filling, any rotation,
+    with and without the radius pre-mask and altitude offsets: all 26 planes, masks bit-exact.
+    """
+    rng = np.random.default_rng(20260101)
+    cases = [(1, 1, 0.0, 0.0, 0.6, 0.0), (2, 1, 0.5, 0.0, 5.0, 1.0), (64, 1, 31.5, 0.0, 40.0, 3.0), (1, 70, 0.0, 30.0, 25.0, 5.9)]
+    for _ in range(26):
+        nx, ny = int(rng.integers(3, 200)), int(rng.integers(3, 200))
+        r0 = float(10 ** rng.uniform(-0.3, 2.4))
+        x0, y0 = float(rng.uniform(-0.3 * nx, 1.3 * nx)), float(rng.uniform(-0.3 * ny, 1.3 * ny))
+        cases.append((nx, ny, x0, y0, r0, float(rng.uniform(0, 2 * np.pi))))
+    for i, (nx, ny, x0, y0, r0, rot) in enumerate(cases):
+        g = saturn if i % 5 == 4 else jupiter
+        opt = bool(i % 3)
+        alt = [0.0, 0.0, 1500.0, -300.0][i % 4]
+        engine.set_geometry(g)
+        engine.set_disc(x0, y0, r0, rot, nx, ny, opt)
+        d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny, optimize_speed=opt)
+        d.rotation_rad = rot
+        out = engine.backplanes_img(oracle.PLANE_NAMES, alt=alt)
+        ref = oracle.backplanes_img(g, d, oracle.PLANE_NAMES, alt=alt)
+        for n in oracle.PLANE_NAMES:
+            assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (i, n, nx, ny, x0, y0, r0, rot)
+        _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)

@@ -922,3 +922,40 @@ def test_random_discs_and_frames_fuzz(engine, oracle, jupiter, saturn):
         for n in oracle.PLANE_NAMES:
             assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (i, n, nx, ny, x0, y0, r0, rot)
         _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)
+
+
+def test_random_reprojection_fuzz(engine, oracle, jupiter):
+    """
+    Seeded sweep over small frames, discs, NaN / inf patterns, dtypes and every interpolation mode
+    of map_img (both NaN policies), on rectangular maps of random resolution: mapped planes against
+    the oracle on the GPU's own x/y maps (NaN masks identical, values to 1e-9 of the data scale).
+    """
+    rng = np.random.default_rng(77)
+    modes = ['nearest', 'linear', 'quadratic', 'cubic', (1, 3), (4, 2), 'smooth']
+    for i in range(14):
+        nx, ny = int(rng.integers(7, 60)), int(rng.integers(7, 60))
+        r0 = float(rng.uniform(0.2, 0.7) * min(nx, ny))
+        x0, y0 = float(rng.uniform(0.3, 0.7) * nx), float(rng.uniform(0.3, 0.7) * ny)
+        engine.set_geometry(jupiter)
+        engine.set_disc(x0, y0, r0, float(rng.uniform(0, 6.28)), nx, ny, True)
+        lon, lat = oracle.rectangular_grid(jupiter, float(rng.choice([5.0, 9.0, 15.0, 30.0])))
+        xm, ym = engine.xy_map(lon, lat)
+        if not np.isfinite(xm).any():
+            continue
+        cube = rng.standard_normal((3, ny, nx)) * 10
+        cube[0][rng.random((ny, nx)) < 0.05] = np.nan
+        cube[1][rng.random((ny, nx)) < 0.03] = np.inf
+        cube[2][ny // 3 : ny // 3 + 2, :] = np.nan
+        if i % 4 == 1:
+            cube = np.nan_to_num(cube, posinf=0).astype(np.float32)
+        elif i % 4 == 2:
+            cube = np.nan_to_num(cube, posinf=0).astype(np.int16)
+        for interp in modes:
+            for prop in (True, False):
+                a = engine.map_cube(cube, xm, ym, interp, prop)
+                b = oracle.map_cube(cube, xm, ym, interp, prop)
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (i, nx, ny, interp, prop)
+                fin = np.isfinite(b)
+                if fin.any():
+                    scale = max(1.0, float(np.abs(b[fin]).max()))
+                    assert np.max(np.abs(a[fin] - b[fin])) <= 1e-9 * scale, (i, nx, ny, interp, prop)

@@ -959,3 +959,25 @@ def test_random_reprojection_fuzz(engine, oracle, jupiter):
                 if fin.any():
                     scale = max(1.0, float(np.abs(b[fin]).max()))
                     assert np.max(np.abs(a[fin] - b[fin])) <= 1e-9 * scale, (i, nx, ny, interp, prop)
+
+
+def test_transforms_with_non_finite_inputs(engine, oracle, jupiter):
+    """Non-finite inputs short-circuit to NaN like the reference (body.py:1023-1029, 1918-1924):
+    NaN / +-inf / 1e300 in either coordinate, every pair of coordinate systems."""
+    nx, ny = 120, 90
+    engine.set_geometry(jupiter)
+    engine.set_disc(60.0, 45.0, 30.0, 0.4, nx, ny, True)
+    d = oracle.make_disc(60.0, 45.0, 30.0, 0.0, nx, ny)
+    d.rotation_rad = 0.4
+    bad = [np.nan, np.inf, -np.inf, 1e300, -1e300]
+    base = {'xy': (60.0, 45.0), 'radec': oracle.transform(jupiter, d, 'xy', 'radec', [60.0], [45.0]),
+            'angular': (1.0, -2.0), 'km': (1000.0, -2000.0), 'lonlat': (150.0, -3.0)}  # fmt: skip
+    for src, (u0, v0) in base.items():
+        a = np.array([float(np.ravel(u0)[0])] + bad + [float(np.ravel(u0)[0])] * len(bad))
+        b = np.array([float(np.ravel(v0)[0])] + [float(np.ravel(v0)[0])] * len(bad) + bad)
+        for dst in base:
+            got = engine.transform(src, dst, a, b)
+            ref = oracle.transform(jupiter, d, src, dst, a, b)
+            assert np.array_equal(np.isnan(got[0]), np.isnan(ref[0])), (src, dst, got[0], ref[0])
+            assert np.array_equal(np.isnan(got[1]), np.isnan(ref[1])), (src, dst)
+            assert np.isfinite(got[0][0]) or src == dst or np.isnan(ref[0][0])

@@ -25,11 +25,11 @@ __device__ __forceinline__ double load_as_f64(const T *p, size_t i)
 // (BodyXY._replace_nans_with_interpolated_values body_xy.py:1871-1904; the reflect-mode
 // `uniform_filter(bad, size=3)` test there is equivalent to "the clipped window holds no
 // finite pixel" because reflection only repeats pixels of the window).
+// cleaned value of pixel (i, j) whose raw value `v` has been loaded already
 template <typename T>
-__device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int ny, int nx, double median,
-                                             bool &needs_median)
+__device__ __forceinline__ double cleaned_value(const T *img, double v, long i, long j, int ny, int nx, double median,
+                                                bool &needs_median)
 {
-    const double v = load_as_f64(img, (size_t)i * nx + j);
     if (isfinite(v)) return v;
     double sum = 0.0;
     int cnt = 0;
@@ -45,17 +45,12 @@ __device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int n
     needs_median = true;
     return median;
 }
-
-// One lane per (map location, plane): BodyXY.map_img body_xy.py:1414 for every plane of
-// Observation._get_mapped_data observation.py:876. blockIdx.y = plane, so the 64 lanes
-// of a wave gather from one plane around neighbouring (x, y) -> the 4-point footprints
-// overlap in L2; the store is coalesced along the map row.
-//
-// The reference interpolates a NaN-cleaned copy of each plane; here the cleaned value of a
-// non-finite corner is computed on the fly from its 3x3 window. Only a corner whose whole
-// window is non-finite needs the plane's nanmedian: with plane_stats == NULL (first pass)
-// such a plane is flagged (plane_flags[pl] = call sequence number) and the host reruns it
-// after k_median_*.
+template <typename T>
+__device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int ny, int nx, double median,
+                                             bool &needs_median)
+{
+    return cleaned_value(img, load_as_f64(img, (size_t)i * nx + j), i, j, ny, nx, median, needs_median);
+}
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 {
@@ -80,18 +75,9 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
         } else {
             const bool have_stats = a.plane_stats != nullptr;
             bool skip = have_stats && a.plane_stats[pl].all_nan;  // body_xy.py:1668-1670
-            if (a.propagate_nan && !skip) {
-                // _should_propagate_nan_to_map body_xy.py:1855-1866
-                if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-                    skip = true;
-                } else {
-                    long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-                    long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-                    double t0 = load_as_f64(img, (size_t)ja * nx + ia), t1 = load_as_f64(img, (size_t)ja * nx + ib);
-                    double t2 = load_as_f64(img, (size_t)jb * nx + ia), t3 = load_as_f64(img, (size_t)jb * nx + ib);
-                    skip = isnan(t0) || isnan(t1) || isnan(t2) || isnan(t3);
-                }
-            }
+            // _should_propagate_nan_to_map body_xy.py:1855-1866, first half: outside the hull of
+            // the pixel centres
+            if (a.propagate_nan && (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1)) skip = true;
             if (!skip) {
                 // RectBivariateSpline(kx=ky=1, s=0).ev == bilinear; FITPACK clamps the
                 // evaluation point to the knot range.
@@ -103,18 +89,28 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
                 if (y0 < 0) y0 = 0;
                 long x1 = x0 + 1 < nx ? x0 + 1 : x0, y1 = y0 + 1 < ny ? y0 + 1 : y0;
                 double fx = xc - (double)x0, fy = yc - (double)y0;
-                const double med = have_stats ? a.plane_stats[pl].median : 0.0;
-                bool nm = false;
-                // corners with zero weight contribute exactly 0 in the reference (their cleaned
-                // value is finite), so they are not evaluated at all
-                const double w00 = (1.0 - fy) * (1.0 - fx), w01 = (1.0 - fy) * fx, w10 = fy * (1.0 - fx), w11 = fy * fx;
-                const double v00 = (fx != 1.0 && fy != 1.0) ? cleaned_at(img, y0, x0, ny, nx, med, nm) : 0.0;
-                const double v01 = (fx != 0.0 && fy != 1.0) ? cleaned_at(img, y0, x1, ny, nx, med, nm) : 0.0;
-                const double v10 = (fx != 1.0 && fy != 0.0) ? cleaned_at(img, y1, x0, ny, nx, med, nm) : 0.0;
-                const double v11 = (fx != 0.0 && fy != 0.0) ? cleaned_at(img, y1, x1, ny, nx, med, nm) : 0.0;
-                (void)w00; (void)w01; (void)w10; (void)w11;
-                val = (1.0 - fy) * ((1.0 - fx) * v00 + fx * v01) + fy * ((1.0 - fx) * v10 + fx * v11);
-                if (nm && !have_stats) atomicMax(&a.plane_flags[pl], a.seq);
+                // Corners with zero weight contribute exactly 0 in the reference (their cleaned
+                // value is finite) and are not touched. The corners WITH weight are exactly the
+                // floor / ceil pixels of the reference's NaN test (second half of
+                // _should_propagate_nan_to_map): one set of loads serves both.
+                const bool u00 = fx != 1.0 && fy != 1.0, u01 = fx != 0.0 && fy != 1.0;
+                const bool u10 = fx != 1.0 && fy != 0.0, u11 = fx != 0.0 && fy != 0.0;
+                const double r00 = u00 ? load_as_f64(img, (size_t)y0 * nx + x0) : 0.0;
+                const double r01 = u01 ? load_as_f64(img, (size_t)y0 * nx + x1) : 0.0;
+                const double r10 = u10 ? load_as_f64(img, (size_t)y1 * nx + x0) : 0.0;
+                const double r11 = u11 ? load_as_f64(img, (size_t)y1 * nx + x1) : 0.0;
+                if (a.propagate_nan && (isnan(r00) || isnan(r01) || isnan(r10) || isnan(r11))) {
+                    skip = true;
+                } else {
+                    const double med = have_stats ? a.plane_stats[pl].median : 0.0;
+                    bool nm = false;
+                    const double v00 = u00 ? cleaned_value(img, r00, y0, x0, ny, nx, med, nm) : 0.0;
+                    const double v01 = u01 ? cleaned_value(img, r01, y0, x1, ny, nx, med, nm) : 0.0;
+                    const double v10 = u10 ? cleaned_value(img, r10, y1, x0, ny, nx, med, nm) : 0.0;
+                    const double v11 = u11 ? cleaned_value(img, r11, y1, x1, ny, nx, med, nm) : 0.0;
+                    val = (1.0 - fy) * ((1.0 - fx) * v00 + fx * v01) + fy * ((1.0 - fx) * v10 + fx * v11);
+                    if (nm && !have_stats) atomicMax(&a.plane_flags[pl], a.seq);
+                }
             }
         }
     }

@@ -44,6 +44,20 @@ int32_t golden_stride(int rows)
     return (int32_t)s;
 }
 
+// ceil(2^32 / d) for pm::mod_uniform (d >= 2)
+static uint32_t mod_magic(uint32_t d) { return d < 2 ? 0u : (uint32_t)(0xFFFFFFFFull / d + 1ull); }
+
+// row / column-block visiting order of the spheroid image kernel for a launch over `rows` rows
+void set_row_order(pm::Params &p, int rows)
+{
+    p.rows = rows;
+    p.row_stride = golden_stride(rows);
+    p.row_magic = mod_magic((uint32_t)rows);
+    p.col_blocks = (uint32_t)((p.nx + pm::kSphBlock - 1) / pm::kSphBlock);
+    p.col_magic = mod_magic(p.col_blocks);
+    p.pad_ = 0;
+}
+
 int ensure_scratch(pm_ctx *ctx, size_t bytes)
 {
     if (bytes <= ctx->scratch_bytes) return PM_OK;
@@ -119,6 +133,25 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     double m00 = s * c, m01 = s * sn, m10 = s * -sn, m11 = s * c;
     p.A[0] = m00; p.A[1] = m01; p.A[2] = -(m00 * d.x0 + m01 * d.y0);
     p.A[3] = m10; p.A[4] = m11; p.A[5] = -(m10 * d.x0 + m11 * d.y0);
+    {
+        // the same map in radians with the RA-like axis negated (body.py:1363: ra = -x), and
+        // whether every pixel of the frame stays inside the range of sincos_tiny
+        const double k = 3.14159265358979323846 / 180.0 / 3600.0;
+        for (int i = 0; i < 3; i++) {
+            p.Ar[i] = -(p.A[i] * k);
+            p.Ar[3 + i] = p.A[3 + i] * k;
+        }
+        double amax = 0.0;
+        for (int cy = 0; cy < 2; cy++)
+            for (int cx = 0; cx < 2; cx++) {
+                const double fx = cx ? (double)(d.nx - 1) : 0.0, fy = cy ? (double)(d.ny - 1) : 0.0;
+                amax = std::fmax(amax, std::fabs(p.Ar[0] * fx + p.Ar[1] * fy + p.Ar[2]));
+                amax = std::fmax(amax, std::fabs(p.Ar[3] * fx + p.Ar[4] * fy + p.Ar[5]));
+            }
+        p.view_tiny = (amax <= 1e-3) ? 1 : 0;  // NaN compares false
+        p.lon_k[0] = g.west_positive ? -1.0 : 1.0;
+        p.lon_k[1] = p.lon_k[0] * g.wdot;
+    }
     double det = m00 * m11 - m01 * m10;
     double i00 = m11 / det, i01 = -m01 / det, i10 = -m10 / det, i11 = m00 / det;
     p.Ai[0] = i00; p.Ai[1] = i01; p.Ai[2] = -(i00 * p.A[2] + i01 * p.A[5]);
@@ -176,9 +209,7 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     p.nx = d.nx;
     p.ny = d.ny;
     p.y_off = 0;
-    p.rows = d.ny;
-    p.row_stride = golden_stride(d.ny);
-    p.pad_ = 0;
+    set_row_order(p, d.ny);
     p.optimize_speed = d.optimize_speed;
     p.n0 = p.n1 = 0;
     p.mask = 0;
@@ -403,8 +434,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
     fill_params(ctx, alt, p);
     p.mask = plane_mask;
     p.y_off = row_begin;
-    p.rows = n_rows;
-    p.row_stride = golden_stride(n_rows);
+    set_row_order(p, n_rows);
     int nreq = 0;
     for (int i = 0; i < PM_NUM_PLANES; i++)
         if ((plane_mask >> i) & 1) {

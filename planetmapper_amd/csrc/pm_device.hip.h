@@ -107,8 +107,22 @@ struct Params {
     int32_t row_stride;  // row visiting order of the image kernels (coprime with `rows`)
     int32_t y_off;       // first image row of this launch (row-block sharding), normally 0
     int32_t rows;        // rows computed by this launch (<= ny); output row r holds image row y_off + r
-    int32_t pad_;
+    int32_t view_tiny;   // every view angle of the frame is below 1e-3 rad: sincos_tiny applies
+    double Ar[6];        // A in radians, first row negated: pixel -> (-ax, ay) of _xy2obsvec_norm
+    double lon_k[2];     // {w, w wdot}, w = -1 for west-positive bodies: lon = w (theta - wdot d)
+    // n mod d on the scalar unit: q = umulhi(n, ceil(2^32 / d)) is the quotient or one more
+    uint32_t row_magic;  // d = rows
+    uint32_t col_blocks, col_magic;  // d = column blocks of the spheroid kernel, ceil(nx / kSphBlock)
+    uint32_t pad_;
 };
+
+// n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands
+// `%` into: magic = ceil(2^32 / d) from the host (pmh::mod_magic), n < 2^32, d >= 2.
+__device__ __forceinline__ uint32_t mod_uniform(uint32_t n, uint32_t d, uint32_t magic)
+{
+    const int32_t r = (int32_t)(n - __umulhi(n, magic) * d);  // in [-d, d)
+    return (uint32_t)(r < 0 ? r + (int32_t)d : r);
+}
 
 constexpr int kBlock = 256;
 // the spheroid image kernel runs one wave per workgroup: finer-grained dispatch mixes the

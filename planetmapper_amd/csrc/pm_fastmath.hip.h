@@ -34,10 +34,12 @@ __device__ __forceinline__ double rcp_fast(double b)
     r = fma(fma(-b, r, 1.0), r, r);
     return r;
 }
-// a / b to ~1 ulp
+// a / b to ~1 ulp. One Newton step on the reciprocal is enough here (2^-46 relative): the
+// residual correction of the quotient squares that error again.
 __device__ __forceinline__ double div_fast(double a, double b)
 {
-    const double r = rcp_fast(b);
+    double r = __builtin_amdgcn_rcp(b);
+    r = fma(fma(-b, r, 1.0), r, r);
     const double q = a * r;
     return fma(fma(-b, q, a), r, q);
 }
@@ -48,21 +50,23 @@ __device__ __forceinline__ double sqrt_fast(double x)
     const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
+    g = fma(g, r, g);  // 1.5 e0^2 = 2^-45 relative from the 2^-23 seed
     h = fma(h, r, h);
-    g = fma(fma(-g, g, x), h, g);
-    g = fma(fma(-g, g, x), h, g);
-    return g;
+    return fma(fma(-g, g, x), h, g);  // exact residual: error squared again, <= 1 ulp
 }
-// 1 / sqrt(x), x > 0 in the normal range, full precision
+// sqrt(x) to 2^-45 relative (sqrt_fast without its closing residual step)
+__device__ __forceinline__ double sqrt_seed(double x)
+{
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    const double g = x * y;
+    return fma(g, fma(-0.5 * y, g, 0.5), g);
+}
+// 1 / sqrt(x), x > 0 in the normal range
 __device__ __forceinline__ double rsqrt_fast(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
     double e = fma(-x * y, y, 1.0);
-    y = fma(y * e, fma(e, 0.375, 0.5), y);
-    e = fma(-x * y, y, 1.0);
-    y = fma(y * e, 0.5, y);
-    return y;
+    return fma(y * e, fma(e, 0.375, 0.5), y);  // third order: e0^3 = 2^-69, ~1 ulp after rounding
 }
 
 // q * z + C with the constant C as a scalar (SGPR) operand of ONE v_fma_f64. Left to
@@ -112,21 +116,27 @@ __device__ __forceinline__ double atan_small(double t)
     return fma(t * z, q, t);
 }
 
-// atan2(y, x) in (-pi, pi]; (y, x) finite and not both zero.
+// atan2(y, x) in (-pi, pi]; (y, x) finite and not both zero. XPOS: x >= 0 is known.
 // atan(mn/mx) with mn <= mx is reduced by atan(q) = pi/4 + atan((q - 1)/(q + 1)) for
 // q > tan(pi/8); numerator and denominator are chosen BEFORE dividing, so the whole
-// function costs one division.
+// function costs one division. max / min of the magnitudes take the |.| operand modifiers
+// directly (through fmax(fabs()) hipcc first canonicalises each operand with an extra
+// v_max_f64), and the reduction is blended in with a 0/1 factor: two FMAs instead of two
+// differences and four selects.
+template <bool XPOS = false>
 __device__ __forceinline__ double atan2_fast(double y, double x)
 {
-    const double ax = fabs(x), ay = fabs(y);
-    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    double mx, mn;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(mx) : "v"(x), "v"(y));
+    asm("v_min_f64 %0, |%1|, |%2|" : "=v"(mn) : "v"(x), "v"(y));
     const bool big = mn > kTanPi8 * mx;
-    const double num = big ? mn - mx : mn;
-    const double den = big ? mn + mx : mx;
+    const double bf = big ? 1.0 : 0.0;
+    const double num = fma(-bf, mx, mn);
+    const double den = fma(bf, mn, mx);
     double a = atan_small(div_fast(num, den));
     a = big ? a + 0.25 * kPiF : a;
-    a = (ay > ax) ? 0.5 * kPiF - a : a;
-    a = (x < 0.0) ? kPiF - a : a;
+    a = (fabs(y) > fabs(x)) ? 0.5 * kPiF - a : a;
+    if (!XPOS) a = (x < 0.0) ? kPiF - a : a;
     return copysign(a, y);
 }
 
@@ -144,6 +154,15 @@ __device__ __forceinline__ void sincos_small(double x, double &s, double &c)
     qc = fma_c(qc, z, -0.0013888888887615533);
     qc = fma_c(qc, z, 0.041666666666666415);
     c = fma(z * z, qc, fma(-0.5, z, 1.0));
+}
+
+// sin and cos for |x| <= 1e-3 (the view angles of a planetary frame, a host-side decision):
+// the next terms, x^5 / 120 and x^6 / 720, are below 1e-17 absolute
+__device__ __forceinline__ void sincos_tiny(double x, double &s, double &c)
+{
+    const double z = x * x;
+    s = x * fma(z, -1.0 / 6.0, 1.0);
+    c = fma(z, fma(z, 1.0 / 24.0, -0.5), 1.0);
 }
 
 // sin and cos for |x| <= 1e5: Cody-Waite reduction by pi/2 in three parts (k = rint(2x/pi)

@@ -187,11 +187,12 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     // each XCD would always get the same image columns, and the columns through the disc
     // centre cost far more than the ones at the frame edge. Rotating the column block by the
     // row index gives every XCD the same mix.
-    const int x = (int)((blockIdx.x + blockIdx.y) % gridDim.x) * kSphBlock + threadIdx.x;
+    const int x = (int)(p.col_blocks < 2 ? 0u : mod_uniform(blockIdx.x + blockIdx.y, p.col_blocks, p.col_magic)) * kSphBlock + threadIdx.x;
     // Rows are visited in a golden-ratio stride order (a bijection: gcd(row_stride, ny) = 1)
     // so that store-only rows off the disc and FP64-heavy rows through it are resident on the
     // chip at the same time: HBM writes of the former overlap the VALU work of the latter.
-    const int yl = (int)(((long long)blockIdx.y * p.row_stride) % p.rows);  // row within this launch
+    // (rows <= 65535, the grid limit, and row_stride < rows: the product fits 32 bits)
+    const int yl = (int)(p.rows < 2 ? 0u : mod_uniform(blockIdx.y * (uint32_t)p.row_stride, (uint32_t)p.rows, p.row_magic));  // row within this launch
     const int y = p.y_off + yl;
     const bool inside = x < p.nx;
     const size_t row_base = (size_t)yl * p.nx;  // wave-uniform
@@ -201,22 +202,27 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     const double dx = (double)x - p.x0, dy = (double)y - p.y0;
     const bool cand = inside && !(p.optimize_speed && (dx * dx + dy * dy) > p.r2);
 
-    double lon_deg = nan, lat_deg = nan, lc_deg = nan, bc_deg = nan;
-    double ph = nan, in = nan, em = nan, az = nan, dist = nan, rv = nan, dop = nan;
     double rr = nan, rl = nan, rd = nan;
     double dist_lt = nan;  // observer -> surface distance (lt * c) of on-disc pixels
+    bool stored = false;   // wave-uniform: the disc planes of this wave have been written
 
     const bool any_cand = __any(cand);
     V3 va = {0.0, 0.0, 0.0};  // unit vector of the pixel in the angular frame
     if (any_cand || (FLAGS & DF_RING)) {
         // pixel -> unit ray (BodyXY._xy2obsvec_norm body_xy.py:375)
+        // (the affine map is taken in radians: folding arcsec -> rad into its six constants moves
+        //  an angle of 1e-4 rad by 1 ulp)
         const double fx = (double)x, fy = (double)y;
-        const double ax = fma(p.A[0], fx, fma(p.A[1], fy, p.A[2]));
-        const double ay = fma(p.A[3], fx, fma(p.A[4], fy, p.A[5]));
+        const double ra = fma(p.Ar[0], fx, fma(p.Ar[1], fy, p.Ar[2]));
+        const double de = fma(p.Ar[3], fx, fma(p.Ar[4], fy, p.Ar[5]));
         double sr, cr, sd, cd;
-        constexpr double kArcsec = kRad / 3600.0;  // arcsec -> rad (1 ulp from (a / 3600) * kRad)
-        sincos_auto(-(ax * kArcsec), sr, cr);
-        sincos_auto(ay * kArcsec, sd, cd);
+        if (p.view_tiny) {  // kernel-argument flag: a scalar branch, no wave vote
+            sincos_tiny(ra, sr, cr);
+            sincos_tiny(de, sd, cd);
+        } else {
+            sincos_auto(ra, sr, cr);
+            sincos_auto(de, sd, cd);
+        }
         va = v3(cr * cd, sr * cd, sd);
     }
 
@@ -234,17 +240,22 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         double lt = p.g.lt_c, d = 0.0, k = 0.0, root = 0.0;
         V3 P = {0.0, 0.0, 0.0};
         bool hit = cand;
-#pragma unroll 1
-        for (int it = 0; it < 10; it++) {
-            // wave-uniform exit once no lane is still iterating
-            const double te = p.g.et - lt;
-            d = te - p.t0;
-            // (the target's acceleration moves it by A d^2 / 2 < 1e-8 km over the |d| <= R / c of a
-            //  disc intercept, 10x below the rounding of the ray itself: not carried here)
+        // An FMA takes one scalar operand: with VBs there, O0s has to sit in vector registers.
+        // Pinned outside the loop (left alone, hipcc re-copies the three pairs every evaluation).
+        double o0x = p.O0s[0], o0y = p.O0s[1], o0z = p.O0s[2];
+        if (!TRI) asm volatile("" : "+v"(o0x), "+v"(o0y), "+v"(o0z));
+        // One evaluation of the intercept with the target taken d seconds after t0; returns the
+        // light time it implies. (The target's acceleration moves it by A d^2 / 2 < 1e-8 km over
+        // the |d| <= R / c of a disc intercept, 10x below the rounding of the ray itself: not
+        // carried here.)
+        auto evaluate = [&](const double dd, const bool first) -> double {
             V3 Y;
-            if (TRI) {
-                const V3 obs = {fma(-p.VB[0], d, p.O0[0]), fma(-p.VB[1], d, p.O0[1]), fma(-p.VB[2], d, p.O0[2])};
-                const double dl = p.g.wdot * d, d2 = dl * dl;  // |dl| < 1e-3 (host check)
+            if (first) {
+                // t0 = et - lt_c on the host, the same subtraction as on the device: d == 0 exactly
+                Y = TRI ? v3(p.O0[0] * p.ir[0], p.O0[1] * p.ir[1], p.O0[2] * p.ir[2]) : v3(o0x, o0y, o0z);
+            } else if (TRI) {
+                const V3 obs = {fma(-p.VB[0], dd, p.O0[0]), fma(-p.VB[1], dd, p.O0[1]), fma(-p.VB[2], dd, p.O0[2])};
+                const double dl = p.g.wdot * dd, d2 = dl * dl;  // |dl| < 1e-3 (host check)
                 cz = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
                 sz = dl * fma(d2, -1.0 / 6.0, 1.0);
                 const V3 ub = {fma(cz, u.x, sz * u.y), fma(cz, u.y, -sz * u.x), u.z};
@@ -252,7 +263,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 ixx = rcp_fast(dot(X, X));
                 Y = {fma(cz, obs.x, sz * obs.y) * p.ir[0], fma(cz, obs.y, -sz * obs.x) * p.ir[1], obs.z * p.ir[2]};
             } else {
-                Y = {fma(-p.VBs[0], d, p.O0s[0]), fma(-p.VBs[1], d, p.O0s[1]), fma(-p.VBs[2], d, p.O0s[2])};
+                Y = {fma(-p.VBs[0], dd, o0x), fma(-p.VBs[1], dd, o0y), fma(-p.VBs[2], dd, o0z)};
             }
             const double yx = dot(Y, X);
             k = yx * ixx;
@@ -261,41 +272,67 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // (an observer inside the body, Y.Y <= 1, never reaches this kernel: the
             //  launcher requires |O0| scaled > 1 and the target moves km, not radii)
             if (p2 > 1.0 || yx > 0.0) hit = false;
-            root = sqrt_fast(fmax(0.0, 1.0 - p2) * ixx);
-            const double nlt = (-k - root) * p.inv_c;
-            const double err = fabs(nlt - lt);
-            const bool done = !hit || err <= lt_tol;
+            const double r2 = fmax(0.0, 1.0 - p2) * ixx;
+            // the first light time only seeds the next epoch (an error e in it moves the target
+            // by VB e): 2^-45 relative is plenty there
+            root = first ? sqrt_seed(r2) : sqrt_fast(r2);
+            return (-k - root) * p.inv_c;
+        };
+        // The first evaluation, at t0 itself, is never the last: |lt - lt_c| would have to be
+        // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
+        // converged light time changes nothing. No test, no select after it.
+        lt = evaluate(0.0, true);
+#pragma unroll 1
+        for (int it = 1; it < 10; it++) {
+            d = (p.g.et - lt) - p.t0;  // two roundings, as the epoch et - lt of the reference has them
+            const double nlt = evaluate(d, false);
+            const bool done = !hit || fabs(nlt - lt) <= lt_tol;
             if (hit) lt = nlt;
+            // wave-uniform exit once no lane is still iterating
             if (__all(done)) break;
         }
 
-        if (hit) {
+        // From here on EVERY lane of a wave that holds at least one intercept computes: no
+        // exec masking and no NaN-initialised result registers (16 v_mov per candidate wave).
+        // Lanes without an intercept carry harmless garbage; `miss` (NaN for them, 0.0 for
+        // hits) is the addend of each plane's closing radians -> degrees FMA.
+        if (__any(hit)) {
+            stored = true;
+            const double miss = hit ? 0.0 : nan;
             // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
-            const double tau = -k - root;  // distance observer -> point along the ray
-            if (FLAGS & (DF_RING | DF_STATE)) dist_lt = lt * p.g.clight;
+            if (FLAGS & (DF_RING | DF_STATE)) dist_lt = fma(lt, p.g.clight, miss);
             const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
             // body-fixed at te for TRI, B0 otherwise (body-fixed = Rz_frame(delta) * B0)
             const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[1], Xf.z * p.radii[2]};
-            const double delta = TRI ? 0.0 : p.g.wdot * d;
             // (for a spheroid x and y share their radius: longitude and latitude follow from the
             //  scaled intercept Xf directly, sp / rho are only needed by the triaxial variant)
             const V3 ll = TRI ? sp : Xf;
             const double rho = sqrt_fast(fma(ll.x, ll.x, ll.y * ll.y));
             const bool polar = (ll.x == 0.0 && ll.y == 0.0);
-            // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - delta
-            const double le = polar ? 0.0 : atan2_fast(ll.y, ll.x) - delta;
-            double l = p.g.west_positive ? -le : le;
+            // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - wdot d,
+            // sign by the body's convention (lon_k = {+-1, +-wdot}), then into [0, 2 pi]
+            const double theta = polar ? 0.0 : atan2_fast(ll.y, ll.x);
+            double l = TRI ? p.lon_k[0] * theta : fma(-p.lon_k[1], d, p.lon_k[0] * theta);
             if (l < 0.0) l += kTwoPi;
-            if (l >= kTwoPi) l -= kTwoPi;
-            lon_deg = l * kDeg;
-            lat_deg = ((polar && sp.z == 0.0) ? kHalfPi : atan2_fast(TRI ? sp.z * p.lat_k : Xf.z * p.a_over_c, rho)) * kDeg;
+            const double lon_deg = fma(l, kDeg, miss);
+            const double lat = (polar && sp.z == 0.0) ? kHalfPi
+                                                      : atan2_fast<true>(TRI ? sp.z * p.lat_k : Xf.z * p.a_over_c, rho);
+            const double lat_deg = fma(lat, kDeg, miss);
+            if (inside) {
+                PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
+                PM_PUT_ROW(PM_LAT_GRAPHIC, lat_deg);
+                if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT_ROW(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
+            }
             if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
                 // reclat_c body.py:2905: east-positive, (-pi, pi]
-                double lc = le;
+                double lc = TRI ? theta : fma(-p.g.wdot, d, theta);
                 if (lc <= -kPi) lc += kTwoPi;
                 if (lc > kPi) lc -= kTwoPi;
-                lc_deg = lc * kDeg;
-                bc_deg = ((polar && sp.z == 0.0) ? 0.0 : atan2_fast(TRI ? sp.z : Xf.z / p.a_over_c, rho)) * kDeg;
+                const double bc = (polar && sp.z == 0.0) ? 0.0 : atan2_fast<true>(TRI ? sp.z : Xf.z / p.a_over_c, rho);
+                if (inside) {
+                    PM_PUT_ROW(PM_LON_CENTRIC, fma(lc, kDeg, miss));
+                    PM_PUT_ROW(PM_LAT_CENTRIC, fma(bc, kDeg, miss));
+                }
             }
             // the point in B0 (for the Sun / observer geometry, which lives there)
             const V3 sp0 = TRI ? v3(fma(cz, sp.x, -sz * sp.y), fma(sz, sp.x, cz * sp.y), sp.z) : sp;
@@ -317,23 +354,50 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 V3 n = {Xf.x * p.ir[0], Xf.y * p.ir[1], Xf.z * p.ir[2]};  // surfnm_c: sp / radii^2 = Xf / radii
                 if (TRI) n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
                 n = rsqrt_fast(dot(n, n)) * n;
-                ph = vsep_fast(sunb, ob) * kDeg;
-                in = vsep_fast(n, sunb) * kDeg;
-                em = vsep_fast(n, ob) * kDeg;
-                if (PM_WANT(PM_AZIMUTH)) az = azimuth_deg(ph, in, em);
+                const double ph = fma(vsep_fast(sunb, ob), kDeg, miss);
+                const double in = fma(vsep_fast(n, sunb), kDeg, miss);
+                const double em = fma(vsep_fast(n, ob), kDeg, miss);
+                if (inside) {
+                    PM_PUT_ROW(PM_PHASE, ph);
+                    PM_PUT_ROW(PM_INCIDENCE, in);
+                    PM_PUT_ROW(PM_EMISSION, em);
+                    if (PM_WANT(PM_AZIMUTH)) PM_PUT_ROW(PM_AZIMUTH, azimuth_deg(ph, in, em));
+                }
             }
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
-                dist = dist_lt;
                 const V3 vp = {fma(p.AB[0], d, p.VB[0]) - p.g.wdot * sp0.y, fma(p.AB[1], d, p.VB[1]) + p.g.wdot * sp0.x,
                                fma(p.AB[2], d, p.VB[2])};
                 const V3 vo = ld3(p.VOB);
                 const double dlt = (dot(u, vp - vo) * p.inv_c) / (1.0 + dot(u, vp) * p.inv_c);
-                rv = dot((1.0 - dlt) * vp - vo, u);
+                const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;
                 const double beta = rv / p.g.clight;
-                dop = sqrt((1.0 + beta) / (1.0 - beta));
-                (void)tau;
+                if (inside) {
+                    PM_PUT_ROW(PM_DISTANCE, dist_lt);
+                    PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);
+                    PM_PUT_ROW(PM_DOPPLER, sqrt((1.0 + beta) / (1.0 - beta)));
+                }
             }
+        }
+    }
+
+    if (!stored && inside) {
+        // no intercept anywhere in this wave: every disc plane is NaN
+        PM_PUT_ROW(PM_LON_GRAPHIC, nan);
+        PM_PUT_ROW(PM_LAT_GRAPHIC, nan);
+        PM_PUT_ROW(PM_LON_CENTRIC, nan);
+        PM_PUT_ROW(PM_LAT_CENTRIC, nan);
+        PM_PUT_ROW(PM_LOCAL_SOLAR_TIME, nan);
+        if (FLAGS & DF_ILLUM) {
+            PM_PUT_ROW(PM_PHASE, nan);
+            PM_PUT_ROW(PM_INCIDENCE, nan);
+            PM_PUT_ROW(PM_EMISSION, nan);
+            PM_PUT_ROW(PM_AZIMUTH, nan);
+        }
+        if (FLAGS & DF_STATE) {
+            PM_PUT_ROW(PM_DISTANCE, nan);
+            PM_PUT_ROW(PM_RADIAL_VELOCITY, nan);
+            PM_PUT_ROW(PM_DOPPLER, nan);
         }
     }
 
@@ -374,28 +438,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         }
     }
 
-    if (inside) {
-        if (FLAGS & DF_RING) {
-            PM_PUT_ROW(PM_RING_RADIUS, rr);
-            PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
-            PM_PUT_ROW(PM_RING_DISTANCE, rd);
-        }
-        PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
-        PM_PUT_ROW(PM_LAT_GRAPHIC, lat_deg);
-        PM_PUT_ROW(PM_LON_CENTRIC, lc_deg);
-        PM_PUT_ROW(PM_LAT_CENTRIC, bc_deg);
-        if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT_ROW(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
-        if (FLAGS & DF_ILLUM) {
-            PM_PUT_ROW(PM_PHASE, ph);
-            PM_PUT_ROW(PM_INCIDENCE, in);
-            PM_PUT_ROW(PM_EMISSION, em);
-            PM_PUT_ROW(PM_AZIMUTH, az);
-        }
-        if (FLAGS & DF_STATE) {
-            PM_PUT_ROW(PM_DISTANCE, dist);
-            PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);
-            PM_PUT_ROW(PM_DOPPLER, dop);
-        }
+    if ((FLAGS & DF_RING) && inside) {
+        PM_PUT_ROW(PM_RING_RADIUS, rr);
+        PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
+        PM_PUT_ROW(PM_RING_DISTANCE, rd);
     }
 }
 

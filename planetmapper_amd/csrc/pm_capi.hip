@@ -168,6 +168,7 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     double kdet = k00 * k11 - k01 * k10;
     p.K[0] = k11 / kdet; p.K[1] = -k01 / kdet; p.K[2] = -k10 / kdet; p.K[3] = k00 / kdet;
     p.t0 = g.et - g.lt_c;
+    p.lt_tol = 1e-17 * std::fabs(p.t0);
     // spheroid fast-path constants (B0 frame)
     auto rot = [&](const double *v, double *o, double sgn) {
         for (int i = 0; i < 3; i++) o[i] = sgn * (g.R0[3 * i] * v[0] + g.R0[3 * i + 1] * v[1] + g.R0[3 * i + 2] * v[2]);

@@ -114,6 +114,7 @@ struct Params {
     uint32_t row_magic;  // d = rows
     uint32_t col_blocks, col_magic;  // d = column blocks of the spheroid kernel, ceil(nx / kSphBlock)
     uint32_t pad_;
+    double lt_tol;       // CSPICE's light-time stopping rule: 1e-17 |et - lt|  (lt varies by 1e-9 relative over a disc)
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

@@ -54,10 +54,20 @@ __device__ __forceinline__ double sqrt_fast(double x)
     h = fma(h, r, h);
     return fma(fma(-g, g, x), h, g);  // exact residual: error squared again, <= 1 ulp
 }
-// sqrt(x) to 2^-45 relative (sqrt_fast without its closing residual step)
-__device__ __forceinline__ double sqrt_seed(double x)
+// the same for x >= 1e-300 (no guard of the seed)
+__device__ __forceinline__ double sqrt_pos(double x)
 {
-    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);
+}
+// sqrt(x), x >= 1e-300, to 2^-45 relative (sqrt_pos without its closing residual step)
+__device__ __forceinline__ double sqrt_seed_pos(double x)
+{
+    const double y = __builtin_amdgcn_rsq(x);
     const double g = x * y;
     return fma(g, fma(-0.5 * y, g, 0.5), g);
 }

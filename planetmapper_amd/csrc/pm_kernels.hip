@@ -236,10 +236,11 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
         // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
-        const double lt_tol = 1e-17 * fabs(p.t0);
         double lt = p.g.lt_c, d = 0.0, k = 0.0, root = 0.0;
         V3 P = {0.0, 0.0, 0.0};
-        bool hit = cand;
+        // lanes still holding an intercept, as a wave-uniform mask in scalar registers (a
+        // per-lane bool carried around the loop costs four VALU operations per evaluation)
+        unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(cand);
         // An FMA takes one scalar operand: with VBs there, O0s has to sit in vector registers.
         // Pinned outside the loop (left alone, hipcc re-copies the three pairs every evaluation).
         double o0x = p.O0s[0], o0y = p.O0s[1], o0z = p.O0s[2];
@@ -271,11 +272,13 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double p2 = dot(P, P);
             // (an observer inside the body, Y.Y <= 1, never reaches this kernel: the
             //  launcher requires |O0| scaled > 1 and the target moves km, not radii)
-            if (p2 > 1.0 || yx > 0.0) hit = false;
-            const double r2 = fmax(0.0, 1.0 - p2) * ixx;
+            hit_mask &= ~(__builtin_amdgcn_ballot_w64(p2 > 1.0) | __builtin_amdgcn_ballot_w64(yx > 0.0));
+            // (clamped away from 0 once, for the reciprocal square root: a grazing ray gets
+            //  root = 1e-150 instead of 0)
+            const double r2 = fmax((1.0 - p2) * ixx, 1e-300);
             // the first light time only seeds the next epoch (an error e in it moves the target
             // by VB e): 2^-45 relative is plenty there
-            root = first ? sqrt_seed(r2) : sqrt_fast(r2);
+            root = first ? sqrt_seed_pos(r2) : sqrt_pos(r2);
             return (-k - root) * p.inv_c;
         };
         // The first evaluation, at t0 itself, is never the last: |lt - lt_c| would have to be
@@ -286,17 +289,18 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         for (int it = 1; it < 10; it++) {
             d = (p.g.et - lt) - p.t0;  // two roundings, as the epoch et - lt of the reference has them
             const double nlt = evaluate(d, false);
-            const bool done = !hit || fabs(nlt - lt) <= lt_tol;
-            if (hit) lt = nlt;
-            // wave-uniform exit once no lane is still iterating
-            if (__all(done)) break;
+            const bool moving = !(fabs(nlt - lt) <= p.lt_tol);
+            lt = nlt;  // (lanes without an intercept carry a value nobody reads)
+            // wave-uniform exit once no lane with an intercept is still moving
+            if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
         }
 
         // From here on EVERY lane of a wave that holds at least one intercept computes: no
         // exec masking and no NaN-initialised result registers (16 v_mov per candidate wave).
         // Lanes without an intercept carry harmless garbage; `miss` (NaN for them, 0.0 for
         // hits) is the addend of each plane's closing radians -> degrees FMA.
-        if (__any(hit)) {
+        if (hit_mask != 0) {
+            const bool hit = (hit_mask >> threadIdx.x) & 1;  // one wave per workgroup
             stored = true;
             const double miss = hit ? 0.0 : nan;
             // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
@@ -315,8 +319,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             double l = TRI ? p.lon_k[0] * theta : fma(-p.lon_k[1], d, p.lon_k[0] * theta);
             if (l < 0.0) l += kTwoPi;
             const double lon_deg = fma(l, kDeg, miss);
-            const double lat = (polar && sp.z == 0.0) ? kHalfPi
-                                                      : atan2_fast<true>(TRI ? sp.z * p.lat_k : Xf.z * p.a_over_c, rho);
+            // (|Xf| = 1: rho and z never vanish together, atan2 needs no guard here)
+            const double lat = atan2_fast<true>(TRI ? sp.z * p.lat_k : Xf.z * p.a_over_c, rho);
             const double lat_deg = fma(lat, kDeg, miss);
             if (inside) {
                 PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
@@ -328,7 +332,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 double lc = TRI ? theta : fma(-p.g.wdot, d, theta);
                 if (lc <= -kPi) lc += kTwoPi;
                 if (lc > kPi) lc -= kTwoPi;
-                const double bc = (polar && sp.z == 0.0) ? 0.0 : atan2_fast<true>(TRI ? sp.z : Xf.z / p.a_over_c, rho);
+                const double bc = atan2_fast<true>(TRI ? sp.z : Xf.z / p.a_over_c, rho);
                 if (inside) {
                     PM_PUT_ROW(PM_LON_CENTRIC, fma(lc, kDeg, miss));
                     PM_PUT_ROW(PM_LAT_CENTRIC, fma(bc, kDeg, miss));

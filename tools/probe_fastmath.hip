@@ -54,7 +54,7 @@ __global__ void k_probe(double *worst, int per_thread)
         w[F_RCP] = fmax(w[F_RCP], ulps(pm::rcp_fast(b), 1.0 / b));
         w[F_DIV] = fmax(w[F_DIV], ulps(pm::div_fast(a, b), a / b));
         w[F_SQRT] = fmax(w[F_SQRT], ulps(pm::sqrt_fast(b), sqrt(b)));
-        w[F_SQRT_SEED] = fmax(w[F_SQRT_SEED], ulps(pm::sqrt_seed(b), sqrt(b)));
+        w[F_SQRT_SEED] = fmax(w[F_SQRT_SEED], ulps(pm::sqrt_seed_pos(b), sqrt(b)));
         w[F_RSQRT] = fmax(w[F_RSQRT], ulps(pm::rsqrt_fast(b), 1.0 / sqrt(b)));
         const double h = uniform(s) - 0.5;
         w[F_ASIN] = fmax(w[F_ASIN], fabs(pm::asin_half(h) - asin(h)));

@@ -1,0 +1,76 @@
+// probe_issue.hip -- VALU issue cost on gfx950 by instruction class: how many SIMD cycles a
+// wave64 FP64 FMA, a 32-bit integer op, a select and a mix of them take when 8 waves share a SIMD.
+// The spheroid image kernel is VALU-bound; this says which instructions are worth removing.
+//
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probe_issue.hip -o tools/probe_issue
+//   ./tools/probe_issue     # one JSON line per mode; ns_per_inst is per wave instruction per SIMD
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int MODE>
+__global__ __launch_bounds__(64) void k_issue(double *out, int iters, double x, double y, unsigned m)
+{
+    double a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    unsigned b0 = threadIdx.x, b1 = b0 + 1, b2 = b0 + 2, b3 = b0 + 3, b4 = b0 + 4, b5 = b0 + 5, b6 = b0 + 6, b7 = b0 + 7;
+#define FMA(j) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(a##j) : "v"(x), "v"(y));
+#define MUL(j) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(a##j) : "v"(x));
+#define XOR(j) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(b##j) : "v"(m));
+#define CND(j) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(b##j) : "v"(m) : "vcc");
+#define MOV(j) asm volatile("v_mov_b32 %0, %1" : "=v"(b##j) : "v"(m));
+#define FMAXOR(j) FMA(j) XOR(j)
+#define FMACND(j) FMA(j) CND(j)
+    for (int i = 0; i < iters; i++) {
+        if (MODE == 0) { REP8(FMA) REP8(FMA) REP8(FMA) REP8(FMA) }
+        if (MODE == 1) { REP8(XOR) REP8(XOR) REP8(XOR) REP8(XOR) }
+        if (MODE == 2) { REP8(CND) REP8(CND) REP8(CND) REP8(CND) }
+        if (MODE == 3) { REP8(FMAXOR) REP8(FMAXOR) REP8(FMAXOR) REP8(FMAXOR) }
+        if (MODE == 4) { REP8(FMACND) REP8(FMACND) REP8(FMACND) REP8(FMACND) }
+        if (MODE == 5) { REP8(MUL) REP8(MUL) REP8(MUL) REP8(MUL) }
+        if (MODE == 6) { REP8(MOV) REP8(MOV) REP8(MOV) REP8(MOV) }
+    }
+    double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7);
+    if (s == 1.2345) out[0] = s;
+}
+
+template <int MODE>
+static void run(const char *name, int per_iter, int waves_per_simd)
+{
+    double *d = nullptr;
+    (void)hipMalloc(&d, 8);
+    const int iters = 20000;
+    const int blocks = 256 * 4 * waves_per_simd;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float best = 1e30f;
+    for (int rep = 0; rep < 4; rep++) {
+        (void)hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(k_issue<MODE>, dim3(blocks), dim3(64), 0, 0, d, iters, 1.0000001, 1e-9, 0x5a5a5a5au);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (rep && ms < best) best = ms;
+    }
+    const double inst = (double)iters * per_iter * waves_per_simd;  // wave instructions per SIMD
+    printf("{\"mode\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"ns_per_inst\": %.4f}\n", name, waves_per_simd, best,
+           best * 1e6 / inst);
+    (void)hipFree(d);
+}
+
+int main()
+{
+    for (int w : {8, 4}) {
+        run<0>("32 x v_fma_f64", 32, w);
+        run<5>("32 x v_mul_f64", 32, w);
+        run<1>("32 x v_xor_b32", 32, w);
+        run<2>("32 x v_cndmask_b32", 32, w);
+        run<6>("32 x v_mov_b32", 32, w);
+        run<3>("32 x (v_fma_f64 + v_xor_b32)", 64, w);
+        run<4>("32 x (v_fma_f64 + v_cndmask_b32)", 64, w);
+    }
+    return 0;
+}

@@ -290,7 +290,9 @@ def main() -> None:
     del yy, xx, mu
     from planetmapper_amd.distributed import map_cube_sharded_device
 
-    gathered = torch.empty((world, 1, n0, n1), dtype=torch.float64, device=dev)
+    # two result buffers used alternately: a gather may stay in flight for two frames before its
+    # buffer is written again (RCCL latency at 8 ranks is not known to be below one 0.19 ms step)
+    gathered = [torch.empty((world, 1, n0, n1), dtype=torch.float64, device=dev) for _ in range(2)]
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -304,16 +306,20 @@ def main() -> None:
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
         # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only),
         # left in flight so that it overlaps the next frame's backplane kernel
-        pending[0] = map_cube_sharded_device(
-            eng, data, np.float64, 1, xm, ym, n0, n1, gathered, rank, 'linear', True, async_op=True, previous=pending[0]
+        k = counter[0] & 1
+        counter[0] += 1
+        pending[k] = map_cube_sharded_device(
+            eng, data, np.float64, 1, xm, ym, n0, n1, gathered[k], rank, 'linear', True, async_op=True, previous=pending[k]
         )
 
-    pending = [None]  # work handle of the all-gather still in flight
+    pending = [None, None]  # work handles of the all-gathers still in flight, one per buffer
+    counter = [0]
 
     def barrier() -> None:
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        for k in range(2):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

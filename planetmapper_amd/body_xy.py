@@ -515,6 +515,122 @@ class BodyXY:
     def angular2km(self, angular_x, angular_y):
         return self._transform('angular', 'km', angular_x, angular_y)
 
+    # ------------------------------------------------------------------ point functions
+    # The per-point siblings of the backplanes (Body.*_from_lonlat, body.py:2152-2415, 2549-2616,
+    # 2830-2913): the same map-space kernel evaluated at caller-supplied longitude / latitude
+    # points, with the reference's float-or-array broadcasting rule.
+    def _point_planes(self, names, lon, lat, *, alt=0.0, planetocentric=False) -> list:
+        if alt != 0.0:
+            # the reference puts these points `alt` km above the unadjusted ellipsoid (pgrrec),
+            # the map kernel works on the altitude-adjusted ellipsoid of the backplanes
+            raise _lib.UnsupportedError('point functions are provided for alt = 0 only')
+        scalar = np.ndim(lon) == 0 and np.ndim(lat) == 0
+        if planetocentric:
+            lon, lat = self.centric2graphic_lonlat(lon, lat)
+        lon_b, lat_b = np.broadcast_arrays(np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64))
+        shape = lon_b.shape
+        if lon_b.size == 0:
+            return [np.empty(shape) for _ in names]
+        lon2 = np.ascontiguousarray(lon_b.reshape(1, -1))
+        lat2 = np.ascontiguousarray(lat_b.reshape(1, -1))
+        out = self._bind().backplanes_map(list(names), lon2, lat2, alt=0.0)
+        res = [out[n].reshape(shape) for n in names]
+        return [float(r) for r in res] if scalar else res
+
+    def illumination_angles_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):
+        """(phase, incidence, emission) in degrees. body.py:2295-2332"""
+        ph, inc, em = self._point_planes(['PHASE', 'INCIDENCE', 'EMISSION'], lon, lat, alt=alt, planetocentric=planetocentric)
+        return ph, inc, em
+
+    def azimuth_angle_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):
+        """body.py:2334-2374"""
+        return self._point_planes(['AZIMUTH'], lon, lat, alt=alt, planetocentric=planetocentric)[0]
+
+    def distance_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):
+        """Observer -> point distance in km. body.py:2885-2903"""
+        return self._point_planes(['DISTANCE'], lon, lat, alt=alt, planetocentric=planetocentric)[0]
+
+    def radial_velocity_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):
+        """Line-of-sight velocity in km/s. body.py:2858-2883"""
+        return self._point_planes(['RADIAL-VELOCITY'], lon, lat, alt=alt, planetocentric=planetocentric)[0]
+
+    def local_solar_time_from_lon(self, lon):
+        """Local solar time in local hours (et2lst, whole seconds). body.py:2376-2398"""
+        return self._point_planes(['LOCAL-SOLAR-TIME'], lon, np.zeros_like(np.asarray(lon, dtype=np.float64)))[0]
+
+    def local_solar_time_string_from_lon(self, lon) -> str:
+        """'HH:MM:SS', '' for a non-finite longitude. body.py:2400-2415"""
+        lst = float(self.local_solar_time_from_lon(float(lon)))
+        if not math.isfinite(lst):
+            return ''
+        sec = int(round(lst * 3600.0))
+        return f'{sec // 3600:02d}:{sec // 60 % 60:02d}:{sec % 60:02d}'
+
+    def test_if_lonlat_illuminated(self, lon, lat, *, alt=0.0, planetocentric=False):
+        """illumf's `lit` flag: incidence < 90 deg; False for invalid points. body.py:2549-2577"""
+        inc = self._point_planes(['INCIDENCE'], lon, lat, alt=alt, planetocentric=planetocentric)[0]
+        lit = np.asarray(inc) < 90.0
+        return bool(lit) if lit.ndim == 0 else lit
+
+    def test_if_lonlat_visible(self, lon, lat, *, alt=0.0, planetocentric=False):
+        """
+        Whether a point on (or `alt` km above) the body can be seen by the observer
+        (body.py:2152-2180): the `not_visible_nan` rule of the lon/lat transforms.
+        """
+        ra, _ = self.lonlat2radec(lon, lat, alt=alt, not_visible_nan=True, planetocentric=planetocentric)
+        vis = np.isfinite(np.asarray(ra))
+        return bool(vis) if vis.ndim == 0 else vis
+
+    def graphic2centric_lonlat(self, lon, lat, *, alt=0.0):
+        """
+        Planetographic -> planetocentric (east-positive longitude in (-180, 180]) of the point
+        `alt` km above the surface: pgrrec_c then reclat_c (body.py:2915-2943), closed forms.
+        """
+        scalar = np.ndim(lon) == 0 and np.ndim(lat) == 0
+        lon_b, lat_b = np.broadcast_arrays(np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64))
+        a, c = float(self.radii[0]), float(self.radii[2])
+        with np.errstate(invalid='ignore'):
+            ok = np.isfinite(lon_b) & np.isfinite(lat_b)
+            le = np.deg2rad(np.where(ok, lon_b, 0.0)) * (-1.0 if self.positive_longitude_direction == 'W' else 1.0)
+            phi = np.deg2rad(np.where(ok, lat_b, 0.0))
+            e2 = 1.0 - (c / a) ** 2
+            n = a / np.sqrt(1.0 - e2 * np.sin(phi) ** 2)  # georec_c
+            rho = (n + alt) * np.cos(phi)
+            x, y, z = rho * np.cos(le), rho * np.sin(le), (n * (1.0 - e2) + alt) * np.sin(phi)
+            lon_c = np.rad2deg(np.arctan2(y, x))
+            lat_c = np.rad2deg(np.arctan2(z, np.hypot(x, y)))
+        lon_c = np.where(ok, lon_c, np.nan)
+        lat_c = np.where(ok, lat_c, np.nan)
+        return (float(lon_c), float(lat_c)) if scalar else (lon_c, lat_c)
+
+    def centric2graphic_lonlat(self, lon_centric, lat_centric, *, alt=0.0):
+        """
+        Planetocentric -> planetographic: the surface point in that direction (latsrf_c), then
+        recpgr_c (body.py:2945-2982). Spheroids, alt = 0.
+        """
+        if alt != 0.0 or self.radii[0] != self.radii[1]:
+            raise _lib.UnsupportedError('centric2graphic_lonlat is provided for spheroids at alt = 0')
+        scalar = np.ndim(lon_centric) == 0 and np.ndim(lat_centric) == 0
+        lon_b, lat_b = np.broadcast_arrays(
+            np.asarray(lon_centric, dtype=np.float64), np.asarray(lat_centric, dtype=np.float64)
+        )
+        a, c = float(self.radii[0]), float(self.radii[2])
+        with np.errstate(invalid='ignore'):
+            ok = np.isfinite(lon_b) & np.isfinite(lat_b)
+            lam = np.deg2rad(np.where(ok, lon_b, 0.0))
+            th = np.deg2rad(np.where(ok, lat_b, 0.0))
+            # a surface point in direction th has z / rho = tan th; its normal has
+            # tan(graphic latitude) = (a / c)^2 z / rho
+            lat_g = np.rad2deg(np.arctan2((a / c) ** 2 * np.sin(th), np.cos(th)))
+            le = np.arctan2(np.sin(lam) * np.cos(th), np.cos(lam) * np.cos(th))  # recpgr: atan2(y, x)
+            polar = np.cos(th) == 0.0
+            lon_g = np.rad2deg(-le if self.positive_longitude_direction == 'W' else le)
+            lon_g = np.where(lon_g < 0.0, lon_g + 360.0, lon_g)
+            lon_g = np.where(polar, 0.0, lon_g)
+        lon_g = np.where(ok, lon_g, np.nan) + 0.0
+        lat_g = np.where(ok, lat_g, np.nan)
+        return (float(lon_g), float(lat_g)) if scalar else (lon_g, lat_g)
+
     # ------------------------------------------------------------------ map coordinates
     def generate_map_coordinates(
         self,

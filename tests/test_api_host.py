@@ -557,3 +557,88 @@ def test_disc_helpers_kats(jupiter):
                        ((-151724.69753899056, 130727.50016257458), (-125236.31445765976, 117241.42226096484)))  # fmt: skip
     assert np.allclose(body.get_img_limits_angular(),
                        ((-31.984379466325663, 27.98633203326517), (-21.98926088314898, 17.99121344984992)))  # fmt: skip
+
+
+def test_point_functions_kats(body):
+    """
+    The per-point siblings of the backplanes, value tables of the reference's tests/test_body.py:
+    illumination :1826-1863, azimuth :1865-1898, local solar time :1900-1914, visibility
+    :1732-1798, illuminated :1979-2006, radial velocity :2486-2519, distance :2521-2552,
+    graphic <-> centric :2554-2595 (Body('Jupiter', observer='HST', utc='2005-01-01')).
+    """
+    close = lambda a, b, **kw: np.allclose(a, b, equal_nan=True, **kw)  # noqa: E731
+    invalid = [(nan, nan), (nan, 0), (0, nan), (np.inf, np.inf)]
+
+    def both_conventions(func, lonlat, expected, eq=close, **kw):
+        assert eq(func(*lonlat, **kw), expected), (func.__name__, lonlat)
+        for planetocentric in (False, True):
+            ll = body.graphic2centric_lonlat(*lonlat, **{k: v for k, v in kw.items() if k == 'alt'}) if planetocentric else lonlat
+            assert eq(func(*ll, planetocentric=planetocentric, **kw), expected), (func.__name__, lonlat, planetocentric)
+
+    gie = [
+        ((0, 0), (10.31594976458697, 163.2795134457034, 152.99822832991876)),
+        ((123.456, -78.9), (10.316968817304499, 79.16351827229181, 77.68583738495468)),
+    ] + [(ll, (nan, nan, nan)) for ll in invalid]
+    for lonlat, angles in gie:
+        both_conventions(body.illumination_angles_from_lonlat, lonlat, angles)
+    az = [((0, 0), 177.66817822757469), ((123.456, -78.9), 169.57651996164563)] + [(ll, nan) for ll in invalid]
+    for lonlat, angle in az:
+        both_conventions(body.azimuth_angle_from_lonlat, lonlat, angle)
+    rv = [((0, 0), -20.796924908179438), ((45, 45), -17.75706386255955)] + [(ll, nan) for ll in invalid]
+    for lonlat, x in rv:
+        both_conventions(body.radial_velocity_from_lonlat, lonlat, x)
+    dist = [((0, 0), 819701772.0279644), ((45, 45), 819656453.7301536)] + [(ll, nan) for ll in invalid]
+    for lonlat, x in dist:
+        both_conventions(body.distance_from_lonlat, lonlat, x)
+    assert isinstance(body.distance_from_lonlat(0, 0), float)
+    ph, inc, em = body.illumination_angles_from_lonlat(np.array([0.0, 123.456]), np.array([0.0, -78.9]))  # arrays
+    assert ph.shape == (2,) and close(em, (152.99822832991876, 77.68583738495468))
+
+    lst = [
+        (0, 22.89638888888889, '22:53:47'),
+        (-90, 4.896388888888889, '04:53:47'),
+        (123.456, 14.666111111111112, '14:39:58'),
+        (999.999, 4.229722222222223, '04:13:47'),
+        (nan, nan, ''),
+        (np.inf, nan, ''),
+    ]
+    for lon, expected, s in lst:
+        assert np.isclose(body.local_solar_time_from_lon(lon), expected, equal_nan=True), lon
+        assert body.local_solar_time_string_from_lon(lon) == s
+
+    same = lambda a, b: a == b  # noqa: E731
+    for lonlat, visible in [((0, 0), False), ((180, 12), True), ((50, -80), True)] + [(ll, False) for ll in invalid]:
+        both_conventions(body.test_if_lonlat_visible, lonlat, visible, eq=same)
+    for (lon, lat, alt), visible in [
+        ((0, 0, 0), False),
+        ((0, 0, 1000000.0), True),
+        ((153.1, -3.0, 0), True),
+        ((153.1, -3.0, -1), False),
+        ((153.1, -3.0, 1), True),
+        ((153.1, nan, 1), False),
+    ]:
+        assert body.test_if_lonlat_visible(lon, lat, alt=alt) == visible, (lon, lat, alt)
+        assert body.test_if_lonlat_visible(lon, lat, alt=alt, planetocentric=False) == visible
+    for lonlat, lit in [((0, 0), False), ((180, 12), True), ((50, -80), False)] + [(ll, False) for ll in invalid]:
+        both_conventions(body.test_if_lonlat_illuminated, lonlat, lit, eq=same)
+    assert list(body.test_if_lonlat_illuminated(np.array([0.0, 180.0]), np.array([0.0, 12.0]))) == [False, True]
+
+    pairs = [
+        [(0, 0), (0, 0)],
+        [(0, 90), (0, 90)],
+        [(0, -90), (0, -90)],
+        [(90, 0), (-90, 0)],
+        [(123.4, 56.789), (-123.4, 53.17999536010973)],
+        [
+            (np.array([1.0, 2.0, 3.0, nan]), np.array([40.0, 50.0, 60.0, nan])),
+            (np.array([-1.0, -2.0, -3.0, nan]), np.array([36.26969371, 46.18216311, 56.56575448, nan])),
+        ],
+    ]
+    for graphic, centric in pairs:
+        assert close(body.graphic2centric_lonlat(*graphic), centric), graphic
+        assert close(body.centric2graphic_lonlat(*centric), graphic), centric
+    for a in invalid:
+        assert close(body.graphic2centric_lonlat(*a), (nan, nan))
+        assert close(body.centric2graphic_lonlat(*a), (nan, nan))
+    with pytest.raises(UnsupportedError):
+        body.illumination_angles_from_lonlat(0, 0, alt=10.0)

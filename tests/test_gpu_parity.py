@@ -981,3 +981,36 @@ def test_transforms_with_non_finite_inputs(engine, oracle, jupiter):
             assert np.array_equal(np.isnan(got[0]), np.isnan(ref[0])), (src, dst, got[0], ref[0])
             assert np.array_equal(np.isnan(got[1]), np.isnan(ref[1])), (src, dst)
             assert np.isfinite(got[0][0]) or src == dst or np.isnan(ref[0][0])
+
+
+def test_point_functions_on_gpu(jupiter):
+    """
+    Body.*_from_lonlat on the real engine against the reference's value tables
+    (tests/test_body.py:1826-1835, 1866-1868, 1901-1905, 1733-1737, 1764-1771, 1980-1983,
+    2487-2489, 2522-2524) - the same tables tests/test_api_host.py runs on the oracle.
+    """
+    from planetmapper_amd import BodyXY
+
+    body = BodyXY('Jupiter', '2005-01-01T00:00:00', observer='HST', geometry=jupiter)
+    nan = np.nan
+    close = lambda a, b: np.allclose(a, b, equal_nan=True)  # noqa: E731
+    assert close(body.illumination_angles_from_lonlat(0, 0), (10.31594976458697, 163.2795134457034, 152.99822832991876))
+    assert close(
+        body.illumination_angles_from_lonlat(123.456, -78.9), (10.316968817304499, 79.16351827229181, 77.68583738495468)
+    )
+    assert close(body.illumination_angles_from_lonlat(nan, 0), (nan, nan, nan))
+    c = body.graphic2centric_lonlat(123.456, -78.9)
+    assert close(
+        body.illumination_angles_from_lonlat(*c, planetocentric=True),
+        (10.316968817304499, 79.16351827229181, 77.68583738495468),
+    )
+    assert close(body.azimuth_angle_from_lonlat(0, 0), 177.66817822757469)
+    assert close(body.azimuth_angle_from_lonlat(123.456, -78.9), 169.57651996164563)
+    assert close(body.radial_velocity_from_lonlat(np.array([0.0, 45.0]), np.array([0.0, 45.0])), (-20.796924908179438, -17.75706386255955))
+    assert close(body.distance_from_lonlat(45, 45), 819656453.7301536)
+    for lon, expected, s in [(0, 22.89638888888889, '22:53:47'), (999.999, 4.229722222222223, '04:13:47'), (nan, nan, '')]:
+        assert np.isclose(body.local_solar_time_from_lon(lon), expected, equal_nan=True)
+        assert body.local_solar_time_string_from_lon(lon) == s
+    assert [body.test_if_lonlat_visible(*ll) for ll in [(0, 0), (180, 12), (50, -80), (nan, 0)]] == [False, True, True, False]
+    assert [body.test_if_lonlat_visible(lo, la, alt=al) for lo, la, al in [(0, 0, 1e6), (153.1, -3.0, -1), (153.1, -3.0, 1)]] == [True, False, True]
+    assert [body.test_if_lonlat_illuminated(*ll) for ll in [(0, 0), (180, 12), (50, -80), (np.inf, np.inf)]] == [False, True, False, False]

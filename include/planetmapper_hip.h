@@ -253,6 +253,19 @@ int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a,
                  const double *b, double alt, int flags, double *out_a, double *out_b,
                  int mem);
 
+/*
+ * replaces the point forms of the ring / limb backplane loops and of radec2lonlat for n sky
+ * points: Body.radec2lonlat (body.py:1083-1112), Body.ring_plane_coordinates
+ * (body.py:2617-2658; ring_only_visible = its only_visible argument, rule :2598-2611) and
+ * Body.limb_coordinates_from_radec (body.py:2040-2110).
+ * out: 8 arrays of n doubles, array k at out + k * n: planetographic lon, lat [deg] of the
+ * intercept (NaN off the disc), ring-plane radius [km], longitude [deg], distance [km],
+ * limb longitude, latitude [deg], distance above the limb [km]. alt: altitude adjustment of the
+ * surface. Non-finite RA/Dec give NaN rows.
+ */
+int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *dec_deg,
+                   double alt, int ring_only_visible, double *out, int mem);
+
 /* Map-space ---------------------------------------------------------------------- */
 /*
  * replaces BodyXY._get_targvec_map (body_xy.py:3227), _get_illumf_map (:3667),

@@ -52,7 +52,7 @@ EXPORTS = (
     'pm_synchronize', 'pm_stream', 'pm_set_stream', 'pm_device_malloc', 'pm_device_free',
     'pm_memcpy_h2d', 'pm_memcpy_d2h', 'pm_set_geometry', 'pm_set_disc',
     'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube', 'pm_transform',
-    'pm_set_smooth_options', 'pm_backplanes_img_rows', 'pm_set_spline_smoothing',
+    'pm_set_smooth_options', 'pm_backplanes_img_rows', 'pm_set_spline_smoothing', 'pm_radec_query',
 )  # fmt: skip
 
 
@@ -117,6 +117,7 @@ def load() -> ctypes.CDLL:
     lib.pm_transform.argtypes = [
         vp, c_int, c_int, ctypes.c_uint64, vp, vp, ctypes.c_double, c_int, vp, vp, c_int,
     ]  # fmt: skip
+    lib.pm_radec_query.argtypes = [vp, ctypes.c_uint64, vp, vp, ctypes.c_double, c_int, vp, c_int]
     lib.pm_map_cube.argtypes = [
         vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int,
     ]  # fmt: skip

@@ -581,6 +581,28 @@ class BodyXY:
         vis = np.isfinite(np.asarray(ra))
         return bool(vis) if vis.ndim == 0 else vis
 
+    def ring_plane_coordinates(self, ra, dec, only_visible: bool = True):
+        """
+        (ring_radius [km], ring_longitude [deg], ring_distance [km]) of the point of the target's
+        equatorial plane seen at RA/Dec; NaN where that point is hidden by the body when
+        `only_visible`. body.py:2577-2658
+        """
+        scalar = np.ndim(ra) == 0 and np.ndim(dec) == 0
+        q = self._bind().radec_query(ra, dec, ring_only_visible=only_visible)
+        return (float(q[2]), float(q[3]), float(q[4])) if scalar else (q[2], q[3], q[4])
+
+    def limb_coordinates_from_radec(self, ra, dec, *, alt=0.0, planetocentric=False):
+        """
+        (lon, lat, dist): the point of the limb nearest to the RA/Dec ray and the distance of
+        the ray above it in km (negative on the disc). body.py:2040-2110
+        """
+        scalar = np.ndim(ra) == 0 and np.ndim(dec) == 0
+        q = self._bind().radec_query(ra, dec, alt=alt)
+        lon, lat, dist = q[5], q[6], q[7]
+        if planetocentric:
+            lon, lat = self.graphic2centric_lonlat(lon, lat)
+        return (float(lon), float(lat), float(dist)) if scalar else (lon, lat, dist)
+
     def graphic2centric_lonlat(self, lon, lat, *, alt=0.0):
         """
         Planetographic -> planetocentric (east-positive longitude in (-180, 180]) of the point

@@ -600,6 +600,35 @@ int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a, con
     return PM_OK;
 }
 
+int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *dec_deg, double alt,
+                   int ring_only_visible, double *out, int mem)
+{
+    int rc = check_ready(ctx, true);
+    if (rc != PM_OK) return rc;
+    if (n == 0) return PM_OK;
+    if (!ra_deg || !dec_deg || !out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (n > 0xffffffffull * 256ull) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "too many points");
+    if (!std::isfinite(alt))
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Cannot adjust surface altitude with non-finite alt value");
+    pm::Params p;
+    fill_params(ctx, alt, p);
+    if (mem == PM_MEM_DEVICE) {
+        pm_launch_radec_query(p, ra_deg, dec_deg, n, ring_only_visible, out, ctx->stream);
+        PM_HIP(ctx, hipGetLastError());
+        return PM_OK;
+    }
+    rc = ensure_scratch(ctx, (size_t)n * 10 * sizeof(double));
+    if (rc != PM_OK) return rc;
+    double *base = (double *)ctx->scratch;
+    PM_HIP(ctx, hipMemcpyAsync(base, ra_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PM_HIP(ctx, hipMemcpyAsync(base + n, dec_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    pm_launch_radec_query(p, base, base + n, n, ring_only_visible, base + 2 * n, ctx->stream);
+    PM_HIP(ctx, hipGetLastError());
+    PM_HIP(ctx, hipMemcpyAsync(out, base + 2 * n, n * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PM_OK;
+}
+
 int pm_xy_map(pm_ctx *ctx, const double *lon_deg, const double *lat_deg, int n0, int n1, double alt, double *x_map,
               double *y_map, int mem)
 {

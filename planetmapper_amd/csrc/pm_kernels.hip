@@ -742,6 +742,52 @@ __global__ __launch_bounds__(kBlock) void k_transform(const Params p, const Tran
     t.ob[i] = rb_out;
 }
 
+// Sky points -> everything the per-pixel loops derive from a ray, for caller-supplied RA/Dec:
+// Body.radec2lonlat body.py:1083, Body.ring_plane_coordinates body.py:2617-2658 (with its
+// only_visible rule :2598-2611), Body.limb_coordinates_from_radec body.py:2040-2110.
+// out: 8 arrays of n doubles = lon, lat, ring radius, ring lon, ring distance, limb lon,
+// limb lat, limb distance.
+__global__ __launch_bounds__(kBlock) void k_radec_query(const Params p, const double *__restrict__ ra_deg,
+                                                        const double *__restrict__ dec_deg, unsigned long long n,
+                                                        int ring_only_visible, double *__restrict__ out)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double nan = __builtin_nan("");
+    double o[8] = {nan, nan, nan, nan, nan, nan, nan, nan};
+    const double ra = ra_deg[i] * kRad, dec = dec_deg[i] * kRad;
+    if (isfinite(ra) && isfinite(dec)) {  // body.py:964-967
+        const V3 ray = radrec(ra, dec);
+        V3 sp = {nan, nan, nan};
+        double lt = 0.0;
+        const bool hit = sincpt(p, ray, sp, lt);
+        if (hit) {
+            double lon, lat;
+            recpgr_surface(p, sp, lon, lat);
+            o[0] = lon * kDeg;
+            o[1] = lat * kDeg;
+        }
+        double rr, rl, rd;
+        ring_coords(p, ray, rr, rl, rd);
+        if (ring_only_visible && !isnan(rr)) {
+            if (rr - p.radii[0] < 0.0) {
+                rr = rl = rd = nan;  // inside the planet
+            } else if (hit) {
+                V3 pos;
+                M3 R;
+                point_lt<1>(p, sp, lt, pos, R);
+                if (lt * p.g.clight < rd) rr = rl = rd = nan;  // behind the disc
+            }
+        }
+        o[2] = rr;
+        o[3] = rl;
+        o[4] = rd;
+        limb_coords(p, ray, o[5], o[6], o[7]);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[(size_t)k * n + i] = o[k];
+}
+
 }  // namespace pm
 
 // ------------------------------------------------------------------ launchers (called from pm_capi.hip)
@@ -800,6 +846,14 @@ void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStr
 {
     unsigned long long blocks = (t.n + pm::kBlock - 1) / pm::kBlock;
     hipLaunchKernelGGL(pm::k_transform, dim3((unsigned)blocks), dim3(pm::kBlock), 0, s, p, t);
+}
+
+void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *dec, unsigned long long n,
+                           int ring_only_visible, double *out, hipStream_t s)
+{
+    unsigned long long blocks = (n + pm::kBlock - 1) / pm::kBlock;
+    hipLaunchKernelGGL(pm::k_radec_query, dim3((unsigned)blocks), dim3(pm::kBlock), 0, s, p, ra, dec, n,
+                       ring_only_visible, out);
 }
 
 void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s)

@@ -272,6 +272,25 @@ class Engine:
         )
         return oa.reshape(shape), ob.reshape(shape)
 
+    def radec_query(self, ra, dec, *, alt: float = 0.0, ring_only_visible: bool = True) -> np.ndarray:
+        """
+        For sky points (broadcast together): an (8,) + shape array of planetographic lon / lat of
+        the intercept, ring-plane radius / longitude / distance and limb longitude / latitude /
+        distance (Body.radec2lonlat, ring_plane_coordinates, limb_coordinates_from_radec).
+        """
+        ra, dec = np.broadcast_arrays(np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64))
+        shape = ra.shape
+        ra = np.ascontiguousarray(ra).ravel()
+        dec = np.ascontiguousarray(dec).ravel()
+        out = np.empty((8, ra.size), dtype=np.float64)
+        self._check(
+            self._lib.pm_radec_query(
+                self._ctx, ra.size, ra.ctypes.data, dec.ctypes.data, float(alt), 1 if ring_only_visible else 0,
+                out.ctypes.data, _lib.PM_MEM_HOST,
+            )
+        )
+        return out.reshape((8,) + shape)
+
     # ------------------------------------------------------------------ reprojection
     def set_smooth_options(self, oversample_by: int = 5, max_oversampled_img_size: int = 10_000) -> None:
         """`smooth_oversample_by` / `smooth_max_oversampled_img_size` of map_img (body_xy.py:1427-1428)"""

@@ -60,6 +60,11 @@ class OracleEngine:
         res = self.map_cube(cube.numpy()[:n_planes], x_map.numpy(), y_map.numpy(), interpolation, propagate_nan)
         out.reshape(n_planes, n0, n1).copy_(torch.from_numpy(res))
 
+    def radec_query(self, ra, dec, *, alt=0.0, ring_only_visible=True):
+        ra, dec = np.broadcast_arrays(np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64))
+        q = oracle.radec_query(self._g, ra.ravel(), dec.ravel(), alt=alt, ring_only_visible=ring_only_visible)
+        return np.ascontiguousarray(q.T).reshape((8,) + ra.shape)
+
     def transform(self, src, dst, a, b, *, alt=0.0, not_visible_nan=False, planetocentric=False):
         self.calls.append(('transform', src, dst))
         return oracle.transform(self._g, self._d, src, dst, a, b, alt=alt, not_visible_nan=not_visible_nan,

@@ -642,3 +642,36 @@ def test_point_functions_kats(body):
         assert close(body.centric2graphic_lonlat(*a), (nan, nan))
     with pytest.raises(UnsupportedError):
         body.illumination_angles_from_lonlat(0, 0, alt=10.0)
+
+
+def test_ring_and_limb_point_functions_kats(body):
+    """tests/test_body.py:2008-2049 (ring plane) and :1683-1730 (limb, rtol 1e-5 there)"""
+    close = lambda a, b, **kw: np.allclose(a, b, equal_nan=True, **kw)  # noqa: E731
+    ring = [
+        ((0, 0), (nan, nan, nan)),
+        ((196.37198562427025, -5.565793847134351), (nan, nan, nan)),
+        ((196.37347182693253, -5.561472466522512), (1377914.753652832, 152.91772706249577, 818261707.8278764)),
+        ((196.3696997398314, -5.569843641306982), (nan, nan, nan)),
+        ((196.3, -5.5), (9305877.091704229, 145.3644753085151, 810435703.2382222)),
+        ((nan, 0), (nan, nan, nan)),
+    ]
+    for radec, expected in ring:
+        assert close(body.ring_plane_coordinates(*radec), expected), radec
+    assert close(
+        body.ring_plane_coordinates(196.37198562427025, -5.565793847134351, only_visible=False),
+        (4638.105239104683, 156.0690984698183, 819638074.3312378),
+    )
+    r, lo, d = body.ring_plane_coordinates(np.array([196.3, nan]), np.array([-5.5, 0.0]))
+    assert r.shape == (2,) and close(r, (9305877.091704229, nan)) and close(lo, (145.3644753085151, nan))
+    limb = [
+        ((0, 0), (82.72145635455739, -7.331180721378409, 243226446.365406)),
+        ((196.3719829300016, -5.565779946690757), (67.23274105785333, 58.34599234749429, -68089.8880967631)),
+        ((196.372, -5.566), (248.13985326986065, -64.83923990338549, -64857.80811442864)),
+        ((196.3, -5.5), (64.1290135632679, 20.79992677586983, 1320579.9259661217)),
+    ]
+    for radec, expected in limb:
+        assert close(body.limb_coordinates_from_radec(*radec), expected, rtol=1e-5), radec
+        lon_c, lat_c = body.graphic2centric_lonlat(*expected[:2])
+        got = body.limb_coordinates_from_radec(*radec, planetocentric=True)
+        assert close(got, (lon_c, lat_c, expected[2]), rtol=1e-5)
+    assert close(body.limb_coordinates_from_radec(nan, 0), (nan, nan, nan))

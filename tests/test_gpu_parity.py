@@ -1014,3 +1014,49 @@ def test_point_functions_on_gpu(jupiter):
     assert [body.test_if_lonlat_visible(*ll) for ll in [(0, 0), (180, 12), (50, -80), (nan, 0)]] == [False, True, True, False]
     assert [body.test_if_lonlat_visible(lo, la, alt=al) for lo, la, al in [(0, 0, 1e6), (153.1, -3.0, -1), (153.1, -3.0, 1)]] == [True, False, True]
     assert [body.test_if_lonlat_illuminated(*ll) for ll in [(0, 0), (180, 12), (50, -80), (np.inf, np.inf)]] == [False, True, False, False]
+
+
+def test_radec_query_vs_oracle_and_kats(engine, oracle, jupiter, saturn):
+    """
+    pm_radec_query (Body.ring_plane_coordinates / limb_coordinates_from_radec / radec2lonlat at
+    sky points): the reference's value tables (tests/test_body.py:2008-2049, 1683-1730) and the
+    oracle on a grid of sky points around the body, both ring visibility rules, with altitude.
+    """
+    engine.set_geometry(jupiter)
+    engine.set_disc(2.5, 3.1, 3.9, 0.0, 7, 10, True)
+    q = engine.radec_query([196.37347182693253, 196.3, 196.37198562427025, np.nan], [-5.561472466522512, -5.5, -5.565793847134351, 0.0])
+    assert np.allclose(q[2:5, 0], (1377914.753652832, 152.91772706249577, 818261707.8278764))
+    assert np.allclose(q[2:5, 1], (9305877.091704229, 145.3644753085151, 810435703.2382222))
+    assert np.isnan(q[2:5, 2:]).all() and np.isnan(q[:, 3]).all()
+    q = engine.radec_query(196.37198562427025, -5.565793847134351, ring_only_visible=False)
+    assert q.shape == (8,) and np.allclose(q[2:5], (4638.105239104683, 156.0690984698183, 819638074.3312378))
+    q = engine.radec_query([0, 196.3719829300016, 196.372, 196.3], [0, -5.565779946690757, -5.566, -5.5])
+    exp = [
+        (82.72145635455739, -7.331180721378409, 243226446.365406),
+        (67.23274105785333, 58.34599234749429, -68089.8880967631),
+        (248.13985326986065, -64.83923990338549, -64857.80811442864),
+        (64.1290135632679, 20.79992677586983, 1320579.9259661217),
+    ]
+    assert np.allclose(q[5:8].T, exp, rtol=1e-5)
+    rng = np.random.default_rng(7)
+    for g in (jupiter, saturn):
+        engine.set_geometry(g)
+        engine.set_disc(2.5, 3.1, 3.9, 0.0, 7, 10, True)
+        t0 = np.array(g.T0[:])  # observer -> target centre, J2000
+        ra0 = np.rad2deg(np.arctan2(t0[1], t0[0])) % 360.0
+        dec0 = np.rad2deg(np.arcsin(t0[2] / np.linalg.norm(t0)))
+        span = 1.2 * g.diameter_arcsec / 3600.0
+        ra = ra0 + rng.uniform(-span, span, 4000) / np.cos(np.deg2rad(dec0))
+        dec = dec0 + rng.uniform(-span, span, 4000)
+        ra[::97] = np.nan
+        dec[::89] = np.inf
+        for alt, vis in ((0.0, True), (0.0, False), (2500.0, True)):
+            got = engine.radec_query(ra, dec, alt=alt, ring_only_visible=vis)
+            ref = oracle.radec_query(g, ra, dec, alt=alt, ring_only_visible=vis).T
+            assert np.array_equal(np.isnan(got), np.isnan(ref)), (alt, vis)
+            fin = np.isfinite(ref)
+            d = np.abs(got - ref)
+            d[[0, 3, 5]] = np.minimum(d[[0, 3, 5]], 360.0 - d[[0, 3, 5]])
+            scale = np.array([1e-6, 1e-6, 1e-3, 1e-6, 1e-3, 1e-6, 1e-6, 1e-3])[:, None]  # deg / km
+            assert np.all(d[fin] <= np.broadcast_to(scale, d.shape)[fin]), (alt, vis, np.nanmax(d / scale))
+            assert fin[0].sum() > 100 and fin[2].sum() > 1000

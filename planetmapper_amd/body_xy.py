@@ -603,6 +603,53 @@ class BodyXY:
             lon, lat = self.graphic2centric_lonlat(lon, lat)
         return (float(lon), float(lat), float(dist)) if scalar else (lon, lat, dist)
 
+    # Wireframe coordinate producers that are plain applications of the lon/lat transforms
+    # (the limb / terminator ellipses need CSPICE's limbpt / edterm and are not provided).
+    def ring_radec(self, radius: float, npts: int = 360, only_visible: bool = True):
+        """RA/Dec of a ring of `radius` km in the equatorial plane. body.py:2660-2692"""
+        lons = np.linspace(0, 360, npts)
+        return self.lonlat2radec(lons, np.zeros(npts), alt=radius - self.r_eq, not_visible_nan=only_visible)
+
+    def ring_xy(self, radius: float, **kwargs):
+        """body_xy.py:1238-1249"""
+        return self.radec2xy(*self.ring_radec(radius, **kwargs))
+
+    def visible_lon_grid_radec(self, lons, npts: int = 60, *, lat_limit: float = 90.0, alt: float = 0.0,
+                               planetocentric: bool = False) -> list:
+        """Visible parts of lines of constant longitude. body.py:2725-2779"""
+        lats = np.linspace(-lat_limit, lat_limit, npts)
+        out = []
+        for lon in lons:
+            lo, la = np.full(npts, float(lon)), lats
+            if planetocentric:
+                lo, la = self.centric2graphic_lonlat(lo, la)
+            out.append(self.lonlat2radec(lo, la, alt=alt, not_visible_nan=True))
+        return out
+
+    def visible_lat_grid_radec(self, lats, npts: int = 120, *, lat_limit: float = 90.0, alt: float = 0.0,
+                               planetocentric: bool = False) -> list:
+        """Visible parts of lines of constant latitude. body.py:2781-2835"""
+        lons = np.linspace(0, 360, npts)
+        out = []
+        for lat in lats:
+            if abs(lat) > lat_limit:
+                continue
+            lo, la = lons, np.full(npts, float(lat))
+            if planetocentric:
+                lo, la = self.centric2graphic_lonlat(lo, la)
+            out.append(self.lonlat2radec(lo, la, alt=alt, not_visible_nan=True))
+        return out
+
+    def visible_lonlat_grid_radec(self, interval: float = 30, **kwargs) -> list:
+        """Longitude then latitude gridlines every `interval` degrees. body.py:2695-2723"""
+        return self.visible_lon_grid_radec(np.arange(0, 360, interval), **kwargs) + self.visible_lat_grid_radec(
+            np.arange(-90, 90, interval), **kwargs
+        )
+
+    def visible_lonlat_grid_xy(self, *args, **kwargs) -> list:
+        """body_xy.py:1220-1236"""
+        return [self.radec2xy(*rd) for rd in self.visible_lonlat_grid_radec(*args, **kwargs)]
+
     def graphic2centric_lonlat(self, lon, lat, *, alt=0.0):
         """
         Planetographic -> planetocentric (east-positive longitude in (-180, 180]) of the point

@@ -675,3 +675,43 @@ def test_ring_and_limb_point_functions_kats(body):
         got = body.limb_coordinates_from_radec(*radec, planetocentric=True)
         assert close(got, (lon_c, lat_c, expected[2]), rtol=1e-5)
     assert close(body.limb_coordinates_from_radec(nan, 0), (nan, nan, nan))
+
+
+def test_ring_and_grid_wireframe_coordinates_kats(body):
+    """tests/test_body.py:2051-2081 (ring_radec) and :2107-2190 (visible_lonlat_grid_radec)"""
+    close = lambda a, b, **kw: np.allclose(a, b, equal_nan=True, **kw)  # noqa: E731
+    assert close(body.ring_radec(10000, npts=5), (np.full(5, nan), np.full(5, nan)))  # inside Jupiter
+    assert close(
+        body.ring_radec(100000, npts=5),
+        ([nan, 196.36633034, 196.37500382, 196.37764017, nan], [nan, -5.56310623, -5.56681892, -5.56848105, nan]),
+    )
+    assert close(
+        body.ring_radec(123456.789, npts=3, only_visible=False),
+        ([196.36825958, 196.37571178, 196.36825958], [-5.56452821, -5.56705935, -5.56452821]),
+    )
+    assert close(body.ring_radec(nan, npts=2, only_visible=False), ([nan, nan], [nan, nan]))
+    pole = (196.3700663, -5.57005326)
+    expected = [
+        ([pole[0], nan, nan, nan, nan], [pole[1], nan, nan, nan, nan]),
+        ([pole[0], nan, nan, nan, nan], [pole[1], nan, nan, nan, nan]),
+        ([pole[0], 196.36772166, 196.36794262, 196.37034361, nan], [pole[1], -5.56729981, -5.56387245, -5.56148116, nan]),
+        ([pole[0], 196.36970087, 196.37065239, 196.37232288, nan], [pole[1], -5.56808941, -5.56495336, -5.56227057, nan]),
+        ([pole[0], 196.37225066, 196.37414339, 196.37487263, nan], [pole[1], -5.56923855, -5.5665267, -5.56341971, nan]),
+        ([pole[0], 196.37387716, 196.37637019, 196.37649901, nan], [pole[1], -5.57007398, -5.56767064, -5.56425534, nan]),
+        ([pole[0], nan, nan, nan, nan], [pole[1], nan, nan, nan, nan]),
+        ([pole[0], nan, nan, nan, nan], [pole[1], nan, nan, nan, nan]),
+        ([pole[0]] * 5, [pole[1]] * 5),
+        ([nan, 196.36772166, 196.37225066, nan, nan], [nan, -5.56729981, -5.56923855, nan, nan]),
+        ([nan, 196.36794262, 196.37414339, nan, nan], [nan, -5.56387245, -5.5665267, nan, nan]),
+        ([nan, 196.37034361, 196.37487263, nan, nan], [nan, -5.56148116, -5.56341971, nan, nan]),
+    ]
+    got = body.visible_lonlat_grid_radec(interval=45, npts=5)
+    assert len(got) == len(expected)
+    for g, e in zip(got, expected):
+        assert close(g, e), (g, e)
+    # the xy forms are radec2xy of the above (body_xy.py:1220-1249)
+    body.set_img_size(15, 10)
+    body.set_disc_params(5, 8, 3, 45)
+    for (x, y), (ra, dec) in zip(body.visible_lonlat_grid_xy(interval=45, npts=5), got):
+        assert close((x, y), body.radec2xy(ra, dec))
+    assert close(body.ring_xy(123456.789, npts=3, only_visible=False), body.radec2xy(*body.ring_radec(123456.789, npts=3, only_visible=False)))

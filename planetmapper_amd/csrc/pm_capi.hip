@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -21,6 +22,8 @@ namespace pmh {
 
 int fail(pm_ctx *ctx, int code, const char *fmt, ...)
 {
+    static std::mutex mu;  // the smoothing-spline workers report from their own threads
+    std::lock_guard<std::mutex> lock(mu);
     if (ctx) {
         char buf[512];
         va_list ap;
@@ -300,8 +303,11 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->limits) (void)hipFree(ctx->limits);
-    if (ctx->sm_arena) (void)hipFree(ctx->sm_arena);
-    if (ctx->sm_tables_host) (void)hipHostFree(ctx->sm_tables_host);
+    for (auto &w : ctx->sm_workers) {
+        if (w.arena) (void)hipFree(w.arena);
+        if (w.tables_host) (void)hipHostFree(w.tables_host);
+        if (w.stream) (void)hipStreamDestroy(w.stream);
+    }
     for (auto &ac : ctx->axis) {
         if (ac.t) (void)hipFree(ac.t);
         if (ac.lu) (void)hipFree(ac.lu);

@@ -73,9 +73,17 @@ struct pm_ctx {
     int smooth_max_size = 10000;
     double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
     double spline_smoothing = 0.0;  // map_img spline_smoothing (FITPACK s), 0 = interpolating splines
-    void *sm_arena = nullptr;       // device workspace of the smoothing-spline fit
-    void *sm_tables_host = nullptr; // pinned mirror of its table block
-    size_t sm_arena_bytes = 0;
+    // smoothing-spline fits: the planes of a cube are fitted by kSmWorkers host threads, each with
+    // its own stream and workspace (a fit is a chain of small launches + a read-back: several
+    // in flight keep the GPU busy)
+    struct SmWorker {
+        hipStream_t stream = nullptr;
+        void *arena = nullptr;        // device workspace of the fits of one plane
+        void *tables_host = nullptr;  // pinned mirror of its table block
+        size_t arena_bytes = 0;
+    };
+    static constexpr int kSmWorkers = 8;  // upper bound; PM_SM_WORKERS=n selects fewer (default 4)
+    SmWorker sm_workers[kSmWorkers];
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
     bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)

@@ -3,6 +3,9 @@
 // pm_kernels_reproject.hip. Host work here is set-up only: knots + banded factors of the spline
 // axes, the footprint / oversampling grid of 'smooth', and the scalar knot / parameter search of
 // the smoothing splines; all per-pixel arithmetic runs on the GPU.
+#include <atomic>
+#include <thread>
+
 #include "pm_host.hip.h"
 
 namespace pmh {
@@ -302,8 +305,8 @@ struct SmAxis {
     }
 };
 
-// Device workspace of the fits of one (ny, nx) plane (ctx->sm_arena). The small per-fit tables
-// form ONE contiguous block with a pinned host mirror of the same layout (ctx->sm_tables_host):
+// Device workspace of the fits of one (ny, nx) plane (one per worker, pm_ctx::SmWorker). The small
+// per-fit tables form ONE contiguous block with a pinned host mirror of the same layout:
 // a fit uploads them with a single asynchronous copy and reads its residual sums back with another.
 struct SmTables {  // byte offsets inside the table block
     size_t hb_y, hb_x, R_y, R_x, Bp_y, Bp_x, t_y, t_x, lb_y, lb_x, fl_y, fl_x, span_y, span_x, sums, bytes;
@@ -317,8 +320,9 @@ struct SmDevice {
     template <typename T> T *host(size_t off) const { return (T *)(tables_host + off); }
 };
 
-int ensure_sm_arena(pm_ctx *ctx, int ny, int nx, SmDevice &d)
+int ensure_sm_arena(pm_ctx *ctx, pm_ctx::SmWorker &w, int ny, int nx, SmDevice &d)
 {
+    if (!w.stream) PM_HIP(ctx, hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
     const size_t npx = (size_t)ny * nx, mx = (size_t)std::max(ny, nx) + 8;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -334,20 +338,20 @@ int ensure_sm_arena(pm_ctx *ctx, int ny, int nx, SmDevice &d)
     t.sums = take(2 * mx * 8);   // row sums then column sums, read back per fit
     const size_t table_bytes = off;
     const size_t oU = take(npx * 8), oUT = take(npx * 8), oG = take(npx * 8), oCT = take(npx * 8), oRB = take(npx * 8);
-    if (off > ctx->sm_arena_bytes) {
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->sm_arena) PM_HIP(ctx, hipFree(ctx->sm_arena));
-        if (ctx->sm_tables_host) PM_HIP(ctx, hipHostFree(ctx->sm_tables_host));
-        ctx->sm_arena = nullptr;
-        ctx->sm_tables_host = nullptr;
-        ctx->sm_arena_bytes = 0;
-        if (hipMalloc(&ctx->sm_arena, off) != hipSuccess || hipHostMalloc(&ctx->sm_tables_host, table_bytes) != hipSuccess)
+    if (off > w.arena_bytes) {
+        PM_HIP(ctx, hipStreamSynchronize(w.stream));
+        if (w.arena) PM_HIP(ctx, hipFree(w.arena));
+        if (w.tables_host) PM_HIP(ctx, hipHostFree(w.tables_host));
+        w.arena = nullptr;
+        w.tables_host = nullptr;
+        w.arena_bytes = 0;
+        if (hipMalloc(&w.arena, off) != hipSuccess || hipHostMalloc(&w.tables_host, table_bytes) != hipSuccess)
             return fail(ctx, PM_ERR_ALLOC, "allocation of the smoothing-spline workspace (%zu bytes) failed", off);
-        ctx->sm_arena_bytes = off;
+        w.arena_bytes = off;
     }
-    char *b = (char *)ctx->sm_arena;
+    char *b = (char *)w.arena;
     d.tables = b;
-    d.tables_host = (char *)ctx->sm_tables_host;
+    d.tables_host = (char *)w.tables_host;
     d.U = (double *)(b + oU); d.UT = (double *)(b + oUT); d.G = (double *)(b + oG); d.CT = (double *)(b + oCT);
     d.RB = (double *)(b + oRB);
     return PM_OK;
@@ -355,9 +359,8 @@ int ensure_sm_arena(pm_ctx *ctx, int ny, int nx, SmDevice &d)
 
 // one fit for the current knots and p (p <= 0: least-squares spline); returns fp and updates
 // the per-interval residual sums of both axes. z: cleaned plane on the device.
-int sm_fit(pm_ctx *ctx, const double *z, SmAxis &ay, SmAxis &ax, double p, const SmDevice &d, double &fp)
+int sm_fit(pm_ctx *ctx, hipStream_t s, const double *z, SmAxis &ay, SmAxis &ax, double p, const SmDevice &d, double &fp)
 {
-    hipStream_t s = ctx->stream;
     const SmTables &t = d.o;
     auto put = [&](size_t off, const void *src, size_t bytes) { std::memcpy(d.tables_host + off, src, bytes); };
     // (the mirror is rewritten only after the previous fit's read-back has synchronised the stream)
@@ -416,8 +419,8 @@ int sm_fit(pm_ctx *ctx, const double *z, SmAxis &ay, SmAxis &ax, double p, const
 }
 
 // FITPACK fpregr for one cleaned plane: on return ay / ax hold the knots and d.CT the coefficients
-int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_cols, double s, SmAxis &ay, SmAxis &ax,
-              const SmDevice &d)
+int sm_regrid(pm_ctx *ctx, hipStream_t stream, const double *z, int ny, int nx, int k_rows, int k_cols, double s,
+              SmAxis &ay, SmAxis &ax, const SmDevice &d)
 {
     const double tol = 0.001, con1 = 0.1, con9 = 0.9, con4 = 0.04;
     const int maxit = 20;
@@ -431,7 +434,7 @@ int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_co
     // (FITPACK's "x" is the first array axis = image rows, "y" the image columns)
     for (int iter = 0; iter < ny + nx; iter++) {
         poly = (ay.n == nminy && ax.n == nminx);
-        rc = sm_fit(ctx, z, ay, ax, -1.0, d, fp);
+        rc = sm_fit(ctx, stream, z, ay, ax, -1.0, d, fp);
         if (rc != PM_OK) return rc;
         if (poly) fp0 = fp;
         fpms = fp - s;
@@ -464,7 +467,7 @@ int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_co
         double p1 = 0.0, f1 = fp0 - s, p3 = -1.0, f3 = fpms, p = 1.0;
         bool ich1 = false, ich3 = false;
         for (int iter = 0; iter < maxit; iter++) {
-            rc = sm_fit(ctx, z, ay, ax, p, d, fp);
+            rc = sm_fit(ctx, stream, z, ay, ax, p, d, fp);
             if (rc != PM_OK) return rc;
             fpms = fp - s;
             if (std::fabs(fpms) < acc || iter == maxit - 1) break;
@@ -504,19 +507,27 @@ int sm_regrid(pm_ctx *ctx, const double *z, int ny, int nx, int k_rows, int k_co
 int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols, double s)
 {
     const size_t plane_elems = (size_t)a.ny * a.nx;
-    SmDevice d;
-    int rc = ensure_sm_arena(ctx, a.ny, a.nx, d);
-    if (rc != PM_OK) return rc;
     size_t chunk = (size_t)(1ull << 30) / (plane_elems * sizeof(double));
     chunk = std::max<size_t>(1, std::min<size_t>(chunk, (size_t)a.n_planes));
     if (chunk > 32768) chunk = 32768;
-    rc = ensure_work(ctx, chunk * plane_elems * sizeof(double));
+    int rc = ensure_work(ctx, chunk * plane_elems * sizeof(double));
     if (rc != PM_OK) return rc;
     rc = ensure_stats(ctx, chunk);
     if (rc != PM_OK) return rc;
+    // The fit of a plane is a host-driven search (a few dozen fits, each a chain of small launches
+    // and a read-back the next decision waits for): planes are dealt to worker threads, each with
+    // its own stream and workspace, so that several such chains are in flight.
+    int want = 4;
+    if (const char *e = std::getenv("PM_SM_WORKERS")) want = std::atoi(e);
+    want = std::max(1, std::min(want, (int)pm_ctx::kSmWorkers));
+    const int n_workers = (int)std::min<size_t>((size_t)want, std::min<size_t>(chunk, (size_t)a.n_planes));
+    std::vector<SmDevice> devs(n_workers);
+    for (int w = 0; w < n_workers; w++) {
+        rc = ensure_sm_arena(ctx, ctx->sm_workers[w], a.ny, a.nx, devs[w]);
+        if (rc != PM_OK) return rc;
+    }
     std::vector<pm::PlaneStats> stats(chunk);
-    std::vector<double> nan_row((size_t)a.n_map, std::nan(""));
-    SmAxis ay, ax;
+    const std::vector<double> nan_row((size_t)a.n_map, std::nan(""));
     for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += chunk) {
         const int np = (int)std::min(chunk, (size_t)a.n_planes - p0);
         pm::ReprojectArgs b = a;
@@ -530,24 +541,43 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         pm_launch_clean(b, ctx->work, dtype, ctx->stream);
         PM_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->stats, (size_t)np * sizeof(pm::PlaneStats), hipMemcpyDeviceToHost,
                                    ctx->stream));
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int pl = 0; pl < np; pl++) {
-            if (stats[pl].all_nan) {  // body_xy.py:1668-1670: the map of an all-NaN image is all NaN
-                PM_HIP(ctx, hipMemcpyAsync(b.out + (size_t)pl * a.n_map, nan_row.data(), (size_t)a.n_map * 8,
-                                           hipMemcpyHostToDevice, ctx->stream));
-                continue;
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cleaned planes + statistics are complete
+        std::atomic<int> next{0};
+        std::vector<int> rcs(n_workers, PM_OK);
+        auto worker = [&](int w) -> int {
+            PM_HIP(ctx, hipSetDevice(ctx->device));
+            const hipStream_t st = ctx->sm_workers[w].stream;
+            const SmDevice &d = devs[w];
+            SmAxis ay, ax;
+            for (int pl = next.fetch_add(1); pl < np; pl = next.fetch_add(1)) {
+                if (stats[pl].all_nan) {  // body_xy.py:1668-1670: the map of an all-NaN image is all NaN
+                    PM_HIP(ctx, hipMemcpyAsync(b.out + (size_t)pl * a.n_map, nan_row.data(), (size_t)a.n_map * 8,
+                                               hipMemcpyHostToDevice, st));
+                    PM_HIP(ctx, hipStreamSynchronize(st));
+                    continue;
+                }
+                const double *z = ctx->work + (size_t)pl * plane_elems;
+                const int r = sm_regrid(ctx, st, z, a.ny, a.nx, k_rows, k_cols, s, ay, ax, d);
+                if (r != PM_OK) return r;
+                // (knots and spans of the final fit are already in the device table block)
+                pm::SmoothEvalArgs e = {d.CT, d.dev<double>(d.o.t_y), d.dev<double>(d.o.t_x), d.dev<int>(d.o.span_y),
+                                        d.dev<int>(d.o.span_x), ay.nc(), ax.nc(), k_rows, k_cols, pl};
+                pm_launch_sm_eval(b, e, dtype, st);
+                PM_HIP(ctx, hipGetLastError());
+                PM_HIP(ctx, hipStreamSynchronize(st));  // knots / spans are reused by the next plane
             }
-            const double *z = ctx->work + (size_t)pl * plane_elems;
-            rc = sm_regrid(ctx, z, a.ny, a.nx, k_rows, k_cols, s, ay, ax, d);
-            if (rc != PM_OK) return rc;
-            // (knots and spans of the final fit are already in the device table block)
-            pm::SmoothEvalArgs e = {d.CT, d.dev<double>(d.o.t_y), d.dev<double>(d.o.t_x), d.dev<int>(d.o.span_y),
-                                    d.dev<int>(d.o.span_x), ay.nc(), ax.nc(), k_rows, k_cols, pl};
-            pm_launch_sm_eval(b, e, dtype, ctx->stream);
-            PM_HIP(ctx, hipGetLastError());
-            PM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // knots / spans are reused by the next plane
+            return PM_OK;
+        };
+        const int active = std::min(n_workers, np);
+        if (active <= 1) {
+            rcs[0] = worker(0);
+        } else {
+            std::vector<std::thread> threads;
+            for (int w = 0; w < active; w++) threads.emplace_back([&, w] { rcs[w] = worker(w); });
+            for (auto &t : threads) t.join();
         }
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int w = 0; w < active; w++)
+            if (rcs[w] != PM_OK) return rcs[w];
     }
     return PM_OK;
 }

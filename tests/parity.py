@@ -100,17 +100,23 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
         tol['LIMB-LAT-GRAPHIC'] = tol['LIMB-LON-GRAPHIC'] = 1e-6
     # ring plane: intercept distance s = k / (n.u); 1 ulp of n.u moves the intercept by
     # ~2e-6 km for Jupiter's 3 deg opening, more towards the plane horizon
+    # (in general: 10 half-ulps of the unit ray x distance / sin(ring opening angle), never below
+    #  the 2e-5 km calibrated on the Jupiter / HST geometry)
+    t0 = np.array(g.T0[:])
+    dist = float(np.linalg.norm(t0))
+    sin_b = max(abs(float(np.dot(np.array(g.ring_n[:]), t0))) / dist, 1e-6)
+    ring_pos = max(2e-5, 10 * 1.11e-16 * dist / sin_b)
     if 'RING-RADIUS' in ref:
         rad = np.abs(ref['RING-RADIUS'])
-        tol['RING-RADIUS'] = 2e-5 + 1e-11 * rad
-        tol['RING-LON-GRAPHIC'] = BASE_DEG + np.rad2deg(2e-5 / np.clip(rad, 1.0, None))
+        tol['RING-RADIUS'] = ring_pos + 1e-11 * rad
+        tol['RING-LON-GRAPHIC'] = BASE_DEG + np.rad2deg(ring_pos / np.clip(rad, 1.0, None))
     else:
         tol['RING-RADIUS'] = 1e-3
         tol['RING-LON-GRAPHIC'] = 1e-7
     if 'RING-DISTANCE' in ref:
         rd = ref['RING-DISTANCE']
         rd_min = np.nanmin(rd) if np.isfinite(rd).any() else 0.0
-        tol['RING-DISTANCE'] = 2e-4 + 1e-11 * np.abs(rd - rd_min)
+        tol['RING-DISTANCE'] = 10 * ring_pos + 1e-11 * np.abs(rd - rd_min)
     else:
         tol['RING-DISTANCE'] = 1e-3
     return tol

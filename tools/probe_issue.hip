@@ -20,6 +20,10 @@ __global__ __launch_bounds__(64) void k_issue(double *out, int iters, double x, 
 #define XOR(j) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(b##j) : "v"(m));
 #define CND(j) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(b##j) : "v"(m) : "vcc");
 #define MOV(j) asm volatile("v_mov_b32 %0, %1" : "=v"(b##j) : "v"(m));
+#define RSQ(j) asm volatile("v_rsq_f64 %0, %0" : "+v"(a##j));
+#define RCP(j) asm volatile("v_rcp_f64 %0, %0" : "+v"(a##j));
+#define CMP(j) asm volatile("v_cmp_lt_f64 vcc, %0, %1" ::"v"(a##j), "v"(x) : "vcc");
+#define FMARSQ(j) FMA(j) FMA(j) FMA(j) RSQ(j)
 #define FMAXOR(j) FMA(j) XOR(j)
 #define FMACND(j) FMA(j) CND(j)
     for (int i = 0; i < iters; i++) {
@@ -30,6 +34,10 @@ __global__ __launch_bounds__(64) void k_issue(double *out, int iters, double x, 
         if (MODE == 4) { REP8(FMACND) REP8(FMACND) REP8(FMACND) REP8(FMACND) }
         if (MODE == 5) { REP8(MUL) REP8(MUL) REP8(MUL) REP8(MUL) }
         if (MODE == 6) { REP8(MOV) REP8(MOV) REP8(MOV) REP8(MOV) }
+        if (MODE == 7) { REP8(RSQ) REP8(RSQ) REP8(RSQ) REP8(RSQ) }
+        if (MODE == 8) { REP8(RCP) REP8(RCP) REP8(RCP) REP8(RCP) }
+        if (MODE == 9) { REP8(CMP) REP8(CMP) REP8(CMP) REP8(CMP) }
+        if (MODE == 10) { REP8(FMARSQ) REP8(FMARSQ) REP8(FMARSQ) REP8(FMARSQ) }
     }
     double s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (double)(b0 ^ b1 ^ b2 ^ b3 ^ b4 ^ b5 ^ b6 ^ b7);
     if (s == 1.2345) out[0] = s;
@@ -71,6 +79,10 @@ int main()
         run<6>("32 x v_mov_b32", 32, w);
         run<3>("32 x (v_fma_f64 + v_xor_b32)", 64, w);
         run<4>("32 x (v_fma_f64 + v_cndmask_b32)", 64, w);
+        run<7>("32 x v_rsq_f64", 32, w);
+        run<8>("32 x v_rcp_f64", 32, w);
+        run<9>("32 x v_cmp_lt_f64", 32, w);
+        run<10>("32 x (3 v_fma_f64 + v_rsq_f64)", 128, w);
     }
     return 0;
 }

@@ -45,6 +45,18 @@ def _try_get_header_value(kw: dict, header: Header, key: str, candidates, value_
             return
 
 
+class GetWavelengthsError(Exception):
+    """utils.GetWavelengthsError"""
+
+
+def _angular_dist(ra1: float, dec1: float, ra2: float, dec2: float) -> float:
+    """SpiceBase.angular_dist base.py:690-716: great-circle separation in degrees"""
+    d1, d2 = np.deg2rad(dec1), np.deg2rad(dec2)
+    return float(
+        np.rad2deg(np.arccos(np.clip(np.sin(d1) * np.sin(d2) + np.cos(d1) * np.cos(d2) * np.cos(np.deg2rad(ra1) - np.deg2rad(ra2)), -1.0, 1.0)))
+    )
+
+
 class Observation(BodyXY):
     """
     Args:
@@ -144,6 +156,114 @@ class Observation(BodyXY):
                 except (KeyError, TypeError):
                     pass
             _try_get_header_value(kw, header, 'utc', ['DATE-OBS', 'DATE-BEG', 'DATE-END', 'MJD-BEG', 'MJD-END'])
+
+    # ------------------------------------------------------------------ automatic disc parameters
+    def reset_disc_params(self) -> str:
+        """
+        observation.py:376-397: the disc parameters a previous run stored in the header, else those
+        implied by the header's WCS, else `BodyXY.reset_disc_params` (centred disc).
+        """
+        try:
+            self.disc_from_header()
+        except ValueError:
+            try:
+                self.disc_from_wcs(suppress_warnings=True)
+            except ValueError:
+                return super().reset_disc_params()
+        return self.get_disc_method()
+
+    def _get_disc_params_from_wcs(self, suppress_warnings: bool = False, validate: bool = True,
+                                  use_header_offsets: bool = True,
+                                  distortion_warning_threshold: float | None = 0.25) -> tuple[float, float, float, float]:
+        """
+        observation.py:434-490 on the numpy gnomonic WCS of `wcs.py` (the reference uses astropy.wcs;
+        headers with distortion terms or another projection raise ValueError here).
+        """
+        from .wcs import TanWCS
+
+        wcs = TanWCS(self.header)
+        x0, y0 = wcs.world_to_pixel_values(self.target_ra, self.target_dec)
+        if not (np.isfinite(x0) and np.isfinite(y0)):
+            raise ValueError('target is not on the hemisphere of the WCS tangent point')
+        b1, b2 = wcs.pixel_to_world_values(x0, y0 + 1)
+        c1, c2 = wcs.pixel_to_world_values(x0, y0)
+        rotation = float(np.rad2deg(np.arctan2(b1 - c1, b2 - c2)))
+        s = _angular_dist(b1, b2, c1, c2)  # degrees per pixel
+        r0 = self.target_diameter_arcsec / (2 * s * 3600.0)
+        x0, y0 = float(x0), float(y0)
+        if use_header_offsets:
+            dra = float(self.header.get('HIERARCH NAV RA_OFFSET', 0.0))
+            ddec = float(self.header.get('HIERARCH NAV DEC_OFFSET', 0.0))
+            if dra != 0 or ddec != 0:
+                # a throwaway BodyXY applies the offsets exactly like add_arcsec_offset
+                body = self.to_body_xy()
+                body.set_disc_params(x0, y0, r0, rotation)
+                body.add_arcsec_offset(dra_arcsec=dra, ddec_arcsec=ddec)
+                x0, y0, r0, rotation = body.get_disc_params()
+        return x0, y0, r0, rotation
+
+    def disc_from_wcs(self, suppress_warnings: bool = False, validate: bool = True, use_header_offsets: bool = True,
+                      distortion_warning_threshold: float | None = 0.25) -> None:
+        """observation.py:502-558"""
+        x0, y0, r0, rotation = self._get_disc_params_from_wcs(
+            suppress_warnings, validate, use_header_offsets, distortion_warning_threshold
+        )
+        self.set_x0(x0)
+        self.set_y0(y0)
+        self.set_r0(r0)
+        self.set_rotation(rotation)
+        self.set_disc_method('wcs')
+
+    def position_from_wcs(self, *args, **kwargs) -> None:
+        """observation.py:560-577"""
+        x0, y0, _, _ = self._get_disc_params_from_wcs(*args, **kwargs)
+        self.set_x0(x0)
+        self.set_y0(y0)
+        self.set_disc_method('wcs_position')
+
+    def rotation_from_wcs(self, *args, **kwargs) -> None:
+        """observation.py:579-594"""
+        self.set_rotation(self._get_disc_params_from_wcs(*args, **kwargs)[3])
+        self.set_disc_method('wcs_rotation')
+
+    def plate_scale_from_wcs(self, *args, **kwargs) -> None:
+        """observation.py:596-612"""
+        self.set_r0(self._get_disc_params_from_wcs(*args, **kwargs)[2])
+        self.set_disc_method('wcs_plate_scale')
+
+    def get_wcs_offset(self, *args, **kwargs) -> tuple[float, float, float, float]:
+        """(dx, dy, dr, drotation) of the current disc from the WCS one. observation.py:614-668"""
+        x0, y0, r0, rotation = self._get_disc_params_from_wcs(*args, **kwargs)
+        return self.get_x0() - x0, self.get_y0() - y0, self.get_r0() - r0, (self.get_rotation() - rotation) % 360
+
+    def get_wcs_arcsec_offset(self, *args, check_is_position_offset_only: bool = True, **kwargs) -> tuple[float, float]:
+        """(dra_arcsec, ddec_arcsec) of the current disc from the WCS one. observation.py:670-748"""
+        dx, dy, dr, drotation = self.get_wcs_offset(*args, **kwargs)
+        ra0, dec0 = self.xy2radec(0, 0)
+        ra1, dec1 = self.xy2radec(dx, dy)
+        if check_is_position_offset_only:
+            if abs(dr) > 1e-3:
+                raise ValueError(f'r0 is different between WCS and observation (dr={dr})')
+            if abs((drotation + 180) % 360 - 180) > 1e-3:
+                raise ValueError(f'rotation is different between WCS and observation (drotation={drotation})')
+        return (ra1 - ra0) * 3600, (dec1 - dec0) * 3600
+
+    def get_wavelengths_from_header(self, *, check_ctype: bool = True) -> np.ndarray:
+        """
+        Wavelengths of the cube's planes from NAXIS3 / CRVAL3 / CDELT3 (or CD3_3) / CRPIX3
+        (observation.py:346-373, utils.generate_wavelengths_from_header).
+        """
+        h = self.header
+        try:
+            if check_ctype and str(h['CTYPE3']).strip() != 'WAVE':
+                raise GetWavelengthsError('Header item CTYPE3 is not WAVE')
+            naxis3 = int(h['NAXIS3'])
+            wavl0 = float(h['CRVAL3'])
+            dwavl = float(h['CDELT3']) if 'CDELT3' in h else float(h['CD3_3'])
+            i0 = float(h.get('CRPIX3', 1))
+        except KeyError as exc:
+            raise GetWavelengthsError('Could not find required header keywords') from exc
+        return wavl0 + (np.arange(1, naxis3 + 1) - i0) * dwavl
 
     def disc_from_header(self) -> None:
         """observation.py:399-425: take x0, y0, r0, rotation from the `HIERARCH PLANMAP DISC ...`

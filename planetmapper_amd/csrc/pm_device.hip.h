@@ -545,7 +545,7 @@ __device__ __forceinline__ void recpgr_general(const Params &p, V3 v, double &lo
 // but Newton starts from the tightest lower bound lam0 = max(a rho - a^2, c|z| - c^2, 0 if
 // outside) - for ring-plane points (z ~ 0) that IS the root, so 1-2 steps suffice - and each
 // step uses reciprocals instead of five divisions.
-__device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lon_east, double &alt)
+__device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lon_east, double &alt, bool care = true)
 {
     const double a = p.radii[0], c = p.radii[2];
     const double a2 = a * a, c2 = c * c;
@@ -555,6 +555,25 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     lon_east = (rho2 == 0.0) ? 0.0 : atan2_fast(v.y, v.x);
     if (q == 0.0) {
         alt = -fmin(a, c);
+        return;
+    }
+    // Ring-plane intercepts lie within a few km of the equatorial plane (PM's obsvec -> targvec
+    // transform is not exactly plane-preserving) and outside the body. For such a point the
+    // multiplier of the near point is lam0 = a (rho - a) up to eps^2 = (c z / (c^2 + lam0))^2 ~ 1e-11
+    // relative, which gives the near point (a (1 - eps^2 / 2), c eps) and the altitude in closed
+    // form: dx sqrt(1 + (dz / dx)^2) = dx (1 + (dz / dx)^2 / 2) with (dz / dx)^2 <= 1e-6 under the
+    // guard below (next term 1e-13 relative). The two reciprocals only scale 1e-5-sized
+    // corrections: raw 2^-24 seeds do. This replaces the Newton iteration and its finish - ten
+    // reciprocal / square-root seeds and ~90 FP64 operations per pixel of a ring frame.
+    // (care: lanes whose result is used; the others must not veto the wave-uniform choice)
+    if (__all(!care || (rho > a && fabs(v.z) <= 1e-3 * (rho - a)))) {
+        const double dxa = rho - a;
+        const double rc = __builtin_amdgcn_rcp(fma(a, dxa, c2));  // 1 / (c^2 + lam0)
+        const double e = (c * v.z) * rc;
+        const double dx = fma(0.5 * a * e, e, dxa);  // rho - a (1 - e^2 / 2)
+        const double dz = fma(-c, e, v.z);
+        const double t = dz * __builtin_amdgcn_rcp(dx);
+        alt = dx * fma(0.5 * t, t, 1.0);
         return;
     }
     const double l1 = (rho != 0.0) ? fma(a, rho, -a2) : -1e300;

@@ -429,7 +429,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1],
                            ob.z + p.g.sub_sp[2]};
             double le, alt;
-            recpgr_alt_lon(p, tv, le, alt);
+            recpgr_alt_lon(p, tv, le, alt, ok);
             double l = p.g.west_positive ? -le : le;
             if (l < 0.0) l += kTwoPi;
             // hidden behind the disc (NaN compares false): body_xy.py:4077-4080

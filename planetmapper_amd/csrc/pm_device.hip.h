@@ -551,12 +551,7 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     const double a2 = a * a, c2 = c * c;
     const double rho2 = fma(v.x, v.x, v.y * v.y);
     const double rho = sqrt_fast(rho2);
-    const double q = rho2 * (p.ira * p.ira) + (v.z * v.z) * (p.irc * p.irc);
     lon_east = (rho2 == 0.0) ? 0.0 : atan2_fast(v.y, v.x);
-    if (q == 0.0) {
-        alt = -fmin(a, c);
-        return;
-    }
     // Ring-plane intercepts lie within a few km of the equatorial plane (PM's obsvec -> targvec
     // transform is not exactly plane-preserving) and outside the body. For such a point the
     // multiplier of the near point is lam0 = a (rho - a) up to eps^2 = (c z / (c^2 + lam0))^2 ~ 1e-11
@@ -574,6 +569,11 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
         const double dz = fma(-c, e, v.z);
         const double t = dz * __builtin_amdgcn_rcp(dx);
         alt = dx * fma(0.5 * t, t, 1.0);
+        return;
+    }
+    const double q = rho2 * (p.ira * p.ira) + (v.z * v.z) * (p.irc * p.irc);
+    if (q == 0.0) {
+        alt = -fmin(a, c);
         return;
     }
     const double l1 = (rho != 0.0) ? fma(a, rho, -a2) : -1e300;

@@ -424,7 +424,12 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double dd = sqrt_fast(dot(w, w)) - p.g.sub_dist;
             const double t = p.g.sub_et - dd * p.inv_c;
             double sa, ca;
-            sincos_auto(p.g.wdot * (t - p.t0), sa, ca);
+            const double ang = p.g.wdot * (t - p.t0);  // spin over the light-time offset: ~1e-4 rad
+            if (__all(!ok || fabs(ang) <= 1e-3)) {
+                sincos_tiny(ang, sa, ca);
+            } else {
+                sincos_auto(ang, sa, ca);
+            }
             const V3 ob = mxv(p.g.R0, off);  // R(t) off = Rz_frame(ang) (R0 off)
             const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1],
                            ob.z + p.g.sub_sp[2]};
@@ -433,7 +438,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             double l = p.g.west_positive ? -le : le;
             if (l < 0.0) l += kTwoPi;
             // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
-            const double rdist = sqrt_fast(dot(ip, ip));
+            // (|ip| = s |ray| and the ray is a unit vector to 1e-16: no norm needed)
+            const double rdist = s;
             if (ok && !(rdist > dist_lt)) {
                 rr = alt + p.radii[0];
                 rl = l * kDeg;

@@ -189,6 +189,9 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     rot(g.VS, p.VSB, 1.0);
     rot(g.AS, p.ASB, 1.0);
     rot(g.VO, p.VOB, 1.0);
+    rot(g.ring_n, p.ring_nb, 1.0);
+    rot(g.sub_obsvec, p.sub_obs_b, 1.0);
+    rot(g.sub_ray, p.sub_ray_b, 1.0);
     p.ira = 1.0 / p.radii[0];
     p.irc = 1.0 / p.radii[2];
     p.inv_c = 1.0 / g.clight;

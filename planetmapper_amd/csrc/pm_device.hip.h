@@ -114,6 +114,7 @@ struct Params {
     uint32_t row_magic;  // d = rows
     uint32_t col_blocks, col_magic;  // d = column blocks of the spheroid kernel, ceil(nx / kSphBlock)
     uint32_t pad_;
+    double ring_nb[3], sub_obs_b[3], sub_ray_b[3];  // R0 ring_n, R0 sub_obsvec, R0 sub_ray: ring block in B0
     double lt_tol;       // CSPICE's light-time stopping rule: 1e-17 |et - lt|  (lt varies by 1e-9 relative over a disc)
 };
 

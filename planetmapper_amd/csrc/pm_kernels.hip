@@ -226,8 +226,55 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         va = v3(cr * cd, sr * cd, sd);
     }
 
+    // the ray in B0 (both the ring and the disc block work there)
+    V3 u = {0.0, 0.0, 0.0};
+    if (any_cand || (FLAGS & DF_RING)) u = mxv(p.C, va);
+
+    if (FLAGS & DF_RING) {
+        // Body._ring_coordinates_from_obsvec(only_visible=False) body.py:2577-2615 for EVERY
+        // pixel: inrypl_c, PM's _obsvec2targvec (body.py:972-1006; it mixes J2000 and body-fixed
+        // components by design) and recpgr_c of the in-plane point. (The reference rebuilds the ray
+        // from RA/Dec in degrees, body_xy.py:3262; that round trip perturbs it by < 1 ulp - below
+        // the rounding of the ray itself - and is not replayed.)
+        // Everything is taken in B0: R0 (s ray - sub_obsvec) = s u - R0 sub_obsvec, lengths and the
+        // plane equation are rotation invariant. The J2000 formulation needs the matrices M and R0
+        // and five J2000 vectors as scalar constants on top of the disc block's - hipcc spilled 104
+        // scalar registers to VGPR lanes (~270 v_readlane / v_writelane per wave); the B0 constants
+        // are three vectors, and 18 FP64 operations of matrix products go as well.
+        const double pd = dot(u, ld3(p.ring_nb));
+        const double kk = p.g.ring_k;
+        const bool ok = (kk == 0.0) ? (pd != 0.0) : (pd > 0.0 && kk < pd * (1.7976931348623157e308 / 3.0));
+        if (__any(ok)) {
+            // lanes without an intersection carry a harmless finite point through the math
+            const double s = !ok ? 1.0 : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
+            const V3 ob = {fma(s, u.x, -p.sub_obs_b[0]), fma(s, u.y, -p.sub_obs_b[1]), fma(s, u.z, -p.sub_obs_b[2])};
+            const V3 w = ob - ld3(p.sub_ray_b);
+            const double dd = sqrt_fast(dot(w, w)) - p.g.sub_dist;
+            const double t = p.g.sub_et - dd * p.inv_c;
+            double sa, ca;
+            const double ang = p.g.wdot * (t - p.t0);  // spin over the light-time offset: ~1e-4 rad
+            if (__all(!ok || fabs(ang) <= 1e-3)) {
+                sincos_tiny(ang, sa, ca);
+            } else {
+                sincos_auto(ang, sa, ca);
+            }
+            // R(t) off = Rz_frame(ang) (R0 off)
+            const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1],
+                           ob.z + p.g.sub_sp[2]};
+            double le, alt;
+            recpgr_alt_lon(p, tv, le, alt, ok);
+            double l = p.g.west_positive ? -le : le;
+            if (l < 0.0) l += kTwoPi;
+            // (|s ray| = s: the ray is a unit vector to 1e-16, no norm needed)
+            if (ok) {
+                rr = alt + p.radii[0];
+                rl = l * kDeg;
+                rd = s;
+            }
+        }
+    }
+
     if (any_cand) {
-        const V3 u = mxv(p.C, va);  // ray in B0
 
         // surfpt_c in scaled coordinates; for a spheroid X and 1/(X.X) are fixed for the pixel
         V3 X = {u.x * p.ir[0], u.y * p.ir[1], u.z * p.ir[2]};
@@ -405,50 +452,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         }
     }
 
-    if (FLAGS & DF_RING) {
-        // Body._ring_coordinates_from_obsvec(only_visible=False) body.py:2577-2615 for EVERY
-        // pixel: inrypl_c with the J2000 ray, PM's _obsvec2targvec (body.py:972-1006; it mixes
-        // J2000 and body-fixed components by design) and recpgr_c of the in-plane point. (The
-        // reference rebuilds the ray from RA/Dec in degrees, body_xy.py:3262; that round trip
-        // perturbs it by < 1 ulp - below the rounding of the ray itself - and is not replayed.)
-        const V3 ray = mtxv(p.g.M, va);
-        const double pd = dot(ray, ld3(p.g.ring_n));
-        const double kk = p.g.ring_k;
-        const bool ok = (kk == 0.0) ? (pd != 0.0) : (pd > 0.0 && kk < pd * (1.7976931348623157e308 / 3.0));
-        if (__any(ok)) {
-            // lanes without an intersection carry a harmless finite point through the math
-            const double s = !ok ? 1.0 : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
-            const V3 ip = s * ray;
-            const V3 off = ip - ld3(p.g.sub_obsvec);
-            const V3 w = off - ld3(p.g.sub_ray);
-            const double dd = sqrt_fast(dot(w, w)) - p.g.sub_dist;
-            const double t = p.g.sub_et - dd * p.inv_c;
-            double sa, ca;
-            const double ang = p.g.wdot * (t - p.t0);  // spin over the light-time offset: ~1e-4 rad
-            if (__all(!ok || fabs(ang) <= 1e-3)) {
-                sincos_tiny(ang, sa, ca);
-            } else {
-                sincos_auto(ang, sa, ca);
-            }
-            const V3 ob = mxv(p.g.R0, off);  // R(t) off = Rz_frame(ang) (R0 off)
-            const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1],
-                           ob.z + p.g.sub_sp[2]};
-            double le, alt;
-            recpgr_alt_lon(p, tv, le, alt, ok);
-            double l = p.g.west_positive ? -le : le;
-            if (l < 0.0) l += kTwoPi;
-            // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
-            // (|ip| = s |ray| and the ray is a unit vector to 1e-16: no norm needed)
-            const double rdist = s;
-            if (ok && !(rdist > dist_lt)) {
-                rr = alt + p.radii[0];
-                rl = l * kDeg;
-                rd = rdist;
-            }
-        }
-    }
-
     if ((FLAGS & DF_RING) && inside) {
+        // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
+        if (rd > dist_lt) rr = rl = rd = nan;
         PM_PUT_ROW(PM_RING_RADIUS, rr);
         PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
         PM_PUT_ROW(PM_RING_DISTANCE, rd);

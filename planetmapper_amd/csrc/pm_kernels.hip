@@ -275,22 +275,28 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     }
 
     if (any_cand) {
+        // The disc block reads its constants through a laundered copy of the kernel-argument pointer:
+        // hipcc otherwise loads them at kernel entry, ahead of the ring block, and - out of scalar
+        // registers - parks them in VGPR lanes (v_writelane / v_readlane) until they are needed here.
+        const __attribute__((address_space(4))) Params *kp =
+            (const __attribute__((address_space(4))) Params *)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
 
         // surfpt_c in scaled coordinates; for a spheroid X and 1/(X.X) are fixed for the pixel
-        V3 X = {u.x * p.ir[0], u.y * p.ir[1], u.z * p.ir[2]};
+        V3 X = {u.x * kp->ir[0], u.y * kp->ir[1], u.z * kp->ir[2]};
         double ixx = rcp_fast(dot(X, X));
         double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
         // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
-        double lt = p.g.lt_c, d = 0.0, k = 0.0, root = 0.0;
+        double lt = kp->g.lt_c, d = 0.0, k = 0.0, root = 0.0;
         V3 P = {0.0, 0.0, 0.0};
         // lanes still holding an intercept, as a wave-uniform mask in scalar registers (a
         // per-lane bool carried around the loop costs four VALU operations per evaluation)
         unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(cand);
         // An FMA takes one scalar operand: with VBs there, O0s has to sit in vector registers.
         // Pinned outside the loop (left alone, hipcc re-copies the three pairs every evaluation).
-        double o0x = p.O0s[0], o0y = p.O0s[1], o0z = p.O0s[2];
+        double o0x = kp->O0s[0], o0y = kp->O0s[1], o0z = kp->O0s[2];
         if (!TRI) asm volatile("" : "+v"(o0x), "+v"(o0y), "+v"(o0z));
         // One evaluation of the intercept with the target taken d seconds after t0; returns the
         // light time it implies. (The target's acceleration moves it by A d^2 / 2 < 1e-8 km over
@@ -300,18 +306,18 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             V3 Y;
             if (first) {
                 // t0 = et - lt_c on the host, the same subtraction as on the device: d == 0 exactly
-                Y = TRI ? v3(p.O0[0] * p.ir[0], p.O0[1] * p.ir[1], p.O0[2] * p.ir[2]) : v3(o0x, o0y, o0z);
+                Y = TRI ? v3(kp->O0[0] * kp->ir[0], kp->O0[1] * kp->ir[1], kp->O0[2] * kp->ir[2]) : v3(o0x, o0y, o0z);
             } else if (TRI) {
-                const V3 obs = {fma(-p.VB[0], dd, p.O0[0]), fma(-p.VB[1], dd, p.O0[1]), fma(-p.VB[2], dd, p.O0[2])};
-                const double dl = p.g.wdot * dd, d2 = dl * dl;  // |dl| < 1e-3 (host check)
+                const V3 obs = {fma(-kp->VB[0], dd, kp->O0[0]), fma(-kp->VB[1], dd, kp->O0[1]), fma(-kp->VB[2], dd, kp->O0[2])};
+                const double dl = kp->g.wdot * dd, d2 = dl * dl;  // |dl| < 1e-3 (host check)
                 cz = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
                 sz = dl * fma(d2, -1.0 / 6.0, 1.0);
                 const V3 ub = {fma(cz, u.x, sz * u.y), fma(cz, u.y, -sz * u.x), u.z};
-                X = {ub.x * p.ir[0], ub.y * p.ir[1], ub.z * p.ir[2]};
+                X = {ub.x * kp->ir[0], ub.y * kp->ir[1], ub.z * kp->ir[2]};
                 ixx = rcp_fast(dot(X, X));
-                Y = {fma(cz, obs.x, sz * obs.y) * p.ir[0], fma(cz, obs.y, -sz * obs.x) * p.ir[1], obs.z * p.ir[2]};
+                Y = {fma(cz, obs.x, sz * obs.y) * kp->ir[0], fma(cz, obs.y, -sz * obs.x) * kp->ir[1], obs.z * kp->ir[2]};
             } else {
-                Y = {fma(-p.VBs[0], dd, o0x), fma(-p.VBs[1], dd, o0y), fma(-p.VBs[2], dd, o0z)};
+                Y = {fma(-kp->VBs[0], dd, o0x), fma(-kp->VBs[1], dd, o0y), fma(-kp->VBs[2], dd, o0z)};
             }
             const double yx = dot(Y, X);
             k = yx * ixx;
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // the first light time only seeds the next epoch (an error e in it moves the target
             // by VB e): 2^-45 relative is plenty there
             root = first ? sqrt_seed_pos(r2) : sqrt_pos(r2);
-            return (-k - root) * p.inv_c;
+            return (-k - root) * kp->inv_c;
         };
         // The first evaluation, at t0 itself, is never the last: |lt - lt_c| would have to be
         // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
@@ -334,9 +340,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         lt = evaluate(0.0, true);
 #pragma unroll 1
         for (int it = 1; it < 10; it++) {
-            d = (p.g.et - lt) - p.t0;  // two roundings, as the epoch et - lt of the reference has them
+            d = (kp->g.et - lt) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
             const double nlt = evaluate(d, false);
-            const bool moving = !(fabs(nlt - lt) <= p.lt_tol);
+            const bool moving = !(fabs(nlt - lt) <= kp->lt_tol);
             lt = nlt;  // (lanes without an intercept carry a value nobody reads)
             // wave-uniform exit once no lane with an intercept is still moving
             if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
@@ -351,10 +357,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             stored = true;
             const double miss = hit ? 0.0 : nan;
             // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
-            if (FLAGS & (DF_RING | DF_STATE)) dist_lt = fma(lt, p.g.clight, miss);
+            if (FLAGS & (DF_RING | DF_STATE)) dist_lt = fma(lt, kp->g.clight, miss);
             const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
             // body-fixed at te for TRI, B0 otherwise (body-fixed = Rz_frame(delta) * B0)
-            const V3 sp = {Xf.x * p.radii[0], Xf.y * p.radii[1], Xf.z * p.radii[2]};
+            const V3 sp = {Xf.x * kp->radii[0], Xf.y * kp->radii[1], Xf.z * kp->radii[2]};
             // (for a spheroid x and y share their radius: longitude and latitude follow from the
             //  scaled intercept Xf directly, sp / rho are only needed by the triaxial variant)
             const V3 ll = TRI ? sp : Xf;
@@ -363,11 +369,11 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - wdot d,
             // sign by the body's convention (lon_k = {+-1, +-wdot}), then into [0, 2 pi]
             const double theta = polar ? 0.0 : atan2_fast(ll.y, ll.x);
-            double l = TRI ? p.lon_k[0] * theta : fma(-p.lon_k[1], d, p.lon_k[0] * theta);
+            double l = TRI ? kp->lon_k[0] * theta : fma(-kp->lon_k[1], d, kp->lon_k[0] * theta);
             if (l < 0.0) l += kTwoPi;
             const double lon_deg = fma(l, kDeg, miss);
             // (|Xf| = 1: rho and z never vanish together, atan2 needs no guard here)
-            const double lat = atan2_fast<true>(TRI ? sp.z * p.lat_k : Xf.z * p.a_over_c, rho);
+            const double lat = atan2_fast<true>(TRI ? sp.z * kp->lat_k : Xf.z * kp->a_over_c, rho);
             const double lat_deg = fma(lat, kDeg, miss);
             if (inside) {
                 PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
@@ -376,10 +382,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             }
             if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
                 // reclat_c body.py:2905: east-positive, (-pi, pi]
-                double lc = TRI ? theta : fma(-p.g.wdot, d, theta);
+                double lc = TRI ? theta : fma(-kp->g.wdot, d, theta);
                 if (lc <= -kPi) lc += kTwoPi;
                 if (lc > kPi) lc -= kTwoPi;
-                const double bc = atan2_fast<true>(TRI ? sp.z : Xf.z / p.a_over_c, rho);
+                const double bc = atan2_fast<true>(TRI ? sp.z : Xf.z / kp->a_over_c, rho);
                 if (inside) {
                     PM_PUT_ROW(PM_LON_CENTRIC, fma(lc, kDeg, miss));
                     PM_PUT_ROW(PM_LAT_CENTRIC, fma(bc, kDeg, miss));
@@ -389,20 +395,20 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const V3 sp0 = TRI ? v3(fma(cz, sp.x, -sz * sp.y), fma(sz, sp.x, cz * sp.y), sp.z) : sp;
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
-                const V3 q = TRI ? v3(fma(p.VB[0], d, sp0.x), fma(p.VB[1], d, sp0.y), fma(p.VB[2], d, sp0.z))
-                                 : v3(fma(p.VBs[0], d, Xf.x) * p.radii[0], fma(p.VBs[1], d, Xf.y) * p.radii[1],
-                                      fma(p.VBs[2], d, Xf.z) * p.radii[2]);
+                const V3 q = TRI ? v3(fma(kp->VB[0], d, sp0.x), fma(kp->VB[1], d, sp0.y), fma(kp->VB[2], d, sp0.z))
+                                 : v3(fma(kp->VBs[0], d, Xf.x) * kp->radii[0], fma(kp->VBs[1], d, Xf.y) * kp->radii[1],
+                                      fma(kp->VBs[2], d, Xf.z) * kp->radii[2]);
                 // Sun light time (spkcpo_c 'CN'): the Sun is taken at te - |S - q| / c. Its epoch
                 // offset from ts0 is d + (lts0 - |SB0 - q| / c), and |SB0 - q| = |SB0| - s0.q up to
                 // q^2 / (2 |SB0|) ~ 3 km, i.e. 1e-5 s of a Sun that moves 0.013 km/s = 1e-7 km at
                 // 8e8 km (2e-16 rad): the square root of the exact form buys nothing, the linear
                 // form is one dot product.
-                const double ds = d + fma(dot(ld3(p.SB0), q), p.sun_k, p.sun_ds0);
-                V3 sv = v3(fma(p.VSB[0], ds, p.SB0[0]) - q.x, fma(p.VSB[1], ds, p.SB0[1]) - q.y,
-                        fma(p.VSB[2], ds, p.SB0[2]) - q.z);
+                const double ds = d + fma(dot(v3(kp->SB0[0], kp->SB0[1], kp->SB0[2]), q), kp->sun_k, kp->sun_ds0);
+                V3 sv = v3(fma(kp->VSB[0], ds, kp->SB0[0]) - q.x, fma(kp->VSB[1], ds, kp->SB0[1]) - q.y,
+                        fma(kp->VSB[2], ds, kp->SB0[2]) - q.z);
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
-                V3 n = {Xf.x * p.ir[0], Xf.y * p.ir[1], Xf.z * p.ir[2]};  // surfnm_c: sp / radii^2 = Xf / radii
+                V3 n = {Xf.x * kp->ir[0], Xf.y * kp->ir[1], Xf.z * kp->ir[2]};  // surfnm_c: sp / radii^2 = Xf / radii
                 if (TRI) n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
                 n = rsqrt_fast(dot(n, n)) * n;
                 const double ph = fma(vsep_fast(sunb, ob), kDeg, miss);
@@ -417,12 +423,12 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             }
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
-                const V3 vp = {fma(p.AB[0], d, p.VB[0]) - p.g.wdot * sp0.y, fma(p.AB[1], d, p.VB[1]) + p.g.wdot * sp0.x,
-                               fma(p.AB[2], d, p.VB[2])};
-                const V3 vo = ld3(p.VOB);
-                const double dlt = (dot(u, vp - vo) * p.inv_c) / (1.0 + dot(u, vp) * p.inv_c);
+                const V3 vp = {fma(kp->AB[0], d, kp->VB[0]) - kp->g.wdot * sp0.y, fma(kp->AB[1], d, kp->VB[1]) + kp->g.wdot * sp0.x,
+                               fma(kp->AB[2], d, kp->VB[2])};
+                const V3 vo = v3(kp->VOB[0], kp->VOB[1], kp->VOB[2]);
+                const double dlt = (dot(u, vp - vo) * kp->inv_c) / (1.0 + dot(u, vp) * kp->inv_c);
                 const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;
-                const double beta = rv / p.g.clight;
+                const double beta = rv / kp->g.clight;
                 if (inside) {
                     PM_PUT_ROW(PM_DISTANCE, dist_lt);
                     PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);

@@ -176,6 +176,20 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
     return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
 }
 
+// asin(n.z) of a unit vector n - the planetographic latitude of a spheroid's surface normal -
+// with the machinery of vsep_fast against the pole: asin on |x| <= 0.5 only (half-chord to the
+// nearer pole beyond 30 deg of latitude). One reciprocal square root; the atan2(z a / c, rho)
+// form costs a square root for rho and a division.
+__device__ __forceinline__ double lat_of_normal(V3 n)
+{
+    const double d = n.z;
+    const double wz = d + ((d > 0.0) ? -1.0 : 1.0);
+    const double s = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
+    const bool mid = fabs(d) < 0.5;
+    const double r = asin_half(mid ? d : s);
+    return mid ? r : (d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi));
+}
+
 // TRI: triaxial ellipsoid (a != b). The shape is no longer invariant under the spin, so each
 // light-time evaluation first turns ray and observer by the spin angle of its epoch (a few
 // 1e-5 rad: series) into the body-fixed frame and rescales the ray; the intercept is then
@@ -364,7 +378,6 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // (for a spheroid x and y share their radius: longitude and latitude follow from the
             //  scaled intercept Xf directly, sp / rho are only needed by the triaxial variant)
             const V3 ll = TRI ? sp : Xf;
-            const double rho = sqrt_fast(fma(ll.x, ll.x, ll.y * ll.y));
             const bool polar = (ll.x == 0.0 && ll.y == 0.0);
             // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - wdot d,
             // sign by the body's convention (lon_k = {+-1, +-wdot}), then into [0, 2 pi]
@@ -372,8 +385,19 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             double l = TRI ? kp->lon_k[0] * theta : fma(-kp->lon_k[1], d, kp->lon_k[0] * theta);
             if (l < 0.0) l += kTwoPi;
             const double lon_deg = fma(l, kDeg, miss);
-            // (|Xf| = 1: rho and z never vanish together, atan2 needs no guard here)
-            const double lat = atan2_fast<true>(TRI ? sp.z * kp->lat_k : Xf.z * kp->a_over_c, rho);
+            // surfnm_c: sp / radii^2 = Xf / radii; for a spheroid its z component IS sin(latitude)
+            // (a triaxial body's latitude refers to the reference spheroid instead, recpgr_c)
+            V3 n = {Xf.x * kp->ir[0], Xf.y * kp->ir[1], Xf.z * kp->ir[2]};
+            constexpr bool kLatFromNormal = (FLAGS & DF_ILLUM) && !TRI;  // (the normal is needed anyway)
+            if (kLatFromNormal) n = rsqrt_fast(dot(n, n)) * n;
+            double lat;
+            if (kLatFromNormal) {
+                lat = lat_of_normal(n);
+            } else {
+                // (|Xf| = 1: rho and z never vanish together, atan2 needs no guard here)
+                const double rho = sqrt_fast(fma(ll.x, ll.x, ll.y * ll.y));
+                lat = atan2_fast<true>(TRI ? sp.z * kp->lat_k : Xf.z * kp->a_over_c, rho);
+            }
             const double lat_deg = fma(lat, kDeg, miss);
             if (inside) {
                 PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
@@ -385,6 +409,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 double lc = TRI ? theta : fma(-kp->g.wdot, d, theta);
                 if (lc <= -kPi) lc += kTwoPi;
                 if (lc > kPi) lc -= kTwoPi;
+                const double rho = sqrt_fast(fma(ll.x, ll.x, ll.y * ll.y));
                 const double bc = atan2_fast<true>(TRI ? sp.z : Xf.z / kp->a_over_c, rho);
                 if (inside) {
                     PM_PUT_ROW(PM_LON_CENTRIC, fma(lc, kDeg, miss));
@@ -408,9 +433,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                         fma(kp->VSB[2], ds, kp->SB0[2]) - q.z);
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
-                V3 n = {Xf.x * kp->ir[0], Xf.y * kp->ir[1], Xf.z * kp->ir[2]};  // surfnm_c: sp / radii^2 = Xf / radii
-                if (TRI) n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
-                n = rsqrt_fast(dot(n, n)) * n;
+                if (TRI) {
+                    n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
+                    n = rsqrt_fast(dot(n, n)) * n;
+                }
                 const double ph = fma(vsep_fast(sunb, ob), kDeg, miss);
                 const double in = fma(vsep_fast(n, sunb), kDeg, miss);
                 const double em = fma(vsep_fast(n, ob), kDeg, miss);

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // The disc block reads its constants through a laundered copy of the kernel-argument pointer:
         // hipcc otherwise loads them at kernel entry, ahead of the ring block, and - out of scalar
         // registers - parks them in VGPR lanes (v_writelane / v_readlane) until they are needed here.
+        // (Params is the kernel's first and only argument: offset 0 of the kernel-argument segment.)
         const __attribute__((address_space(4))) Params *kp =
             (const __attribute__((address_space(4))) Params *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // Lanes without an intercept carry harmless garbage; `miss` (NaN for them, 0.0 for
         // hits) is the addend of each plane's closing radians -> degrees FMA.
         if (hit_mask != 0) {
+            static_assert(kSphBlock == 64, "lane id = threadIdx.x: one wave per workgroup");
             const bool hit = (hit_mask >> threadIdx.x) & 1;  // one wave per workgroup
             stored = true;
             const double miss = hit ? 0.0 : nan;

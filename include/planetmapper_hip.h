@@ -195,6 +195,50 @@ void *pm_stream(pm_ctx *ctx);
 /* Launch on a caller-owned hipStream_t instead (e.g. torch.cuda.current_stream()). */
 int pm_set_stream(pm_ctx *ctx, void *hip_stream);
 
+/*
+ * Per-context options (no reference counterpart except where noted).
+ *   PM_OPT_GENERAL_KERNEL   1: the image planes always go through the general kernel (arbitrary
+ *                           rotations, full quadratic motion model, observer anywhere outside the
+ *                           body) instead of the spheroid fast path the library selects when its
+ *                           guards hold. Results agree within the parity bars; used by the tests
+ *                           to cover both kernels. Default 0 (the environment variable
+ *                           PM_FORCE_GENERAL=1 sets the default to 1 at pm_create).
+ *   PM_OPT_HOST_CHUNK_BYTES bytes per stage of the pipelined host path (PM_MEM_HOST calls move
+ *                           data through pinned staging buffers in chunks of this size so that
+ *                           H2D copies, kernels and D2H copies of consecutive chunks overlap).
+ *                           Default 32 MiB; clamped to [1 MiB, 1 GiB].
+ *   PM_OPT_HOST_COPY_THREADS CPU threads that move pageable caller memory to / from the pinned
+ *                           staging buffers. Default min(8, cores); 1..64.
+ *   PM_OPT_ZERO_COPY        pm_map_cube (nearest / linear) on a PINNED host cube (pm_host_alloc
+ *                           or pm_host_register): 1 = the kernel gathers the pixels it needs
+ *                           straight from host memory over PCIe instead of copying the planes
+ *                           to HBM first; 0 = always copy; -1 (default) = the library chooses.
+ *   PM_OPT_LAST_DISC_KERNEL read-only (pm_get_option): which kernel the latest image-plane call
+ *                           dispatched for the planes that need the intercept: 0 none yet,
+ *                           1 spheroid fast path, 2 its triaxial variant, 3 general kernel.
+ */
+typedef enum pm_option {
+    PM_OPT_GENERAL_KERNEL = 1,
+    PM_OPT_HOST_CHUNK_BYTES = 2,
+    PM_OPT_HOST_COPY_THREADS = 3,
+    PM_OPT_ZERO_COPY = 4,
+    PM_OPT_LAST_DISC_KERNEL = 5
+} pm_option;
+int pm_set_option(pm_ctx *ctx, int option, int64_t value);
+int pm_get_option(pm_ctx *ctx, int option, int64_t *value);
+
+/*
+ * Pinned (page-locked) host memory. PM_MEM_HOST calls accept any host pointer; buffers that
+ * are pinned - allocated here or registered in place - are moved by DMA at the full PCIe rate
+ * without the staging copy, and are the only ones PM_OPT_ZERO_COPY applies to. The reference
+ * hands numpy arrays around (observation.py:240-318 loads the cube, body_xy.py:3166 makes the
+ * planes); planetmapper_amd allocates those arrays from this pool.
+ */
+int pm_host_alloc(pm_ctx *ctx, uint64_t bytes, void **hptr);
+int pm_host_free(pm_ctx *ctx, void *hptr);
+int pm_host_register(pm_ctx *ctx, void *hptr, uint64_t bytes);
+int pm_host_unregister(pm_ctx *ctx, void *hptr);
+
 /* Device memory helpers so non-HIP callers can keep data resident in HBM. */
 int pm_device_malloc(pm_ctx *ctx, uint64_t bytes, void **dptr);
 int pm_device_free(pm_ctx *ctx, void *dptr);

@@ -53,7 +53,15 @@ EXPORTS = (
     'pm_memcpy_h2d', 'pm_memcpy_d2h', 'pm_set_geometry', 'pm_set_disc',
     'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube', 'pm_transform',
     'pm_set_smooth_options', 'pm_backplanes_img_rows', 'pm_set_spline_smoothing', 'pm_radec_query',
+    'pm_set_option', 'pm_get_option', 'pm_host_alloc', 'pm_host_free', 'pm_host_register',
+    'pm_host_unregister',
 )  # fmt: skip
+
+PM_OPT_GENERAL_KERNEL = 1
+PM_OPT_HOST_CHUNK_BYTES = 2
+PM_OPT_HOST_COPY_THREADS = 3
+PM_OPT_ZERO_COPY = 4
+PM_OPT_LAST_DISC_KERNEL = 5
 
 
 class LibraryNotBuiltError(ImportError):
@@ -124,6 +132,12 @@ def load() -> ctypes.CDLL:
     lib.pm_set_smooth_options.argtypes = [vp, c_int, c_int]
     lib.pm_set_spline_smoothing.argtypes = [vp, ctypes.c_double]
     lib.pm_backplanes_img_rows.argtypes = [vp, ctypes.c_uint64, ctypes.c_double, c_int, c_int, dpp, c_int]
+    lib.pm_set_option.argtypes = [vp, c_int, ctypes.c_int64]
+    lib.pm_get_option.argtypes = [vp, c_int, ctypes.POINTER(ctypes.c_int64)]
+    lib.pm_host_alloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
+    lib.pm_host_free.argtypes = [vp, vp]
+    lib.pm_host_register.argtypes = [vp, vp, ctypes.c_uint64]
+    lib.pm_host_unregister.argtypes = [vp, vp]
     del dp
     if lib.pm_abi_version() != 1:
         raise ImportError('libplanetmapper_hip.so ABI version mismatch')

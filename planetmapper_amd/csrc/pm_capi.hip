@@ -348,6 +348,80 @@ int pm_set_stream(pm_ctx *ctx, void *stream)
     return PM_OK;
 }
 
+int pm_set_option(pm_ctx *ctx, int option, int64_t value)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    switch (option) {
+    case PM_OPT_GENERAL_KERNEL:
+        ctx->force_general = value != 0;
+        return PM_OK;
+    case PM_OPT_HOST_CHUNK_BYTES:
+        ctx->host_chunk_bytes = (size_t)std::min<int64_t>(std::max<int64_t>(value, (int64_t)1 << 20), (int64_t)1 << 30);
+        return PM_OK;
+    case PM_OPT_HOST_COPY_THREADS:
+        if (value < 0 || value > 64) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "copy threads must be in 0..64");
+        ctx->host_copy_threads = (int)value;
+        return PM_OK;
+    case PM_OPT_ZERO_COPY:
+        if (value < -1 || value > 1) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1, 0 or 1");
+        ctx->zero_copy = (int)value;
+        return PM_OK;
+    }
+    return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+}
+
+int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
+{
+    if (!ctx || !value) return PM_ERR_INVALID_ARGUMENT;
+    switch (option) {
+    case PM_OPT_GENERAL_KERNEL: *value = ctx->force_general ? 1 : 0; return PM_OK;
+    case PM_OPT_HOST_CHUNK_BYTES: *value = (int64_t)ctx->host_chunk_bytes; return PM_OK;
+    case PM_OPT_HOST_COPY_THREADS: *value = ctx->host_copy_threads; return PM_OK;
+    case PM_OPT_ZERO_COPY: *value = ctx->zero_copy; return PM_OK;
+    case PM_OPT_LAST_DISC_KERNEL: *value = ctx->last_disc_kernel; return PM_OK;
+    }
+    return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+}
+
+int pm_host_alloc(pm_ctx *ctx, uint64_t bytes, void **hptr)
+{
+    if (!ctx || !hptr) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    // non-coherent (coarse-grained) pinned memory: the GPU may cache it, CPU and GPU views meet at
+    // kernel / copy boundaries - which is how every entry point here uses host buffers
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocNonCoherent | hipHostMallocPortable);
+    if (e != hipSuccess)
+        return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc(%llu) failed: %s", (unsigned long long)bytes, hipGetErrorString(e));
+    return PM_OK;
+}
+
+int pm_host_free(pm_ctx *ctx, void *hptr)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    if (!hptr) return PM_OK;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PM_HIP(ctx, hipHostFree(hptr));
+    return PM_OK;
+}
+
+int pm_host_register(pm_ctx *ctx, void *hptr, uint64_t bytes)
+{
+    if (!ctx || !hptr) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipHostRegister(hptr, bytes, hipHostRegisterPortable));
+    return PM_OK;
+}
+
+int pm_host_unregister(pm_ctx *ctx, void *hptr)
+{
+    if (!ctx || !hptr) return PM_ERR_INVALID_ARGUMENT;
+    PM_HIP(ctx, hipSetDevice(ctx->device));
+    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PM_HIP(ctx, hipHostUnregister(hptr));
+    return PM_OK;
+}
+
 int pm_device_malloc(pm_ctx *ctx, uint64_t bytes, void **dptr)
 {
     if (!ctx || !dptr) return PM_ERR_INVALID_ARGUMENT;
@@ -494,6 +568,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else
             pm_launch_disc(pd, flags, ctx->stream);
+        ctx->last_disc_kernel = spheroid ? (pd.radii[0] != pd.radii[1] ? 2 : 1) : 3;
     }
     if (plane_mask & kSkyBits) {
         pm::Params ps = p;
@@ -693,6 +768,12 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     a.propagate_nan = propagate_nan ? 1 : 0;
     a.plane_stats = nullptr;
     a.seq = 0;
+    // a pending asynchronous call still points at the flag array: finish it (flag check and
+    // nanmedian replay) before the array is regrown, which frees and zeroes it
+    if (ctx->pending && (size_t)n_planes > ctx->flags_count) {
+        rc = pm_synchronize(ctx);
+        if (rc != PM_OK) return rc;
+    }
     rc = ensure_flags(ctx, (size_t)n_planes);
     if (rc != PM_OK) return rc;
 

@@ -86,7 +86,13 @@ struct pm_ctx {
     SmWorker sm_workers[kSmWorkers];
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
-    bool force_general = false;   // PM_FORCE_GENERAL=1: never take the spheroid fast path (testing)
+    bool force_general = false;   // PM_OPT_GENERAL_KERNEL: never take the spheroid fast path
+    int last_disc_kernel = 0;     // PM_OPT_LAST_DISC_KERNEL
+    // pipelined host path (pm_hostpipe.hip): options + lazily created state
+    size_t host_chunk_bytes = (size_t)32 << 20;
+    int host_copy_threads = 0;   // 0: min(8, cores)
+    int zero_copy = -1;          // PM_OPT_ZERO_COPY
+    struct HostPipe *pipe = nullptr;
 };
 
 namespace pmh {

@@ -58,37 +58,94 @@ def all_gather_planes(local: np.ndarray, n_planes: int, group=None) -> np.ndarra
     return full.cpu().numpy()
 
 
+def _check_rank_device(obs, group) -> None:
+    """Under RCCL every rank must compute on its own GPU (the one torch has made current)."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.get_backend(group) != 'nccl':
+        return
+    dev = getattr(getattr(obs, '_engine', None), 'device', None)
+    cur = torch.cuda.current_device()
+    if dev is not None and dev != cur:
+        raise RuntimeError(
+            f'this rank\'s engine runs on GPU {dev} but torch.cuda.current_device() is {cur}: build the '
+            'Observation / BodyXY with device=LOCAL_RANK (and torch.cuda.set_device(LOCAL_RANK)) so that '
+            'each rank maps its planes on its own GPU'
+        )
+
+
 def get_mapped_data_sharded(
     obs,
     interpolation='linear',
     *,
+    spline_smoothing: float = 0,
     propagate_nan: bool = True,
+    smooth_oversample_by: int = 5,
+    smooth_max_oversampled_img_size: int = 10_000,
     group=None,
+    local_planes: np.ndarray | None = None,
+    n_planes: int | None = None,
+    gather: bool = True,
     **map_kwargs,
 ) -> np.ndarray:
     """
-    `Observation.get_mapped_data` with the planes of `obs.data` sharded over the ranks
-    of `group` (default: the world). Every rank must hold the same `obs` (same data,
-    disc parameters and map arguments) and receives the full (P, n0, n1) float64 result.
+    `Observation.get_mapped_data` (observation.py:826-905) with the planes of the cube sharded over
+    the ranks of `group` (default: the world): rank r maps the contiguous block
+    `shard_bounds(P, world, r)` on its own GPU and one all-gather assembles the result.
+
+    Where the planes come from:
+      * default: every rank holds the same `obs.data` (P, ny, nx) and slices its block from it;
+      * `local_planes` (+ `n_planes` = P, the size of the whole cube): this rank passes ONLY its own
+        block, shape (stop - start, ny, nx) - e.g. a slice of a memory-mapped FITS cube or planes
+        read by this rank alone - and `obs.data` is not touched, so no rank needs the full cube in
+        host memory (at BASELINE config 5, 512 MiB per rank instead of 4 GiB on each of 8 ranks).
+
+    What comes back:
+      * `gather=True`: the full (P, n0, n1) float64 result on every rank (one all-gather, RCCL over
+        xGMI for the nccl backend);
+      * `gather=False`: this rank's (stop - start, n0, n1) block only, no collective at all (SURVEY
+        8e: "otherwise none - each rank keeps / writes its slice").
+
+    The interpolation arguments are those of `map_img` (body_xy.py:1414-1429).
     """
     import torch.distributed as dist
 
+    interp = dict(
+        interpolation=interpolation, spline_smoothing=spline_smoothing, propagate_nan=propagate_nan,
+        smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
+    )  # fmt: skip
     if not dist.is_initialized():
-        return obs.get_mapped_data(interpolation, propagate_nan=propagate_nan, **map_kwargs)
+        if local_planes is not None:
+            return obs.map_img(local_planes, **interp, **map_kwargs)
+        return obs.get_mapped_data(**interp, **map_kwargs)
+    _check_rank_device(obs, group)
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    n_planes = obs.data.shape[0]
-    start, stop, per_rank = shard_bounds(n_planes, world, rank)
+    if local_planes is None:
+        n_planes = obs.data.shape[0]
+    elif n_planes is None:
+        raise ValueError('n_planes (planes of the whole cube) is required with local_planes')
+    start, stop, per_rank = shard_bounds(int(n_planes), world, rank)
+    if local_planes is None:
+        local_planes = obs.data[start:stop]
+    local_planes = np.asarray(local_planes)
+    if local_planes.ndim == 2:
+        local_planes = local_planes[None]
+    if local_planes.shape[0] != stop - start:
+        raise ValueError(
+            f'rank {rank} of {world} owns planes [{start}, {stop}) of {n_planes} but was given {local_planes.shape[0]}'
+        )
     x_map = obs.get_x_map(**map_kwargs)
     n0, n1 = x_map.shape
-    local = np.full((per_rank, n0, n1), np.nan)
-    if stop > start:
-        local[: stop - start] = obs.map_img(
-            obs.data[start:stop], interpolation=interpolation, propagate_nan=propagate_nan, **map_kwargs
-        )
+    mine = obs.map_img(local_planes, **interp, **map_kwargs) if stop > start else np.empty((0, n0, n1))
+    if not gather:
+        return mine
     if n_planes == 0:
         return np.empty((0, n0, n1))
-    return all_gather_planes(local, n_planes, group)
+    local = np.full((per_rank, n0, n1), np.nan)
+    local[: stop - start] = mine
+    return all_gather_planes(local, int(n_planes), group)
 
 
 def backplanes_img_sharded(engine, names, ny: int, nx: int, *, alt: float = 0.0, group=None) -> dict[str, np.ndarray]:
@@ -124,7 +181,7 @@ def backplanes_img_sharded(engine, names, ny: int, nx: int, *, alt: float = 0.0,
 
 def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_map, n0: int, n1: int,
                             gathered, rank: int, interpolation='linear', propagate_nan=True, group=None,
-                            async_op: bool = False, previous=None):
+                            async_op: bool = False, previous=None, defer_median_check: bool = False):
     """
     Device-resident variant used by the benchmark: this rank's `n_planes_local` planes
     (`cube`, a device tensor / pointer) are mapped straight into its slot of `gathered`
@@ -135,6 +192,13 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
     caller can enqueue independent kernels (the next frame's backplanes) while the gather is
     in flight over xGMI; pass that handle back as `previous` on the next call: it is waited for
     right before this rank's slot is overwritten.
+
+    A device-mode `pm_map_cube` is final only after `pm_synchronize()`: planes in which a sampled
+    pixel needs the plane's nanmedian (+-inf pixels, neighbourhoods without a finite pixel) are
+    completed there. By default this function therefore synchronises the engine BEFORE the
+    collective, so that peers never receive provisional values. `defer_median_check=True` skips
+    that host round trip (fully asynchronous step) for data known to hold no such pixels; the
+    caller's next `engine.synchronize()` still detects a violation and raises.
     """
     import torch.distributed as dist
 
@@ -142,6 +206,8 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
         previous.wait()
     mine = gathered[rank]
     engine.map_cube_device(cube, dtype, n_planes_local, x_map, y_map, n0, n1, mine, interpolation, propagate_nan)
+    if not defer_median_check:
+        engine.synchronize()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         return dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group, async_op=async_op)
     return None

@@ -83,7 +83,11 @@ def _ptr(x) -> int:
 class Engine:
     """One GPU context of the HIP engine. Raises `NoDeviceError` without a gfx950 GPU."""
 
-    def __init__(self, device: int = 0) -> None:
+    def __init__(self, device: int = 0, *, general_kernel: bool | None = None) -> None:
+        """
+        `general_kernel=True` routes every image-plane request through the general kernel
+        (`PM_OPT_GENERAL_KERNEL`) instead of the spheroid fast path; None keeps the library default.
+        """
         self._lib = _lib.load()
         status = ctypes.c_int(0)
         self._ctx = self._lib.pm_create(int(device), ctypes.byref(status))
@@ -97,6 +101,8 @@ class Engine:
         self.device = int(device)
         self._disc: PMDisc | None = None
         self._geometry: PMGeometry | None = None
+        if general_kernel is not None:
+            self.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1 if general_kernel else 0)
 
     # ------------------------------------------------------------------ plumbing
     def close(self) -> None:
@@ -124,6 +130,15 @@ class Engine:
 
     def synchronize(self) -> None:
         self._check(self._lib.pm_synchronize(self._ctx))
+
+    def set_option(self, option: int, value: int) -> None:
+        """`pm_set_option`: `_lib.PM_OPT_*` (general kernel, host-path chunking / threads / zero copy)."""
+        self._check(self._lib.pm_set_option(self._ctx, int(option), int(value)))
+
+    def get_option(self, option: int) -> int:
+        v = ctypes.c_int64(0)
+        self._check(self._lib.pm_get_option(self._ctx, int(option), ctypes.byref(v)))
+        return int(v.value)
 
     @property
     def stream(self) -> int:

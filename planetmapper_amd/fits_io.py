@@ -291,14 +291,12 @@ def _read_header(buf: bytes, pos: int) -> tuple[Header, int]:
 def read(path: str | os.PathLike) -> list[HDU]:
     """All HDUs of a FITS file (data of non-image extensions is None)."""
     path = os.fspath(path)
-    if path.lower().endswith('.gz'):
+    with open(path, 'rb') as f:
+        buf = f.read()
+    if buf[:2] == b'\x1f\x8b':  # gzip magic, whatever the suffix says
         import gzip
 
-        with gzip.open(path, 'rb') as f:
-            buf = f.read()
-    else:
-        with open(path, 'rb') as f:
-            buf = f.read()
+        buf = gzip.decompress(buf)
     pos = 0
     hdus: list[HDU] = []
     while pos < len(buf):
@@ -396,8 +394,15 @@ def write(path: str | os.PathLike, hdus: list[HDU], overwrite: bool = True) -> N
             raw = payload.tobytes()
             out += raw + b'\0' * (-len(raw) % BLOCK)
     tmp = path + '.tmp~'
-    with open(tmp, 'wb') as f:
-        f.write(out)
+    if path.lower().endswith('.gz'):
+        # astropy (the reference's writer) compresses by suffix; read() decompresses by suffix
+        import gzip
+
+        with gzip.open(tmp, 'wb', compresslevel=6) as f:
+            f.write(out)
+    else:
+        with open(tmp, 'wb') as f:
+            f.write(out)
     os.replace(tmp, path)
 
 

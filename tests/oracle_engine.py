@@ -17,6 +17,11 @@ class OracleEngine:
         self._ctx = object()
         self.calls = []  # (kind, names) log, used to assert caching behaviour
 
+    device = 0
+
+    def synchronize(self):
+        self.calls.append(('sync',))
+
     def set_geometry(self, g):
         self._g = g
 

@@ -69,6 +69,24 @@ def _worker(rank: int, world: int, port: int, n_planes: int, tmpdir: str) -> Non
         assert sum(c[1][0] for c in cube_calls) == b - a
         nearest = get_mapped_data_sharded(obs, 'nearest', degree_interval=15)
         assert np.array_equal(nearest, obs.get_mapped_data('nearest', degree_interval=15), equal_nan=True)
+        # per-rank plane blocks: this rank hands over ONLY its own planes (obs.data is not read) ...
+        a, b, _ = shard_bounds(n_planes, world, rank)
+        obs2 = Observation(data=np.zeros((1, 24, 20)), geometry=g, engine=OracleEngine())
+        obs2.set_disc_params(9.5, 12.0, 8.0, 30.0)
+        blockwise = get_mapped_data_sharded(obs2, local_planes=cube[a:b].copy(), n_planes=n_planes, degree_interval=15)
+        assert np.array_equal(blockwise, full, equal_nan=True)
+        # ... and may keep its slice (no collective)
+        mine = get_mapped_data_sharded(obs2, local_planes=cube[a:b].copy(), n_planes=n_planes, gather=False,
+                                       degree_interval=15)
+        assert mine.shape == (b - a, 12, 24) and np.array_equal(mine, full[a:b], equal_nan=True)
+        with pytest.raises(ValueError):
+            get_mapped_data_sharded(obs2, local_planes=np.zeros((b - a + 1, 24, 20)), n_planes=n_planes, degree_interval=15)
+        # the other interpolation arguments of map_img are forwarded
+        cubic = get_mapped_data_sharded(obs, 'cubic', propagate_nan=False, degree_interval=15)
+        assert np.array_equal(cubic, obs.get_mapped_data('cubic', propagate_nan=False, degree_interval=15), equal_nan=True)
+        sm = get_mapped_data_sharded(obs, 'linear', spline_smoothing=3.0, propagate_nan=False, degree_interval=15)
+        assert np.allclose(sm, obs.get_mapped_data('linear', spline_smoothing=3.0, propagate_nan=False, degree_interval=15),
+                           rtol=0, atol=1e-12, equal_nan=True)
         open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
     finally:
         dist.destroy_process_group()
@@ -114,14 +132,18 @@ def _pipeline_worker(rank: int, world: int, port: int, tmpdir: str) -> None:
             frames = rng.standard_normal((world, 2, 24, 20))
             mine = torch.from_numpy(frames[rank].copy())
             pending = map_cube_sharded_device(eng, mine, np.float64, 2, xm, ym, n0, n1, gathered, rank,
-                                              'linear', True, async_op=True, previous=pending)  # fmt: skip
+                                              'linear', True, async_op=True, previous=pending,
+                                              defer_median_check=True)  # fmt: skip
             assert pending is not None
         pending.wait()
+        assert ('sync',) not in eng.calls  # the deferred form never goes back to the host
         expect = np.stack([oracle.map_cube(frames[r], xm.numpy(), ym.numpy()) for r in range(world)])
         assert np.array_equal(gathered.numpy(), expect, equal_nan=True)
         # synchronous form returns the finished handle / None for a single rank
         h = map_cube_sharded_device(eng, mine, np.float64, 2, xm, ym, n0, n1, gathered, rank)
         assert h is None or h.is_completed()
+        # ... after finishing the call (flag check / nanmedian replay) BEFORE the collective
+        assert eng.calls[-1] == ('sync',) and eng.calls[-2][0] == 'cube'
         open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
     finally:
         dist.destroy_process_group()

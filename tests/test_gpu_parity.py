@@ -30,6 +30,20 @@ def engine():
     e.close()
 
 
+@pytest.fixture(scope='module', params=['fast', 'general'])
+def engine_fg(request, engine):
+    """
+    The module engine with the image planes routed through (a) the kernel the library selects
+    (the spheroid fast path for every test geometry observed from afar) and (b) the general kernel
+    `k_disc<FLAGS>` (`PM_OPT_GENERAL_KERNEL`): both must meet the same parity bars.
+    """
+    from planetmapper_amd import _lib
+
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1 if request.param == 'general' else 0)
+    yield engine
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
+
+
 @pytest.fixture(scope='module')
 def oracle():
     from oracle import oracle as o
@@ -97,39 +111,43 @@ def test_golden_maps(engine, oracle, jupiter, name, interp, alt):
 
 
 @pytest.mark.parametrize('sz,rot', [(128, 0.0), (1024, 0.0), (517, 33.3)])
-def test_jupiter_full_set_vs_oracle(engine, oracle, jupiter, sz, rot):
+def test_jupiter_full_set_vs_oracle(engine_fg, oracle, jupiter, sz, rot):
     """BASELINE configs 1-2: centred disc (BodyXY.centre_disc body_xy.py:791), all 26 planes."""
     x0 = y0 = (sz - 1) / 2
     r0 = 0.9 * x0
-    engine.set_geometry(jupiter)
-    engine.set_disc(x0, y0, r0, float(np.deg2rad(rot) % (2 * np.pi)), sz, sz, True)
-    out = engine.backplanes_img(oracle.PLANE_NAMES)
+    engine_fg.set_geometry(jupiter)
+    engine_fg.set_disc(x0, y0, r0, float(np.deg2rad(rot) % (2 * np.pi)), sz, sz, True)
+    out = engine_fg.backplanes_img(oracle.PLANE_NAMES)
+    from planetmapper_amd import _lib
+
+    general = engine_fg.get_option(_lib.PM_OPT_GENERAL_KERNEL)
+    assert engine_fg.get_option(_lib.PM_OPT_LAST_DISC_KERNEL) == (3 if general else 1)
     ref = oracle.backplanes_img(jupiter, oracle.make_disc(x0, y0, r0, rot, sz, sz), oracle.PLANE_NAMES)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter)
     frac = np.isfinite(out['LON-GRAPHIC']).mean()
     assert 0.55 < frac < 0.65
 
 
-def test_no_optimize_speed_and_ragged_sizes(engine, oracle, jupiter):
+def test_no_optimize_speed_and_ragged_sizes(engine_fg, oracle, jupiter):
     """optimize_speed=False (no radius pre-mask) and a width that is not a multiple of 64."""
-    engine.set_geometry(jupiter)
-    engine.set_disc(40.2, 17.7, 30.0, 1.0, 131, 67, False)
-    out = engine.backplanes_img(oracle.PLANE_NAMES, alt=1234.5)
+    engine_fg.set_geometry(jupiter)
+    engine_fg.set_disc(40.2, 17.7, 30.0, 1.0, 131, 67, False)
+    out = engine_fg.backplanes_img(oracle.PLANE_NAMES, alt=1234.5)
     d = oracle.make_disc(40.2, 17.7, 30.0, 0.0, 131, 67, optimize_speed=False)
     d.rotation_rad = 1.0
     ref = oracle.backplanes_img(jupiter, d, oracle.PLANE_NAMES, alt=1234.5)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter)
 
 
-def test_saturn_rings_divergent_path(engine, oracle, saturn):
+def test_saturn_rings_divergent_path(engine_fg, oracle, saturn):
     """BASELINE config 4 geometry at 768^2: ring planes fill the frame (parity unpinned by
     the reference; GPU vs oracle only)."""
     sz = 768
     x0 = y0 = (sz - 1) / 2
-    engine.set_geometry(saturn)
-    engine.set_disc(x0, y0, 150.0, float(np.deg2rad(20.0)), sz, sz, True)
+    engine_fg.set_geometry(saturn)
+    engine_fg.set_disc(x0, y0, 150.0, float(np.deg2rad(20.0)), sz, sz, True)
     names = HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE', 'DISTANCE']
-    out = engine.backplanes_img(names)
+    out = engine_fg.backplanes_img(names)
     ref = oracle.backplanes_img(saturn, oracle.make_disc(x0, y0, 150.0, 20.0, sz, sz), names)
     for n in names:
         assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), n
@@ -318,6 +336,49 @@ def test_nan_preclean_and_median_paths(engine, oracle, jupiter):
     a = engine.map_cube(c32, xm, ym, 'linear', False)
     b = oracle.map_cube(c32, xm, ym, 'linear', False)
     assert np.array_equal(np.isnan(a), np.isnan(b)) and np.nanmax(np.abs(a - b)) <= 1e-5
+
+
+def test_async_map_cube_is_finished_before_its_flags_are_regrown(engine, oracle, jupiter):
+    """
+    A device-mode pm_map_cube stays pending until pm_synchronize() (planes that need the nanmedian
+    are replayed there). A second call with MORE planes regrows the per-plane flag array the pending
+    call points at: the library must finish the first call before it frees that array - the first
+    output is then final, with the median applied (an -inf block: interior pixels need it).
+    """
+    import torch
+
+    from planetmapper_amd.engine import Engine
+
+    eng = Engine(0)  # fresh context: its flag array starts empty and grows with the calls below
+    try:
+        sz = 128
+        x0 = y0 = (sz - 1) / 2
+        eng.set_geometry(jupiter)
+        eng.set_disc(x0, y0, 0.9 * x0, 0.0, sz, sz, True)
+        lon, lat = oracle.rectangular_grid(jupiter, 4.0)
+        d = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)
+        xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+        n0, n1 = xm.shape
+        rng = np.random.default_rng(11)
+        small = rng.standard_normal((2, sz, sz)) + 5.0
+        small[1][40:90, 30:100] = -np.inf
+        big = rng.standard_normal((9, sz, sz))
+        big[7][20:60, 50:110] = np.inf
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        dxm, dym, dsmall, dbig = t(xm), t(ym), t(small), t(big)
+        o_small = torch.full((2, n0, n1), -7.0, dtype=torch.float64, device='cuda')
+        o_big = torch.full((9, n0, n1), -7.0, dtype=torch.float64, device='cuda')
+        eng.map_cube_device(dsmall, np.float64, 2, dxm, dym, n0, n1, o_small)  # pending, flags: 2 entries
+        eng.map_cube_device(dbig, np.float64, 9, dxm, dym, n0, n1, o_big)  # regrow to 9 entries
+        eng.synchronize()
+        for got, cube in ((o_small, small), (o_big, big)):
+            ref = oracle.map_cube(cube, xm, ym, 'linear', True)
+            got = got.cpu().numpy()
+            assert np.array_equal(np.isnan(got), np.isnan(ref))
+            fin = np.isfinite(ref)
+            assert fin.any() and np.max(np.abs(got[fin] - ref[fin])) <= 1e-11
+    finally:
+        eng.close()
 
 
 def test_point_transforms_vs_oracle(engine, oracle, jupiter):
@@ -655,29 +716,35 @@ def _near_field_geometry(distance_km):
     )
 
 
-@pytest.mark.parametrize('distance_km', [181_000.0, 1.2e6])
-def test_near_field_observer(engine, oracle, distance_km):
+@pytest.mark.parametrize('distance_km', [107_238.0, 181_000.0, 1.2e6])
+def test_near_field_observer(engine_fg, oracle, distance_km):
     """
     A close observer: the disc subtends tens of degrees, so the small-angle shortcuts of the
     fast path (series sincos of the view angles, spin angle over the light-time span) are
     outside their range for part of the frame and the wave-uniform fallbacks take over;
-    parallax makes the visible cap much smaller than a hemisphere. All planes + map chain vs
+    parallax makes the visible cap much smaller than a hemisphere. At 107 238 km = 1.5 equatorial
+    radii from the centre the observer is inside two scaled radii, where the library itself
+    dispatches the general kernel (`y2 <= 4` in pm_backplanes_img_rows). All planes + map chain vs
     the oracle (no reference golden for this geometry: "parity unpinned").
     """
     g = _near_field_geometry(distance_km)
     assert g.diameter_arcsec > 5 * 3600
     nx, ny = 261, 197
     x0, y0, r0, rot = 128.0, 101.5, 70.0, 200.0
-    engine.set_geometry(g)
-    engine.set_disc(x0, y0, r0, float(np.deg2rad(rot)), nx, ny, True)
+    engine_fg.set_geometry(g)
+    engine_fg.set_disc(x0, y0, r0, float(np.deg2rad(rot)), nx, ny, True)
     d = oracle.make_disc(x0, y0, r0, rot, nx, ny)
     d.rotation_rad = float(np.deg2rad(rot))
-    out = engine.backplanes_img(oracle.PLANE_NAMES)
+    out = engine_fg.backplanes_img(oracle.PLANE_NAMES)
+    from planetmapper_amd import _lib
+
+    if distance_km < 2 * 66854.0:  # inside two scaled radii: the library's own dispatch
+        assert engine_fg.get_option(_lib.PM_OPT_LAST_DISC_KERNEL) == 3
     ref = oracle.backplanes_img(g, d, oracle.PLANE_NAMES)
     _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)
     assert 0.1 < np.isfinite(out['LON-GRAPHIC']).mean() < 0.6
     lon, lat = oracle.rectangular_grid(g, 5.0)
-    om = engine.backplanes_map(oracle.PLANE_NAMES, lon, lat)
+    om = engine_fg.backplanes_map(oracle.PLANE_NAMES, lon, lat)
     rm = oracle.backplanes_map(g, d, oracle.PLANE_NAMES, lon, lat)
     _compare(om, rm, oracle.PLANE_NAMES, g, r0=r0)
     # test_mapping_visible_areas: a cell is mapped exactly where its emission angle is <= 90 deg
@@ -687,7 +754,7 @@ def test_near_field_observer(engine, oracle, distance_km):
 
 
 @pytest.mark.parametrize('force_names', [None, ['LON-GRAPHIC', 'EMISSION', 'RING-RADIUS', 'RA', 'LIMB-DISTANCE', 'PIXEL-Y']])
-def test_row_blocks_equal_the_full_frame(engine, oracle, jupiter, saturn, force_names):
+def test_row_blocks_equal_the_full_frame(engine_fg, oracle, jupiter, saturn, force_names):
     """
     pm_backplanes_img_rows (the unit of row-block sharding over GPUs): any row block is
     bit-identical to the same rows of the full-frame launch, for the spheroid fast path, the
@@ -695,22 +762,22 @@ def test_row_blocks_equal_the_full_frame(engine, oracle, jupiter, saturn, force_
     """
     names = force_names or oracle.PLANE_NAMES
     for g, (nx, ny) in ((jupiter, (203, 157)), (saturn, (130, 95))):
-        engine.set_geometry(g)
-        engine.set_disc(nx / 2.1, ny / 1.9, 0.3 * nx, 0.7, nx, ny, True)
-        full = engine.backplanes_img(names)
+        engine_fg.set_geometry(g)
+        engine_fg.set_disc(nx / 2.1, ny / 1.9, 0.3 * nx, 0.7, nx, ny, True)
+        full = engine_fg.backplanes_img(names)
         for a, n in ((0, ny), (0, 1), (ny - 1, 1), (ny // 4, ny // 2 + 1), (5, ny - 6), (ny, 0)):
-            block = engine.backplanes_img_rows(names, a, n)
+            block = engine_fg.backplanes_img_rows(names, a, n)
             for k in names:
                 assert block[k].shape == (n, nx)
                 assert np.array_equal(block[k], full[k][a : a + n], equal_nan=True), (k, a, n)
         for a, n in ((-1, 3), (ny - 2, 3), (0, -1)):
             with pytest.raises(ValueError):
-                engine.backplanes_img_rows(names, a, n)
+                engine_fg.backplanes_img_rows(names, a, n)
     import torch
 
     dev = {k: torch.empty((64, 130), dtype=torch.float64, device='cuda') for k in names}
-    engine.backplanes_img_rows_device(dev, 20, 64)
-    engine.synchronize()
+    engine_fg.backplanes_img_rows_device(dev, 20, 64)
+    engine_fg.synchronize()
     for k in names:
         assert np.array_equal(dev[k].cpu().numpy(), full[k][20:84], equal_nan=True), k
 
@@ -786,7 +853,7 @@ def test_smoothing_splines_vs_oracle_kats_and_golden(engine, oracle, jupiter):
                           engine.map_cube(cube[:1], xm, ym, 'cubic', True, spline_smoothing=0.0), equal_nan=True)
 
 
-def test_config4_saturn_rings_full_size(engine, oracle, saturn):
+def test_config4_saturn_rings_full_size(engine_fg, oracle, saturn):
     """
     BASELINE config 4 at its full size: Saturn + rings, 4096^2, r0 = 800 px, rotation 20 deg,
     8 planes. NaN masks (disc limb, ring-plane hits, rings hidden behind the disc) bit-exact and
@@ -794,10 +861,10 @@ def test_config4_saturn_rings_full_size(engine, oracle, saturn):
     """
     sz = 4096
     x0 = y0 = (sz - 1) / 2
-    engine.set_geometry(saturn)
-    engine.set_disc(x0, y0, 800.0, float(np.deg2rad(20.0)), sz, sz, True)
+    engine_fg.set_geometry(saturn)
+    engine_fg.set_disc(x0, y0, 800.0, float(np.deg2rad(20.0)), sz, sz, True)
     names = HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']
-    out = engine.backplanes_img(names)
+    out = engine_fg.backplanes_img(names)
     oracle.set_num_threads(16)
     ref = oracle.backplanes_img(saturn, oracle.make_disc(x0, y0, 800.0, 20.0, sz, sz), names)
     for n in names:
@@ -896,7 +963,7 @@ def test_config5_cube_512_planes_properties(engine, oracle, jupiter):
     assert torch.equal(torch.nan_to_num(out2), torch.nan_to_num(out))
 
 
-def test_random_discs_and_frames_fuzz(engine, oracle, jupiter, saturn):
+def test_random_discs_and_frames_fuzz(engine_fg, oracle, jupiter, saturn):
     """
     Seeded sweep over frame shapes (1 x 1 up to ragged 200-pixel sides), disc positions inside,
     on the edge of and outside the frame, radii from sub-pixel to frame-filling, any rotation,
@@ -913,11 +980,11 @@ def test_random_discs_and_frames_fuzz(engine, oracle, jupiter, saturn):
         g = saturn if i % 5 == 4 else jupiter
         opt = bool(i % 3)
         alt = [0.0, 0.0, 1500.0, -300.0][i % 4]
-        engine.set_geometry(g)
-        engine.set_disc(x0, y0, r0, rot, nx, ny, opt)
+        engine_fg.set_geometry(g)
+        engine_fg.set_disc(x0, y0, r0, rot, nx, ny, opt)
         d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny, optimize_speed=opt)
         d.rotation_rad = rot
-        out = engine.backplanes_img(oracle.PLANE_NAMES, alt=alt)
+        out = engine_fg.backplanes_img(oracle.PLANE_NAMES, alt=alt)
         ref = oracle.backplanes_img(g, d, oracle.PLANE_NAMES, alt=alt)
         for n in oracle.PLANE_NAMES:
             assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (i, n, nx, ny, x0, y0, r0, rot)

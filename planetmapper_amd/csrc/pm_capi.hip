@@ -317,6 +317,7 @@ void pm_destroy(pm_ctx *ctx)
     }
     if (ctx->stats) (void)hipFree(ctx->stats);
     if (ctx->hist) (void)hipFree(ctx->hist);
+    pipe_destroy(ctx);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -409,7 +410,7 @@ int pm_host_register(pm_ctx *ctx, void *hptr, uint64_t bytes)
 {
     if (!ctx || !hptr) return PM_ERR_INVALID_ARGUMENT;
     PM_HIP(ctx, hipSetDevice(ctx->device));
-    PM_HIP(ctx, hipHostRegister(hptr, bytes, hipHostRegisterPortable));
+    PM_HIP(ctx, hipHostRegister(hptr, bytes, hipHostRegisterPortable | hipHostRegisterMapped));
     return PM_OK;
 }
 
@@ -578,10 +579,13 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
     PM_HIP(ctx, hipGetLastError());
 
     if (mem != PM_MEM_DEVICE) {
+        // results -> caller memory at the rate of the link (pm_hostpipe.hip)
         for (int i = 0; i < PM_NUM_PLANES; i++)
-            if ((plane_mask >> i) & 1)
-                PM_HIP(ctx, hipMemcpyAsync(out[i], p.out[i], npx * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if ((plane_mask >> i) & 1) {
+                rc = d2h_issue(ctx, ctx->stream, out[i], p.out[i], npx * sizeof(double));
+                if (rc != PM_OK) return rc;
+            }
+        return d2h_finish(ctx, ctx->stream);
     }
     return PM_OK;
 }
@@ -628,9 +632,11 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, c
     PM_HIP(ctx, hipGetLastError());
     if (mem != PM_MEM_DEVICE) {
         for (int i = 0; i < PM_NUM_PLANES; i++)
-            if ((plane_mask >> i) & 1)
-                PM_HIP(ctx, hipMemcpyAsync(out[i], p.out[i], n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            if ((plane_mask >> i) & 1) {
+                rc = d2h_issue(ctx, ctx->stream, out[i], p.out[i], n * sizeof(double));
+                if (rc != PM_OK) return rc;
+            }
+        return d2h_finish(ctx, ctx->stream);
     }
     return PM_OK;
 }
@@ -678,10 +684,10 @@ int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a, con
     t.a = base; t.b = base + n; t.oa = base + 2 * n; t.ob = base + 3 * n;
     pm_launch_transform(p, t, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
-    PM_HIP(ctx, hipMemcpyAsync(out_a, t.oa, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PM_HIP(ctx, hipMemcpyAsync(out_b, t.ob, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PM_OK;
+    rc = d2h_issue(ctx, ctx->stream, out_a, t.oa, n * sizeof(double));
+    if (rc == PM_OK) rc = d2h_issue(ctx, ctx->stream, out_b, t.ob, n * sizeof(double));
+    if (rc != PM_OK) return rc;
+    return d2h_finish(ctx, ctx->stream);
 }
 
 int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *dec_deg, double alt,
@@ -708,9 +714,9 @@ int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *
     PM_HIP(ctx, hipMemcpyAsync(base + n, dec_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     pm_launch_radec_query(p, base, base + n, n, ring_only_visible, base + 2 * n, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
-    PM_HIP(ctx, hipMemcpyAsync(out, base + 2 * n, n * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return PM_OK;
+    rc = d2h_issue(ctx, ctx->stream, out, base + 2 * n, n * 8 * sizeof(double));
+    if (rc != PM_OK) return rc;
+    return d2h_finish(ctx, ctx->stream);
 }
 
 int pm_xy_map(pm_ctx *ctx, const double *lon_deg, const double *lat_deg, int n0, int n1, double alt, double *x_map,
@@ -830,7 +836,16 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         if (k_rows) return reproject_spline_resident(ctx, a, dtype, k_rows, k_cols);
         return reproject_resident(ctx, a, dtype, /*sync_now=*/force_sync);
     }
-    // host cube: stream it through the device in chunks of planes
+    // host cube, nearest / linear with NaN propagation (the default of get_mapped_data): the
+    // pipelined / zero-copy path of pm_hostpipe.hip
+    if (!smooth && !k_rows && !(smoothing > 0.0) && !force_sync)
+        return map_cube_host_pipelined(ctx, cube, dtype, n_planes, x_map, y_map, nmap, a, out);
+    // the other modes: chunks of planes through the device, one after the other (their fits and
+    // statistics passes are synchronous anyway)
+    if (ctx->pending) {
+        rc = pm_synchronize(ctx);
+        if (rc != PM_OK) return rc;
+    }
     size_t chunk = (size_t)(1ull << 30) / (npx * esz);
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)n_planes) chunk = (size_t)n_planes;
@@ -861,9 +876,9 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
              : k_rows          ? reproject_spline_resident(ctx, b, dtype, k_rows, k_cols)
                       : reproject_resident(ctx, b, dtype, /*sync_now=*/true);
         if (rc != PM_OK) return rc;
-        PM_HIP(ctx, hipMemcpyAsync(out + p0 * nmap, dout, np * nmap * sizeof(double), hipMemcpyDeviceToHost,
-                                   ctx->stream));
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        rc = d2h_issue(ctx, ctx->stream, out + p0 * nmap, dout, np * nmap * sizeof(double));
+        if (rc == PM_OK) rc = d2h_finish(ctx, ctx->stream);
+        if (rc != PM_OK) return rc;
     }
     return PM_OK;
 }

@@ -39,6 +39,8 @@ void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, 
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
 
+namespace pmh { struct HostPipe; }
+
 struct pm_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -92,7 +94,7 @@ struct pm_ctx {
     size_t host_chunk_bytes = (size_t)32 << 20;
     int host_copy_threads = 0;   // 0: min(8, cores)
     int zero_copy = -1;          // PM_OPT_ZERO_COPY
-    struct HostPipe *pipe = nullptr;
+    pmh::HostPipe *pipe = nullptr;
 };
 
 namespace pmh {
@@ -119,5 +121,16 @@ int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype);
 int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols);
 int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype, const double *limits);
 int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols, double s);
+
+
+// pm_hostpipe.hip: the host <-> HBM leg of PM_MEM_HOST calls
+void pipe_destroy(pm_ctx *ctx);
+bool host_is_pinned(const void *p, size_t bytes);
+// dst_host <- src_dev on `stream` (staged through pinned buffers + copy threads for pageable
+// destinations); d2h_finish completes every issued copy and synchronises the stream
+int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_dev, size_t bytes);
+int d2h_finish(pm_ctx *ctx, hipStream_t stream);
+int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
+                            const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out);
 
 }  // namespace pmh

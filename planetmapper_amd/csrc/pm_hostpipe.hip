@@ -1,0 +1,456 @@
+// pm_hostpipe.hip -- the host <-> HBM leg of PM_MEM_HOST calls.
+//
+// The reference hands numpy arrays around: Observation._get_mapped_data (observation.py:876-905)
+// maps a host-resident cube plane by plane and every get_*_img returns a host array
+// (body_xy.py:3166). A drop-in caller therefore sees the PCIe leg, not the kernels - one 4096^2
+// frame is 0.2 ms of GPU work and 671 MB of results. This file makes that leg run at the rate of
+// the link (measured on the MI355X boxes, tools/probe_host_path.hip: 57 GB/s per direction for
+// pinned memory, 49 GB/s each way in duplex):
+//
+//   * results -> pageable caller memory: DMA into a ring of pinned staging buffers, copied out by a
+//     small pool of CPU threads while the next DMA runs (fresh numpy arrays take their page faults
+//     on several cores at once: 74 GB/s with 8 threads against 25 GB/s through the runtime's own
+//     pageable path); results -> pinned caller memory (pm_host_alloc / pm_host_register): one DMA;
+//   * cube planes from pageable memory: chunks of planes through a three-slot device ring - the
+//     H2D copy of chunk k + 1, the kernel of chunk k and the D2H copy of finished output overlap on
+//     three streams;
+//   * cube planes from PINNED memory, nearest / linear: nothing is copied at all. The kernel gathers
+//     the pixels it samples straight from host memory: a 1 deg map touches about a third of the 64-byte
+//     sectors of a 1024^2 plane, so the link carries a third of the bytes (6.1 ms per GiB of cube
+//     against 18.6 ms for the copy alone).
+//
+// No compute happens on the CPU here: the threads move bytes.
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "pm_host.hip.h"
+
+namespace pmh {
+
+namespace {
+
+int usable_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n <= 0) n = 1;
+    // container CPU quota, if any
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%63s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const long quota = std::atol(q);
+            if (quota > 0) n = std::min<long>(n, std::max<long>(1, quota / period));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
+}  // namespace
+
+struct HostPipe {
+    // ---- streams / events of the cube pipeline
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    static constexpr int kRing = 3;
+    hipEvent_t ev_in[kRing] = {}, ev_k[kRing] = {};
+    hipEvent_t ev_tmp = nullptr;
+    // ---- pinned staging ring of the D2H leg
+    static constexpr int kSlots = 4;
+    char *stage[kSlots] = {};
+    size_t stage_bytes = 0;
+    hipEvent_t ev_stage[kSlots] = {};
+    struct Piece {
+        int slot;
+        char *dst;
+        size_t bytes;
+    };
+    std::deque<Piece> inflight;
+    int next_slot = 0;
+    // ---- copy pool
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    char *job_dst = nullptr;
+    const char *job_src = nullptr;
+    size_t job_bytes = 0, job_part = 0;
+    std::atomic<size_t> job_next{0};
+    int job_active = 0;
+    uint64_t job_gen = 0;
+    bool stop = false;
+
+    void run_parts()
+    {
+        for (;;) {
+            const size_t i = job_next.fetch_add(1, std::memory_order_relaxed);
+            const size_t a = i * job_part;
+            if (a >= job_bytes) break;
+            const size_t n = std::min(job_part, job_bytes - a);
+            std::memcpy(job_dst + a, job_src + a, n);
+        }
+    }
+    void worker_main()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || job_gen != seen; });
+                if (stop) return;
+                seen = job_gen;
+            }
+            run_parts();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--job_active == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void start_workers(int threads)
+    {
+        const int want = std::max(0, threads - 1);  // the calling thread copies too
+        if ((int)workers.size() == want) return;
+        stop_workers();
+        stop = false;
+        for (int i = 0; i < want; i++) workers.emplace_back([this] { worker_main(); });
+    }
+    void stop_workers()
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : workers) t.join();
+        workers.clear();
+    }
+    // dst <- src with every pool thread (and the caller) taking 1 MiB+ parts
+    void copy(char *dst, const char *src, size_t bytes)
+    {
+        if (bytes < ((size_t)1 << 20) || workers.empty()) {
+            std::memcpy(dst, src, bytes);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job_dst = dst;
+            job_src = src;
+            job_bytes = bytes;
+            const size_t t = workers.size() + 1;
+            size_t part = (bytes + 2 * t - 1) / (2 * t);
+            part = std::max<size_t>(part, (size_t)1 << 20);
+            job_part = (part + 4095) & ~(size_t)4095;
+            job_next.store(0, std::memory_order_relaxed);
+            job_active = (int)workers.size();
+            job_gen++;
+        }
+        cv_work.notify_all();
+        run_parts();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return job_active == 0; });
+    }
+};
+
+static int pipe_get(pm_ctx *ctx, HostPipe **out)
+{
+    if (!ctx->pipe) {
+        HostPipe *hp = new (std::nothrow) HostPipe();
+        if (!hp) return fail(ctx, PM_ERR_ALLOC, "out of memory");
+        ctx->pipe = hp;
+        PM_HIP(ctx, hipStreamCreateWithFlags(&hp->s_in, hipStreamNonBlocking));
+        PM_HIP(ctx, hipStreamCreateWithFlags(&hp->s_out, hipStreamNonBlocking));
+        for (int i = 0; i < HostPipe::kRing; i++) {
+            PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_in[i], hipEventDisableTiming));
+            PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_k[i], hipEventDisableTiming));
+        }
+        PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_tmp, hipEventDisableTiming));
+        for (int i = 0; i < HostPipe::kSlots; i++)
+            PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_stage[i], hipEventDisableTiming));
+    }
+    HostPipe *hp = ctx->pipe;
+    int threads = ctx->host_copy_threads > 0 ? ctx->host_copy_threads : std::min(8, usable_cores());
+    hp->start_workers(threads);
+    *out = hp;
+    return PM_OK;
+}
+
+void pipe_destroy(pm_ctx *ctx)
+{
+    HostPipe *hp = ctx->pipe;
+    if (!hp) return;
+    hp->stop_workers();
+    for (int i = 0; i < HostPipe::kSlots; i++) {
+        if (hp->stage[i]) (void)hipHostFree(hp->stage[i]);
+        if (hp->ev_stage[i]) (void)hipEventDestroy(hp->ev_stage[i]);
+    }
+    for (int i = 0; i < HostPipe::kRing; i++) {
+        if (hp->ev_in[i]) (void)hipEventDestroy(hp->ev_in[i]);
+        if (hp->ev_k[i]) (void)hipEventDestroy(hp->ev_k[i]);
+    }
+    if (hp->ev_tmp) (void)hipEventDestroy(hp->ev_tmp);
+    if (hp->s_in) (void)hipStreamDestroy(hp->s_in);
+    if (hp->s_out) (void)hipStreamDestroy(hp->s_out);
+    delete hp;
+    ctx->pipe = nullptr;
+}
+
+// Is [p, p + bytes) page-locked host memory the GPU can address (hipHostMalloc / hipHostRegister)?
+bool host_is_pinned(const void *p, size_t bytes)
+{
+    if (!p || bytes == 0) return false;
+    auto pinned_at = [](const void *q) {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();  // plain malloc memory: "invalid value", not an error here
+            return false;
+        }
+        return at.type == hipMemoryTypeHost;
+    };
+    return pinned_at(p) && pinned_at((const char *)p + bytes - 1);
+}
+
+static int ensure_stage(pm_ctx *ctx, HostPipe *hp)
+{
+    const size_t want = std::min<size_t>(std::max<size_t>(ctx->host_chunk_bytes / 2, (size_t)4 << 20), (size_t)64 << 20);
+    if (hp->stage[0] && hp->stage_bytes == want) return PM_OK;
+    for (int i = 0; i < HostPipe::kSlots; i++) {
+        if (hp->stage[i]) PM_HIP(ctx, hipHostFree(hp->stage[i]));
+        hp->stage[i] = nullptr;
+    }
+    for (int i = 0; i < HostPipe::kSlots; i++) {
+        hipError_t e = hipHostMalloc((void **)&hp->stage[i], want, hipHostMallocNonCoherent);
+        if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc of a %zu-byte staging buffer failed", want);
+    }
+    hp->stage_bytes = want;
+    return PM_OK;
+}
+
+// oldest staged piece: wait for its DMA, copy it out
+static int d2h_retire_one(pm_ctx *ctx, HostPipe *hp)
+{
+    const HostPipe::Piece pc = hp->inflight.front();
+    hp->inflight.pop_front();
+    PM_HIP(ctx, hipEventSynchronize(hp->ev_stage[pc.slot]));
+    hp->copy(pc.dst, hp->stage[pc.slot], pc.bytes);
+    return PM_OK;
+}
+
+// Enqueue dst_host <- src_dev on `stream`. Pinned destinations: one DMA. Pageable destinations:
+// pieces through the staging ring; at most kSlots pieces are in flight, the oldest is retired
+// (copied out by the pool) when the ring is full. d2h_finish() completes everything.
+int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (bytes == 0) return PM_OK;
+    HostPipe *hp;
+    int rc = pipe_get(ctx, &hp);
+    if (rc != PM_OK) return rc;
+    if (bytes < ((size_t)256 << 10) || host_is_pinned(dst_host, bytes)) {
+        // (small pageable copies: the runtime's own path is as good as anything)
+        PM_HIP(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, stream));
+        return PM_OK;
+    }
+    rc = ensure_stage(ctx, hp);
+    if (rc != PM_OK) return rc;
+    for (size_t off = 0; off < bytes; off += hp->stage_bytes) {
+        const size_t n = std::min(hp->stage_bytes, bytes - off);
+        if ((int)hp->inflight.size() == HostPipe::kSlots) {
+            rc = d2h_retire_one(ctx, hp);
+            if (rc != PM_OK) return rc;
+        }
+        const int slot = hp->next_slot;
+        hp->next_slot = (slot + 1) % HostPipe::kSlots;
+        PM_HIP(ctx, hipMemcpyAsync(hp->stage[slot], (const char *)src_dev + off, n, hipMemcpyDeviceToHost, stream));
+        PM_HIP(ctx, hipEventRecord(hp->ev_stage[slot], stream));
+        hp->inflight.push_back({slot, (char *)dst_host + off, n});
+    }
+    return PM_OK;
+}
+
+int d2h_finish(pm_ctx *ctx, hipStream_t stream)
+{
+    HostPipe *hp = ctx->pipe;
+    if (hp)
+        while (!hp->inflight.empty()) {
+            int rc = d2h_retire_one(ctx, hp);
+            if (rc != PM_OK) return rc;
+        }
+    PM_HIP(ctx, hipStreamSynchronize(stream));
+    return PM_OK;
+}
+
+// ------------------------------------------------------------------ cube pipeline (nearest / linear, propagate_nan)
+namespace {
+
+struct CubeJob {
+    const char *cube;  // host
+    int dtype;
+    size_t esz, plane_bytes, nmap;
+    int n_planes;
+    const double *x_map, *y_map;  // host
+    double *out;                  // host
+    pm::ReprojectArgs a;          // ny, nx, n_map, interpolation, propagate_nan filled in
+};
+
+// planes whose sampled pixels turned out to need the plane nanmedian: one at a time, synchronously
+// (rare: +-inf pixels or neighbourhoods without a finite pixel)
+int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &planes, const double *dxm, const double *dym,
+                     char *dplane, double *dout)
+{
+    int rc = ensure_stats(ctx, 1);
+    if (rc != PM_OK) return rc;
+    const size_t plane_elems = (size_t)j.a.ny * j.a.nx;
+    for (int p : planes) {
+        PM_HIP(ctx, hipMemcpyAsync(dplane, j.cube + (size_t)p * j.plane_bytes, j.plane_bytes, hipMemcpyHostToDevice, ctx->stream));
+        PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, sizeof(pm::PlaneStats), ctx->stream));
+        PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, 512 * sizeof(unsigned int), ctx->stream));
+        pm_launch_plane_medians(dplane, j.dtype, 1, plane_elems, ctx->stats, ctx->hist, ctx->stream);
+        pm::ReprojectArgs b = j.a;
+        b.cube = dplane;
+        b.x_map = dxm;
+        b.y_map = dym;
+        b.out = dout;
+        b.n_planes = 1;
+        b.plane_flags = ctx->flags + p;
+        b.plane_stats = ctx->stats;
+        pm_launch_reproject(b, j.dtype, ctx->stream);
+        PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(j.out + (size_t)p * j.nmap, dout, j.nmap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return PM_OK;
+}
+
+}  // namespace
+
+// pm_map_cube for host buffers, interpolation nearest / linear with NaN propagation (the default of
+// Observation.get_mapped_data). Caller has validated the arguments and sized ctx->flags.
+int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
+                            const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out)
+{
+    HostPipe *hp;
+    int rc = pipe_get(ctx, &hp);
+    if (rc != PM_OK) return rc;
+    if (ctx->pending) {
+        rc = pm_synchronize(ctx);
+        if (rc != PM_OK) return rc;
+    }
+    CubeJob j;
+    j.cube = (const char *)cube;
+    j.dtype = dtype;
+    j.esz = dtype_size(dtype);
+    j.plane_bytes = (size_t)a.ny * a.nx * j.esz;
+    j.nmap = nmap;
+    j.n_planes = n_planes;
+    j.x_map = x_map;
+    j.y_map = y_map;
+    j.out = out;
+    a.plane_stats = nullptr;
+    a.seq = ++ctx->map_seq;
+    j.a = a;
+
+    const size_t cube_bytes = (size_t)n_planes * j.plane_bytes;
+    const size_t out_bytes = (size_t)n_planes * nmap * sizeof(double);
+    const bool src_pinned = host_is_pinned(cube, cube_bytes);
+    const bool dst_pinned = host_is_pinned(out, out_bytes);
+    const bool zero_copy = src_pinned && ctx->zero_copy != 0;
+    const hipStream_t sk = ctx->stream;
+
+    // planes per chunk of the copy pipeline; per batch of the output buffer
+    size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
+    chunk = std::min<size_t>(std::min<size_t>(chunk, (size_t)n_planes), 32768);
+    if (zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, ((size_t)n_planes + 7) / 8), 32768);
+    const size_t batch = std::min<size_t>((size_t)n_planes, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
+    const size_t slot_bytes = (chunk * j.plane_bytes + 255) & ~(size_t)255;
+    const bool direct_out = zero_copy && dst_pinned;  // the kernel stores into the caller's pinned array
+    size_t need = 2 * nmap * sizeof(double) + 256;
+    if (!zero_copy) need += HostPipe::kRing * slot_bytes;
+    if (!direct_out) need += batch * nmap * sizeof(double);
+    need = std::max(need, 2 * nmap * sizeof(double) + 512 + j.plane_bytes + nmap * sizeof(double));  // median redo
+    rc = ensure_scratch(ctx, need);
+    if (rc != PM_OK) return rc;
+    char *base = (char *)ctx->scratch;
+    double *dxm = (double *)base;
+    double *dym = dxm + nmap;
+    char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
+    double *dout_all = (double *)(ring + (zero_copy ? 0 : HostPipe::kRing * slot_bytes));
+    PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+    PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+
+    const char *cube_dev = nullptr;  // zero copy: the device's view of the caller's pinned cube
+    double *out_dev = nullptr;
+    if (zero_copy) PM_HIP(ctx, hipHostGetDevicePointer((void **)&cube_dev, (void *)cube, 0));
+    if (direct_out) PM_HIP(ctx, hipHostGetDevicePointer((void **)&out_dev, (void *)out, 0));
+
+    // s_out drains finished output while later chunks are still being copied in / mapped
+    size_t c = 0;  // running chunk number (ring slot = c % kRing)
+    for (size_t b0 = 0; b0 < (size_t)n_planes; b0 += batch) {
+        const size_t nb = std::min(batch, (size_t)n_planes - b0);
+        size_t drained = 0;  // planes of this batch already handed to the D2H leg
+        size_t launched = 0;
+        for (size_t p0 = 0; p0 < nb; p0 += chunk, c++) {
+            const size_t np = std::min(chunk, nb - p0);
+            const int slot = (int)(c % HostPipe::kRing);
+            pm::ReprojectArgs b = a;
+            b.x_map = dxm;
+            b.y_map = dym;
+            b.n_planes = (int)np;
+            b.plane_flags = ctx->flags + b0 + p0;
+            b.out = direct_out ? out_dev + (b0 + p0) * nmap : dout_all + p0 * nmap;
+            if (zero_copy) {
+                b.cube = cube_dev + (b0 + p0) * j.plane_bytes;
+            } else {
+                char *dslot = ring + (size_t)slot * slot_bytes;
+                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                PM_HIP(ctx, hipMemcpyAsync(dslot, j.cube + (b0 + p0) * j.plane_bytes, np * j.plane_bytes, hipMemcpyHostToDevice,
+                                           hp->s_in));
+                PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
+                PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
+                b.cube = dslot;
+            }
+            pm_launch_reproject(b, dtype, sk);
+            PM_HIP(ctx, hipGetLastError());
+            PM_HIP(ctx, hipEventRecord(hp->ev_k[slot], sk));
+            launched = p0 + np;
+            // hand finished output to the D2H leg in pieces worth a DMA
+            if (!direct_out && (launched - drained) * nmap * sizeof(double) >= ((size_t)8 << 20)) {
+                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_k[slot], 0));
+                rc = d2h_issue(ctx, hp->s_out, out + (b0 + drained) * nmap, dout_all + drained * nmap,
+                               (launched - drained) * nmap * sizeof(double));
+                if (rc != PM_OK) return rc;
+                drained = launched;
+            }
+        }
+        if (!direct_out) {
+            if (launched > drained) {
+                PM_HIP(ctx, hipEventRecord(hp->ev_tmp, sk));
+                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_tmp, 0));
+                rc = d2h_issue(ctx, hp->s_out, out + (b0 + drained) * nmap, dout_all + drained * nmap,
+                               (launched - drained) * nmap * sizeof(double));
+                if (rc != PM_OK) return rc;
+            }
+            // the next batch reuses dout_all
+            rc = d2h_finish(ctx, hp->s_out);
+            if (rc != PM_OK) return rc;
+        }
+    }
+    // per-plane flags of the whole call: one read-back
+    std::vector<int> hflags((size_t)n_planes);
+    PM_HIP(ctx, hipMemcpyAsync(hflags.data(), ctx->flags, (size_t)n_planes * sizeof(int), hipMemcpyDeviceToHost, sk));
+    PM_HIP(ctx, hipStreamSynchronize(sk));
+    PM_HIP(ctx, hipStreamSynchronize(hp->s_in));
+    ctx->checked_seq = a.seq;
+    std::vector<int> redo;
+    for (int p = 0; p < n_planes; p++)
+        if (hflags[(size_t)p] == a.seq) redo.push_back(p);
+    if (!redo.empty()) {
+        char *dplane = ring;  // scratch was sized for one plane + one mapped plane behind the maps
+        double *dout1 = (double *)(dplane + ((j.plane_bytes + 255) & ~(size_t)255));
+        rc = redo_with_median(ctx, j, redo, dxm, dym, dplane, dout1);
+        if (rc != PM_OK) return rc;
+    }
+    return PM_OK;
+}
+
+}  // namespace pmh

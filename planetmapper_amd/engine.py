@@ -148,6 +148,37 @@ class Engine:
     def set_stream(self, hip_stream: int) -> None:
         self._check(self._lib.pm_set_stream(self._ctx, ctypes.c_void_p(hip_stream)))
 
+    def pinned_empty(self, shape, dtype=np.float64) -> np.ndarray:
+        """
+        An uninitialised numpy array in page-locked host memory (`pm_host_alloc`): host-buffer calls
+        move such arrays by DMA at the full PCIe rate, and `map_cube` reads a pinned cube in place
+        (`PM_OPT_ZERO_COPY`). The memory is released when the array (and every view of it) is gone;
+        it must not outlive the engine.
+        """
+        import weakref
+
+        dt = np.dtype(dtype)
+        shape = (int(shape),) if np.isscalar(shape) else tuple(int(v) for v in shape)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+        p = ctypes.c_void_p()
+        self._check(self._lib.pm_host_alloc(self._ctx, max(nbytes, 1), ctypes.byref(p)))
+        buf = (ctypes.c_char * max(nbytes, 1)).from_address(p.value)
+        weakref.finalize(buf, Engine._release_pinned, weakref.ref(self), p.value)
+        return np.frombuffer(buf, dtype=dt, count=int(np.prod(shape, dtype=np.int64))).reshape(shape)
+
+    @staticmethod
+    def _release_pinned(engine_ref, ptr: int) -> None:
+        eng = engine_ref()
+        if eng is not None and getattr(eng, '_ctx', None):
+            eng._lib.pm_host_free(eng._ctx, ctypes.c_void_p(ptr))
+
+    def pinned_copy(self, arr) -> np.ndarray:
+        """`arr` copied into a new pinned array (see `pinned_empty`)."""
+        arr = np.asarray(arr)
+        out = self.pinned_empty(arr.shape, arr.dtype)
+        out[...] = arr
+        return out
+
     def device_malloc(self, nbytes: int) -> int:
         p = ctypes.c_void_p()
         self._check(self._lib.pm_device_malloc(self._ctx, int(nbytes), ctypes.byref(p)))

@@ -381,6 +381,81 @@ def test_async_map_cube_is_finished_before_its_flags_are_regrown(engine, oracle,
         eng.close()
 
 
+def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
+    """
+    The host <-> HBM leg of PM_MEM_HOST calls (pm_hostpipe.hip): a pageable cube through the
+    three-slot copy pipeline (tiny chunks here: many ring reuses and output drains), a pinned cube
+    copied by DMA, a pinned cube gathered in place (zero copy), pageable / pinned outputs, the
+    staged D2H of frames - all bit-identical to each other and within the bar of the oracle; planes
+    that need the nanmedian (-inf block) are redone behind the pipeline.
+    """
+    from planetmapper_amd import _lib
+
+    sz, planes = 256, 37
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, 0.9 * x0, 0.2, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 2.0)
+    d = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)
+    d.rotation_rad = 0.2
+    xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+    rng = np.random.default_rng(99)
+    cube = rng.standard_normal((planes, sz, sz)) * 4 + 1
+    cube[rng.random(cube.shape) < 2e-3] = np.nan
+    cube[5][90:150, 70:190] = -np.inf
+    cube[30][:] = np.nan
+    try:
+        engine.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 1 << 20)  # 2 planes of 512 KiB per chunk
+        for interp in ('linear', 'nearest'):
+            ref = oracle.map_cube(cube, xm, ym, interp, True)
+            a = engine.map_cube(cube, xm, ym, interp, True)
+            assert np.array_equal(np.isnan(a), np.isnan(ref)) and np.array_equal(np.isinf(a), np.isinf(ref))
+            fin = np.isfinite(ref)
+            assert np.max(np.abs(a[fin] - ref[fin])) <= 1e-11
+            pc = engine.pinned_copy(cube)
+            engine.set_option(_lib.PM_OPT_ZERO_COPY, 0)
+            b = engine.map_cube(pc, xm, ym, interp, True)
+            engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
+            c = engine.map_cube(pc, xm, ym, interp, True)
+            assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), interp
+            # pinned output: the zero-copy kernel stores straight into it
+            po = engine.pinned_empty(a.shape)
+            po[...] = -3.0
+            engine._check(engine._lib.pm_map_cube(
+                engine._ctx, pc.ctypes.data, 0, planes, xm.ctypes.data, ym.ctypes.data, xm.shape[0], xm.shape[1],
+                _lib.PM_INTERP_LINEAR if interp == 'linear' else _lib.PM_INTERP_NEAREST, 1, po.ctypes.data, _lib.PM_MEM_HOST,
+            ))  # fmt: skip
+            assert np.array_equal(po, a, equal_nan=True), interp
+            del pc, po
+        # int16 planes, default chunking
+        engine.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 32 << 20)
+        ci = (rng.standard_normal((planes, sz, sz)) * 1000).astype(np.int16)
+        assert np.array_equal(engine.map_cube(ci, xm, ym), engine.map_cube(engine.pinned_copy(ci), xm, ym), equal_nan=True)
+        assert np.max(np.abs(np.nan_to_num(engine.map_cube(ci, xm, ym) - oracle.map_cube(ci, xm, ym)))) <= 1e-9
+        # frames: staged D2H into pageable arrays == DMA into pinned arrays
+        names = ['LON-GRAPHIC', 'EMISSION', 'RA', 'RING-RADIUS']
+        engine.set_disc(700.3, 511.0, 480.0, 0.4, 1400, 1100, True)  # 12 MB planes: several staging pieces
+        pag = engine.backplanes_img(names)
+        import ctypes
+
+        from planetmapper_amd.engine import PLANE_INDEX, plane_mask
+
+        pin = {n: engine.pinned_empty((1100, 1400)) for n in names}
+        ptrs = (ctypes.c_void_p * _lib.NUM_PLANES)()
+        for n, arr in pin.items():
+            ptrs[PLANE_INDEX[n]] = arr.ctypes.data
+        engine._check(engine._lib.pm_backplanes_img(engine._ctx, plane_mask(names), 0.0, ptrs, _lib.PM_MEM_HOST))
+        dev = {n: __import__('torch').empty((1100, 1400), dtype=__import__('torch').float64, device='cuda') for n in names}
+        engine.backplanes_img_device(dev)
+        engine.synchronize()
+        for n in names:
+            assert np.array_equal(pag[n], pin[n], equal_nan=True), n
+            assert np.array_equal(pag[n], dev[n].cpu().numpy(), equal_nan=True), n
+    finally:
+        engine.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 32 << 20)
+        engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
+
+
 def test_point_transforms_vs_oracle(engine, oracle, jupiter):
     """
     pm_transform (reference xy2lonlat, lonlat2radec, ... on arrays) against the oracle:

@@ -4,17 +4,32 @@ Headline benchmark (BASELINE.json): Mpix/s for the full backplane set
 (LON/LAT-GRAPHIC, PHASE, INCIDENCE, EMISSION) + map reprojection of a 4096 x 4096 frame.
 
 One step = one frame through the hot path, everything resident in HBM:
-  1. pm_backplanes_img   5 planes, 4096^2           (kernel k_disc<ILLUM>)
+  1. pm_backplanes_img   5 planes, 4096^2           (kernel k_disc_sph<ILLUM>)
   2. pm_xy_map           1 deg rectangular grid     (kernel k_map, 180 x 360)
   3. pm_map_cube         1 data plane -> (180, 360) (kernel k_reproject<f64>)
-With N > 1 GPUs every rank processes its own frame (weak scaling, no data-path
-collective in the backplane stage) and the reprojected planes - one per rank, i.e. the
-wavelength planes of `Observation.get_mapped_data` sharded one per GPU - are combined
-by ONE RCCL all-gather, the only exchange step the path has.
+With N > 1 GPUs every rank processes its own frame (weak scaling, no data-path collective in
+the backplane stage) and the reprojected planes - one per rank, i.e. the wavelength planes of
+`Observation.get_mapped_data` sharded one per GPU - are combined by ONE RCCL all-gather, the
+only exchange step the path has.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--size 4096]
-Launch for N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
-                   --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+Beside the headline line the same JSON object carries (rank 0, after the timed region):
+  roofline / step_roofline / fp64   the dominant kernel and the whole step against the HBM peak,
+                                    FP64 rate against the vector peak
+  cpu_baseline(_1thread), cpu_model the CPU oracle on this box's host cores
+  host_path                         PCIe-inclusive time of the same frame into numpy arrays
+  cube_host                         BASELINE config 5, the north star's scaling case: a 512-plane
+                                    1024^2 f64 cube in HOST memory, planes sharded over the ranks,
+                                    each rank feeding its block over its own PCIe link, one RCCL
+                                    all-gather of the mapped planes; step time with and without the
+                                    host feed (the driver's N = 1, 2, 4, 8 runs give the scaling curve)
+
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frame|saturn|cube|cube-host]
+`--gpus N` with N > 1 launches itself: unless it already runs under torch.distributed.run
+(WORLD_SIZE set), the process - before touching the GPU - starts
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` on this
+file as a child, relays its output and exits with its status.
+`--rehearse` runs launcher, process group (gloo), barriers, collectives and reporting on CPU with an
+empty step (no engine, no numbers): the CPU test of the N > 1 plumbing.
 """
 
 from __future__ import annotations
@@ -22,6 +37,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,8 +50,53 @@ if REPO not in sys.path:
 
 HEADLINE = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION']
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64
+METRIC = 'Mpix/s full backplane set (lat/lon/inc/emi/phase) + map-reproject, 4096^2 frame'
 
 
+# ------------------------------------------------------------------ launcher
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--preheat-steps', type=int, default=500, help='untimed clock-ramp steps before the warmup steps')
+    ap.add_argument('--size', type=int, default=4096)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='headline line only: no host_path / cube_host sections')
+    ap.add_argument(
+        '--workload', default='frame', choices=['frame', 'saturn', 'cube', 'cube-host'],
+        help='frame: BASELINE headline (default); saturn: config 4 (Saturn + rings, 8 planes); cube: config 5 with '
+        'the cube resident in HBM; cube-host: config 5 fed from host memory (planes sharded over the GPUs)',
+    )  # fmt: skip
+    ap.add_argument('--planes', type=int, default=512, help='cube workloads: total planes')
+    ap.add_argument('--rehearse', action='store_true', help='CPU / gloo rehearsal of the N > 1 plumbing (no GPU work)')
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    """
+    `python bench.py --gpus N` typed directly: one child per GPU through torch.distributed.run.
+    Runs BEFORE this process imports torch or touches HIP (a process that has initialised the GPU
+    must not exec / fork workers), relays the children's output and returns their exit status.
+    """
+    cmd = [
+        sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+        '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__),
+    ] + sys.argv[1:]  # fmt: skip
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault('OMP_NUM_THREADS', '1')
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------ helpers
 def rectangular_grid(west_positive: bool, degree_interval: float = 1.0):
     """BodyXY.generate_map_coordinates('rectangular') body_xy.py:2899-2907."""
     lons = np.arange(degree_interval / 2, 360, degree_interval)
@@ -45,22 +107,21 @@ def rectangular_grid(west_positive: bool, degree_interval: float = 1.0):
     return np.ascontiguousarray(lon % 360), np.ascontiguousarray(lat)
 
 
-def measured_traffic(kernel_prefix: str):
+def profile_record(kernel_prefix: str) -> dict:
     """
-    HBM bytes per launch of the dominant kernel from the PMC passes of tools/pmc_profile.sh
-    (WRITE_SIZE + FETCH_SIZE, separate rocprofv3 --pmc runs; profiles/traffic.json). PMC
-    counters cannot be collected inside this process, so the last profiled value is reported;
-    None if no profile has been recorded.
+    Per-launch PMC figures of a kernel from the separate rocprofv3 --pmc passes of
+    tools/pmc_profile.sh (profiles/traffic.json: WRITE_SIZE + FETCH_SIZE bytes, FP64 operations).
+    PMC counters cannot be collected inside this process, so the last profiled values are reported.
     """
     try:
         with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
         for k, v in t.items():
             if k.startswith(kernel_prefix):
-                return int(v['hbm_bytes'])
+                return v
     except (OSError, ValueError, KeyError):
         pass
-    return None
+    return {}
 
 
 def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
@@ -80,63 +141,299 @@ def host_cores() -> int:
     return n
 
 
-def cpu_baseline(g, sz: int, budget_s: float = 12.0) -> dict:
+def cpu_model() -> str:
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(g, sz: int, threads: int, budget_s: float, max_frames: int) -> dict:
     """
-    The CPU oracle (a port: the reference's own Python + CSPICE path cannot run here)
-    timed on this box's host cores on the same 5-plane frame; all cores via OpenMP.
+    The CPU oracle (a port: the reference's own Python + CSPICE path cannot run here) timed on this
+    box's host cores on the same 5-plane frame + reprojection, OpenMP over rows on `threads` threads.
     """
     from oracle import oracle
 
-    cores = host_cores()
-    oracle.set_num_threads(cores)
+    oracle.set_num_threads(threads)
     x0 = y0 = (sz - 1) / 2
     disc = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)
     lon, lat = rectangular_grid(bool(g.west_positive))
     img = np.zeros((sz, sz))
-    # bounded sample: whole frames until the budget is used (at least one)
     t0 = time.perf_counter()
     frames = 0
-    while True:
+    while True:  # bounded sample: whole frames until the budget is used (at least one)
         oracle.backplanes_img(g, disc, HEADLINE)
         xm, ym = oracle.xy_map(g, disc, lon, lat)
         oracle.map_cube(img, xm, ym, 'linear', True)
         frames += 1
         dt = time.perf_counter() - t0
-        if dt > budget_s or frames >= 8:
+        if dt > budget_s or frames >= max_frames:
             break
     return {
         'value': round(frames * sz * sz / dt / 1e6, 3),
         'unit': 'Mpix/s',
-        'cores': cores,
+        'cores': threads,
         'kind': 'port',
         'sample': f'{frames} full {sz}x{sz} frame(s), 5 planes + 1 deg reprojection, OpenMP over rows',
     }
 
 
+class Dist:
+    """The process group of this run (or a single process): barrier, max-over-ranks, cleanup."""
+
+    def __init__(self, args):
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.world = int(os.environ.get('WORLD_SIZE', '1'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.rehearse = args.rehearse
+        if self.world != args.gpus:
+            raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE is {self.world}')
+        import torch
+
+        self.torch = torch
+        if self.rehearse:
+            self.dev = torch.device('cpu')
+        else:
+            if not torch.cuda.is_available():
+                raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device('cuda', self.local_rank)
+        if self.world > 1:
+            import torch.distributed as dist
+
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if self.rehearse:
+                dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
+            self.dist = dist
+
+    def sync(self) -> None:
+        if not self.rehearse:
+            self.torch.cuda.synchronize()
+
+    def barrier(self) -> None:
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def max_over_ranks(self, v: float) -> float:
+        if self.world == 1:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_gather(self, gathered, mine, async_op=False):
+        if self.world == 1:
+            return None
+        return self.dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), async_op=async_op)
+
+    def close(self) -> None:
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed_steps(d: Dist, step, args, preheat: int):
+    """
+    The contract's timed region: W untimed warm-up steps, then EXACTLY K steps bracketed by a barrier
+    + device synchronisation on both sides; the time is the maximum over the ranks.
+    Before that an untimed clock ramp: a fresh box starts in a low power state and the shader clock
+    takes tens of milliseconds of sustained load to settle (a fixed count, not a wall-clock loop:
+    every rank must issue the same collectives).
+    """
+    for _ in range(preheat):
+        step(None)
+    d.barrier()
+    for _ in range(args.warmup):
+        step(None)
+    d.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    d.barrier()
+    return d.max_over_ranks(time.perf_counter() - t0)
+
+
+# ------------------------------------------------------------------ rehearsal (CPU, gloo)
+def rehearse(args) -> None:
+    d = Dist(args)
+    torch = d.torch
+    n0, n1 = 180, 360
+    gathered = torch.zeros((d.world, 1, n0, n1), dtype=torch.float64)
+    fail_rank = int(os.environ.get('PM_BENCH_FAIL_RANK', '-1'))
+
+    def step(i):
+        if i is not None and d.rank == fail_rank:
+            raise RuntimeError('rehearsal: injected failure on this rank')
+        gathered[d.rank].fill_(float(d.rank + 1))
+        d.all_gather(gathered, gathered[d.rank])
+
+    dt = timed_steps(d, step, args, preheat=2)
+    assert all(float(gathered[r, 0, 0, 0]) == r + 1 for r in range(d.world))
+    if d.rank == 0:
+        print(json.dumps({
+            'metric': METRIC, 'value': 0.0, 'unit': 'Mpix/s', 'n_gpus': d.world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'none', 'rehearsal': True,
+            'config': {'workload': 'CPU / gloo rehearsal of launcher, barriers, all-gather and reporting: no engine work'},
+        }), flush=True)  # fmt: skip
+    d.close()
+
+
+# ------------------------------------------------------------------ config 5 fed from host memory
+def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_resident: int) -> dict:
+    """
+    BASELINE config 5 as the reference runs it (observation.py:876-905 maps a HOST cube): P x 1024^2
+    f64 planes in host memory, contiguous blocks of ceil(P / N) planes per rank
+    (`distributed.shard_bounds`), each rank feeding its block from its own pinned host buffer over
+    its own PCIe link (`PM_MEM_HOST_CUBE`: the kernel gathers the sampled pixels in place), ONE RCCL
+    all-gather of the mapped planes. Returns step times with the host feed and with the block
+    already resident in HBM, max over ranks.
+    """
+    torch = d.torch
+    from planetmapper_amd.distributed import shard_bounds
+
+    sz = 1024
+    x0 = (sz - 1) / 2
+    eng.set_geometry(g)
+    eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+    a, b, per_rank = shard_bounds(planes, d.world, d.rank)
+    mine_n = b - a
+    lon_h, lat_h = rectangular_grid(bool(g.west_positive))
+    n0, n1 = lon_h.shape
+    lon_d, lat_d = torch.from_numpy(lon_h).to(d.dev), torch.from_numpy(lat_h).to(d.dev)
+    xm = torch.empty((n0, n1), dtype=torch.float64, device=d.dev)
+    ym = torch.empty((n0, n1), dtype=torch.float64, device=d.dev)
+    gen = torch.Generator(device=d.dev).manual_seed(5 + d.rank)
+    cube_d = torch.randn((max(mine_n, 1), sz, sz), generator=gen, device=d.dev, dtype=torch.float64)
+    cube_d[torch.rand(cube_d.shape, generator=gen, device=d.dev) < 1e-3] = float('nan')
+    t = time.perf_counter()
+    cube_h = eng.pinned_empty((max(mine_n, 1), sz, sz))  # what a loader reads this rank's planes into
+    t_pin = time.perf_counter() - t
+    torch.from_numpy(cube_h).copy_(cube_d)
+    gathered = torch.full((d.world, per_rank, n0, n1), float('nan'), dtype=torch.float64, device=d.dev)
+    mine = gathered[d.rank][:mine_n] if mine_n else None
+
+    def step(fed: bool):
+        eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
+        if mine_n:
+            if fed:
+                eng.map_cube_host_to_device(cube_h[:mine_n], xm, ym, n0, n1, mine)
+            else:
+                eng.map_cube_device(cube_d, np.float64, mine_n, xm, ym, n0, n1, mine)
+            eng.synchronize()  # finished (flag check) before peers see it
+        d.all_gather(gathered, gathered[d.rank])
+
+    def run(fed: bool, steps: int) -> float:
+        for _ in range(2):
+            step(fed)
+        d.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(fed)
+        d.barrier()
+        return d.max_over_ranks(time.perf_counter() - t0) / steps
+
+    t_res = run(False, steps_resident)
+    ref = gathered.clone()
+    t_fed = run(True, steps_fed)
+    same = bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+    pix = planes * sz * sz
+    block_bytes = mine_n * sz * sz * 8
+    return {
+        'workload': f'host-resident IFU cube {planes}x{sz}x{sz} f64 -> 1 deg map ({n0}x{n1}), bilinear, '
+        f'{per_rank} planes per rank from pinned host memory, RCCL all-gather of the mapped planes'
+        + ('' if d.world > 1 else ' (skipped at N=1)'),
+        'rccl_ranks': d.world,
+        'planes': planes,
+        'planes_per_rank': per_rank,
+        'ms_per_step_host_fed': round(t_fed * 1e3, 3),
+        'ms_per_step_resident': round(t_res * 1e3, 4),
+        'Mpix_s_host_fed': round(pix / t_fed / 1e6, 1),
+        'Mpix_s_resident': round(pix / t_res / 1e6, 1),
+        'host_feed_GBps_per_rank': round(block_bytes / t_fed / 1e9, 2),
+        'host_feed': 'zero copy: the reprojection kernel gathers the sampled pixels from pinned host memory',
+        'fed_equals_resident': same,
+        'all_gather_bytes_per_rank': per_rank * n0 * n1 * 8,
+        'pinned_alloc_ms': round(t_pin * 1e3, 1),
+        'scaling': 'strong',
+    }
+
+
+def host_path_section(eng, g, sz: int) -> dict:
+    """PCIe-inclusive time of the headline frame into numpy arrays (what get_*_img() callers see)."""
+    import ctypes
+
+    from planetmapper_amd import _lib
+    from planetmapper_amd.engine import PLANE_INDEX, plane_mask
+
+    x0 = (sz - 1) / 2
+    eng.set_geometry(g)
+    eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+    nbytes = len(HEADLINE) * sz * sz * 8
+    eng.backplanes_img(HEADLINE)
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            r = fn()
+            ts.append(time.perf_counter() - t)
+            del r
+        return min(ts)
+
+    t_fresh = best(lambda: eng.backplanes_img(HEADLINE))
+    pinned = {n: eng.pinned_empty((sz, sz)) for n in HEADLINE}
+    ptrs = (ctypes.c_void_p * _lib.NUM_PLANES)()
+    for n, arr in pinned.items():
+        ptrs[PLANE_INDEX[n]] = arr.ctypes.data
+
+    def into_pinned():
+        eng._check(eng._lib.pm_backplanes_img(eng._ctx, plane_mask(HEADLINE), 0.0, ptrs, _lib.PM_MEM_HOST))
+
+    t_pin = best(into_pinned)
+    return {
+        'frame': f'{sz}x{sz} x {len(HEADLINE)} planes = {nbytes / 1e6:.0f} MB to host',
+        'ms_fresh_numpy_arrays': round(t_fresh * 1e3, 2),
+        'GBps_fresh_numpy_arrays': round(nbytes / t_fresh / 1e9, 1),
+        'ms_pinned_arrays': round(t_pin * 1e3, 2),
+        'GBps_pinned_arrays': round(nbytes / t_pin / 1e9, 1),
+        'pcie_gen5_x16_spec_GBps': 63.0,
+        'Mpix_s_fresh_numpy_arrays': round(sz * sz / t_fresh / 1e6, 1),
+    }
+
+
+# ------------------------------------------------------------------ secondary workloads
 def other_workloads(args) -> None:
     """Secondary BASELINE configs (4 and 5); same JSON contract, their own metric names."""
-    import torch
-    import torch.distributed as dist
-
+    d = Dist(args)
+    torch = d.torch
     from planetmapper_amd.distributed import map_cube_sharded_device, shard_bounds
     from planetmapper_amd.engine import Engine
     from planetmapper_amd.scenarios import load_scenario
 
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-    eng = Engine(local_rank)
+    eng = Engine(d.local_rank)
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    if args.workload == 'cube-host':
+        g = load_scenario('jupiter_hst_2005')
+        sec = cube_host_section(d, eng, g, args.planes, max(3, min(args.steps, 20)), max(20, args.steps))
+        if d.rank == 0:
+            print(json.dumps({
+                'metric': 'Mpix/s of cube pixels map-projected from HOST memory (get_mapped_data, 1 deg rectangular map, bilinear)',
+                'value': sec['Mpix_s_host_fed'], 'unit': 'Mpix/s', 'n_gpus': d.world, 'steps': max(3, min(args.steps, 20)),
+                'warmup': 2, 'ms_per_step': sec['ms_per_step_host_fed'], 'higher_is_better': True, 'scaling': 'strong',
+                'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': sec['workload']},
+                'cube_host': sec,
+            }), flush=True)  # fmt: skip
+        d.close()
+        eng.close()
+        return
 
     if args.workload == 'saturn':
         # SURVEY 8d config 4: Saturn-like spheroid, 4096^2, r0 = 800 px, rotation 20 deg
@@ -146,9 +443,9 @@ def other_workloads(args) -> None:
         eng.set_geometry(g)
         x0 = (sz - 1) / 2
         eng.set_disc(x0, x0, 800.0 * sz / 4096, float(np.deg2rad(20.0)), sz, sz, True)
-        planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
+        planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=d.dev) for n in names}
 
-        def step():
+        def work():
             eng.backplanes_img_device(planes)
 
         units = sz * sz
@@ -157,60 +454,55 @@ def other_workloads(args) -> None:
         alg = sz * sz * 8 * len(names)
         scaling = 'weak'
     else:
-        # IFU cube P x 1024 x 1024 f64, 1 deg map, planes sharded over ranks
+        # IFU cube P x 1024 x 1024 f64 resident in HBM, planes sharded over ranks
         sz = 1024
         g = load_scenario('jupiter_hst_2005')
         eng.set_geometry(g)
         x0 = (sz - 1) / 2
         eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
-        a, b, per_rank = shard_bounds(args.planes, world, rank)
-        gen = torch.Generator(device=dev).manual_seed(5 + rank)
-        cube = torch.randn((per_rank, sz, sz), generator=gen, device=dev, dtype=torch.float64)
-        cube[torch.rand((per_rank, sz, sz), generator=gen, device=dev) < 1e-3] = float('nan')
+        a, b, per_rank = shard_bounds(args.planes, d.world, d.rank)
+        gen = torch.Generator(device=d.dev).manual_seed(5 + d.rank)
+        cube = torch.randn((per_rank, sz, sz), generator=gen, device=d.dev, dtype=torch.float64)
+        cube[torch.rand((per_rank, sz, sz), generator=gen, device=d.dev) < 1e-3] = float('nan')
         lon_h, lat_h = rectangular_grid(bool(g.west_positive))
         n0, n1 = lon_h.shape
-        lon_d, lat_d = torch.from_numpy(lon_h).to(dev), torch.from_numpy(lat_h).to(dev)
-        xm = torch.empty((n0, n1), dtype=torch.float64, device=dev)
-        ym = torch.empty((n0, n1), dtype=torch.float64, device=dev)
-        gathered = torch.empty((world, per_rank, n0, n1), dtype=torch.float64, device=dev)
+        lon_d, lat_d = torch.from_numpy(lon_h).to(d.dev), torch.from_numpy(lat_h).to(d.dev)
+        xm = torch.empty((n0, n1), dtype=torch.float64, device=d.dev)
+        ym = torch.empty((n0, n1), dtype=torch.float64, device=d.dev)
+        gathered = torch.empty((d.world, per_rank, n0, n1), dtype=torch.float64, device=d.dev)
 
-        def step():
+        def work():
             eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-            map_cube_sharded_device(eng, cube, np.float64, per_rank, xm, ym, n0, n1, gathered, rank)
+            # (the synthetic cube holds NaNs but no +-inf: no plane needs its nanmedian; the closing
+            #  eng.synchronize() would raise otherwise)
+            map_cube_sharded_device(eng, cube, np.float64, per_rank, xm, ym, n0, n1, gathered, d.rank,
+                                    defer_median_check=True)  # fmt: skip
 
         units = args.planes * sz * sz
         metric = 'Mpix/s of cube pixels map-projected (get_mapped_data, 1 deg rectangular map, bilinear)'
         workload = (
             f'synthetic IFU cube {args.planes}x{sz}x{sz} f64 resident in HBM, {per_rank} planes per GPU, '
-            f'map {n0}x{n1}, RCCL all-gather of mapped planes' + ('' if world > 1 else ' (skipped at N=1)')
+            f'map {n0}x{n1}, RCCL all-gather of mapped planes' + ('' if d.world > 1 else ' (skipped at N=1)')
         )
         alg = n0 * n1 * (16 + 40 * per_rank)
         scaling = 'strong'
-    for _ in range(min(args.preheat_steps, 200)):  # untimed clock ramp (see main)
-        step()
-    barrier()
-    for _ in range(args.warmup):
-        step()
-    barrier()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for e0, e1 in evs:
-        e0.record()
-        step()
-        e1.record()
-    barrier()
-    dt = time.perf_counter() - t0
+
+    def step(i):
+        if i is not None:
+            evs[i][0].record()
+        work()
+        if i is not None:
+            evs[i][1].record()
+
+    dt = timed_steps(d, step, args, preheat=min(args.preheat_steps, 200))
     eng.synchronize()
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     step_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-    if rank == 0:
-        n_units = units * (world if scaling == 'weak' else 1)
+    if d.rank == 0:
+        n_units = units * (d.world if scaling == 'weak' else 1)
         print(json.dumps({
             'metric': metric, 'value': round(n_units * args.steps / dt / 1e6, 2), 'unit': 'Mpix/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': d.world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload},
@@ -218,58 +510,27 @@ def other_workloads(args) -> None:
                          'unit': 'GB/s', 'frac': round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          'traffic': None, 'kernel_ms': round(step_ms, 4), 'algorithmic_bytes': alg},
         }), flush=True)  # fmt: skip
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    d.close()
     eng.close()
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--preheat-steps', type=int, default=500, help='untimed clock-ramp steps before the warmup steps')
-    ap.add_argument('--size', type=int, default=4096)
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument(
-        '--workload', default='frame', choices=['frame', 'saturn', 'cube'],
-        help="frame: BASELINE headline (default); saturn: config 4 (Saturn + rings, 8 planes); "
-        "cube: config 5 (512 x 1024^2 f64 cube -> 1 deg map, planes sharded over the GPUs)",
-    )  # fmt: skip
-    ap.add_argument('--planes', type=int, default=512, help='cube workload: total planes')
-    args = ap.parse_args()
-    if args.workload != 'frame':
-        return other_workloads(args)
-
-    import torch
-    import torch.distributed as dist
-
+# ------------------------------------------------------------------ headline
+def headline(args) -> None:
+    d = Dist(args)
+    torch = d.torch
+    from planetmapper_amd.distributed import map_cube_sharded_device
     from planetmapper_amd.engine import Engine
     from planetmapper_amd.scenarios import load_scenario
-
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N > 1')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU (the engine has no CPU fallback)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
 
     sz = args.size
     g = load_scenario('jupiter_hst_2005')
     x0 = y0 = (sz - 1) / 2
-    eng = Engine(local_rank)
+    eng = Engine(d.local_rank)
     # launch on torch's current stream so torch events / RCCL order with our kernels
     eng.set_stream(torch.cuda.current_stream().cuda_stream)
     eng.set_geometry(g)
     eng.set_disc(x0, y0, 0.9 * x0, 0.0, sz, sz, True)  # BodyXY.centre_disc body_xy.py:791
+    dev = d.dev
 
     planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in HEADLINE}
     lon_h, lat_h = rectangular_grid(bool(g.west_positive))
@@ -279,7 +540,7 @@ def main() -> None:
     xm = torch.empty((n0, n1), dtype=torch.float64, device=dev)
     ym = torch.empty((n0, n1), dtype=torch.float64, device=dev)
     # synthetic data plane: limb-darkened disc + noise (SURVEY 8d config 3 recipe)
-    gen = torch.Generator(device=dev).manual_seed(20050101 + rank)
+    gen = torch.Generator(device=dev).manual_seed(20050101 + d.rank)
     yy, xx = torch.meshgrid(
         torch.arange(sz, device=dev, dtype=torch.float64),
         torch.arange(sz, device=dev, dtype=torch.float64),
@@ -288,77 +549,68 @@ def main() -> None:
     mu = torch.sqrt(torch.clamp(1 - ((xx - x0) ** 2 + (yy - y0) ** 2) / (0.9 * x0) ** 2, min=0))
     data = mu + 0.05 * torch.randn((sz, sz), generator=gen, device=dev, dtype=torch.float64)
     del yy, xx, mu
-    from planetmapper_amd.distributed import map_cube_sharded_device
 
     # two result buffers used alternately: a gather may stay in flight for two frames before its
     # buffer is written again (RCCL latency at 8 ranks is not known to be below one 0.19 ms step)
-    gathered = [torch.empty((world, 1, n0, n1), dtype=torch.float64, device=dev) for _ in range(2)]
-
+    gathered = [torch.empty((d.world, 1, n0, n1), dtype=torch.float64, device=dev) for _ in range(2)]
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    pending = [None, None]  # work handles of the all-gathers still in flight, one per buffer
+    counter = [0]
 
-    def step(i: int | None) -> None:
+    def step(i) -> None:
         if i is not None:
             ev0[i].record()
         eng.backplanes_img_device(planes)
         if i is not None:
             ev1[i].record()
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-        # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only),
-        # left in flight so that it overlaps the next frame's backplane kernel
+        # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only), left
+        # in flight so that it overlaps the next frame's backplane kernel. The data plane is finite
+        # by construction (no +-inf: no plane needs its nanmedian), so the engine's flag check is
+        # deferred to the closing synchronize(), which raises if that assumption were violated.
         k = counter[0] & 1
         counter[0] += 1
         pending[k] = map_cube_sharded_device(
-            eng, data, np.float64, 1, xm, ym, n0, n1, gathered[k], rank, 'linear', True, async_op=True, previous=pending[k]
-        )
+            eng, data, np.float64, 1, xm, ym, n0, n1, gathered[k], d.rank, 'linear', True, async_op=True,
+            previous=pending[k], defer_median_check=True,
+        )  # fmt: skip
 
-    pending = [None, None]  # work handles of the all-gathers still in flight, one per buffer
-    counter = [0]
-
-    def barrier() -> None:
+    def drain() -> None:
         for k in range(2):
             if pending[k] is not None:
                 pending[k].wait()
                 pending[k] = None
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    # Untimed clock ramp: a fresh box starts in a low power state and the shader clock takes
-    # tens of milliseconds of sustained load to settle; without it the first ~50 frames (all
-    # of a short run) are timed on the way up. Same step as the timed one, never counted.
-    # (a fixed count, not a wall-clock loop: every rank must issue the same collectives)
-    for _ in range(args.preheat_steps):
-        step(None)
-    barrier()
-    for _ in range(args.warmup):
-        step(None)
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    barrier()
-    dt = time.perf_counter() - t0
+    class DrainingDist:  # the barrier of the timed region also completes the gathers in flight
+        def __getattr__(self, name):
+            return getattr(d, name)
+
+        def barrier(self):
+            drain()
+            d.barrier()
+
+    dt = timed_steps(DrainingDist(), step, args, preheat=args.preheat_steps)
     eng.synchronize()  # surfaces deferred device-side errors
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     frac_on_disc = float(torch.isfinite(planes['LON-GRAPHIC']).double().mean().item())
-
-    if rank == 0:
+    line = None
+    if d.rank == 0:
         alg = algorithmic_bytes(sz, sz, len(HEADLINE))
         achieved = alg / (kernel_ms * 1e-3) / 1e9
+        ms_per_step = dt / args.steps * 1e3
+        rec = profile_record('pm::k_disc_sph<1,') if sz == 4096 else {}
+        # step-level bytes: 5 planes + x/y map (16 B in + 16 B out per cell) + 1-plane reprojection
+        step_bytes = alg + n0 * n1 * 32 + n0 * n1 * (16 + 40)
         line = {
-            'metric': 'Mpix/s full backplane set (lat/lon/inc/emi/phase) + map-reproject, 4096^2 frame',
-            'value': round(world * sz * sz * args.steps / dt / 1e6, 2),
+            'metric': METRIC,
+            'value': round(d.world * sz * sz * args.steps / dt / 1e6, 2),
             'unit': 'Mpix/s',
-            'n_gpus': world,
+            'n_gpus': d.world,
             'steps': args.steps,
             'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'ms_per_step': round(ms_per_step, 4),
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
@@ -371,8 +623,8 @@ def main() -> None:
                 'frame': [sz, sz],
                 'planes': len(HEADLINE),
                 'map': [n0, n1],
-                'parallelism': f'frames (and their mapped planes) sharded 1 per GPU x{world}'
-                + (', RCCL all-gather of mapped planes' if world > 1 else ''),
+                'parallelism': f'frames (and their mapped planes) sharded 1 per GPU x{d.world}'
+                + (', RCCL all-gather of mapped planes' if d.world > 1 else ''),
                 'preheat_steps': args.preheat_steps,
             },
             'roofline': {
@@ -382,18 +634,56 @@ def main() -> None:
                 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                'traffic': measured_traffic('pm::k_disc_sph<1,') if sz == 4096 else None,
+                'traffic': int(rec['hbm_bytes']) if 'hbm_bytes' in rec else None,
                 'kernel_ms': round(kernel_ms, 4),
                 'algorithmic_bytes': alg,
             },
+            'step_roofline': {
+                'bound': 'hbm',
+                'algorithmic_bytes': step_bytes,
+                'achieved': round(step_bytes / (ms_per_step * 1e-3) / 1e9, 2),
+                'peak': HBM_PEAK_GBS,
+                'unit': 'GB/s',
+                'frac': round(step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            },
         }
-        if not args.no_cpu_baseline and world == 1:
-            line['cpu_baseline'] = cpu_baseline(g, sz)
+        if 'fp64_flop' in rec:
+            tf = rec['fp64_flop'] / (kernel_ms * 1e-3) / 1e12
+            line['fp64'] = {
+                'flop_per_launch': int(rec['fp64_flop']),
+                'source': 'rocprofv3 --pmc SQ_INSTS_VALU_{FMA,ADD,MUL,TRANS}_F64 (profiles/), FMA = 2, x 64 lanes',
+                'tflops': round(tf, 2),
+                'peak_tflops': FP64_VECTOR_PEAK_TFLOPS,
+                'frac': round(tf / FP64_VECTOR_PEAK_TFLOPS, 4),
+            }
+    if d.world == 1 and d.rank == 0 and not args.no_cpu_baseline:
+        cores = host_cores()
+        line['cpu_baseline'] = cpu_baseline(g, sz, cores, budget_s=12.0, max_frames=8)
+        line['cpu_baseline_1thread'] = cpu_baseline(g, sz, 1, budget_s=8.0, max_frames=1)
+        line['cpu_model'] = cpu_model()
+    if not args.no_extras:
+        if d.world == 1 and d.rank == 0:
+            line['host_path'] = host_path_section(eng, g, sz)
+        sec = cube_host_section(d, eng, g, args.planes, steps_fed=5, steps_resident=50)
+        if d.rank == 0:
+            line['cube_host'] = sec
+    if d.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    d.close()
     eng.close()
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(self_launch(args))
+    if args.rehearse:
+        return rehearse(args)
+    if args.workload != 'frame':
+        return other_workloads(args)
+    return headline(args)
 
 
 if __name__ == '__main__':

@@ -45,7 +45,11 @@ typedef enum pm_status {
     PM_ERR_UNSUPPORTED = -6       /* valid in the reference, not implemented here yet */
 } pm_status;
 
-typedef enum pm_mem { PM_MEM_HOST = 0, PM_MEM_DEVICE = 1 } pm_mem;
+/* PM_MEM_HOST_CUBE (pm_map_cube only): `cube` is a HOST pointer, x_map / y_map / out are DEVICE
+ * pointers - the planes are fed from host memory (pinned: gathered in place, asynchronous like a
+ * PM_MEM_DEVICE call; pageable: pipelined copy, synchronous) and the mapped planes stay in HBM,
+ * e.g. as this rank's slot of an RCCL all-gather. nearest / linear with NaN propagation. */
+typedef enum pm_mem { PM_MEM_HOST = 0, PM_MEM_DEVICE = 1, PM_MEM_HOST_CUBE = 2 } pm_mem;
 
 /*
  * Backplane identifiers: bit positions of `plane_mask`, in the order of the

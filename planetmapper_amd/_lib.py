@@ -37,6 +37,7 @@ PM_ERR_UNSUPPORTED = -6
 
 PM_MEM_HOST = 0
 PM_MEM_DEVICE = 1
+PM_MEM_HOST_CUBE = 2
 
 COORDS = {'xy': 0, 'radec': 1, 'angular': 2, 'km': 3, 'lonlat': 4}
 PM_TF_NOT_VISIBLE_NAN = 1

@@ -805,6 +805,8 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         }
     }
     const bool smooth = interpolation == PM_INTERP_SMOOTH;
+    if (mem == PM_MEM_HOST_CUBE && smooth)
+        return fail(ctx, PM_ERR_UNSUPPORTED, "PM_MEM_HOST_CUBE supports nearest / linear with NaN propagation only");
     double limits[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
     if (smooth && mem == PM_MEM_DEVICE) {
         // footprint of the map on the image: tiny reduction + 32-byte read-back
@@ -824,6 +826,26 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
             }
         }
     }
+    if (mem == PM_MEM_HOST_CUBE) {
+        // the cube in host memory, maps and result in HBM (the per-rank step of a sharded cube: the
+        // mapped planes feed an RCCL all-gather)
+        if (smooth || k_rows || smoothing > 0.0 || force_sync)
+            return fail(ctx, PM_ERR_UNSUPPORTED, "PM_MEM_HOST_CUBE supports nearest / linear with NaN propagation only");
+        const size_t cube_bytes = (size_t)n_planes * npx * esz;
+        if (ctx->zero_copy != 0 && host_is_pinned(cube, cube_bytes)) {
+            // pinned: the kernel gathers from host memory in place - enqueue like a device call
+            const void *dcube = nullptr;
+            PM_HIP(ctx, hipHostGetDevicePointer((void **)&dcube, const_cast<void *>(cube), 0));
+            a.cube = dcube;
+            a.x_map = x_map;
+            a.y_map = y_map;
+            a.out = out;
+            a.plane_flags = ctx->flags;
+            a.n_planes = n_planes;
+            return reproject_resident(ctx, a, dtype, /*sync_now=*/false);
+        }
+        return map_cube_host_pipelined(ctx, cube, dtype, n_planes, x_map, y_map, nmap, a, out, true);
+    }
     if (mem == PM_MEM_DEVICE) {
         a.cube = cube;
         a.x_map = x_map;
@@ -839,7 +861,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     // host cube, nearest / linear with NaN propagation (the default of get_mapped_data): the
     // pipelined / zero-copy path of pm_hostpipe.hip
     if (!smooth && !k_rows && !(smoothing > 0.0) && !force_sync)
-        return map_cube_host_pipelined(ctx, cube, dtype, n_planes, x_map, y_map, nmap, a, out);
+        return map_cube_host_pipelined(ctx, cube, dtype, n_planes, x_map, y_map, nmap, a, out, false);
     // the other modes: chunks of planes through the device, one after the other (their fits and
     // statistics passes are synchronous anyway)
     if (ctx->pending) {

@@ -131,6 +131,6 @@ bool host_is_pinned(const void *p, size_t bytes);
 int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_dev, size_t bytes);
 int d2h_finish(pm_ctx *ctx, hipStream_t stream);
 int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
-                            const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out);
+                            const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out);
 
 }  // namespace pmh

@@ -289,7 +289,8 @@ struct CubeJob {
     size_t esz, plane_bytes, nmap;
     int n_planes;
     const double *x_map, *y_map;  // host
-    double *out;                  // host
+    double *out;                  // host (device with device_out)
+    bool device_out;
     pm::ReprojectArgs a;          // ny, nx, n_map, interpolation, propagate_nan filled in
 };
 
@@ -316,7 +317,8 @@ int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &plan
         b.plane_stats = ctx->stats;
         pm_launch_reproject(b, j.dtype, ctx->stream);
         PM_HIP(ctx, hipGetLastError());
-        PM_HIP(ctx, hipMemcpyAsync(j.out + (size_t)p * j.nmap, dout, j.nmap * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipMemcpyAsync(j.out + (size_t)p * j.nmap, dout, j.nmap * sizeof(double),
+                                   j.device_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
     return PM_OK;
@@ -326,8 +328,9 @@ int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &plan
 
 // pm_map_cube for host buffers, interpolation nearest / linear with NaN propagation (the default of
 // Observation.get_mapped_data). Caller has validated the arguments and sized ctx->flags.
+// `device_out`: x_map / y_map / out are DEVICE pointers (PM_MEM_HOST_CUBE): only the cube travels.
 int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
-                            const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out)
+                            const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
 {
     HostPipe *hp;
     int rc = pipe_get(ctx, &hp);
@@ -346,6 +349,7 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     j.x_map = x_map;
     j.y_map = y_map;
     j.out = out;
+    j.device_out = device_out;
     a.plane_stats = nullptr;
     a.seq = ++ctx->map_seq;
     j.a = a;
@@ -353,7 +357,7 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     const size_t cube_bytes = (size_t)n_planes * j.plane_bytes;
     const size_t out_bytes = (size_t)n_planes * nmap * sizeof(double);
     const bool src_pinned = host_is_pinned(cube, cube_bytes);
-    const bool dst_pinned = host_is_pinned(out, out_bytes);
+    const bool dst_pinned = !device_out && host_is_pinned(out, out_bytes);
     const bool zero_copy = src_pinned && ctx->zero_copy != 0;
     const hipStream_t sk = ctx->stream;
 
@@ -363,7 +367,8 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     if (zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, ((size_t)n_planes + 7) / 8), 32768);
     const size_t batch = std::min<size_t>((size_t)n_planes, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
     const size_t slot_bytes = (chunk * j.plane_bytes + 255) & ~(size_t)255;
-    const bool direct_out = zero_copy && dst_pinned;  // the kernel stores into the caller's pinned array
+    // the kernel stores straight into the caller's array: device memory, or pinned memory next to a zero-copy cube
+    const bool direct_out = device_out || (zero_copy && dst_pinned);
     size_t need = 2 * nmap * sizeof(double) + 256;
     if (!zero_copy) need += HostPipe::kRing * slot_bytes;
     if (!direct_out) need += batch * nmap * sizeof(double);
@@ -375,13 +380,21 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     double *dym = dxm + nmap;
     char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
     double *dout_all = (double *)(ring + (zero_copy ? 0 : HostPipe::kRing * slot_bytes));
-    PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
-    PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+    if (device_out) {
+        dxm = const_cast<double *>(x_map);
+        dym = const_cast<double *>(y_map);
+    } else {
+        PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+        PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+    }
 
     const char *cube_dev = nullptr;  // zero copy: the device's view of the caller's pinned cube
     double *out_dev = nullptr;
     if (zero_copy) PM_HIP(ctx, hipHostGetDevicePointer((void **)&cube_dev, (void *)cube, 0));
-    if (direct_out) PM_HIP(ctx, hipHostGetDevicePointer((void **)&out_dev, (void *)out, 0));
+    if (device_out)
+        out_dev = out;
+    else if (direct_out)
+        PM_HIP(ctx, hipHostGetDevicePointer((void **)&out_dev, (void *)out, 0));
 
     // s_out drains finished output while later chunks are still being copied in / mapped
     size_t c = 0;  // running chunk number (ring slot = c % kRing)

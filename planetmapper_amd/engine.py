@@ -396,6 +396,26 @@ class Engine:
         )
 
 
+    def map_cube_host_to_device(
+        self, cube: np.ndarray, x_map, y_map, n0: int, n1: int, out, interpolation='linear', propagate_nan=True,
+    ) -> None:  # fmt: skip
+        """
+        Reproject a HOST cube (numpy; pinned arrays from `pinned_empty` are gathered in place, others
+        are copied through the pipelined path) into a DEVICE output with device x/y maps
+        (`PM_MEM_HOST_CUBE`): the per-rank step of a plane-sharded cube, whose mapped planes feed an
+        all-gather. Asynchronous for pinned cubes (finish with `synchronize()`).
+        """
+        self.set_spline_smoothing(0.0)
+        assert cube.flags.c_contiguous and cube.ndim == 3
+        self._check(
+            self._lib.pm_map_cube(
+                self._ctx, cube.ctypes.data, dtype_code(cube.dtype), int(cube.shape[0]), _ptr(x_map), _ptr(y_map),
+                int(n0), int(n1), interpolation_code(interpolation), 1 if propagate_nan else 0, _ptr(out),
+                _lib.PM_MEM_HOST_CUBE,
+            )
+        )
+
+
 def device_count() -> int:
     return int(_lib.load().pm_device_count())
 

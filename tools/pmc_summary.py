@@ -24,5 +24,12 @@ for k, cs in sorted(acc.items()):
         r = sum(cs['FETCH_SIZE']) / len(cs['FETCH_SIZE']) * 1024
         name = k.replace('void ', '')
         traffic[name] = {'write_bytes': w, 'fetch_bytes_raw': r, 'hbm_bytes': w + r}
+    f64 = ['SQ_INSTS_VALU_FMA_F64', 'SQ_INSTS_VALU_ADD_F64', 'SQ_INSTS_VALU_MUL_F64', 'SQ_INSTS_VALU_TRANS_F64']
+    if all(c in cs for c in f64):
+        # wave-instructions per launch -> FP64 operations: 64 lanes, an FMA counts 2
+        m = {c: sum(cs[c]) / len(cs[c]) for c in f64}
+        name = k.replace('void ', '')
+        traffic.setdefault(name, {})['fp64_flop'] = 64.0 * (2 * m[f64[0]] + m[f64[1]] + m[f64[2]] + m[f64[3]])
+        traffic[name]['fp64_wave_insts'] = sum(m.values())
 with open(os.path.join(root, 'traffic.json'), 'w') as f:
     json.dump(traffic, f, indent=1)

@@ -153,6 +153,47 @@ def backplanes_img(g: PMGeometry, d: PMDisc, names, alt: float = 0.0) -> dict[st
     return outs
 
 
+_quad = None
+
+
+def quad_lib() -> ctypes.CDLL:
+    """libpm_oracle_quad.so: pm_oracle.c compiled in IEEE binary128 (oracle/pm_oracle_quad.c)."""
+    global _quad
+    if _quad is None:
+        path = os.path.join(_HERE, 'libpm_oracle_quad.so')
+        src = [os.path.join(_HERE, f) for f in ('pm_oracle_quad.c', 'pm_oracle.c')]
+        if not os.path.exists(path) or any(os.path.getmtime(f) > os.path.getmtime(path) for f in src):
+            subprocess.run(['make', '-C', _HERE, 'libpm_oracle_quad.so'], check=True, capture_output=True)
+        _quad = ctypes.CDLL(path)
+        _quad.pmoq_backplanes_img_rows.argtypes = [
+            ctypes.POINTER(PMGeometry), ctypes.c_int, ctypes.POINTER(PMDisc), ctypes.c_double, ctypes.c_uint64,
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)),
+        ]  # fmt: skip
+    return _quad
+
+
+def backplanes_img_rows_quad(g: PMGeometry, d: PMDisc, names, row_begin: int, n_rows: int, alt: float = 0.0,
+                             threads: int | None = None) -> dict[str, np.ndarray]:
+    """
+    Image rows [row_begin, row_begin + n_rows) of the named planes evaluated in binary128 and rounded
+    to binary64: the exact value of the oracle's formulation on the same binary64 inputs (the truth the
+    parity bars are measured against, tests/test_truth_f128.py). ~60x slower than the binary64 oracle.
+    """
+    names = list(names)
+    q = quad_lib()
+    if threads:
+        q.pmoq_set_num_threads(int(threads))
+    outs = {n: np.empty((int(n_rows), d.nx), dtype=np.float64) for n in names}
+    ptrs = (ctypes.POINTER(ctypes.c_double) * NUM_PLANES)()
+    for n, a in outs.items():
+        ptrs[PLANE_INDEX[n]] = _dptr(a)
+    rc = q.pmoq_backplanes_img_rows(ctypes.byref(g), ctypes.sizeof(PMGeometry), ctypes.byref(d), float(alt),
+                                    mask_of(names), int(row_begin), int(n_rows), ptrs)  # fmt: skip
+    if rc != 0:
+        raise ValueError(f'quad oracle error {rc}')
+    return outs
+
+
 def backplanes_map(g, d, names, lon_deg, lat_deg, alt: float = 0.0) -> dict[str, np.ndarray]:
     names = list(names)
     lon = np.ascontiguousarray(lon_deg, dtype=np.float64)

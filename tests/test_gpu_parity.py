@@ -278,6 +278,47 @@ def test_reference_api_on_gpu(jupiter):
     assert np.isfinite(b.get_lon_img()).sum() == np.isfinite(b.get_emission_angle_img()).sum() > 9000
 
 
+@pytest.mark.parametrize(
+    'name,kw',
+    [
+        ('map_orthographic_1', dict(projection='orthographic', size=10)),
+        ('map_orthographic_2', dict(projection='orthographic', lat=90, size=5)),
+        ('map_orthographic_3', dict(projection='orthographic', lat=-21.3, lon=-42, size=4)),
+        ('map_azimuthal_1', dict(projection='azimuthal', size=10)),
+        ('map_azimuthal_2', dict(projection='azimuthal', lat=-90, size=5)),
+        ('map_azimuthal_3', dict(projection='azimuthal', lat=42, lon=12.345, size=4)),
+    ],
+)
+def test_projected_golden_maps_through_the_hip_map_kernel(jupiter, oracle, name, kw):
+    """
+    The reference's six orthographic / azimuthal golden maps (tests/test_observation.py:1123-1153;
+    tests/data/outputs/map_orthographic-*.fits, map_azimuthal-*.fits): the projected lon/lat grid
+    (closed-form, planetmapper_amd/projections.py) goes through the HIP `k_map` kernel for all 26
+    map-space planes and through `k_reproject` for the 10-plane cube, at the reference's tolerance,
+    with bit-exact NaN masks, and against the oracle on the same grid.
+    """
+    from planetmapper_amd import BodyXY
+
+    gold = np.load(os.path.join(GOLDEN, f'golden_{name}.npz'))
+    body = BodyXY('Jupiter', '2005-01-01T00:00:00', observer='HST', geometry=jupiter, nx=7, ny=10)
+    body.set_disc_params(2.5, 3.1, 3.9, 123.456)
+    lons, lats, *_ = body.generate_map_coordinates(**kw)
+    assert np.array_equal(np.isnan(lons), np.isnan(gold['LON-GRAPHIC']))
+    d = oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10)
+    ref = oracle.backplanes_map(jupiter, d, oracle.PLANE_NAMES, lons, lats)
+    got = {}
+    for n in body.backplanes:
+        if n in gold.files:
+            got[n] = body.get_backplane_map(n, **kw)
+            assert np.array_equal(np.isnan(got[n]), np.isnan(gold[n])), n
+            assert np.allclose(got[n], gold[n], rtol=1e-5, atol=1e-6, equal_nan=True), n
+    _compare(got, ref, list(got), jupiter, r0=3.9)
+    cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
+    mapped = body.map_img(cube, **kw)
+    assert np.array_equal(np.isnan(mapped), np.isnan(gold['PRIMARY']))
+    assert np.allclose(mapped, gold['PRIMARY'], rtol=1e-5, atol=1e-6, equal_nan=True)
+
+
 def test_nan_preclean_and_median_paths(engine, oracle, jupiter):
     """
     propagate_nan=False and +-inf pixels: the NaN pre-clean of

@@ -1,0 +1,145 @@
+"""
+Parity against the TRUTH of the formulation: oracle/pm_oracle_quad.c evaluates the oracle's source
+in IEEE binary128 on the same binary64 inputs. The parity bars of tests/parity.py rest on a
+noise-floor argument (two correct binary64 evaluations differ by up to ~1e-7 deg at the limb);
+with the binary128 values in hand that argument is measured instead of asserted:
+
+  * CPU (`-m "not gpu"`): the binary64 oracle against the truth - identical masks, errors at the
+    level of binary64 rounding conditioned by the viewing geometry;
+  * GPU (`-m gpu`): on the 4096^2 headline frame the HIP engine is as close to the truth as the
+    binary64 oracle is, plane by plane: max, 99.9th percentile, and the share of pixels inside the
+    north star's flat 1e-9 deg.
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+HEADLINE = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION']
+
+
+def _stats(err):
+    err = err[np.isfinite(err)]
+    return {
+        'max': float(err.max()),
+        'p999': float(np.quantile(err, 0.999)),
+        'p99': float(np.quantile(err, 0.99)),
+        'median': float(np.median(err)),
+        'inside_1e-9': float((err <= 1e-9).mean()),
+    }
+
+
+def test_binary64_oracle_against_binary128_truth(jupiter, saturn):
+    from oracle import oracle
+
+    for g, sz, r0, rot, names in (
+        (jupiter, 192, 80.0, 33.0, oracle.PLANE_NAMES),
+        (saturn, 160, 35.0, 20.0, HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE', 'DISTANCE']),
+    ):
+        x0 = y0 = (sz - 1) / 2
+        d = oracle.make_disc(x0, y0, r0, rot, sz, sz)
+        o64 = oracle.backplanes_img(g, d, names)
+        tru = oracle.backplanes_img_rows_quad(g, d, names, 0, sz)
+        for n in names:
+            assert np.array_equal(np.isnan(o64[n]), np.isnan(tru[n])), n  # masks: bit-exact
+        for n in HEADLINE:
+            st = _stats(np.abs(o64[n] - tru[n]))
+            # binary64 rounding of a unit ray from 8e8 km moves the surface point by ~1e-7 km / cos(e):
+            # a few 1e-11 deg over most of the disc, up to 1e-6 deg in the last pixels of the limb
+            assert st['median'] < 5e-10 and st['max'] < 5e-6, (n, st)
+        if g is jupiter:
+            # LOCAL-SOLAR-TIME is truncated to whole seconds: equal, or one second apart where the
+            # truth sits within rounding of a second boundary
+            dl = np.abs(o64['LOCAL-SOLAR-TIME'] - tru['LOCAL-SOLAR-TIME'])
+            dl = dl[np.isfinite(dl)]
+            assert np.all((dl < 1e-12) | (np.abs(dl - 1 / 3600) < 1e-9))
+            assert (dl > 1e-12).mean() < 1e-3
+        # a row block is the same pixels
+        blk = oracle.backplanes_img_rows_quad(g, d, HEADLINE, 37, 11)
+        for n in HEADLINE:
+            assert np.array_equal(blk[n], tru[n][37:48], equal_nan=True)
+
+
+def test_reference_goldens_against_binary128_truth(jupiter):
+    """
+    The reference's golden planes (tests/data/outputs/test_nav.fits, CSPICE in binary64) against
+    the binary128 evaluation on this repo's geometry block. The residual the binary64 oracle shows
+    against the goldens (2.4e-9 deg in longitude, tests/test_oracle_golden.py) is NOT the oracle's:
+    the truth shows the same residual - one pixel at 79 deg emission (condition number 5) carries
+    it, the rest sit at 3-5e-10 deg, with a mean offset of one ulp of the prime-meridian angle
+    W ~ 1.6e6 deg (2.3e-10 deg) that an exact-rational W on the host does not remove (tried:
+    tools note in DESIGN.md) - i.e. it is the rounding of the reference's own evaluation.
+    Conditioned by cos(emission) every golden pixel is within 1e-9 deg of the truth.
+    """
+    from conftest import GOLDEN
+    from oracle import oracle
+
+    gold = np.load(os.path.join(GOLDEN, 'golden_test_nav.npz'))
+    d = oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10)
+    names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION']
+    tru = oracle.backplanes_img_rows_quad(jupiter, d, names, 0, 10)
+    o64 = oracle.backplanes_img(jupiter, d, names)
+    m = np.isfinite(gold['LON-GRAPHIC'])
+    cos_e = np.cos(np.deg2rad(gold['EMISSION'][m]))
+    for n in names:
+        assert np.array_equal(np.isnan(tru[n]), np.isnan(gold[n])), n
+        e_tg = (tru[n] - gold[n])[m]
+        e_og = (o64[n] - gold[n])[m]
+        assert np.abs(e_tg * cos_e).max() <= 1e-9, (n, np.abs(e_tg * cos_e).max())
+        assert np.abs(e_tg).max() <= 4e-9, n
+        # the oracle is no further from the goldens than the truth is (+ its own rounding)
+        assert np.abs(e_og).max() <= np.abs(e_tg).max() + 1e-9, n
+    assert np.abs((tru['PHASE'] - gold['PHASE'])[m]).max() <= 1e-13
+
+
+@pytest.mark.gpu
+def test_hip_is_as_close_to_the_truth_as_the_binary64_oracle(jupiter):
+    """
+    4096^2 headline frame (BASELINE metric config), 512 rows in 64 bands of 8 spread over the frame
+    (every band crosses the limb twice): |HIP - truth| against |oracle64 - truth| per plane.
+    """
+    from oracle import oracle
+    from planetmapper_amd.engine import Engine
+
+    sz = 4096
+    x0 = y0 = (sz - 1) / 2
+    r0 = 0.9 * x0
+    eng = Engine(0)
+    try:
+        eng.set_geometry(jupiter)
+        eng.set_disc(x0, y0, r0, 0.0, sz, sz, True)
+        hip = eng.backplanes_img(HEADLINE)
+    finally:
+        eng.close()
+    d = oracle.make_disc(x0, y0, r0, 0.0, sz, sz)
+    o64 = oracle.backplanes_img(jupiter, d, HEADLINE)
+    bands = [(int(b), 8) for b in np.linspace(200, sz - 208, 64)]
+    err_h = {n: [] for n in HEADLINE}
+    err_o = {n: [] for n in HEADLINE}
+    for a, nrow in bands:
+        tru = oracle.backplanes_img_rows_quad(jupiter, d, HEADLINE, a, nrow)
+        for n in HEADLINE:
+            t = tru[n]
+            assert np.array_equal(np.isnan(hip[n][a : a + nrow]), np.isnan(t)), n  # mask vs the truth: bit-exact
+            err_h[n].append(np.abs(hip[n][a : a + nrow] - t)[np.isfinite(t)])
+            err_o[n].append(np.abs(o64[n][a : a + nrow] - t)[np.isfinite(t)])
+    report = {}
+    for n in HEADLINE:
+        sh, so = _stats(np.concatenate(err_h[n])), _stats(np.concatenate(err_o[n]))
+        report[n] = {'hip_vs_truth': sh, 'oracle64_vs_truth': so}
+        # HIP is no further from the exact value of the formulation than a strict binary64
+        # evaluation of it is (factor 2: the worst limb pixel of two roundings of the same ray)
+        assert sh['max'] <= 2.0 * so['max'] + 1e-10, (n, sh, so)
+        assert sh['p999'] <= 2.0 * so['p999'] + 1e-10, (n, sh, so)
+        assert sh['p99'] <= 1.5 * so['p99'] + 5e-11, (n, sh, so)
+        assert sh['inside_1e-9'] >= so['inside_1e-9'] - 0.01, (n, sh, so)
+        assert sh['inside_1e-9'] >= 0.98, (n, sh)
+    out = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'truth_f128_report.json'), 'w') as f:
+            json.dump({'frame': [sz, sz], 'rows_sampled': 512, 'pixels_on_disc': int(sum(len(e) for e in err_h['PHASE'])),
+                       'planes': report}, f, indent=1)  # fmt: skip

@@ -353,8 +353,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
         // converged light time changes nothing. No test, no select after it.
         lt = evaluate(0.0, true);
+        // (a wave of the pre-mask annulus - candidates, but every ray misses - is done after that one
+        //  evaluation: nothing is left to converge)
 #pragma unroll 1
-        for (int it = 1; it < 10; it++) {
+        for (int it = 1; it < 10 && hit_mask != 0; it++) {
             d = (kp->g.et - lt) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
             const double nlt = evaluate(d, false);
             const bool moving = !(fabs(nlt - lt) <= kp->lt_tol);

@@ -352,6 +352,37 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
                 int interpolation, int propagate_nan, double *out, int mem);
 
 /*
+ * Plane sharding over the GPUs of one node -------------------------------------------------
+ * The planes of a cube are independent (observation.py:892-904): rank r of `world` maps the
+ * contiguous block [start, stop) = pm_shard_bounds(P, world, r), per_rank = ceil(P / world) planes
+ * (trailing ranks may own fewer, or none), on its own GPU; ONE all-gather of the mapped planes
+ * (RCCL over xGMI) assembles the result on every rank. One process (and one pm_ctx) per GPU.
+ *
+ * pm_comm: an RCCL communicator bound at run time (dlopen of librccl.so.1; PM_ERR_UNSUPPORTED if
+ * RCCL is not installed). Rank 0 calls pm_comm_unique_id() and hands the 128 bytes to the other
+ * ranks by any means (file, socket, MPI, torch.distributed); every rank then calls
+ * pm_comm_create() - a collective call. A process that drives the sharding through
+ * torch.distributed instead (planetmapper_amd.distributed) needs none of this.
+ *
+ * pm_map_cube_sharded(): `local_cube` holds ONLY this rank's planes [start, stop) (host memory
+ * with mem = PM_MEM_HOST_CUBE - each rank feeds its block over its own PCIe link - or HBM with
+ * PM_MEM_DEVICE); x_map / y_map / out_all are device pointers; out_all has room for
+ * world * per_rank * n0 * n1 doubles, block r at out_all + r * per_rank * n0 * n1 (planes beyond P
+ * are NaN padding). With gather != 0 the all-gather is enqueued on the context stream
+ * (pm_synchronize() waits for it); with gather == 0, or comm == NULL (single process), only this
+ * rank's block is written - no collective (each rank keeps / writes its slice).
+ */
+typedef struct pm_comm pm_comm; /* opaque */
+int pm_shard_bounds(int n_planes, int world, int rank, int *start, int *stop, int *per_rank);
+int pm_comm_unique_id(void *id128);
+int pm_comm_create(pm_ctx *ctx, int world, int rank, const void *id128, pm_comm **comm);
+int pm_comm_destroy(pm_comm *comm);
+int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int dtype,
+                        int n_planes_total, const double *x_map, const double *y_map, int n0,
+                        int n1, int interpolation, int propagate_nan, double *out_all, int mem,
+                        int gather);
+
+/*
  * Options of PM_INTERP_SMOOTH: the `smooth_oversample_by` and
  * `smooth_max_oversampled_img_size` arguments of BodyXY.map_img (body_xy.py:1427-1428,
  * used at :1724-1741). Defaults 5 and 10000, as in the reference; oversample_by <= 1

@@ -55,7 +55,8 @@ EXPORTS = (
     'pm_backplanes_img', 'pm_xy_map', 'pm_backplanes_map', 'pm_map_cube', 'pm_transform',
     'pm_set_smooth_options', 'pm_backplanes_img_rows', 'pm_set_spline_smoothing', 'pm_radec_query',
     'pm_set_option', 'pm_get_option', 'pm_host_alloc', 'pm_host_free', 'pm_host_register',
-    'pm_host_unregister',
+    'pm_host_unregister', 'pm_shard_bounds', 'pm_comm_unique_id', 'pm_comm_create', 'pm_comm_destroy',
+    'pm_map_cube_sharded',
 )  # fmt: skip
 
 PM_OPT_GENERAL_KERNEL = 1
@@ -139,6 +140,14 @@ def load() -> ctypes.CDLL:
     lib.pm_host_free.argtypes = [vp, vp]
     lib.pm_host_register.argtypes = [vp, vp, ctypes.c_uint64]
     lib.pm_host_unregister.argtypes = [vp, vp]
+    ip = ctypes.POINTER(c_int)
+    lib.pm_shard_bounds.argtypes = [c_int, c_int, c_int, ip, ip, ip]
+    lib.pm_comm_unique_id.argtypes = [vp]
+    lib.pm_comm_create.argtypes = [vp, c_int, c_int, vp, ctypes.POINTER(vp)]
+    lib.pm_comm_destroy.argtypes = [vp]
+    lib.pm_map_cube_sharded.argtypes = [
+        vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int, c_int,
+    ]  # fmt: skip
     del dp
     if lib.pm_abi_version() != 1:
         raise ImportError('libplanetmapper_hip.so ABI version mismatch')

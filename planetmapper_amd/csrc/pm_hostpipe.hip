@@ -67,8 +67,57 @@ struct HostPipe {
         char *dst;
         size_t bytes;
     };
+    // pieces whose DMA has been enqueued, oldest first; the retire thread waits for each DMA and has
+    // the pool copy the piece out, so the calling thread stays free to feed the next chunk
     std::deque<Piece> inflight;
     int next_slot = 0;
+    std::thread retirer;
+    std::mutex rmu;
+    std::condition_variable cv_piece, cv_slot;
+    int pieces_out = 0;  // issued and not yet retired (<= kSlots)
+    bool rstop = false;
+    int device = 0;
+    hipError_t rerror = hipSuccess;
+
+    void retire_main()
+    {
+        (void)hipSetDevice(device);
+        for (;;) {
+            Piece pc;
+            {
+                std::unique_lock<std::mutex> lk(rmu);
+                cv_piece.wait(lk, [&] { return rstop || !inflight.empty(); });
+                if (inflight.empty()) return;  // rstop
+                pc = inflight.front();
+                inflight.pop_front();
+            }
+            const hipError_t e = hipEventSynchronize(ev_stage[pc.slot]);
+            if (e == hipSuccess) copy(pc.dst, stage[pc.slot], pc.bytes);
+            {
+                std::lock_guard<std::mutex> lk(rmu);
+                if (e != hipSuccess && rerror == hipSuccess) rerror = e;
+                pieces_out--;
+            }
+            cv_slot.notify_all();
+        }
+    }
+    void start_retirer(int dev)
+    {
+        if (retirer.joinable()) return;
+        device = dev;
+        rstop = false;
+        retirer = std::thread([this] { retire_main(); });
+    }
+    void stop_retirer()
+    {
+        if (!retirer.joinable()) return;
+        {
+            std::lock_guard<std::mutex> lk(rmu);
+            rstop = true;
+        }
+        cv_piece.notify_all();
+        retirer.join();
+    }
     // ---- copy pool
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -172,6 +221,7 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
     HostPipe *hp = ctx->pipe;
     int threads = ctx->host_copy_threads > 0 ? ctx->host_copy_threads : std::min(8, usable_cores());
     hp->start_workers(threads);
+    hp->start_retirer(ctx->device);
     *out = hp;
     return PM_OK;
 }
@@ -180,6 +230,7 @@ void pipe_destroy(pm_ctx *ctx)
 {
     HostPipe *hp = ctx->pipe;
     if (!hp) return;
+    hp->stop_retirer();
     hp->stop_workers();
     for (int i = 0; i < HostPipe::kSlots; i++) {
         if (hp->stage[i]) (void)hipHostFree(hp->stage[i]);
@@ -215,6 +266,10 @@ static int ensure_stage(pm_ctx *ctx, HostPipe *hp)
 {
     const size_t want = std::min<size_t>(std::max<size_t>(ctx->host_chunk_bytes / 2, (size_t)4 << 20), (size_t)64 << 20);
     if (hp->stage[0] && hp->stage_bytes == want) return PM_OK;
+    {
+        std::unique_lock<std::mutex> lk(hp->rmu);  // (resized between calls only; nothing is out then)
+        hp->cv_slot.wait(lk, [&] { return hp->pieces_out == 0; });
+    }
     for (int i = 0; i < HostPipe::kSlots; i++) {
         if (hp->stage[i]) PM_HIP(ctx, hipHostFree(hp->stage[i]));
         hp->stage[i] = nullptr;
@@ -227,19 +282,9 @@ static int ensure_stage(pm_ctx *ctx, HostPipe *hp)
     return PM_OK;
 }
 
-// oldest staged piece: wait for its DMA, copy it out
-static int d2h_retire_one(pm_ctx *ctx, HostPipe *hp)
-{
-    const HostPipe::Piece pc = hp->inflight.front();
-    hp->inflight.pop_front();
-    PM_HIP(ctx, hipEventSynchronize(hp->ev_stage[pc.slot]));
-    hp->copy(pc.dst, hp->stage[pc.slot], pc.bytes);
-    return PM_OK;
-}
-
 // Enqueue dst_host <- src_dev on `stream`. Pinned destinations: one DMA. Pageable destinations:
-// pieces through the staging ring; at most kSlots pieces are in flight, the oldest is retired
-// (copied out by the pool) when the ring is full. d2h_finish() completes everything.
+// pieces through the staging ring; at most kSlots pieces are out at a time (DMA in flight or being
+// copied out by the retire thread and the pool). d2h_finish() completes everything.
 int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_dev, size_t bytes)
 {
     if (bytes == 0) return PM_OK;
@@ -255,15 +300,22 @@ int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_d
     if (rc != PM_OK) return rc;
     for (size_t off = 0; off < bytes; off += hp->stage_bytes) {
         const size_t n = std::min(hp->stage_bytes, bytes - off);
-        if ((int)hp->inflight.size() == HostPipe::kSlots) {
-            rc = d2h_retire_one(ctx, hp);
-            if (rc != PM_OK) return rc;
+        {
+            // the slot about to be reused is the oldest one out: wait until it has been copied out
+            std::unique_lock<std::mutex> lk(hp->rmu);
+            hp->cv_slot.wait(lk, [&] { return hp->pieces_out < HostPipe::kSlots; });
+            if (hp->rerror != hipSuccess) return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(hp->rerror));
         }
         const int slot = hp->next_slot;
         hp->next_slot = (slot + 1) % HostPipe::kSlots;
         PM_HIP(ctx, hipMemcpyAsync(hp->stage[slot], (const char *)src_dev + off, n, hipMemcpyDeviceToHost, stream));
         PM_HIP(ctx, hipEventRecord(hp->ev_stage[slot], stream));
-        hp->inflight.push_back({slot, (char *)dst_host + off, n});
+        {
+            std::lock_guard<std::mutex> lk(hp->rmu);
+            hp->inflight.push_back({slot, (char *)dst_host + off, n});
+            hp->pieces_out++;
+        }
+        hp->cv_piece.notify_one();
     }
     return PM_OK;
 }
@@ -271,11 +323,15 @@ int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_d
 int d2h_finish(pm_ctx *ctx, hipStream_t stream)
 {
     HostPipe *hp = ctx->pipe;
-    if (hp)
-        while (!hp->inflight.empty()) {
-            int rc = d2h_retire_one(ctx, hp);
-            if (rc != PM_OK) return rc;
+    if (hp) {
+        std::unique_lock<std::mutex> lk(hp->rmu);
+        hp->cv_slot.wait(lk, [&] { return hp->pieces_out == 0; });
+        if (hp->rerror != hipSuccess) {
+            const hipError_t e = hp->rerror;
+            hp->rerror = hipSuccess;
+            return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(e));
         }
+    }
     PM_HIP(ctx, hipStreamSynchronize(stream));
     return PM_OK;
 }

@@ -211,3 +211,62 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
     if dist.is_initialized() and dist.get_world_size(group) > 1:
         return dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group, async_op=async_op)
     return None
+
+
+class Comm:
+    """
+    RCCL communicator behind the C ABI (`pm_comm_*`, include/planetmapper_hip.h): for callers that
+    shard a cube WITHOUT torch.distributed. Rank 0 makes the 128-byte id with `Comm.unique_id()`
+    and hands it to the other ranks (file, socket, MPI ...); every rank then constructs
+    `Comm(engine, world, rank, id)` - a collective call - and maps with `map_cube_sharded`.
+    """
+
+    def __init__(self, engine, world: int, rank: int, unique_id: bytes) -> None:
+        import ctypes
+
+        if len(unique_id) != 128:
+            raise ValueError('unique_id must be the 128 bytes of Comm.unique_id()')
+        self.engine, self.world, self.rank = engine, int(world), int(rank)
+        h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        engine._check(engine._lib.pm_comm_create(engine._ctx, self.world, self.rank, buf, ctypes.byref(h)))
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+
+        from . import _lib
+
+        buf = ctypes.create_string_buffer(128)
+        rc = _lib.load().pm_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError(f'pm_comm_unique_id failed with status {rc} (is RCCL installed?)')
+        return buf.raw
+
+    def close(self) -> None:
+        if getattr(self, '_h', None):
+            self.engine._lib.pm_comm_destroy(self._h)
+            self._h = None
+
+    def map_cube_sharded(self, local_cube, dtype, n_planes_total: int, x_map, y_map, n0: int, n1: int, out_all,
+                         interpolation='linear', propagate_nan=True, host_cube: bool = False, gather: bool = True) -> None:
+        """
+        `pm_map_cube_sharded`: this rank's planes `shard_bounds(n_planes_total, world, rank)` (a device
+        tensor / pointer, or a numpy array with `host_cube=True`) are mapped into its block of
+        `out_all` (device, world * per_rank * n0 * n1 doubles) and, with `gather`, all blocks are
+        exchanged by one RCCL all-gather enqueued on the engine's stream.
+        """
+        from . import _lib
+        from .engine import _ptr, dtype_code, interpolation_code
+
+        eng = self.engine
+        eng.set_spline_smoothing(0.0)
+        eng._check(
+            eng._lib.pm_map_cube_sharded(
+                eng._ctx, self._h, _ptr(local_cube) if local_cube is not None else None, dtype_code(dtype),
+                int(n_planes_total), _ptr(x_map), _ptr(y_map), int(n0), int(n1), interpolation_code(interpolation),
+                1 if propagate_nan else 0, _ptr(out_all), _lib.PM_MEM_HOST_CUBE if host_cube else _lib.PM_MEM_DEVICE,
+                1 if gather else 0,
+            )
+        )

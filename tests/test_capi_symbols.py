@@ -60,3 +60,17 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(root, f), encoding='utf-8').read()
                 assert 'import oracle' not in text and 'from oracle' not in text, f
                 assert 'pm_oracle' not in text and 'libpm_oracle' not in text, f
+
+
+def test_c_shard_bounds_equal_the_python_ones():
+    """pm_shard_bounds (pure arithmetic: callable without a GPU) == distributed.shard_bounds"""
+    from planetmapper_amd.distributed import shard_bounds
+
+    lib = _lib.load()
+    for n in (0, 1, 3, 10, 13, 512, 513):
+        for world in (1, 2, 3, 8):
+            for rank in range(world):
+                a, b, c = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+                assert lib.pm_shard_bounds(n, world, rank, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
+                assert (a.value, b.value, c.value) == shard_bounds(n, world, rank)
+    assert lib.pm_shard_bounds(4, 2, 2, None, None, None) == _lib.PM_ERR_INVALID_ARGUMENT

@@ -497,6 +497,51 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
 
 
+def test_c_abi_sharded_cube_with_an_rccl_communicator(engine, oracle, jupiter):
+    """
+    pm_comm_* / pm_map_cube_sharded (the C-ABI form of the plane sharding; multi-rank runs need a
+    multi-GPU node, so here: a real RCCL communicator of ONE rank, the block arithmetic, the NaN
+    padding of short blocks, device and host-fed cubes, gather on and off).
+    """
+    import torch
+
+    from planetmapper_amd.distributed import Comm, shard_bounds
+
+    sz, planes = 128, 5
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, y0, 0.9 * x0, 0.1, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 6.0)
+    d = oracle.make_disc(x0, y0, 0.9 * x0, 0.0, sz, sz)
+    d.rotation_rad = 0.1
+    xm, ym = oracle.xy_map(jupiter, d, lon, lat)
+    n0, n1 = xm.shape
+    rng = np.random.default_rng(3)
+    cube = rng.standard_normal((planes, sz, sz))
+    cube[rng.random(cube.shape) < 1e-2] = np.nan
+    ref = oracle.map_cube(cube, xm, ym, 'linear', True)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    dxm, dym, dcube = t(xm), t(ym), t(cube)
+    comm = Comm(engine, 1, 0, Comm.unique_id())
+    try:
+        a, b, per_rank = shard_bounds(planes, 1, 0)
+        out = torch.full((1, per_rank, n0, n1), -1.0, dtype=torch.float64, device='cuda')
+        comm.map_cube_sharded(dcube, np.float64, planes, dxm, dym, n0, n1, out)
+        engine.synchronize()
+        got = out.cpu().numpy()[0]
+        assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.nanmax(np.abs(got - ref)) <= 1e-12
+        out.fill_(-1.0)
+        comm.map_cube_sharded(engine.pinned_copy(cube), np.float64, planes, dxm, dym, n0, n1, out, host_cube=True, gather=False)
+        engine.synchronize()
+        assert np.array_equal(out.cpu().numpy()[0], got, equal_nan=True)
+        out.fill_(-1.0)
+        comm.map_cube_sharded(cube, np.float64, planes, dxm, dym, n0, n1, out, host_cube=True)  # pageable block
+        engine.synchronize()
+        assert np.array_equal(out.cpu().numpy()[0], got, equal_nan=True)
+    finally:
+        comm.close()
+
+
 def test_point_transforms_vs_oracle(engine, oracle, jupiter):
     """
     pm_transform (reference xy2lonlat, lonlat2radec, ... on arrays) against the oracle:

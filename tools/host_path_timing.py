@@ -36,8 +36,9 @@ def best(fn, reps):
     ts = []
     for _ in range(reps):
         t = time.perf_counter()
-        fn()
+        r = fn()
         ts.append(time.perf_counter() - t)
+        del r  # (releasing a previous result - munmap of its pages - is not part of the call)
     return min(ts), float(np.median(ts))
 
 
@@ -52,9 +53,10 @@ def frame(eng, g, sz, reps):
     out = {}
 
     def fresh():
-        out['a'] = eng.backplanes_img(HEADLINE)  # np.empty per plane: first-touch page faults included
+        return eng.backplanes_img(HEADLINE)  # np.empty per plane: first-touch page faults included
 
     lo, med = best(fresh, reps)
+    out['a'] = fresh()
     yield {'case': 'frame -> fresh pageable numpy arrays', 'ms_best': lo * 1e3, 'ms_median': med * 1e3,
            'GBps': nbytes / lo / 1e9, 'Mpix_s': sz * sz / lo / 1e6}
     keep = out['a']
@@ -79,7 +81,7 @@ def frame(eng, g, sz, reps):
         assert np.array_equal(pinned[n], keep[n], equal_nan=True), n
 
 
-def cube(eng, g, planes, reps):
+def cube(eng, g, planes, reps, chunks=(32,)):
     sz = 1024
     x0 = (sz - 1) / 2
     eng.set_geometry(g)
@@ -99,18 +101,23 @@ def cube(eng, g, planes, reps):
     res = {}
 
     def run(c, key):
+        res.pop(key, None)
         res[key] = eng.map_cube(c, xm, ym, 'linear', True)
 
     eng.map_cube(pageable[:8], xm, ym, 'linear', True)  # warm-up
-    lo, med = best(lambda: run(pageable, 'pageable'), reps)
-    yield {'case': 'cube pageable -> pipelined copy', 'planes': planes, 'ms_best': lo * 1e3, 'ms_median': med * 1e3,
-           'cube_GBps': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
-    eng.set_option(_lib.PM_OPT_ZERO_COPY, 0)
-    lo, med = best(lambda: run(pinned, 'pinned_copy'), reps)
-    yield {'case': 'cube pinned -> pipelined DMA (zero copy off)', 'planes': planes, 'ms_best': lo * 1e3,
-           'ms_median': med * 1e3, 'cube_GBps': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6,
-           'pinned_alloc_ms': t_alloc * 1e3}
-    eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
+    for chunk_mib in chunks:
+        eng.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, chunk_mib << 20)
+        eng.map_cube(pageable[:64], xm, ym, 'linear', True)  # (re)allocations of the ring
+        lo, med = best(lambda: run(pageable, 'pageable'), reps)
+        yield {'case': 'cube pageable -> pipelined copy', 'chunk_MiB': chunk_mib, 'planes': planes, 'ms_best': lo * 1e3,
+               'ms_median': med * 1e3, 'cube_GBps': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
+        eng.set_option(_lib.PM_OPT_ZERO_COPY, 0)
+        lo, med = best(lambda: run(pinned, 'pinned_copy'), reps)
+        yield {'case': 'cube pinned -> pipelined DMA (zero copy off)', 'chunk_MiB': chunk_mib, 'planes': planes,
+               'ms_best': lo * 1e3, 'ms_median': med * 1e3, 'cube_GBps': nbytes / lo / 1e9,
+               'Mpix_s': planes * sz * sz / lo / 1e6, 'pinned_alloc_ms': t_alloc * 1e3}
+        eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
+    eng.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 32 << 20)
     lo, med = best(lambda: run(pinned, 'zero_copy'), reps)
     yield {'case': 'cube pinned -> gathered in place (zero copy)', 'planes': planes, 'ms_best': lo * 1e3,
            'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
@@ -124,6 +131,22 @@ def cube(eng, g, planes, reps):
     lo, med = best(direct, reps)
     yield {'case': 'cube pinned -> gathered in place, pinned output', 'planes': planes, 'ms_best': lo * 1e3,
            'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
+    # where the output leg goes: the same calls into a reused (touched) pageable array / a pinned array
+    out_touched = np.zeros((planes,) + xm.shape)
+
+    def call(cube_arr, out_arr):
+        eng._check(eng._lib.pm_map_cube(eng._ctx, cube_arr.ctypes.data, 0, planes, xm.ctypes.data, ym.ctypes.data,
+                                        xm.shape[0], xm.shape[1], _lib.PM_INTERP_LINEAR, 1, out_arr.ctypes.data,
+                                        _lib.PM_MEM_HOST))
+
+    for label, zc in (('DMA', 0), ('zero copy', -1)):
+        eng.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+        for oname, oarr in (('reused pageable output', out_touched), ('pinned output', out_pinned)):
+            lo, med = best(lambda: call(pinned, oarr), reps)
+            yield {'case': f'cube pinned ({label}) -> {oname}', 'planes': planes, 'ms_best': lo * 1e3, 'ms_median': med * 1e3}
+        lo, med = best(lambda: call(pageable, out_pinned), reps)
+        yield {'case': f'cube pageable -> pinned output (zero_copy={zc})', 'planes': planes, 'ms_best': lo * 1e3, 'ms_median': med * 1e3}
+    eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
     for k in ('pinned_copy', 'zero_copy'):
         assert np.array_equal(res[k], res['pageable'], equal_nan=True), k
     assert np.array_equal(out_pinned, res['pageable'], equal_nan=True)
@@ -135,6 +158,7 @@ def main():
     ap.add_argument('--planes', type=int, default=512)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', choices=['frame', 'cube'])
+    ap.add_argument('--chunks-mib', default='32', help='comma-separated PM_OPT_HOST_CHUNK_BYTES values to sweep (cube)')
     args = ap.parse_args()
     eng = Engine(0)
     g = load_scenario('jupiter_hst_2005')
@@ -142,7 +166,7 @@ def main():
         for r in frame(eng, g, args.size, args.reps):
             print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
     if args.only in (None, 'cube'):
-        for r in cube(eng, g, args.planes, args.reps):
+        for r in cube(eng, g, args.planes, args.reps, tuple(int(c) for c in args.chunks_mib.split(','))):
             print(json.dumps({k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()}), flush=True)
     eng.close()
 

@@ -628,7 +628,12 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, c
         for (int i = 0; i < PM_NUM_PLANES; i++)
             if ((plane_mask >> i) & 1) p.out[i] = base + (size_t)(k++) * n;
     }
-    pm_launch_map(p, dlon, dlat, ctx->stream);
+    // the x/y map alone (what a reprojection asks for) has its own short kernel; PM_OPT_GENERAL_KERNEL
+    // keeps it on the general one, like the image planes
+    if ((plane_mask & ~(bit(PM_PIXEL_X) | bit(PM_PIXEL_Y))) == 0 && !ctx->force_general)
+        pm_launch_map_xy(p, dlon, dlat, ctx->stream);
+    else
+        pm_launch_map(p, dlon, dlat, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
     if (mem != PM_MEM_DEVICE) {
         for (int i = 0; i < PM_NUM_PLANES; i++)

@@ -5,8 +5,9 @@ Headline benchmark (BASELINE.json): Mpix/s for the full backplane set
 
 One step = one frame through the hot path, everything resident in HBM:
   1. pm_backplanes_img   5 planes, 4096^2           (kernel k_disc_sph<ILLUM>)
-  2. pm_xy_map           1 deg rectangular grid     (kernel k_map, 180 x 360)
-  3. pm_map_cube         1 data plane -> (180, 360) (kernel k_reproject<f64>)
+  2. pm_mapped_data      x/y map of the 1 deg rectangular grid (180 x 360) + bilinear reprojection of
+                         1 data plane onto it = get_mapped_data (kernel k_mapped_data<f64>; the same
+                         results as pm_xy_map + pm_map_cube, kernels k_map_xy + k_reproject)
 With N > 1 GPUs every rank processes its own frame (weak scaling, no data-path collective in
 the backplane stage) and the reprojected planes - one per rank, i.e. the wavelength planes of
 `Observation.get_mapped_data` sharded one per GPU - are combined by ONE RCCL all-gather, the
@@ -564,8 +565,8 @@ def headline(args) -> None:
         eng.backplanes_img_device(planes)
         if i is not None:
             ev1[i].record()
-        eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-        # this rank's plane -> its slot; slots exchanged by one RCCL all-gather (N > 1 only), left
+        # x/y map of the 1 deg grid + this rank's plane -> its slot (pm_mapped_data: the C form of
+        # get_mapped_data, one launch); slots exchanged by one RCCL all-gather (N > 1 only), left
         # in flight so that it overlaps the next frame's backplane kernel. The data plane is finite
         # by construction (no +-inf: no plane needs its nanmedian), so the engine's flag check is
         # deferred to the closing synchronize(), which raises if that assumption were violated.
@@ -573,7 +574,7 @@ def headline(args) -> None:
         counter[0] += 1
         pending[k] = map_cube_sharded_device(
             eng, data, np.float64, 1, xm, ym, n0, n1, gathered[k], d.rank, 'linear', True, async_op=True,
-            previous=pending[k], defer_median_check=True,
+            previous=pending[k], defer_median_check=True, lonlat=(lon_d, lat_d),
         )  # fmt: skip
 
     def drain() -> None:

@@ -352,6 +352,19 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
                 int interpolation, int propagate_nan, double *out, int mem);
 
 /*
+ * replaces Observation.get_mapped_data (observation.py:826-905) as a whole: the x/y map of a
+ * lon/lat grid (pm_xy_map) AND the reprojection of the cube's planes onto it (pm_map_cube), with the
+ * same results as those two calls. With device buffers, nearest / linear interpolation and up to 8
+ * planes it is ONE kernel launch (one lane per map cell: pixel coordinates, then the planes), which
+ * is what a frame-by-frame caller wants; any other request runs the two calls. x_map / y_map
+ * (n0*n1 doubles each) receive the map - they are outputs here and must stay valid until
+ * pm_synchronize() like the other buffers of an asynchronous pm_map_cube.
+ */
+int pm_mapped_data(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *lon_deg,
+                   const double *lat_deg, int n0, int n1, double alt, int interpolation,
+                   int propagate_nan, double *x_map, double *y_map, double *out, int mem);
+
+/*
  * Plane sharding over the GPUs of one node -------------------------------------------------
  * The planes of a cube are independent (observation.py:892-904): rank r of `world` maps the
  * contiguous block [start, stop) = pm_shard_bounds(P, world, r), per_rank = ceil(P / world) planes

@@ -56,7 +56,7 @@ EXPORTS = (
     'pm_set_smooth_options', 'pm_backplanes_img_rows', 'pm_set_spline_smoothing', 'pm_radec_query',
     'pm_set_option', 'pm_get_option', 'pm_host_alloc', 'pm_host_free', 'pm_host_register',
     'pm_host_unregister', 'pm_shard_bounds', 'pm_comm_unique_id', 'pm_comm_create', 'pm_comm_destroy',
-    'pm_map_cube_sharded',
+    'pm_map_cube_sharded', 'pm_mapped_data',
 )  # fmt: skip
 
 PM_OPT_GENERAL_KERNEL = 1
@@ -130,6 +130,9 @@ def load() -> ctypes.CDLL:
     lib.pm_radec_query.argtypes = [vp, ctypes.c_uint64, vp, vp, ctypes.c_double, c_int, vp, c_int]
     lib.pm_map_cube.argtypes = [
         vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int,
+    ]  # fmt: skip
+    lib.pm_mapped_data.argtypes = [
+        vp, vp, c_int, c_int, vp, vp, c_int, c_int, ctypes.c_double, c_int, c_int, vp, vp, vp, c_int,
     ]  # fmt: skip
     lib.pm_set_smooth_options.argtypes = [vp, c_int, c_int]
     lib.pm_set_spline_smoothing.argtypes = [vp, ctypes.c_double]

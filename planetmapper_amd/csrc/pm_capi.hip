@@ -910,6 +910,68 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     return PM_OK;
 }
 
+int pm_mapped_data(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *lon_deg, const double *lat_deg,
+                   int n0, int n1, double alt, int interpolation, int propagate_nan, double *x_map, double *y_map, double *out,
+                   int mem)
+{
+    int rc = check_ready(ctx, true);
+    if (rc != PM_OK) return rc;
+    if (!cube || !lon_deg || !lat_deg || !x_map || !y_map || !out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!std::isfinite(alt)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "alt must be finite");
+    const size_t esz = dtype_size(dtype);
+    if (esz == 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
+    if (n_planes < 0 || n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative shape");
+    const pm_disc &d = ctx->disc;
+    // one launch: device buffers, a handful of planes, nearest / linear, image at least 2 x 2 ... anything
+    // else takes the two calls it stands for
+    const bool simple = interpolation == PM_INTERP_NEAREST || (interpolation == PM_INTERP_LINEAR && !(ctx->spline_smoothing > 0.0));
+    const bool fused = mem == PM_MEM_DEVICE && simple && n_planes >= 1 && n_planes <= 8 && d.nx >= 1 && d.ny >= 1 &&
+                       (size_t)n0 * n1 > 0 && !ctx->force_general;
+    if (!fused) {
+        rc = pm_xy_map(ctx, lon_deg, lat_deg, n0, n1, alt, x_map, y_map, mem);
+        if (rc != PM_OK) return rc;
+        return pm_map_cube(ctx, cube, dtype, n_planes, x_map, y_map, n0, n1, interpolation, propagate_nan, out, mem);
+    }
+    for (int i = 0; i < 3; i++)
+        if (!(ctx->geometry.radii[i] + alt > 0.0)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "radii + alt must be positive");
+    if (ctx->pending && (size_t)n_planes > ctx->flags_count) {
+        rc = pm_synchronize(ctx);
+        if (rc != PM_OK) return rc;
+    }
+    rc = ensure_flags(ctx, (size_t)n_planes);
+    if (rc != PM_OK) return rc;
+    const bool force_sync = interpolation == PM_INTERP_LINEAR && !propagate_nan;
+    if (force_sync && ctx->pending) {
+        rc = pm_synchronize(ctx);
+        if (rc != PM_OK) return rc;
+    }
+    pm::Params p;
+    fill_params(ctx, alt, p);
+    p.n0 = n0;
+    p.n1 = n1;
+    pm::ReprojectArgs a;
+    a.cube = cube;
+    a.x_map = x_map;
+    a.y_map = y_map;
+    a.out = out;
+    a.plane_flags = ctx->flags;
+    a.seq = ++ctx->map_seq;
+    a.plane_stats = nullptr;
+    a.n_planes = n_planes;
+    a.ny = d.ny;
+    a.nx = d.nx;
+    a.n_map = n0 * n1;
+    a.interpolation = interpolation;
+    a.propagate_nan = propagate_nan ? 1 : 0;
+    pm_launch_mapped_data(p, a, lon_deg, lat_deg, x_map, y_map, dtype, ctx->stream);
+    PM_HIP(ctx, hipGetLastError());
+    if (force_sync) return finish_reproject(ctx, a, dtype);
+    ctx->pending = true;
+    ctx->pending_args = a;
+    ctx->pending_dtype = dtype;
+    return PM_OK;
+}
+
 int pm_set_smooth_options(pm_ctx *ctx, int oversample_by, int max_oversampled_img_size)
 {
     if (!ctx) return PM_ERR_INVALID_ARGUMENT;

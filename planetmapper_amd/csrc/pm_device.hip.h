@@ -873,4 +873,93 @@ __device__ __forceinline__ V3 xy2ray(const Params &p, double x, double y)
     return mtxv(p.g.M, v);
 }
 
+
+// ------------------------------------------------------------------ one map cell -> pixel coordinates
+// Kernel-argument block read in place: constants are loaded where they are used instead of at kernel
+// entry (hipcc otherwise parks them in VGPR lanes once the scalar registers run out). Valid in kernels
+// whose FIRST argument is the Params block (offset 0 of the kernel-argument segment).
+typedef const __attribute__((address_space(4))) Params *KParams;
+__device__ __forceinline__ KParams kernarg_params()
+{
+    KParams kp = (KParams)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
+// Pixel coordinates (px, py) of the map cell (lon_deg, lat_deg), NaN where the cell is not visible or
+// falls outside the frame: the chain BodyXY._get_targvec_map -> _get_illumf_map -> _get_obsvec_map ->
+// _get_radec_map -> _get_xy_map (body_xy.py:3227-3300, 3419-3491, 3667) as k_map_xy / k_mapped_data
+// evaluate it (derivation: pm_kernels.hip, "x/y map alone").
+__device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double lat_deg, double &px_out, double &py_out)
+{
+    const double nan = __builtin_nan("");
+    const bool have = isfinite(lon_deg) && isfinite(lat_deg);
+    const double lon = have ? lon_deg * kRad : 0.0, lat = have ? lat_deg * kRad : 0.0;
+    // pgrrec_c, altitude 0: (a^2 cos(lat) cos(l), a^2 cos(lat) sin(l), c^2 sin(lat)) / sqrt(a^2 cos^2 + c^2 sin^2)
+    const double a = kp->radii[0], c = kp->radii[2];
+    double sl, cl, so, co;
+    sincos_auto(lat, sl, cl);
+    sincos_auto(kp->g.west_positive ? -lon : lon, so, co);
+    const double acl = a * cl, csl = c * sl;
+    const double den = rsqrt_fast(fma(acl, acl, csl * csl));
+    const double ha = a * acl * den;
+    const V3 tv = {ha * co, ha * so, c * csl * den};
+
+    // light time of the point, two passes from the centre value: pos(te) = T(te) + R(te)^T tv, in B0
+    // w(d) = VB d + AB d^2 / 2 - O0 + Rz(wdot d)^T tv
+    const double wdot = kp->g.wdot;
+    double lt = kp->g.lt_c;
+    V3 w = {0.0, 0.0, 0.0}, q = tv;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const double d = (kp->g.et - lt) - kp->t0;
+        const double h = 0.5 * d * d;
+        const double ang = wdot * d;
+        double sa, ca;
+        if (__all(fabs(ang) <= 1e-3)) {
+            sincos_tiny(ang, sa, ca);
+        } else {
+            sincos_auto(ang, sa, ca);
+        }
+        q = {fma(ca, tv.x, -sa * tv.y), fma(sa, tv.x, ca * tv.y), tv.z};
+        w = {fma(kp->AB[0], h, fma(kp->VB[0], d, q.x - kp->O0[0])), fma(kp->AB[1], h, fma(kp->VB[1], d, q.y - kp->O0[1])),
+             fma(kp->AB[2], h, fma(kp->VB[2], d, q.z - kp->O0[2]))};
+        if (it == 0) lt = sqrt_fast(dot(w, w)) * kp->inv_c;
+    }
+    // visible <=> the outward normal (q / radii^2, turned like q) faces the observer (at -w from the point)
+    const double facing = -fma(q.x * kp->ir[0] * kp->ir[0], w.x, fma(q.y * kp->ir[1] * kp->ir[1], w.y, q.z * kp->ir[2] * kp->ir[2] * w.z));
+    const bool vis = have && facing > 0.0;
+
+    // Body._targvec2obsvec: the point's own light-time offset from the sub-observer point
+    const V3 off = {tv.x - kp->g.sub_sp[0], tv.y - kp->g.sub_sp[1], tv.z - kp->g.sub_sp[2]};
+    const V3 sr = {kp->g.sub_ray[0] + off.x, kp->g.sub_ray[1] + off.y, kp->g.sub_ray[2] + off.z};
+    const double dist = sqrt_fast(dot(sr, sr)) - kp->g.sub_dist;
+    const double t = kp->g.sub_et - dist * kp->inv_c;
+    const double ang2 = wdot * (t - kp->t0);
+    double s2, c2;
+    if (__all(fabs(ang2) <= 1e-3)) {
+        sincos_tiny(ang2, s2, c2);
+    } else {
+        sincos_auto(ang2, s2, c2);
+    }
+    // R0 ov = R0 sub_obsvec + Rz(ang2)^T off
+    const V3 b = {kp->sub_obs_b[0] + fma(c2, off.x, -s2 * off.y), kp->sub_obs_b[1] + fma(s2, off.x, c2 * off.y),
+                  kp->sub_obs_b[2] + off.z};
+    // Body._obsvec2angular: M ov = C^T (R0 ov); recrad_c is scale free
+    const V3 m = {fma(kp->C[0], b.x, fma(kp->C[3], b.y, kp->C[6] * b.z)), fma(kp->C[1], b.x, fma(kp->C[4], b.y, kp->C[7] * b.z)),
+                  fma(kp->C[2], b.x, fma(kp->C[5], b.y, kp->C[8] * b.z))};
+    double ra, dec;
+    recrad_f(m, ra, dec);
+    double xx = -(ra * kDeg);
+    if (xx < 0.0) xx += 360.0;
+    if (xx > 180.0) xx -= 360.0;
+    const double ax = xx * 3600.0, ay = (dec * kDeg) * 3600.0;
+    const double px = fma(kp->Ai[0], ax, fma(kp->Ai[1], ay, kp->Ai[2]));
+    const double py = fma(kp->Ai[3], ax, fma(kp->Ai[4], ay, kp->Ai[5]));
+    // BodyXY._xy_in_image_frame body_xy.py:1868
+    const bool in_frame = vis && -0.5 < px && px < kp->nx - 0.5 && -0.5 < py && py < kp->ny - 0.5;
+    px_out = in_frame ? px : nan;
+    py_out = in_frame ? py : nan;
+}
+
 }  // namespace pm

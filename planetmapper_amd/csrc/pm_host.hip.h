@@ -28,6 +28,8 @@ void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *
                            int ring_only_visible, double *out, hipStream_t s);
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
+void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat, double *xo,
+                           double *yo, int dtype, hipStream_t s);
 void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
 void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
@@ -115,6 +117,7 @@ size_t dtype_size(int dtype);
 int ensure_scratch(pm_ctx *ctx, size_t bytes);  // grow-only device buffers of the context
 int ensure_flags(pm_ctx *ctx, size_t count);
 int ensure_stats(pm_ctx *ctx, size_t count);
+void fill_params(const pm_ctx *ctx, double alt, pm::Params &p);
 
 // pm_reproject.hip: reprojection of planes resident on the device
 int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_now);

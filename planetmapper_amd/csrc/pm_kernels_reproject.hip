@@ -51,17 +51,14 @@ __device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int n
 {
     return cleaned_value(img, load_as_f64(img, (size_t)i * nx + j), i, j, ny, nx, median, needs_median);
 }
+// One (map cell, plane) sample of BodyXY.map_img for 'nearest' / 'linear' (body_xy.py:1633-1702,
+// 1855-1904): the value at pixel coordinates (x, y) of plane `pl`, NaN where the reference gives NaN.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
+__device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int pl, double x, double y)
 {
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
-    if (m >= a.n_map) return;
     const double nan = __builtin_nan("");
     const int nx = a.nx, ny = a.ny;
     const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
-    double *o = a.out + (size_t)pl * a.n_map;
-    double x = a.x_map[m], y = a.y_map[m];
     double val = nan;
     if (!isnan(x)) {
         if (a.interpolation == PM_INTERP_NEAREST) {
@@ -114,7 +111,38 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
             }
         }
     }
-    o[m] = val;
+    return val;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const int pl = blockIdx.y;
+    if (m >= a.n_map) return;
+    a.out[(size_t)pl * a.n_map + m] = reproject_sample<T>(a, pl, a.x_map[m], a.y_map[m]);
+}
+
+// Observation.get_mapped_data in ONE launch for a handful of planes (observation.py:826-905: the x/y
+// map of the grid, then map_img of every plane): one lane per map cell computes its pixel
+// coordinates (map_cell_xy), stores them (the x/y map stays available, e.g. for the replay of planes
+// that need their nanmedian) and samples the planes one after the other. Saves the launch boundary
+// and the x/y-map round trip through memory between k_map_xy and k_reproject - a fifth of the time
+// of those two small kernels in the frame benchmark; for cubes of many planes the two-kernel form
+// (planes on the grid's y axis) has the parallelism this form lacks.
+template <typename T>
+__global__ __launch_bounds__(kSphBlock) void k_mapped_data(const Params p, const ReprojectArgs a, const double *__restrict__ lon_in,
+                                                           const double *__restrict__ lat_in, double *__restrict__ x_map_out,
+                                                           double *__restrict__ y_map_out)
+{
+    const KParams kp = kernarg_params();
+    const int m = blockIdx.x * kSphBlock + threadIdx.x;
+    if (m >= a.n_map) return;
+    double x, y;
+    map_cell_xy(kp, lon_in[m], lat_in[m], x, y);
+    x_map_out[m] = x;
+    y_map_out[m] = y;
+    for (int pl = 0; pl < a.n_planes; pl++) a.out[(size_t)pl * a.n_map + m] = reproject_sample<T>(a, pl, x, y);
 }
 
 // ------------------------------------------------------------------ spline reprojection
@@ -704,6 +732,27 @@ void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s)
 {
     hipLaunchKernelGGL(pm::k_map_limits, dim3(1), dim3(pm::kBlock), 0, s, x_map, y_map, n, limits);
+}
+
+template <typename T>
+static void launch_mapped_data_t(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat,
+                                 double *xo, double *yo, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_mapped_data<T>, dim3((a.n_map + pm::kSphBlock - 1) / pm::kSphBlock), dim3(pm::kSphBlock), 0, s, p, a,
+                       lon, lat, xo, yo);
+}
+
+void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat, double *xo,
+                           double *yo, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_mapped_data_t<double>(p, a, lon, lat, xo, yo, s); break;
+    case PM_F32: launch_mapped_data_t<float>(p, a, lon, lat, xo, yo, s); break;
+    case PM_I16: launch_mapped_data_t<int16_t>(p, a, lon, lat, xo, yo, s); break;
+    case PM_I32: launch_mapped_data_t<int32_t>(p, a, lon, lat, xo, yo, s); break;
+    case PM_U8: launch_mapped_data_t<uint8_t>(p, a, lon, lat, xo, yo, s); break;
+    case PM_U16: launch_mapped_data_t<uint16_t>(p, a, lon, lat, xo, yo, s); break;
+    }
 }
 
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)

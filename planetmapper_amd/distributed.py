@@ -181,7 +181,7 @@ def backplanes_img_sharded(engine, names, ny: int, nx: int, *, alt: float = 0.0,
 
 def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_map, n0: int, n1: int,
                             gathered, rank: int, interpolation='linear', propagate_nan=True, group=None,
-                            async_op: bool = False, previous=None, defer_median_check: bool = False):
+                            async_op: bool = False, previous=None, defer_median_check: bool = False, lonlat=None):
     """
     Device-resident variant used by the benchmark: this rank's `n_planes_local` planes
     (`cube`, a device tensor / pointer) are mapped straight into its slot of `gathered`
@@ -205,7 +205,13 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
     if previous is not None:
         previous.wait()
     mine = gathered[rank]
-    engine.map_cube_device(cube, dtype, n_planes_local, x_map, y_map, n0, n1, mine, interpolation, propagate_nan)
+    if lonlat is not None:
+        # `lonlat` = (lon, lat) device grids: the x/y map is computed by the same call (`pm_mapped_data`,
+        # one launch for up to 8 planes) into x_map / y_map instead of being read from them
+        engine.mapped_data_device(cube, dtype, n_planes_local, lonlat[0], lonlat[1], n0, n1, x_map, y_map, mine,
+                                  interpolation, propagate_nan)
+    else:
+        engine.map_cube_device(cube, dtype, n_planes_local, x_map, y_map, n0, n1, mine, interpolation, propagate_nan)
     if not defer_median_check:
         engine.synchronize()
     if dist.is_initialized() and dist.get_world_size(group) > 1:

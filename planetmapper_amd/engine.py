@@ -416,6 +416,22 @@ class Engine:
         )
 
 
+    def mapped_data_device(self, cube, dtype, n_planes: int, lon, lat, n0: int, n1: int, x_map, y_map, out,
+                           interpolation='linear', propagate_nan=True, alt: float = 0.0) -> None:
+        """
+        `pm_mapped_data` on device buffers: x/y map of the lon/lat grid and reprojection of the planes
+        in one call (one launch for up to 8 planes, nearest / linear) - Observation.get_mapped_data.
+        """
+        self.set_spline_smoothing(0.0)
+        self._check(
+            self._lib.pm_mapped_data(
+                self._ctx, _ptr(cube), dtype_code(dtype), int(n_planes), _ptr(lon), _ptr(lat), int(n0), int(n1),
+                float(alt), interpolation_code(interpolation), 1 if propagate_nan else 0, _ptr(x_map), _ptr(y_map),
+                _ptr(out), _lib.PM_MEM_DEVICE,
+            )
+        )
+
+
 def device_count() -> int:
     return int(_lib.load().pm_device_count())
 

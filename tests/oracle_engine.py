@@ -65,6 +65,16 @@ class OracleEngine:
         res = self.map_cube(cube.numpy()[:n_planes], x_map.numpy(), y_map.numpy(), interpolation, propagate_nan)
         out.reshape(n_planes, n0, n1).copy_(torch.from_numpy(res))
 
+    def mapped_data_device(self, cube, dtype, n_planes, lon, lat, n0, n1, x_map, y_map, out, interpolation='linear',
+                           propagate_nan=True, alt=0.0):
+        """stand-in for pm_mapped_data: x/y map written into x_map / y_map, planes mapped with it"""
+        import torch
+
+        o = self.backplanes_map(['PIXEL-X', 'PIXEL-Y'], lon.numpy(), lat.numpy(), alt=alt)
+        x_map.copy_(torch.from_numpy(o['PIXEL-X']))
+        y_map.copy_(torch.from_numpy(o['PIXEL-Y']))
+        self.map_cube_device(cube, dtype, n_planes, x_map, y_map, n0, n1, out, interpolation, propagate_nan)
+
     def radec_query(self, ra, dec, *, alt=0.0, ring_only_visible=True):
         ra, dec = np.broadcast_arrays(np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64))
         q = oracle.radec_query(self._g, ra.ravel(), dec.ravel(), alt=alt, ring_only_visible=ring_only_visible)

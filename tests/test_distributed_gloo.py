@@ -139,6 +139,15 @@ def _pipeline_worker(rank: int, world: int, port: int, tmpdir: str) -> None:
         assert ('sync',) not in eng.calls  # the deferred form never goes back to the host
         expect = np.stack([oracle.map_cube(frames[r], xm.numpy(), ym.numpy()) for r in range(world)])
         assert np.array_equal(gathered.numpy(), expect, equal_nan=True)
+        # the fused form (x/y map computed by the same call, bench.py's step) gives the same slots
+        g2 = torch.full((world, 2, n0, n1), float('nan'), dtype=torch.float64)
+        xm2, ym2 = torch.empty_like(xm), torch.empty_like(ym)
+        h2 = map_cube_sharded_device(eng, mine, np.float64, 2, xm2, ym2, n0, n1, g2, rank, 'linear', True,
+                                     lonlat=(torch.from_numpy(lon.copy()), torch.from_numpy(lat.copy())))
+        if h2 is not None:
+            h2.wait()
+        assert np.array_equal(g2.numpy(), gathered.numpy(), equal_nan=True)
+        assert np.array_equal(xm2.numpy(), xm.numpy(), equal_nan=True)
         # synchronous form returns the finished handle / None for a single rank
         h = map_cube_sharded_device(eng, mine, np.float64, 2, xm, ym, n0, n1, gathered, rank)
         assert h is None or h.is_completed()

@@ -542,6 +542,56 @@ def test_c_abi_sharded_cube_with_an_rccl_communicator(engine, oracle, jupiter):
         comm.close()
 
 
+def test_fused_mapped_data_equals_the_two_calls(engine, oracle, jupiter):
+    """
+    pm_mapped_data (x/y map + reprojection in one launch for <= 8 planes) against pm_xy_map followed by
+    pm_map_cube: identical x/y maps and mapped planes for nearest / linear with both NaN policies,
+    planes that need their nanmedian (finished by pm_synchronize), an altitude, and the fall-back to
+    the two calls beyond 8 planes.
+    """
+    import torch
+
+    sz = 200
+    x0 = y0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0 + 3.3, y0 - 7.1, 0.8 * x0, 0.6, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 3.0)
+    lon[5, 7] = np.nan  # a hole in the grid (manual grids may have them)
+    n0, n1 = lon.shape
+    rng = np.random.default_rng(17)
+    cube = rng.standard_normal((11, sz, sz)) + 2.0
+    cube[rng.random(cube.shape) < 5e-3] = np.nan
+    cube[2][60:120, 50:150] = np.inf
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    dlon, dlat, dcube = t(lon), t(lat), t(cube)
+    for alt in (0.0, 2500.0):
+        for interp in ('linear', 'nearest'):
+            for prop in (True, False):
+                for planes in (1, 3, 8, 11):
+                    xa, ya = (torch.empty((n0, n1), dtype=torch.float64, device='cuda') for _ in range(2))
+                    xb, yb = torch.full_like(xa, -5.0), torch.full_like(xa, -5.0)
+                    oa = torch.full((planes, n0, n1), -9.0, dtype=torch.float64, device='cuda')
+                    ob = torch.full_like(oa, -9.0)
+                    engine.xy_map_device(dlon, dlat, n0, n1, xa, ya, alt=alt)
+                    engine.map_cube_device(dcube, np.float64, planes, xa, ya, n0, n1, oa, interp, prop)
+                    engine.synchronize()
+                    engine.mapped_data_device(dcube, np.float64, planes, dlon, dlat, n0, n1, xb, yb, ob, interp, prop, alt=alt)
+                    engine.synchronize()
+                    key = (alt, interp, prop, planes)
+                    assert torch.equal(torch.nan_to_num(xa, nan=-1.0), torch.nan_to_num(xb, nan=-1.0)), key
+                    assert torch.equal(torch.nan_to_num(ya, nan=-1.0), torch.nan_to_num(yb, nan=-1.0)), key
+                    assert torch.equal(torch.nan_to_num(oa, nan=-1.0, posinf=7e300, neginf=-7e300),
+                                       torch.nan_to_num(ob, nan=-1.0, posinf=7e300, neginf=-7e300)), key
+    # and against the oracle
+    d = oracle.make_disc(x0 + 3.3, y0 - 7.1, 0.8 * x0, 0.0, sz, sz)
+    d.rotation_rad = 0.6
+    xr, yr = oracle.xy_map(jupiter, d, lon, lat, alt=2500.0)
+    assert np.array_equal(np.isnan(xr), np.isnan(xb.cpu().numpy()))
+    ref = oracle.map_cube(cube, xr, yr, 'nearest', False)
+    got = ob.cpu().numpy()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+
+
 def test_point_transforms_vs_oracle(engine, oracle, jupiter):
     """
     pm_transform (reference xy2lonlat, lonlat2radec, ... on arrays) against the oracle:

@@ -7,17 +7,19 @@
 // the link (measured on the MI355X boxes, tools/probe_host_path.hip: 57 GB/s per direction for
 // pinned memory, 49 GB/s each way in duplex):
 //
-//   * results -> pageable caller memory: DMA into a ring of pinned staging buffers, copied out by a
-//     small pool of CPU threads while the next DMA runs (fresh numpy arrays take their page faults
-//     on several cores at once: 74 GB/s with 8 threads against 25 GB/s through the runtime's own
-//     pageable path); results -> pinned caller memory (pm_host_alloc / pm_host_register): one DMA;
+//   * results -> pageable caller memory: DMA into a ring of pinned staging buffers; a retire thread
+//     waits for each DMA and a small pool of CPU threads copies the piece out while the next DMAs
+//     run (fresh numpy arrays take their page faults on several cores at once: 74 GB/s with 8
+//     threads against 25 GB/s through the runtime's own pageable path); results -> pinned caller
+//     memory (pm_host_alloc / pm_host_register): one DMA;
 //   * cube planes from pageable memory: chunks of planes through a three-slot device ring - the
 //     H2D copy of chunk k + 1, the kernel of chunk k and the D2H copy of finished output overlap on
-//     three streams;
+//     three streams (4.3 GB cube: 89 ms, 48 GB/s sustained);
 //   * cube planes from PINNED memory, nearest / linear: nothing is copied at all. The kernel gathers
-//     the pixels it samples straight from host memory: a 1 deg map touches about a third of the 64-byte
-//     sectors of a 1024^2 plane, so the link carries a third of the bytes (6.1 ms per GiB of cube
-//     against 18.6 ms for the copy alone).
+//     the pixels it samples straight from host memory. Host reads have the 128-byte line granularity
+//     HBM reads have (tools/probe_gather.hip): a 1 deg map touches about half the lines of a 1024^2
+//     plane, so the link carries 2.3 GB instead of 4.3 GB (68-71 ms), and the result can be stored
+//     straight into a pinned output.
 //
 // No compute happens on the CPU here: the threads move bytes.
 #include <atomic>

@@ -288,7 +288,8 @@ def rehearse(args) -> None:
 
 
 # ------------------------------------------------------------------ config 5 fed from host memory
-def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_resident: int) -> dict:
+def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_resident: int, sz: int = 1024,
+                      degree_interval: float = 1.0) -> dict:
     """
     BASELINE config 5 as the reference runs it (observation.py:876-905 maps a HOST cube): P x 1024^2
     f64 planes in host memory, contiguous blocks of ceil(P / N) planes per rank
@@ -300,13 +301,12 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     torch = d.torch
     from planetmapper_amd.distributed import shard_bounds
 
-    sz = 1024
     x0 = (sz - 1) / 2
     eng.set_geometry(g)
     eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
     a, b, per_rank = shard_bounds(planes, d.world, d.rank)
     mine_n = b - a
-    lon_h, lat_h = rectangular_grid(bool(g.west_positive))
+    lon_h, lat_h = rectangular_grid(bool(g.west_positive), degree_interval)
     n0, n1 = lon_h.shape
     lon_d, lat_d = torch.from_numpy(lon_h).to(d.dev), torch.from_numpy(lat_h).to(d.dev)
     xm = torch.empty((n0, n1), dtype=torch.float64, device=d.dev)

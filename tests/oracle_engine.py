@@ -75,6 +75,25 @@ class OracleEngine:
         y_map.copy_(torch.from_numpy(o['PIXEL-Y']))
         self.map_cube_device(cube, dtype, n_planes, x_map, y_map, n0, n1, out, interpolation, propagate_nan)
 
+    # stand-ins for the device / pinned-memory calls of bench.py's host-fed cube section (CPU tensors)
+    def pinned_empty(self, shape, dtype=np.float64):
+        return np.empty(shape, dtype=dtype)
+
+    def xy_map_device(self, lon, lat, n0, n1, x_map, y_map, alt=0.0):
+        import torch
+
+        o = self.backplanes_map(['PIXEL-X', 'PIXEL-Y'], lon.numpy(), lat.numpy(), alt=alt)
+        x_map.copy_(torch.from_numpy(o['PIXEL-X']))
+        y_map.copy_(torch.from_numpy(o['PIXEL-Y']))
+
+    def map_cube_host_to_device(self, cube, x_map, y_map, n0, n1, out, interpolation='linear', propagate_nan=True):
+        import torch
+
+        self.calls.append(('host_cube', cube.shape))
+        out.reshape(cube.shape[0], n0, n1).copy_(
+            torch.from_numpy(oracle.map_cube(cube, x_map.numpy(), y_map.numpy(), interpolation, propagate_nan))
+        )
+
     def radec_query(self, ra, dec, *, alt=0.0, ring_only_visible=True):
         ra, dec = np.broadcast_arrays(np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64))
         q = oracle.radec_query(self._g, ra.ravel(), dec.ravel(), alt=alt, ring_only_visible=ring_only_visible)

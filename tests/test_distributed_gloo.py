@@ -206,3 +206,44 @@ def test_row_block_sharded_backplanes_world_size_2(tmp_path, ny):
     world = 2
     mp.spawn(_rows_worker, args=(world, _free_port(), ny, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def _cube_host_worker(rank: int, world: int, port: int, planes: int, tmpdir: str) -> None:
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))  # fmt: skip
+    import bench
+    from oracle_engine import OracleEngine
+    from planetmapper_amd.scenarios import load_scenario
+
+    d = bench.Dist(bench.parse_args(['--gpus', str(world), '--rehearse']))  # gloo group, CPU tensors
+    try:
+        eng = OracleEngine()
+        g = load_scenario('jupiter_hst_2005')
+        sec = bench.cube_host_section(d, eng, g, planes, steps_fed=1, steps_resident=1, sz=48, degree_interval=20.0)
+        a, b, per_rank = shard_bounds(planes, world, rank)
+        assert sec['rccl_ranks'] == world and sec['planes_per_rank'] == per_rank
+        assert sec['fed_equals_resident'] is True  # the gathered cube of the host-fed step == the resident one
+        fed = [c for c in eng.calls if c[0] == 'host_cube']
+        assert all(c[1][0] == b - a for c in fed) and (len(fed) > 0) == (b > a)
+        # every step finishes this rank's planes before the collective
+        kinds = [c[0] for c in eng.calls]
+        assert all(kinds[i + 1] == 'sync' for i, k in enumerate(kinds) if k in ('host_cube', 'cube'))
+        open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
+    finally:
+        d.close()
+
+
+@pytest.mark.parametrize('planes', [6, 5, 1])
+def test_bench_cube_host_section_world_size_2(tmp_path, planes):
+    """
+    bench.py's host-fed cube section - the code the driver's N = 1, 2, 4, 8 runs execute for the north
+    star's scaling case - with two gloo ranks and the oracle-backed engine double: shard bounds,
+    per-rank slots, the all-gather, uneven and empty shards.
+    """
+    world = 2
+    mp.spawn(_cube_host_worker, args=(world, _free_port(), planes, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))

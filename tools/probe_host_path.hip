@@ -223,6 +223,34 @@ int main(int argc, char **argv)
             printf("{\"probe\": \"kernel gather from HBM\", \"planes\": %d, \"ms\": %.3f}\n", planes, ms);
         }
     }
+    // ---- do a zero-copy gather and a DMA copy share the link, or add up? (same direction: host -> GPU)
+    {
+        const int nx = 1024, n_map = 64800, planes = 128;
+        double *out = (double *)dev2;
+        hipEvent_t e0, e1, f0, f1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
+        for (int with_dma = 0; with_dma < 2; with_dma++) {
+            CK(hipDeviceSynchronize());
+            double t0 = now();
+            CK(hipEventRecord(e0, s0));
+            for (int r = 0; r < 4; r++)
+                hipLaunchKernelGGL(k_gather, dim3((n_map + 255) / 256, planes), dim3(256), 0, s0, (const double *)pin2, (size_t)nx * nx, nx, n_map, out);
+            CK(hipEventRecord(e1, s0));
+            if (with_dma) {
+                CK(hipEventRecord(f0, s1));
+                CK(hipMemcpyAsync(dev, pin, 1024 * MB, hipMemcpyHostToDevice, s1));
+                CK(hipEventRecord(f1, s1));
+            }
+            CK(hipStreamSynchronize(s0));
+            CK(hipStreamSynchronize(s1));
+            double wall = now() - t0;
+            float gms, dms = 0;
+            CK(hipEventElapsedTime(&gms, e0, e1));
+            if (with_dma) CK(hipEventElapsedTime(&dms, f0, f1));
+            printf("{\"probe\": \"gather 4 x 128 planes from pinned %s\", \"gather_ms\": %.2f, \"dma_1GiB_ms\": %.2f, \"wall_ms\": %.2f}\n",
+                   with_dma ? "WITH a concurrent 1 GiB H2D DMA" : "alone", gms, dms, wall * 1e3);
+        }
+    }
     (void)argc;
     (void)argv;
     return 0;

@@ -169,7 +169,29 @@ def quad_lib() -> ctypes.CDLL:
             ctypes.POINTER(PMGeometry), ctypes.c_int, ctypes.POINTER(PMDisc), ctypes.c_double, ctypes.c_uint64,
             ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.POINTER(ctypes.c_double)),
         ]  # fmt: skip
+        dp = ctypes.POINTER(ctypes.c_double)
+        _quad.pmoq_backplanes_map.argtypes = [
+            ctypes.POINTER(PMGeometry), ctypes.c_int, ctypes.POINTER(PMDisc), ctypes.c_double, ctypes.c_uint64, dp, dp,
+            ctypes.c_int, ctypes.c_int, ctypes.POINTER(dp),
+        ]  # fmt: skip
     return _quad
+
+
+def backplanes_map_quad(g: PMGeometry, d: PMDisc, names, lon_deg, lat_deg, alt: float = 0.0) -> dict[str, np.ndarray]:
+    """Map-space planes of a lon/lat grid evaluated in binary128 and rounded to binary64 (the truth)."""
+    names = list(names)
+    lon = np.ascontiguousarray(lon_deg, dtype=np.float64)
+    lat = np.ascontiguousarray(lat_deg, dtype=np.float64)
+    n0, n1 = lon.shape
+    outs = {n: np.empty((n0, n1), dtype=np.float64) for n in names}
+    ptrs = (ctypes.POINTER(ctypes.c_double) * NUM_PLANES)()
+    for n, a in outs.items():
+        ptrs[PLANE_INDEX[n]] = _dptr(a)
+    rc = quad_lib().pmoq_backplanes_map(ctypes.byref(g), ctypes.sizeof(PMGeometry), ctypes.byref(d), float(alt),
+                                        mask_of(names), _dptr(lon), _dptr(lat), n0, n1, ptrs)  # fmt: skip
+    if rc != 0:
+        raise ValueError(f'quad oracle error {rc}')
+    return outs
 
 
 def backplanes_img_rows_quad(g: PMGeometry, d: PMDisc, names, row_begin: int, n_rows: int, alt: float = 0.0,

@@ -135,3 +135,58 @@ int pmoq_backplanes_img_rows(const void *geometry64, int geometry64_bytes, const
     for (int p = 0; p < PM_NUM_PLANES; p++) free(tmp[p]);
     return rc;
 }
+
+/*
+ * Map-space planes of a lon/lat grid (n0 * n1 cells) in binary128, rounded to binary64: the chain
+ * pm_backplanes_map / pm_xy_map replace (body_xy.py:3227-3300, 3419-3491, 3667). out[p]: n0 * n1
+ * doubles for every requested plane.
+ */
+int pmoq_backplanes_map(const void *geometry64, int geometry64_bytes, const void *disc64_ptr, f64 alt, uint64_t mask,
+                        const f64 *lon_deg, const f64 *lat_deg, int n0, int n1, f64 *const *out)
+{
+    const int k = (geometry64_bytes - 8) / 8;
+    if (k <= 0 || (size_t)(16 * k) != offsetof(pmq_geometry, west_positive) || n0 < 0 || n1 < 0) return PM_ERR_INVALID_ARGUMENT;
+    pmq_geometry g;
+    memset(&g, 0, sizeof(g));
+    const f64 *src = (const f64 *)geometry64;
+    __float128 *dst = (__float128 *)&g;
+    for (int i = 0; i < k; i++) dst[i] = (__float128)src[i];
+    memcpy(&g.west_positive, (const char *)geometry64 + 8 * k, 8);
+    const disc64 *d64 = (const disc64 *)disc64_ptr;
+    pmq_disc d;
+    d.x0 = d64->x0;
+    d.y0 = d64->y0;
+    d.r0 = d64->r0;
+    d.rotation_rad = d64->rotation_rad;
+    d.nx = d64->nx;
+    d.ny = d64->ny;
+    d.optimize_speed = d64->optimize_speed;
+    d.reserved = 0;
+    const size_t n = (size_t)n0 * n1;
+    if (n == 0) return PM_OK;
+    int rc = PM_OK;
+    __float128 *lon = (__float128 *)malloc(n * sizeof(__float128)), *lat = (__float128 *)malloc(n * sizeof(__float128));
+    __float128 *tmp[PM_NUM_PLANES];
+    for (int p = 0; p < PM_NUM_PLANES; p++) tmp[p] = NULL;
+    if (!lon || !lat) rc = PM_ERR_ALLOC;
+    for (int p = 0; p < PM_NUM_PLANES && rc == PM_OK; p++)
+        if ((mask >> p) & 1) {
+            tmp[p] = (__float128 *)malloc(n * sizeof(__float128));
+            if (!tmp[p]) rc = PM_ERR_ALLOC;
+        }
+    if (rc == PM_OK) {
+        for (size_t i = 0; i < n; i++) {
+            lon[i] = lon_deg[i];
+            lat[i] = lat_deg[i];
+        }
+        rc = pmoq_raw_backplanes_map(&g, &d, (__float128)alt, mask, lon, lat, n0, n1, tmp);
+    }
+    if (rc == PM_OK)
+        for (int p = 0; p < PM_NUM_PLANES; p++)
+            if (tmp[p])
+                for (size_t i = 0; i < n; i++) out[p][i] = (f64)tmp[p][i];
+    for (int p = 0; p < PM_NUM_PLANES; p++) free(tmp[p]);
+    free(lon);
+    free(lat);
+    return rc;
+}

@@ -205,3 +205,54 @@ def test_every_plane_against_the_truth(jupiter, saturn, which):
     if os.path.isdir(out):
         with open(os.path.join(out, f'truth_f128_all_planes_{which}.json'), 'w') as f:
             json.dump({'frame': [sz, sz], 'planes': report}, f, indent=1)
+
+
+@pytest.mark.gpu
+def test_map_planes_against_the_truth(jupiter):
+    """
+    The map chain on the BASELINE config-3 frame (2048^2 disc, 1 deg grid): all 26 map-space planes
+    of the general map kernel and the x/y map of the short `k_map_xy` kernel (which does not replay
+    the reference's RA/Dec degree round trip) against the binary128 truth, next to the strict
+    binary64 oracle (which does replay it, and carries its 2e-10 arcsec of rounding: 1.7e-8 px here).
+    """
+    from oracle import oracle
+    from planetmapper_amd.engine import Engine
+
+    sz = 2048
+    x0 = y0 = (sz - 1) / 2
+    r0 = 0.9 * x0
+    lon, lat = oracle.rectangular_grid(jupiter, 1.0)
+    eng = Engine(0)
+    try:
+        eng.set_geometry(jupiter)
+        eng.set_disc(x0, y0, r0, 0.0, sz, sz, True)
+        hip = eng.backplanes_map(oracle.PLANE_NAMES, lon, lat)  # general kernel: every plane
+        xm, ym = eng.xy_map(lon, lat)  # k_map_xy
+    finally:
+        eng.close()
+    d = oracle.make_disc(x0, y0, r0, 0.0, sz, sz)
+    o64 = oracle.backplanes_map(jupiter, d, oracle.PLANE_NAMES, lon, lat)
+    tru = oracle.backplanes_map_quad(jupiter, d, oracle.PLANE_NAMES, lon, lat)
+    report = {}
+    floors = dict(_FLOOR, **{'PIXEL-X': 1e-9, 'PIXEL-Y': 1e-9})
+    cases = [(n, hip[n]) for n in oracle.PLANE_NAMES if n != 'LOCAL-SOLAR-TIME'] + [('PIXEL-X', xm), ('PIXEL-Y', ym)]
+    for i, (n, got) in enumerate(cases):
+        assert np.array_equal(np.isnan(got), np.isnan(tru[n])), n
+        fin = np.isfinite(tru[n])
+        if not fin.any():
+            continue
+        eh, eo = np.abs(got - tru[n])[fin], np.abs(o64[n] - tru[n])[fin]
+        if 'LON' in n or n == 'RA':
+            eh, eo = np.minimum(eh, 360 - eh), np.minimum(eo, 360 - eo)
+        sh, so = _stats(eh), _stats(eo)
+        report[n + (' (k_map_xy)' if i >= len(cases) - 2 else '')] = {'hip_vs_truth': sh, 'oracle64_vs_truth': so}
+        floor = floors.get(n, 2e-11)
+        assert sh['max'] <= 3.0 * so['max'] + floor, (n, sh, so)
+        assert sh['p999'] <= 3.0 * so['p999'] + floor, (n, sh, so)
+    assert np.array_equal(hip['LOCAL-SOLAR-TIME'], tru['LOCAL-SOLAR-TIME'], equal_nan=True) or (
+        np.nanmax(np.abs(hip['LOCAL-SOLAR-TIME'] - tru['LOCAL-SOLAR-TIME'])) <= 1 / 3600 + 1e-9
+    )
+    out = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'truth_f128_map_planes.json'), 'w') as f:
+            json.dump({'frame': [sz, sz], 'map': list(lon.shape), 'planes': report}, f, indent=1)

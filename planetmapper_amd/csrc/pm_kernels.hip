@@ -42,8 +42,10 @@ enum DiscFlags : int {
 // get_radial_velocity_img :3895, get_doppler_img :3938,
 // _get_ring_plane_coordinate_imgs :4059.
 template <int FLAGS>
-__global__ __launch_bounds__(kBlock) void k_disc(const Params p)
+__global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
 {
+    // constants through the laundered kernel-argument pointer, loaded where they are used (k_map)
+    const Params &p = *(const Params *)kernarg_params();
     const int x = blockIdx.x * kBlock + threadIdx.x;
     const int y = p.y_off + (int)blockIdx.y;
     const bool inside = x < p.nx;
@@ -557,9 +559,12 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p)
 // STATE: distance / radial velocity / doppler. The x/y-map request of a reprojection needs
 // neither: only the emission angle (visibility) is evaluated then.
 template <bool SUN, bool STATE>
-__global__ __launch_bounds__(kBlock) void k_map(const Params p, const double *__restrict__ lon_in,
+__global__ __launch_bounds__(kBlock) void k_map(const Params p_, const double *__restrict__ lon_in,
                                                 const double *__restrict__ lat_in)
 {
+    // constants through the laundered kernel-argument pointer: loaded where they are used (see
+    // kernarg_params; after inlining the address space is inferred back, the loads stay scalar)
+    const Params &p = *(const Params *)kernarg_params();
     const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const size_t n = (size_t)p.n0 * p.n1;
     if (idx >= n) return;
@@ -730,8 +735,9 @@ __device__ __forceinline__ bool targvec_visible(const Params &p, V3 tv, bool on_
     return lt_p < lt_i;
 }
 
-__global__ __launch_bounds__(kBlock) void k_transform(const Params p, const TransformArgs t)
+__global__ __launch_bounds__(kBlock) void k_transform(const Params p_, const TransformArgs t)
 {
+    const Params &p = *(const Params *)kernarg_params();  // constants loaded where they are used (k_map)
     const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= t.n) return;
     const double nan = __builtin_nan("");
@@ -829,10 +835,11 @@ __global__ __launch_bounds__(kBlock) void k_transform(const Params p, const Tran
 // only_visible rule :2598-2611), Body.limb_coordinates_from_radec body.py:2040-2110.
 // out: 8 arrays of n doubles = lon, lat, ring radius, ring lon, ring distance, limb lon,
 // limb lat, limb distance.
-__global__ __launch_bounds__(kBlock) void k_radec_query(const Params p, const double *__restrict__ ra_deg,
+__global__ __launch_bounds__(kBlock) void k_radec_query(const Params p_, const double *__restrict__ ra_deg,
                                                         const double *__restrict__ dec_deg, unsigned long long n,
                                                         int ring_only_visible, double *__restrict__ out)
 {
+    const Params &p = *(const Params *)kernarg_params();  // constants loaded where they are used (k_map)
     const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const double nan = __builtin_nan("");

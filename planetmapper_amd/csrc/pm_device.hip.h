@@ -365,6 +365,21 @@ __device__ __forceinline__ V3 unit(V3 a)
     double s = (n > 0.0) ? 1.0 / n : 0.0;
     return s * a;
 }
+// a / |a| for a finite non-zero vector (reciprocal square root + Newton, pm_fastmath.hip.h)
+__device__ __forceinline__ V3 unit_f(V3 a) { return rsqrt_fast(dot(a, a)) * a; }
+// vsep_c of two UNIT vectors with asin on |x| <= 0.5 only: 2 asin(|u - v| / 2) below 60 deg (and the
+// supplement form above 120 deg) like CSPICE's vsep_c, pi/2 - asin(u . v) in between
+__device__ __forceinline__ double vsep_fast(V3 u, V3 v)
+{
+    const double d = dot(u, v);
+    const double sg = (d > 0.0) ? -1.0 : 1.0;
+    const V3 w = {fma(sg, v.x, u.x), fma(sg, v.y, u.y), fma(sg, v.z, u.z)};
+    const double s = 0.5 * sqrt_fast(dot(w, w));
+    const bool mid = fabs(d) < 0.5;
+    const double r = asin_half(mid ? d : s);
+    return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
+}
+
 
 // ------------------------------------------------------------------ time-dependent state
 // R(t) = rot3(wdot (t - t0)) R0   (pxform / pxfrm2 of the reference, body.py:940-1000)
@@ -375,12 +390,14 @@ __device__ __forceinline__ void rot_at(const Params &p, double t, M3 &R)
 {
     double ang = p.g.wdot * (t - p.t0);
     double s, c;
-    if (SMALL && fabs(ang) < 1e-3) {
+    if (SMALL ? fabs(ang) < 1e-3 : __all(fabs(ang) < 1e-3)) {
         double a2 = ang * ang;
         s = ang * fma(a2, fma(a2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
         c = fma(a2, fma(a2, fma(a2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
-    } else {
+    } else if (SMALL) {
         sincos(ang, &s, &c);
+    } else {
+        sincos_auto(ang, s, c);  // (wave-uniform choice of the range-aware polynomials, libm beyond 1e5)
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -440,6 +457,34 @@ __device__ __forceinline__ bool surfpt(V3 o, V3 u, const double *radii, V3 &pt)
     return true;
 }
 
+// surfpt_c with the host's reciprocals of the radii (ir[i] = 1 / radii[i], as the spheroid fast path
+// scales its vectors) and the Newton square roots: six IEEE divisions and two libm roots fewer per
+// light-time evaluation of the general kernels
+__device__ __forceinline__ bool surfpt_ir(V3 o, V3 u, const double *radii, const double *ir, V3 &pt)
+{
+    V3 X = {u.x * ir[0], u.y * ir[1], u.z * ir[2]};
+    V3 Y = {o.x * ir[0], o.y * ir[1], o.z * ir[2]};
+    double xx = dot(X, X);
+    if (xx == 0.0) return false;
+    double yx = dot(Y, X);
+    double k = div_fast(yx, xx);
+    V3 P = {fma(-k, X.x, Y.x), fma(-k, X.y, Y.y), fma(-k, X.z, Y.z)};
+    double p2 = dot(P, P), y2 = dot(Y, Y);
+    double sign;
+    if (y2 > 1.0) {
+        if (p2 > 1.0 || yx > 0.0) return false;
+        sign = -1.0;
+    } else if (y2 == 1.0) {
+        pt = o;
+        return true;
+    } else {
+        sign = 1.0;
+    }
+    double s = sign * sqrt_fast(fmax(0.0, 1.0 - p2)) * rsqrt_fast(xx);
+    pt = {fma(s, X.x, P.x) * radii[0], fma(s, X.y, P.y) * radii[1], fma(s, X.z, P.z) * radii[2]};
+    return true;
+}
+
 // sincpt_c('ELLIPSOID', ..., 'CN', ..., ray): Body._obsvec_norm2targvec body.py:1008-1020.
 // Converged-Newtonian light time: repeat the intercept at te = et - lt until the light
 // time moves by <= 1e-17 |te| (CSPICE's rule), at most 10 evaluations. The contraction
@@ -456,8 +501,8 @@ __device__ __forceinline__ bool sincpt(const Params &p, V3 ray, V3 &sp, double &
         rot_at<true>(p, te, R);
         V3 obs = neg(mxv(R, target_at(p, te)));
         V3 u = mxv(R, ray);
-        if (!surfpt(obs, u, p.radii, sp)) return false;
-        double nlt = norm(sp - obs) / p.g.clight;
+        if (!surfpt_ir(obs, u, p.radii, p.ir, sp)) return false;
+        double nlt = norm_f(sp - obs) * p.inv_c;
         double err = fabs(nlt - lt);
         lt = nlt;
         if (err <= 1e-17 * fabs(p.g.et - lt)) break;
@@ -469,17 +514,15 @@ __device__ __forceinline__ bool sincpt(const Params &p, V3 ray, V3 &sp, double &
 // geodetic latitude from the surface normal (x/a^2, y/a^2, z/c^2).
 __device__ __forceinline__ void recpgr_surface(const Params &p, V3 v, double &lon, double &lat)
 {
-    double a = p.radii[0], c = p.radii[2];
-    double m = fmin(a, c);
-    double a1 = m / a, c1 = m / c;
-    double nx = v.x * (a1 * a1), ny = v.y * (a1 * a1), nz = v.z * (c1 * c1);
+    // (limb_n = (m / a)^2, (m / c)^2 with m = min(a, c): the host's copy of this scaling)
+    double nx = v.x * p.limb_n[0], ny = v.y * p.limb_n[0], nz = v.z * p.limb_n[1];
     if (nx == 0.0 && ny == 0.0 && nz == 0.0) {
         lon = 0.0;
         lat = kHalfPi;
         return;
     }
-    lat = atan2(nz, sqrt(fma(nx, nx, ny * ny)));
-    double l = (v.x == 0.0 && v.y == 0.0) ? 0.0 : atan2(v.y, v.x);
+    lat = atan2_fast<true>(nz, sqrt_fast(fma(nx, nx, ny * ny)));
+    double l = (v.x == 0.0 && v.y == 0.0) ? 0.0 : atan2_fast(v.y, v.x);
     if (p.g.west_positive) l = -l;
     if (l < 0.0) l += kTwoPi;
     lon = l;
@@ -646,7 +689,7 @@ __device__ __forceinline__ void point_lt(const Params &p, V3 sp, double &lt, V3 
         double te = p.g.et - lt;
         rot_at<true>(p, te, R);
         pos = target_at(p, te) + mtxv(R, sp);
-        lt = norm(pos) / p.g.clight;
+        lt = norm_f(pos) * p.inv_c;
     }
     double te = p.g.et - lt;
     rot_at<true>(p, te, R);
@@ -668,29 +711,25 @@ __device__ __forceinline__ void illum_angles(const Params &p, V3 sp, double lt, 
 #pragma unroll
     for (int it = 0; it < 2; it++) {
         sv = sun_at(p, te - lts) - q;
-        lts = norm(sv) / p.g.clight;
+        lts = norm_f(sv) * p.inv_c;
     }
     sv = sun_at(p, te - lts) - q;
-    V3 sunb = unit(mxv(R, sv));
-    V3 ob = unit(obsv);
-    // surfnm_c
-    double m = fmin(p.radii[0], fmin(p.radii[1], p.radii[2]));
-    double a1 = m / p.radii[0], b1 = m / p.radii[1], c1 = m / p.radii[2];
-    V3 n = unit(v3(sp.x * (a1 * a1), sp.y * (b1 * b1), sp.z * (c1 * c1)));
-    phase = vsep_unit(sunb, ob);
-    inc = vsep_unit(n, sunb);
-    emi = vsep_unit(n, ob);
+    V3 sunb = unit_f(mxv(R, sv));
+    V3 ob = unit_f(obsv);
+    // surfnm_c: sp / radii^2, normalised (the common scale of CSPICE's form drops out)
+    V3 n = unit_f(v3(sp.x * (p.ir[0] * p.ir[0]), sp.y * (p.ir[1] * p.ir[1]), sp.z * (p.ir[2] * p.ir[2])));
+    phase = vsep_fast(sunb, ob);
+    inc = vsep_fast(n, sunb);
+    emi = vsep_fast(n, ob);
 }
 
 // emission angle alone (the `visibl` flag of illumf_c: emission < 90 deg), for callers that
 // need no Sun geometry: same operations as in illum_angles
 __device__ __forceinline__ double emission_angle(const Params &p, V3 sp, V3 pos, const M3 &R)
 {
-    V3 ob = unit(neg(mxv(R, pos)));
-    double m = fmin(p.radii[0], fmin(p.radii[1], p.radii[2]));
-    double a1 = m / p.radii[0], b1 = m / p.radii[1], c1 = m / p.radii[2];
-    V3 n = unit(v3(sp.x * (a1 * a1), sp.y * (b1 * b1), sp.z * (c1 * c1)));
-    return vsep_unit(n, ob);
+    V3 ob = unit_f(neg(mxv(R, pos)));
+    V3 n = unit_f(v3(sp.x * (p.ir[0] * p.ir[0]), sp.y * (p.ir[1] * p.ir[1]), sp.z * (p.ir[2] * p.ir[2])));
+    return vsep_fast(n, ob);
 }
 
 // Body._azimuth_angle_from_gie_radians body.py:2319 on degree images (body_xy.py:3742)
@@ -713,9 +752,9 @@ __device__ __forceinline__ double radial_velocity(const Params &p, V3 sp, double
     V3 w = p.g.wdot * cross(z, off);
     V3 vp = {fma(p.g.AT[0], d, p.g.VT[0]) + w.x, fma(p.g.AT[1], d, p.g.VT[1]) + w.y,
              fma(p.g.AT[2], d, p.g.VT[2]) + w.z};
-    V3 rh = unit(pos);
+    V3 rh = unit_f(pos);
     V3 vo = ld3(p.g.VO);
-    double dlt = (dot(rh, vp - vo) / p.g.clight) / (1.0 + dot(rh, vp) / p.g.clight);
+    double dlt = div_fast(dot(rh, vp - vo) * p.inv_c, fma(dot(rh, vp), p.inv_c, 1.0));
     V3 vel = (1.0 - dlt) * vp - vo;
     return dot(vel, rh);
 }
@@ -725,8 +764,8 @@ __device__ __forceinline__ double radial_velocity(const Params &p, V3 sp, double
 __device__ __forceinline__ V3 targvec2obsvec(const Params &p, V3 tv)
 {
     V3 off = tv - ld3(p.g.sub_sp);
-    double dist = norm(ld3(p.g.sub_ray) + off) - p.g.sub_dist;
-    double t = p.g.sub_et - dist / p.g.clight;
+    double dist = norm_f(ld3(p.g.sub_ray) + off) - p.g.sub_dist;
+    double t = p.g.sub_et - dist * p.inv_c;
     M3 R;
     rot_at<false>(p, t, R);
     return ld3(p.g.sub_obsvec) + mtxv(R, off);
@@ -735,8 +774,8 @@ __device__ __forceinline__ V3 targvec2obsvec(const Params &p, V3 tv)
 __device__ __forceinline__ V3 obsvec2targvec(const Params &p, V3 ov)
 {
     V3 off = ov - ld3(p.g.sub_obsvec);
-    double dist = norm(off - ld3(p.g.sub_ray)) - p.g.sub_dist;
-    double t = p.g.sub_et - dist / p.g.clight;
+    double dist = norm_f(off - ld3(p.g.sub_ray)) - p.g.sub_dist;
+    double t = p.g.sub_et - dist * p.inv_c;
     M3 R;
     rot_at<false>(p, t, R);
     return ld3(p.g.sub_sp) + mxv(R, off);
@@ -869,7 +908,7 @@ __device__ __forceinline__ V3 xy2ray(const Params &p, double x, double y)
 {
     double ax = fma(p.A[0], x, fma(p.A[1], y, p.A[2]));
     double ay = fma(p.A[3], x, fma(p.A[4], y, p.A[5]));
-    V3 v = radrec(-((ax / 3600.0) * kRad), (ay / 3600.0) * kRad);
+    V3 v = radrec_f(-(div_fast(ax, 3600.0) * kRad), div_fast(ay, 3600.0) * kRad);
     return mtxv(p.g.M, v);
 }
 

@@ -64,8 +64,8 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
     V3 ray2 = ray;
     if (FLAGS & DF_RING) {
         double ra, dec;
-        recrad(ray, ra, dec);
-        ray2 = radrec((ra * kDeg) * kRad, (dec * kDeg) * kRad);
+        recrad_f(ray, ra, dec);
+        ray2 = radrec_f((ra * kDeg) * kRad, (dec * kDeg) * kRad);
     }
 
     V3 sp = {nan, nan, nan};
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
         double lc = nan, bc = nan;
         if (on_disc) {
             // reclat_c: Body._targvec2lonlat_centric body.py:2905
-            bc = atan2(sp.z, sqrt(fma(sp.x, sp.x, sp.y * sp.y))) * kDeg;
-            lc = ((sp.x == 0.0 && sp.y == 0.0) ? 0.0 : atan2(sp.y, sp.x)) * kDeg;
+            bc = atan2_fast<true>(sp.z, sqrt_fast(fma(sp.x, sp.x, sp.y * sp.y))) * kDeg;
+            lc = ((sp.x == 0.0 && sp.y == 0.0) ? 0.0 : atan2_fast(sp.y, sp.x)) * kDeg;
         }
         if (inside) {
             PM_PUT_ROW(PM_LON_CENTRIC, lc);
@@ -167,17 +167,6 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
 // its position relative to the observer is tau * ray), one sqrt per intercept.
 // vsep angles use asin on |x| <= 0.5 only: 2 asin(|u-v|/2) for angles < 60 deg (and the
 // supplement form > 120 deg) like CSPICE's vsep_c, pi/2 - asin(u.v) in between.
-__device__ __forceinline__ double vsep_fast(V3 u, V3 v)
-{
-    const double d = dot(u, v);
-    const double sg = (d > 0.0) ? -1.0 : 1.0;
-    const V3 w = {fma(sg, v.x, u.x), fma(sg, v.y, u.y), fma(sg, v.z, u.z)};
-    const double s = 0.5 * sqrt_fast(dot(w, w));
-    const bool mid = fabs(d) < 0.5;
-    const double r = asin_half(mid ? d : s);
-    return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
-}
-
 // asin(n.z) of a unit vector n - the planetographic latitude of a spheroid's surface normal -
 // with the machinery of vsep_fast against the pole: asin on |x| <= 0.5 only (half-chord to the
 // nearer pole beyond 30 deg of latitude). One reciprocal square root; the atan2(z a / c, rho)
@@ -748,9 +737,10 @@ __global__ __launch_bounds__(kBlock) void k_transform(const Params p_, const Tra
     V3 ov = {nan, nan, nan};
     if (t.from == CS_LONLAT) {
         Params p0 = p;
-        p0.radii[0] = t.radii0[0];
-        p0.radii[1] = t.radii0[1];
-        p0.radii[2] = t.radii0[2];
+        for (int k = 0; k < 3; k++) {
+            p0.radii[k] = t.radii0[k];
+            p0.ir[k] = 1.0 / t.radii0[k];  // (the helpers scale by the reciprocals)
+        }
         double lon = pa, lat = pb;
         if (centric) {
             // centric2graphic_lonlat body.py:2970: latsrf_c + targvec2lonlat(alt)

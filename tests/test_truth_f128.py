@@ -155,7 +155,7 @@ _FLOOR = {
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('which', ['jupiter', 'saturn'])
+@pytest.mark.parametrize('which', ['jupiter', 'saturn', 'jupiter_general', 'saturn_general'])
 def test_every_plane_against_the_truth(jupiter, saturn, which):
     """
     All 26 image planes (Jupiter 1024^2, BASELINE config 2 with every plane; Saturn with rings 768^2,
@@ -169,10 +169,11 @@ def test_every_plane_against_the_truth(jupiter, saturn, which):
     from oracle import oracle
     from planetmapper_amd.engine import Engine
 
-    g, sz, r0, rot = (jupiter, 1024, 0.9 * 511.5, 0.0) if which == 'jupiter' else (saturn, 768, 150.0, 20.0)
+    g, sz, r0, rot = (jupiter, 1024, 0.9 * 511.5, 0.0) if which.startswith('jupiter') else (saturn, 768, 150.0, 20.0)
     x0 = y0 = (sz - 1) / 2
     names = [n for n in oracle.PLANE_NAMES if n != 'LOCAL-SOLAR-TIME']
-    eng = Engine(0)
+    # (`_general`: the same frame through the general kernel k_disc<FLAGS>, PM_OPT_GENERAL_KERNEL)
+    eng = Engine(0, general_kernel=which.endswith('_general'))
     try:
         eng.set_geometry(g)
         eng.set_disc(x0, y0, r0, float(np.deg2rad(rot)), sz, sz, True)

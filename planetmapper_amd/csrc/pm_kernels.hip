@@ -174,9 +174,16 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
 __device__ __forceinline__ double lat_of_normal(V3 n)
 {
     const double d = n.z;
-    const double wz = d + ((d > 0.0) ? -1.0 : 1.0);
-    const double s = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
     const bool mid = fabs(d) < 0.5;
+    // (half-chord to the nearer pole: (1 - |n.z|) / 2 while that keeps its accuracy, see vsep_fast)
+    const double h = fma(-0.5, fabs(d), 0.5);
+    double s;
+    if (__all(mid || h > 5e-5)) {
+        s = sqrt_fast(h);
+    } else {
+        const double wz = d + ((d > 0.0) ? -1.0 : 1.0);
+        s = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
+    }
     const double r = asin_half(mid ? d : s);
     return mid ? r : (d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi));
 }

@@ -206,6 +206,27 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         p.sun_ds0 = (p.t0 - g.ts0) - sb / g.clight;
         p.sun_k = 1.0 / (sb * g.clight);
     }
+    {
+        // phase-angle series of the fast path (Params::ph): expansion point = the body centre
+        const double so = std::sqrt(p.O0[0] * p.O0[0] + p.O0[1] * p.O0[1] + p.O0[2] * p.O0[2]);
+        const double ss = std::sqrt(p.SB0[0] * p.SB0[0] + p.SB0[1] * p.SB0[1] + p.SB0[2] * p.SB0[2]);
+        const double c0 = (p.O0[0] * p.SB0[0] + p.O0[1] * p.SB0[1] + p.O0[2] * p.SB0[2]) / (so * ss);
+        const double s2 = 1.0 - c0 * c0, s1 = std::sqrt(std::fmax(s2, 0.0));
+        const double rmax_ = std::fmax(p.radii[0], std::fmax(p.radii[1], p.radii[2]));
+        // largest excursion of the phase angle over the disc (point anywhere within rmax of the centre, the
+        // target's motion over the light-time span included) against sin(g0): the ratio of the series
+        const double dg = 1.25 * rmax_ * (1.0 / so + 1.0 / ss) + 1e-7;
+        p.phase_series = (s1 > 1e-3 && dg / s1 <= 1.5e-3) ? 1 : 0;
+        p.ph[0] = c0;
+        p.ph[1] = std::acos(std::fmin(1.0, std::fmax(-1.0, c0)));
+        // d/dc acos = -(1 - c^2)^(-1/2); further derivatives in closed form, divided by n!
+        const double i1 = s1 > 0.0 ? 1.0 / s1 : 0.0, i2 = i1 * i1;
+        p.ph[2] = -i1;
+        p.ph[3] = -0.5 * c0 * i1 * i2;
+        p.ph[4] = -(1.0 + 2.0 * c0 * c0) * i1 * i2 * i2 / 6.0;
+        p.ph[5] = -c0 * (9.0 + 6.0 * c0 * c0) * i1 * i2 * i2 * i2 / 24.0;
+        p.pad2_ = 0;
+    }
     for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
     {
         double m = std::fmin(p.radii[0], p.radii[2]);

@@ -116,6 +116,13 @@ struct Params {
     uint32_t pad_;
     double ring_nb[3], sub_obs_b[3], sub_ray_b[3];  // R0 ring_n, R0 sub_obsvec, R0 sub_ray: ring block in B0
     double lt_tol;       // CSPICE's light-time stopping rule: 1e-17 |et - lt|  (lt varies by 1e-9 relative over a disc)
+    // Phase angle of the spheroid fast path as a series in the cosine: over a disc seen from afar the
+    // phase angle g moves by ~R (1/D_obs + 1/D_sun) ~ 1e-4 rad around its value g0 at the body centre, so
+    // g = acos(c) is a short Taylor series about c0 = cos g0 (host: pm_capi.hip fill_params, with the
+    // guard that decides whether it applies): ph[0] = c0, ph[1] = g0, ph[2..5] = acos^(n)(c0) / n!
+    double ph[6];
+    int32_t phase_series;  // 1: the series holds to < 1e-15 rad over this frame's disc
+    int32_t pad2_;
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

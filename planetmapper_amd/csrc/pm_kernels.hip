@@ -439,7 +439,16 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
                     n = rsqrt_fast(dot(n, n)) * n;
                 }
-                const double ph = fma(vsep_fast(sunb, ob), kDeg, miss);
+                // phase angle: a four-term series in cos g about the body centre's value where the host
+                // found it good to 1e-15 rad (every planet seen from afar), vsep_c otherwise
+                double phr;
+                if (kp->phase_series) {  // kernel-argument flag: a scalar branch
+                    const double t = dot(sunb, ob) - kp->ph[0];
+                    phr = fma(t, fma(t, fma(t, fma(t, kp->ph[5], kp->ph[4]), kp->ph[3]), kp->ph[2]), kp->ph[1]);
+                } else {
+                    phr = vsep_fast(sunb, ob);
+                }
+                const double ph = fma(phr, kDeg, miss);
                 const double in = fma(vsep_fast(n, sunb), kDeg, miss);
                 const double em = fma(vsep_fast(n, ob), kDeg, miss);
                 if (inside) {

@@ -214,9 +214,12 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *   PM_OPT_HOST_COPY_THREADS CPU threads that move pageable caller memory to / from the pinned
  *                           staging buffers. Default min(8, cores); 1..64.
  *   PM_OPT_ZERO_COPY        pm_map_cube (nearest / linear) on a PINNED host cube (pm_host_alloc
- *                           or pm_host_register): 1 = the kernel gathers the pixels it needs
- *                           straight from host memory over PCIe instead of copying the planes
- *                           to HBM first; 0 = always copy; -1 (default) = the library chooses.
+ *                           or pm_host_register): 0 = copy whole planes to HBM by DMA; 1 = the
+ *                           kernel gathers the pixels it needs straight from host memory over
+ *                           PCIe; 2 = the 256-byte blocks of a plane that the map samples (the
+ *                           same in every plane) are listed once, fetched once each into a table
+ *                           in HBM and sampled from there; -1 (default) = the library chooses:
+ *                           2 when the map touches under 80 % of a plane, else 0.
  *   PM_OPT_LAST_DISC_KERNEL read-only (pm_get_option): which kernel the latest image-plane call
  *                           dispatched for the planes that need the intercept: 0 none yet,
  *                           1 spheroid fast path, 2 its triaxial variant, 3 general kernel.

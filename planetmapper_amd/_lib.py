@@ -96,6 +96,14 @@ def load() -> ctypes.CDLL:
             '(or `python -c "import __graft_entry__ as g; g.build()"`). '
             'planetmapper_amd has no CPU fallback.'
         )
+    # PyTorch wheels carry their own libamdhip64 / libhsa-runtime64. A process that loads the
+    # system's HIP runtime first (through this library) and torch's afterwards ends up with two
+    # runtimes, and the second one finds no GPU ("No HIP GPUs are available"). Importing torch
+    # first makes its copy the one this library binds to as well, whatever the caller's import order.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp = ctypes.c_void_p
     dp = ctypes.POINTER(ctypes.c_double)

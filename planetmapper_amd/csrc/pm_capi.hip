@@ -385,7 +385,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         ctx->host_copy_threads = (int)value;
         return PM_OK;
     case PM_OPT_ZERO_COPY:
-        if (value < -1 || value > 1) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1, 0 or 1");
+        if (value < -1 || value > 2) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1, 0, 1 or 2");
         ctx->zero_copy = (int)value;
         return PM_OK;
     }
@@ -858,8 +858,8 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         if (smooth || k_rows || smoothing > 0.0 || force_sync)
             return fail(ctx, PM_ERR_UNSUPPORTED, "PM_MEM_HOST_CUBE supports nearest / linear with NaN propagation only");
         const size_t cube_bytes = (size_t)n_planes * npx * esz;
-        if (ctx->zero_copy != 0 && host_is_pinned(cube, cube_bytes)) {
-            // pinned: the kernel gathers from host memory in place - enqueue like a device call
+        if (ctx->zero_copy == 1 && host_is_pinned(cube, cube_bytes)) {
+            // pinned, in-place gather asked for: enqueue like a device call
             const void *dcube = nullptr;
             PM_HIP(ctx, hipHostGetDevicePointer((void **)&dcube, const_cast<void *>(cube), 0));
             a.cube = dcube;

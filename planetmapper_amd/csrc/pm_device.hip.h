@@ -214,6 +214,17 @@ struct ReprojectArgs {
     int propagate_nan;
 };
 
+// The sparse host path of pm_map_cube (k_fetch_blocks / k_reproject_blocks): the 256-byte blocks of
+// a plane that the map samples, the same in every plane of the cube.
+constexpr int kBlkShift = 8;
+struct BlockTable {
+    const int *blkmap;   // [plane_bytes >> kBlkShift] block of the plane -> row of the table, -1 = not fetched
+    const int *blklist;  // [n_list] row of the table -> block of the plane
+    char *table;         // [planes of the chunk][n_list][256] the fetched blocks
+    unsigned n_list;
+    size_t plane_bytes;  // a multiple of 256
+};
+
 // One axis of the oversampled grid of 'smooth' interpolation (get_xy_pchip
 // body_xy.py:1724-1741): the original pixel coordinates first..last, optionally refined
 // to `num` points with numpy.linspace arithmetic (i * step + first, last point exact).

@@ -382,6 +382,48 @@ int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &plan
     return PM_OK;
 }
 
+// The 256-byte blocks of a plane that k_reproject's sampling of (x_map, y_map) loads from - the same
+// pixel arithmetic as reproject_sample_from (pm_kernels_reproject.hip), all four corners of a bilinear
+// cell whatever their weights. A block this list misses is not an error: the kernel reads such a pixel
+// from the host plane directly.
+void list_blocks(const CubeJob &j, const double *x_map, const double *y_map, std::vector<int> &blkmap, std::vector<int> &blklist)
+{
+    const int nx = j.a.nx, ny = j.a.ny;
+    const size_t n_blk = (j.plane_bytes + ((size_t)1 << pm::kBlkShift) - 1) >> pm::kBlkShift;
+    blkmap.assign(n_blk, -1);
+    auto mark = [&](long yi, long xi) { blkmap[(((size_t)yi * nx + xi) * j.esz) >> pm::kBlkShift] = 0; };
+    for (size_t m = 0; m < j.nmap; m++) {
+        const double x = x_map[m], y = y_map[m];
+        if (std::isnan(x)) continue;
+        if (j.a.interpolation == PM_INTERP_NEAREST) {
+            if (std::isnan(y)) continue;
+            long xi = (long)std::rint(x), yi = (long)std::rint(y);
+            if (xi < 0) xi += nx;
+            if (yi < 0) yi += ny;
+            if (xi >= 0 && xi < nx && yi >= 0 && yi < ny) mark(yi, xi);
+        } else {
+            if (j.a.propagate_nan && (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1)) continue;
+            const double xc = std::fmin(std::fmax(x, 0.0), nx - 1.0), yc = std::fmin(std::fmax(y, 0.0), ny - 1.0);
+            long x0 = (long)std::floor(xc), y0 = (long)std::floor(yc);
+            if (x0 > nx - 2) x0 = nx - 2;
+            if (y0 > ny - 2) y0 = ny - 2;
+            if (x0 < 0) x0 = 0;
+            if (y0 < 0) y0 = 0;
+            const long x1 = x0 + 1 < nx ? x0 + 1 : x0, y1 = y0 + 1 < ny ? y0 + 1 : y0;
+            mark(y0, x0);
+            mark(y0, x1);
+            mark(y1, x0);
+            mark(y1, x1);
+        }
+    }
+    blklist.clear();
+    for (size_t b = 0; b < n_blk; b++)
+        if (blkmap[b] == 0) {
+            blkmap[b] = (int)blklist.size();
+            blklist.push_back((int)b);
+        }
+}
+
 }  // namespace
 
 // pm_map_cube for host buffers, interpolation nearest / linear with NaN propagation (the default of
@@ -416,13 +458,40 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     const size_t out_bytes = (size_t)n_planes * nmap * sizeof(double);
     const bool src_pinned = host_is_pinned(cube, cube_bytes);
     const bool dst_pinned = !device_out && host_is_pinned(out, out_bytes);
-    const bool zero_copy = src_pinned && ctx->zero_copy != 0;
     const hipStream_t sk = ctx->stream;
+    // How a pinned cube is read (PM_OPT_ZERO_COPY): whole planes by DMA, the kernel gathering from
+    // host memory in place, or - what the library picks for a map that samples a plane sparsely -
+    // the blocks the map touches fetched once into a table in HBM.
+    bool gather = src_pinned && ctx->zero_copy == 1, blocks = false;
+    std::vector<int> blkmap, blklist;
+    std::vector<double> hmaps;
+    if (src_pinned && (ctx->zero_copy < 0 || ctx->zero_copy == 2)) {
+        const double *hx = x_map, *hy = y_map;
+        if (device_out) {
+            hmaps.resize(2 * nmap);
+            PM_HIP(ctx, hipMemcpyAsync(hmaps.data(), x_map, nmap * sizeof(double), hipMemcpyDeviceToHost, sk));
+            PM_HIP(ctx, hipMemcpyAsync(hmaps.data() + nmap, y_map, nmap * sizeof(double), hipMemcpyDeviceToHost, sk));
+            PM_HIP(ctx, hipStreamSynchronize(sk));
+            hx = hmaps.data();
+            hy = hx + nmap;
+        }
+        list_blocks(j, hx, hy, blkmap, blklist);
+        const bool table_ok = j.plane_bytes % ((size_t)1 << pm::kBlkShift) == 0 && !blklist.empty();
+        const bool sparse = ((size_t)blklist.size() << pm::kBlkShift) * 5 < j.plane_bytes * 4;
+        if (table_ok && (sparse || ctx->zero_copy == 2))
+            blocks = true;
+        else if (sparse || ctx->zero_copy == 2)
+            gather = true;  // planes that do not split into whole blocks
+        // else: a dense map reads most of every plane - DMA of whole planes is the faster way
+    }
+    const bool zero_copy = gather || blocks;  // no staging ring: the kernels read the caller's cube
 
     // planes per chunk of the copy pipeline; per batch of the output buffer
     size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
     chunk = std::min<size_t>(std::min<size_t>(chunk, (size_t)n_planes), 32768);
     if (zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, ((size_t)n_planes + 7) / 8), 32768);
+    const size_t table_row_bytes = (size_t)blklist.size() << pm::kBlkShift;  // one plane's rows of the block table
+    if (blocks) chunk = std::max<size_t>(1, std::min<size_t>(chunk, ((size_t)256 << 20) / table_row_bytes));
     const size_t batch = std::min<size_t>((size_t)n_planes, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
     const size_t slot_bytes = (chunk * j.plane_bytes + 255) & ~(size_t)255;
     // the kernel stores straight into the caller's array: device memory, or pinned memory next to a zero-copy cube
@@ -430,6 +499,10 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     size_t need = 2 * nmap * sizeof(double) + 256;
     if (!zero_copy) need += HostPipe::kRing * slot_bytes;
     if (!direct_out) need += batch * nmap * sizeof(double);
+    const size_t blk_off = (need + 255) & ~(size_t)255;  // block map, block list, table
+    const size_t blkmap_bytes = (blkmap.size() * sizeof(int) + 255) & ~(size_t)255;
+    const size_t blklist_bytes = (blklist.size() * sizeof(int) + 255) & ~(size_t)255;
+    if (blocks) need = blk_off + blkmap_bytes + blklist_bytes + chunk * table_row_bytes;
     need = std::max(need, 2 * nmap * sizeof(double) + 512 + j.plane_bytes + nmap * sizeof(double));  // median redo
     rc = ensure_scratch(ctx, need);
     if (rc != PM_OK) return rc;
@@ -446,6 +519,17 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
         PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
     }
 
+    pm::BlockTable table{};
+    if (blocks) {
+        int *dmap = (int *)(base + blk_off), *dlist = (int *)(base + blk_off + blkmap_bytes);
+        PM_HIP(ctx, hipMemcpyAsync(dmap, blkmap.data(), blkmap.size() * sizeof(int), hipMemcpyHostToDevice, sk));
+        PM_HIP(ctx, hipMemcpyAsync(dlist, blklist.data(), blklist.size() * sizeof(int), hipMemcpyHostToDevice, sk));
+        table.blkmap = dmap;
+        table.blklist = dlist;
+        table.table = base + blk_off + blkmap_bytes + blklist_bytes;
+        table.n_list = (unsigned)blklist.size();
+        table.plane_bytes = j.plane_bytes;
+    }
     const char *cube_dev = nullptr;  // zero copy: the device's view of the caller's pinned cube
     double *out_dev = nullptr;
     if (zero_copy) PM_HIP(ctx, hipHostGetDevicePointer((void **)&cube_dev, (void *)cube, 0));
@@ -480,7 +564,10 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
                 PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
                 b.cube = dslot;
             }
-            pm_launch_reproject(b, dtype, sk);
+            if (blocks)
+                pm_launch_reproject_blocks(b, table, dtype, sk);
+            else
+                pm_launch_reproject(b, dtype, sk);
             PM_HIP(ctx, hipGetLastError());
             PM_HIP(ctx, hipEventRecord(hp->ev_k[slot], sk));
             launched = p0 + np;

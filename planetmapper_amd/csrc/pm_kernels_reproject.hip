@@ -53,12 +53,22 @@ __device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int n
 }
 // One (map cell, plane) sample of BodyXY.map_img for 'nearest' / 'linear' (body_xy.py:1633-1702,
 // 1855-1904): the value at pixel coordinates (x, y) of plane `pl`, NaN where the reference gives NaN.
+//
+// `ld(i)` loads pixel i of the plane as a double: straight from the plane (PlaneLoader) or through
+// the table of fetched 256-byte blocks (BlockLoader, the sparse host path below). `img` is the
+// plane itself, which the rare NaN pre-clean reads around a non-finite pixel.
 template <typename T>
-__device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int pl, double x, double y)
+struct PlaneLoader {
+    const T *img;
+    __device__ __forceinline__ double operator()(size_t i) const { return (double)img[i]; }
+};
+
+template <typename T, typename L>
+__device__ __forceinline__ double reproject_sample_from(const ReprojectArgs &a, int pl, const T *img, const L &ld, double x,
+                                                        double y)
 {
     const double nan = __builtin_nan("");
     const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
     double val = nan;
     if (!isnan(x)) {
         if (a.interpolation == PM_INTERP_NEAREST) {
@@ -68,7 +78,7 @@ __device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int p
             if (yi < 0) yi += ny;
             // maps made by pm_xy_map are always inside the frame; a caller-supplied map that is
             // not (the reference raises IndexError there) must not read outside the plane
-            if (xi >= 0 && xi < nx && yi >= 0 && yi < ny && !isnan(y)) val = load_as_f64(img, (size_t)yi * nx + xi);
+            if (xi >= 0 && xi < nx && yi >= 0 && yi < ny && !isnan(y)) val = ld((size_t)yi * nx + xi);
         } else {
             const bool have_stats = a.plane_stats != nullptr;
             bool skip = have_stats && a.plane_stats[pl].all_nan;  // body_xy.py:1668-1670
@@ -92,10 +102,10 @@ __device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int p
                 // _should_propagate_nan_to_map): one set of loads serves both.
                 const bool u00 = fx != 1.0 && fy != 1.0, u01 = fx != 0.0 && fy != 1.0;
                 const bool u10 = fx != 1.0 && fy != 0.0, u11 = fx != 0.0 && fy != 0.0;
-                const double r00 = u00 ? load_as_f64(img, (size_t)y0 * nx + x0) : 0.0;
-                const double r01 = u01 ? load_as_f64(img, (size_t)y0 * nx + x1) : 0.0;
-                const double r10 = u10 ? load_as_f64(img, (size_t)y1 * nx + x0) : 0.0;
-                const double r11 = u11 ? load_as_f64(img, (size_t)y1 * nx + x1) : 0.0;
+                const double r00 = u00 ? ld((size_t)y0 * nx + x0) : 0.0;
+                const double r01 = u01 ? ld((size_t)y0 * nx + x1) : 0.0;
+                const double r10 = u10 ? ld((size_t)y1 * nx + x0) : 0.0;
+                const double r11 = u11 ? ld((size_t)y1 * nx + x1) : 0.0;
                 if (a.propagate_nan && (isnan(r00) || isnan(r01) || isnan(r10) || isnan(r11))) {
                     skip = true;
                 } else {
@@ -105,7 +115,16 @@ __device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int p
                     const double v01 = u01 ? cleaned_value(img, r01, y0, x1, ny, nx, med, nm) : 0.0;
                     const double v10 = u10 ? cleaned_value(img, r10, y1, x0, ny, nx, med, nm) : 0.0;
                     const double v11 = u11 ? cleaned_value(img, r11, y1, x1, ny, nx, med, nm) : 0.0;
-                    val = (1.0 - fy) * ((1.0 - fx) * v00 + fx * v01) + fy * ((1.0 - fx) * v10 + fx * v11);
+                    {
+                        // no fused multiply-adds here: every instantiation of this function (resident,
+                        // zero-copy, block table) then blends to the same bits whatever the compiler
+                        // makes of the code around it
+#pragma clang fp contract(off)
+                        const double gx = 1.0 - fx, gy = 1.0 - fy;
+                        const double top = gx * v00 + fx * v01;
+                        const double bot = gx * v10 + fx * v11;
+                        val = gy * top + fy * bot;
+                    }
                     if (nm && !have_stats) atomicMax(&a.plane_flags[pl], a.seq);
                 }
             }
@@ -115,12 +134,66 @@ __device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int p
 }
 
 template <typename T>
+__device__ __forceinline__ double reproject_sample(const ReprojectArgs &a, int pl, double x, double y)
+{
+    const T *img = (const T *)a.cube + (size_t)pl * a.ny * a.nx;
+    return reproject_sample_from<T>(a, pl, img, PlaneLoader<T>{img}, x, y);
+}
+
+template <typename T>
 __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 {
     const int m = blockIdx.x * kBlock + threadIdx.x;
     const int pl = blockIdx.y;
     if (m >= a.n_map) return;
     a.out[(size_t)pl * a.n_map + m] = reproject_sample<T>(a, pl, a.x_map[m], a.y_map[m]);
+}
+
+// ------------------------------------------------------------------ sparse host path: block table
+// A cube in pinned HOST memory is sampled over PCIe, where what counts is how many bytes cross the
+// link and in which request sizes (tools/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of
+// 256 bytes and more 55 GB/s, and the gather of k_reproject - uncached, so neighbouring waves fetch
+// the same lines again - 32 GB/s of lines). A coarse map touches a fraction of each plane, the SAME
+// 256-byte blocks in every plane. So the host lists those blocks once per call (pm_hostpipe.hip),
+// k_fetch_blocks pulls exactly them, each once, 16 lanes on one block, into a dense table in HBM,
+// and k_reproject_blocks samples the table.
+
+// blockIdx.y = plane of the chunk; 16 lanes x 16 bytes per block, 4 blocks per wave
+__global__ __launch_bounds__(kBlock) void k_fetch_blocks(const char *__restrict__ cube, const BlockTable t)
+{
+    const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+    const unsigned row = q >> 4, piece = q & 15u;
+    if (row >= t.n_list) return;
+    const size_t pl = blockIdx.y;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 *src = (const u32x4 *)(cube + pl * t.plane_bytes + ((size_t)t.blklist[row] << kBlkShift)) + piece;
+    u32x4 *dst = (u32x4 *)(t.table + ((pl * t.n_list + row) << kBlkShift)) + piece;
+    *dst = *src;
+}
+
+template <typename T>
+struct BlockLoader {
+    const T *img;       // the plane in host memory (blocks the list does not hold)
+    const int *blkmap;
+    const char *rows;   // this plane's rows of the table
+    __device__ __forceinline__ double operator()(size_t i) const
+    {
+        const size_t byte = i * sizeof(T);
+        const int row = blkmap[byte >> kBlkShift];
+        const T *p = row >= 0 ? (const T *)(rows + ((size_t)row << kBlkShift) + (byte & ((1u << kBlkShift) - 1))) : img + i;
+        return (double)*p;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reproject_blocks(const ReprojectArgs a, const BlockTable t)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    const int pl = blockIdx.y;
+    if (m >= a.n_map) return;
+    const T *img = (const T *)a.cube + (size_t)pl * a.ny * a.nx;
+    const BlockLoader<T> ld{img, t.blkmap, t.table + (((size_t)pl * t.n_list) << kBlkShift)};
+    a.out[(size_t)pl * a.n_map + m] = reproject_sample_from<T>(a, pl, img, ld, a.x_map[m], a.y_map[m]);
 }
 
 // Observation.get_mapped_data in ONE launch for a handful of planes (observation.py:826-905: the x/y
@@ -764,6 +837,29 @@ void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s)
     case PM_I32: launch_reproject_t<int32_t>(a, s); break;
     case PM_U8: launch_reproject_t<uint8_t>(a, s); break;
     case PM_U16: launch_reproject_t<uint16_t>(a, s); break;
+    }
+}
+
+// the sparse host path: `a.cube` is the device's view of the pinned cube chunk, `t.table` has room
+// for a.n_planes x t.n_list blocks
+template <typename T>
+static void launch_reproject_blocks_t(const pm::ReprojectArgs &a, const pm::BlockTable &t, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_reproject_blocks<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
+                       0, s, a, t);
+}
+
+void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s)
+{
+    hipLaunchKernelGGL(pm::k_fetch_blocks, dim3((t.n_list * 16 + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock), 0,
+                       s, (const char *)a.cube, t);
+    switch (dtype) {
+    case PM_F64: launch_reproject_blocks_t<double>(a, t, s); break;
+    case PM_F32: launch_reproject_blocks_t<float>(a, t, s); break;
+    case PM_I16: launch_reproject_blocks_t<int16_t>(a, t, s); break;
+    case PM_I32: launch_reproject_blocks_t<int32_t>(a, t, s); break;
+    case PM_U8: launch_reproject_blocks_t<uint8_t>(a, t, s); break;
+    case PM_U16: launch_reproject_blocks_t<uint16_t>(a, t, s); break;
     }
 }
 

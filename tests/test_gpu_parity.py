@@ -456,9 +456,12 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
             pc = engine.pinned_copy(cube)
             engine.set_option(_lib.PM_OPT_ZERO_COPY, 0)
             b = engine.map_cube(pc, xm, ym, interp, True)
-            engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
-            c = engine.map_cube(pc, xm, ym, interp, True)
-            assert np.array_equal(a, b, equal_nan=True) and np.array_equal(a, c, equal_nan=True), interp
+            assert np.array_equal(a, b, equal_nan=True), interp
+            # gathered in place (1), through the table of sampled 256-byte blocks (2), the library's choice (-1)
+            for zc in (1, 2, -1):
+                engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+                c = engine.map_cube(pc, xm, ym, interp, True)
+                assert np.array_equal(a, c, equal_nan=True), (interp, zc)
             # pinned output: the zero-copy kernel stores straight into it
             po = engine.pinned_empty(a.shape)
             po[...] = -3.0
@@ -468,11 +471,34 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
             ))  # fmt: skip
             assert np.array_equal(po, a, equal_nan=True), interp
             del pc, po
-        # int16 planes, default chunking
+        # int16 planes, default chunking; every way of reading the pinned cube
         engine.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 32 << 20)
         ci = (rng.standard_normal((planes, sz, sz)) * 1000).astype(np.int16)
-        assert np.array_equal(engine.map_cube(ci, xm, ym), engine.map_cube(engine.pinned_copy(ci), xm, ym), equal_nan=True)
+        pci = engine.pinned_copy(ci)
+        for zc in (-1, 0, 1, 2):
+            engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+            assert np.array_equal(engine.map_cube(ci, xm, ym), engine.map_cube(pci, xm, ym), equal_nan=True), zc
+        engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
         assert np.max(np.abs(np.nan_to_num(engine.map_cube(ci, xm, ym) - oracle.map_cube(ci, xm, ym)))) <= 1e-9
+        # planes that are not a whole number of 256-byte blocks (uint8, 250 x 250), and a map fine
+        # enough to touch all of a plane (the library then copies whole planes)
+        c8 = rng.integers(0, 255, (5, 250, 250), dtype=np.uint8)
+        d8 = oracle.make_disc(124.5, 124.5, 110.0, 0.0, 250, 250)
+        xm8, ym8 = oracle.xy_map(jupiter, d8, lon, lat)
+        lonf, latf = oracle.rectangular_grid(jupiter, 0.25)
+        xmf, ymf = oracle.xy_map(jupiter, d, lonf, latf)
+        p8, p6 = engine.pinned_copy(c8), engine.pinned_copy(cube[:6])
+        fine = engine.map_cube(cube[:6], xmf, ymf)
+        for zc in (-1, 1, 2):
+            engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+            assert np.array_equal(fine, engine.map_cube(p6, xmf, ymf), equal_nan=True), zc
+        engine.set_disc(124.5, 124.5, 110.0, 0.0, 250, 250, True)
+        small = engine.map_cube(c8, xm8, ym8)
+        assert np.max(np.abs(np.nan_to_num(small - oracle.map_cube(c8, xm8, ym8)))) <= 1e-11
+        for zc in (-1, 1, 2):
+            engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+            assert np.array_equal(small, engine.map_cube(p8, xm8, ym8), equal_nan=True), zc
+        engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
         # frames: staged D2H into pageable arrays == DMA into pinned arrays
         names = ['LON-GRAPHIC', 'EMISSION', 'RA', 'RING-RADIUS']
         engine.set_disc(700.3, 511.0, 480.0, 0.4, 1400, 1100, True)  # 12 MB planes: several staging pieces

@@ -5,7 +5,7 @@ drop-in caller of get_*_img() / get_mapped_data() sees. One JSON object per line
 
   frame      4096^2 x 5 planes into fresh pageable numpy arrays / reused arrays / pinned arrays
   cube       512 x 1024^2 f64 host cube -> 1 deg map: pageable cube (pipelined copy), pinned cube
-             copied (PM_OPT_ZERO_COPY=0), pinned cube gathered in place (zero copy)
+             copied (PM_OPT_ZERO_COPY=0), gathered in place (1), through the block table (2)
 """
 import argparse
 import json
@@ -118,9 +118,15 @@ def cube(eng, g, planes, reps, chunks=(32,)):
                'Mpix_s': planes * sz * sz / lo / 1e6, 'pinned_alloc_ms': t_alloc * 1e3}
         eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
     eng.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 32 << 20)
+    eng.set_option(_lib.PM_OPT_ZERO_COPY, 1)
     lo, med = best(lambda: run(pinned, 'zero_copy'), reps)
     yield {'case': 'cube pinned -> gathered in place (zero copy)', 'planes': planes, 'ms_best': lo * 1e3,
            'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
+    eng.set_option(_lib.PM_OPT_ZERO_COPY, 2)
+    lo, med = best(lambda: run(pinned, 'blocks'), reps)
+    yield {'case': 'cube pinned -> table of sampled 256-byte blocks', 'planes': planes, 'ms_best': lo * 1e3,
+           'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
+    eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
     out_pinned = eng.pinned_empty((planes,) + xm.shape)
 
     def direct():
@@ -139,7 +145,7 @@ def cube(eng, g, planes, reps, chunks=(32,)):
                                         xm.shape[0], xm.shape[1], _lib.PM_INTERP_LINEAR, 1, out_arr.ctypes.data,
                                         _lib.PM_MEM_HOST))
 
-    for label, zc in (('DMA', 0), ('zero copy', -1)):
+    for label, zc in (('DMA', 0), ('gather', 1), ('block table', 2)):
         eng.set_option(_lib.PM_OPT_ZERO_COPY, zc)
         for oname, oarr in (('reused pageable output', out_touched), ('pinned output', out_pinned)):
             lo, med = best(lambda: call(pinned, oarr), reps)
@@ -147,7 +153,7 @@ def cube(eng, g, planes, reps, chunks=(32,)):
         lo, med = best(lambda: call(pageable, out_pinned), reps)
         yield {'case': f'cube pageable -> pinned output (zero_copy={zc})', 'planes': planes, 'ms_best': lo * 1e3, 'ms_median': med * 1e3}
     eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
-    for k in ('pinned_copy', 'zero_copy'):
+    for k in ('pinned_copy', 'zero_copy', 'blocks'):
         assert np.array_equal(res[k], res['pageable'], equal_nan=True), k
     assert np.array_equal(out_pinned, res['pageable'], equal_nan=True)
 

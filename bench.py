@@ -298,7 +298,7 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     BASELINE config 5 as the reference runs it (observation.py:876-905 maps a HOST cube): P x 1024^2
     f64 planes in host memory, contiguous blocks of ceil(P / N) planes per rank
     (`distributed.shard_bounds`), each rank feeding its block from its own pinned host buffer over
-    its own PCIe link (`PM_MEM_HOST_CUBE`: only the 256-byte blocks the map samples cross it), ONE RCCL
+    its own PCIe link (`PM_MEM_HOST_CUBE`: only the 16-byte blocks the map samples cross it), ONE RCCL
     all-gather of the mapped planes. Returns step times with the host feed and with the block
     already resident in HBM, max over ranks.
     """
@@ -363,8 +363,9 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         'Mpix_s_host_fed': round(pix / t_fed / 1e6, 1),
         'Mpix_s_resident': round(pix / t_res / 1e6, 1),
         'host_feed_GBps_per_rank': round(block_bytes / t_fed / 1e9, 2),
-        'host_feed': 'sparse: the 256-byte blocks of each plane that the map samples are fetched once from pinned '
-        'host memory into a table in HBM and sampled there (PM_OPT_ZERO_COPY default)',
+        'host_feed': 'sparse: the 16-byte blocks of each plane that the map samples (flagged once by the sampling '
+        'kernel) are collected by the copy threads into pinned staging, sent by DMA chunk by chunk and sampled '
+        'from the table in HBM (PM_OPT_ZERO_COPY default)',
         'fed_equals_resident': same,
         'all_gather_bytes_per_rank': per_rank * n0 * n1 * 8,
         'pinned_alloc_ms': round(t_pin * 1e3, 1),

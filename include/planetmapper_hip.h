@@ -213,13 +213,21 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           Default 32 MiB; clamped to [1 MiB, 1 GiB].
  *   PM_OPT_HOST_COPY_THREADS CPU threads that move pageable caller memory to / from the pinned
  *                           staging buffers. Default min(8, cores); 1..64.
- *   PM_OPT_ZERO_COPY        pm_map_cube (nearest / linear) on a PINNED host cube (pm_host_alloc
- *                           or pm_host_register): 0 = copy whole planes to HBM by DMA; 1 = the
- *                           kernel gathers the pixels it needs straight from host memory over
- *                           PCIe; 2 = the 256-byte blocks of a plane that the map samples (the
- *                           same in every plane) are listed once, fetched once each into a table
- *                           in HBM and sampled from there; -1 (default) = the library chooses:
- *                           2 when the map touches under 80 % of a plane, else 0.
+ *   PM_OPT_ZERO_COPY        how the host cube of pm_map_cube (nearest / linear) crosses PCIe:
+ *                           0 = whole planes by DMA;
+ *                           1 = a PINNED cube (pm_host_alloc / pm_host_register) is gathered in
+ *                               place by the reprojection kernel;
+ *                           2 = the 256-byte blocks of a plane that the map samples (the same in
+ *                               every plane; found once per call by the sampling code itself) are
+ *                               fetched by the GPU from a PINNED cube, once each, into a table in
+ *                               HBM and sampled from there;
+ *                           3 = the same table in 16-byte blocks, collected by the copy threads
+ *                               into pinned staging and sent by DMA - any host memory; the link
+ *                               carries little more than the sampled pixels;
+ *                          -1 (default) = the library chooses: 3 when the table is under 40 % of
+ *                               the size of the planes, else 0.
+ *                           (1 and 2 on pageable memory, 2 and 3 on planes that are not a whole
+ *                           number of blocks: as 0.)
  *   PM_OPT_LAST_DISC_KERNEL read-only (pm_get_option): which kernel the latest image-plane call
  *                           dispatched for the planes that need the intercept: 0 none yet,
  *                           1 spheroid fast path, 2 its triaxial variant, 3 general kernel.

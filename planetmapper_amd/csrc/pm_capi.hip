@@ -385,7 +385,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         ctx->host_copy_threads = (int)value;
         return PM_OK;
     case PM_OPT_ZERO_COPY:
-        if (value < -1 || value > 2) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1, 0, 1 or 2");
+        if (value < -1 || value > 3) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1 .. 3");
         ctx->zero_copy = (int)value;
         return PM_OK;
     }

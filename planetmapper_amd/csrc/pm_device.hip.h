@@ -214,15 +214,19 @@ struct ReprojectArgs {
     int propagate_nan;
 };
 
-// The sparse host path of pm_map_cube (k_fetch_blocks / k_reproject_blocks): the 256-byte blocks of
-// a plane that the map samples, the same in every plane of the cube.
-constexpr int kBlkShift = 8;
+// The sparse host path of pm_map_cube (pm_hostpipe.hip; k_mark_blocks / k_fetch_blocks /
+// k_reproject_blocks): the blocks of a plane that the map samples - the same in every plane of the
+// cube - and the table they are collected into. Blocks are 16 bytes when CPU threads collect them
+// into pinned staging (the link then carries little more than the sampled pixels), 256 bytes when
+// the GPU fetches them from pinned host memory itself (the request size PCIe reads run at full rate at).
+constexpr int kBlkShiftHost = 4, kBlkShiftFetch = 8;
 struct BlockTable {
-    const int *blkmap;   // [plane_bytes >> kBlkShift] block of the plane -> row of the table, -1 = not fetched
-    const int *blklist;  // [n_list] row of the table -> block of the plane
-    char *table;         // [planes of the chunk][n_list][256] the fetched blocks
+    const int *blkmap;   // [plane_bytes >> shift] block of the plane -> row of the table, -1 = not in it
+    const int *blklist;  // [n_list] row of the table -> block of the plane (k_fetch_blocks only)
+    char *table;         // [planes of the chunk][n_list][1 << shift] the blocks
     unsigned n_list;
-    size_t plane_bytes;  // a multiple of 256
+    int shift;
+    size_t plane_bytes;  // a multiple of the block size
 };
 
 // One axis of the oversampled grid of 'smooth' interpolation (get_xy_pchip

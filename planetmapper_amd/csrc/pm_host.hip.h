@@ -28,7 +28,8 @@ void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *
                            int ring_only_visible, double *out, hipStream_t s);
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
-void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s);
+void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int shift, int dtype, hipStream_t s);
+void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s, bool fetch);
 void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat, double *xo,
                            double *yo, int dtype, hipStream_t s);
 void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);

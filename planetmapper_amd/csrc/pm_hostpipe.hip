@@ -12,16 +12,25 @@
 //     run (fresh numpy arrays take their page faults on several cores at once: 74 GB/s with 8
 //     threads against 25 GB/s through the runtime's own pageable path); results -> pinned caller
 //     memory (pm_host_alloc / pm_host_register): one DMA;
-//   * cube planes from pageable memory: chunks of planes through a three-slot device ring - the
-//     H2D copy of chunk k + 1, the kernel of chunk k and the D2H copy of finished output overlap on
-//     three streams (4.3 GB cube: 89 ms, 48 GB/s sustained);
-//   * cube planes from PINNED memory, nearest / linear: nothing is copied at all. The kernel gathers
-//     the pixels it samples straight from host memory. Host reads have the 128-byte line granularity
-//     HBM reads have (tools/probe_gather.hip): a 1 deg map touches about half the lines of a 1024^2
-//     plane, so the link carries 2.3 GB instead of 4.3 GB (68-71 ms), and the result can be stored
-//     straight into a pinned output.
+//   * cube planes, whole (PM_OPT_ZERO_COPY 0, and what the library picks for a map fine enough to
+//     read most of every plane): chunks of planes through a three-slot device ring - the H2D copy of
+//     chunk k + 1, the kernel of chunk k and the D2H copy of finished output overlap on three
+//     streams (4.3 GB cube: 89-94 ms, 46-48 GB/s sustained);
+//   * cube planes, sparse (the default for a coarse map - config 5's 1 deg map reads 12 % of each
+//     plane): k_mark_blocks runs the sampling code once and flags the 16-byte blocks of a plane it
+//     loads from - the same in every plane; the copy threads collect those blocks of each chunk of
+//     planes into pinned staging (prefetching by hand: scattered reads defeat the hardware
+//     prefetchers) while the DMA of the previous chunk's table runs, and k_reproject_blocks samples
+//     the table: 0.7 GB cross the link instead of 4.3 GB (16-35 ms depending on the host, pageable
+//     or pinned cube alike);
+//   * a PINNED cube without CPU threads: the GPU fetches the 256-byte blocks the map samples, each
+//     once, into the table (PM_OPT_ZERO_COPY 2: 2.4 GB at the full PCIe rate, 47 ms), or the
+//     reprojection kernel gathers from host memory in place (1: uncached 128-byte line requests that
+//     neighbouring waves repeat, 68-71 ms; the result can be stored straight into a pinned output).
 //
 // No compute happens on the CPU here: the threads move bytes.
+#include <emmintrin.h>
+
 #include <atomic>
 #include <condition_variable>
 #include <deque>
@@ -29,6 +38,14 @@
 #include <thread>
 
 #include "pm_host.hip.h"
+
+// how far ahead of the copy the pool's block gather requests cache lines, and into which level
+#ifndef PM_GATHER_AHEAD_BYTES
+#define PM_GATHER_AHEAD_BYTES 4096
+#endif
+#ifndef PM_GATHER_HINT
+#define PM_GATHER_HINT _MM_HINT_T0
+#endif
 
 namespace pmh {
 
@@ -59,6 +76,9 @@ struct HostPipe {
     static constexpr int kRing = 3;
     hipEvent_t ev_in[kRing] = {}, ev_k[kRing] = {};
     hipEvent_t ev_tmp = nullptr;
+    // ---- pinned staging of the H2D leg of block tables collected by the pool (one per ring slot)
+    char *in_stage[kRing] = {};
+    size_t in_stage_bytes = 0;
     // ---- pinned staging ring of the D2H leg
     static constexpr int kSlots = 4;
     char *stage[kSlots] = {};
@@ -124,9 +144,14 @@ struct HostPipe {
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
+    std::mutex job_mu;  // one job at a time (the retire thread and the calling thread both post jobs)
     char *job_dst = nullptr;
     const char *job_src = nullptr;
-    size_t job_bytes = 0, job_part = 0;
+    size_t job_bytes = 0, job_part = 0;  // units: bytes (copy) or blocks (gather)
+    // gather job: block i of the destination is block job_list[i % job_nlist] of source plane i / job_nlist
+    const int *job_list = nullptr;
+    size_t job_nlist = 0, job_plane_bytes = 0;
+    int job_shift = 0;  // log2 of the block size (>= 4)
     std::atomic<size_t> job_next{0};
     int job_active = 0;
     uint64_t job_gen = 0;
@@ -139,7 +164,38 @@ struct HostPipe {
             const size_t a = i * job_part;
             if (a >= job_bytes) break;
             const size_t n = std::min(job_part, job_bytes - a);
-            std::memcpy(job_dst + a, job_src + a, n);
+            if (!job_list) {
+                std::memcpy(job_dst + a, job_src + a, n);
+                continue;
+            }
+            // Scattered small reads: the hardware prefetchers see no stream, so the cache line of the
+            // block kAhead rows on is requested by hand (once per line); the table itself is written
+            // around the caches - it is read next by the DMA engine, not by this core.
+            const int sh = job_shift;
+            const size_t kB = (size_t)1 << sh;
+            const size_t ahead = PM_GATHER_AHEAD_BYTES >> sh;
+            size_t plane = a / job_nlist, row = a % job_nlist;
+            const char *src = job_src + plane * job_plane_bytes;
+            char *dst = job_dst + a * kB;
+            size_t last_line = ~(size_t)0;
+            for (size_t q = 0; q < n; q++, dst += kB) {
+                if (row + ahead < job_nlist) {
+                    const size_t o = (size_t)job_list[row + ahead] << sh;
+                    for (size_t l = o; l < o + kB; l += 64)
+                        if ((l >> 6) != last_line) {
+                            _mm_prefetch(src + l, PM_GATHER_HINT);
+                            last_line = l >> 6;
+                        }
+                }
+                const char *from = src + ((size_t)job_list[row] << sh);
+                for (size_t l = 0; l < kB; l += 16)
+                    _mm_stream_si128((__m128i *)(dst + l), _mm_loadu_si128((const __m128i *)(from + l)));
+                if (++row == job_nlist) {
+                    row = 0;
+                    src += job_plane_bytes;
+                }
+            }
+            _mm_sfence();
         }
     }
     void worker_main()
@@ -184,15 +240,42 @@ struct HostPipe {
             std::memcpy(dst, src, bytes);
             return;
         }
+        std::lock_guard<std::mutex> jl(job_mu);
         {
             std::lock_guard<std::mutex> lk(mu);
             job_dst = dst;
             job_src = src;
             job_bytes = bytes;
+            job_list = nullptr;
             const size_t t = workers.size() + 1;
             size_t part = (bytes + 2 * t - 1) / (2 * t);
             part = std::max<size_t>(part, (size_t)1 << 20);
             job_part = (part + 4095) & ~(size_t)4095;
+            job_next.store(0, std::memory_order_relaxed);
+            job_active = (int)workers.size();
+            job_gen++;
+        }
+        cv_work.notify_all();
+        run_parts();
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return job_active == 0; });
+    }
+    // dst[plane][row] <- the (1 << shift)-byte block list[row] of source plane `plane`, for n_planes planes
+    // plane_bytes apart: the rows of a block table (pm::BlockTable), collected by the pool
+    void gather(char *dst, const char *src, size_t plane_bytes, size_t n_planes, const int *list, size_t n_list, int shift)
+    {
+        std::lock_guard<std::mutex> jl(job_mu);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job_dst = dst;
+            job_src = src;
+            job_bytes = n_planes * n_list;
+            job_list = list;
+            job_nlist = n_list;
+            job_plane_bytes = plane_bytes;
+            job_shift = shift;
+            const size_t t = workers.size() + 1;
+            job_part = std::max<size_t>((job_bytes + 4 * t - 1) / (4 * t), ((size_t)256 << 10) >> shift);
             job_next.store(0, std::memory_order_relaxed);
             job_active = (int)workers.size();
             job_gen++;
@@ -239,6 +322,7 @@ void pipe_destroy(pm_ctx *ctx)
         if (hp->ev_stage[i]) (void)hipEventDestroy(hp->ev_stage[i]);
     }
     for (int i = 0; i < HostPipe::kRing; i++) {
+        if (hp->in_stage[i]) (void)hipHostFree(hp->in_stage[i]);
         if (hp->ev_in[i]) (void)hipEventDestroy(hp->ev_in[i]);
         if (hp->ev_k[i]) (void)hipEventDestroy(hp->ev_k[i]);
     }
@@ -281,6 +365,24 @@ static int ensure_stage(pm_ctx *ctx, HostPipe *hp)
         if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc of a %zu-byte staging buffer failed", want);
     }
     hp->stage_bytes = want;
+    return PM_OK;
+}
+
+// pinned buffers the pool collects block tables into, one per slot of the device ring
+static int ensure_in_stage(pm_ctx *ctx, HostPipe *hp, size_t bytes)
+{
+    if (hp->in_stage[0] && hp->in_stage_bytes >= bytes) return PM_OK;
+    PM_HIP(ctx, hipStreamSynchronize(hp->s_in));
+    for (int i = 0; i < HostPipe::kRing; i++) {
+        if (hp->in_stage[i]) PM_HIP(ctx, hipHostFree(hp->in_stage[i]));
+        hp->in_stage[i] = nullptr;
+    }
+    hp->in_stage_bytes = 0;
+    for (int i = 0; i < HostPipe::kRing; i++) {
+        hipError_t e = hipHostMalloc((void **)&hp->in_stage[i], bytes, hipHostMallocNonCoherent);
+        if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc of a %zu-byte staging buffer failed", bytes);
+    }
+    hp->in_stage_bytes = bytes;
     return PM_OK;
 }
 
@@ -382,48 +484,6 @@ int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &plan
     return PM_OK;
 }
 
-// The 256-byte blocks of a plane that k_reproject's sampling of (x_map, y_map) loads from - the same
-// pixel arithmetic as reproject_sample_from (pm_kernels_reproject.hip), all four corners of a bilinear
-// cell whatever their weights. A block this list misses is not an error: the kernel reads such a pixel
-// from the host plane directly.
-void list_blocks(const CubeJob &j, const double *x_map, const double *y_map, std::vector<int> &blkmap, std::vector<int> &blklist)
-{
-    const int nx = j.a.nx, ny = j.a.ny;
-    const size_t n_blk = (j.plane_bytes + ((size_t)1 << pm::kBlkShift) - 1) >> pm::kBlkShift;
-    blkmap.assign(n_blk, -1);
-    auto mark = [&](long yi, long xi) { blkmap[(((size_t)yi * nx + xi) * j.esz) >> pm::kBlkShift] = 0; };
-    for (size_t m = 0; m < j.nmap; m++) {
-        const double x = x_map[m], y = y_map[m];
-        if (std::isnan(x)) continue;
-        if (j.a.interpolation == PM_INTERP_NEAREST) {
-            if (std::isnan(y)) continue;
-            long xi = (long)std::rint(x), yi = (long)std::rint(y);
-            if (xi < 0) xi += nx;
-            if (yi < 0) yi += ny;
-            if (xi >= 0 && xi < nx && yi >= 0 && yi < ny) mark(yi, xi);
-        } else {
-            if (j.a.propagate_nan && (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1)) continue;
-            const double xc = std::fmin(std::fmax(x, 0.0), nx - 1.0), yc = std::fmin(std::fmax(y, 0.0), ny - 1.0);
-            long x0 = (long)std::floor(xc), y0 = (long)std::floor(yc);
-            if (x0 > nx - 2) x0 = nx - 2;
-            if (y0 > ny - 2) y0 = ny - 2;
-            if (x0 < 0) x0 = 0;
-            if (y0 < 0) y0 = 0;
-            const long x1 = x0 + 1 < nx ? x0 + 1 : x0, y1 = y0 + 1 < ny ? y0 + 1 : y0;
-            mark(y0, x0);
-            mark(y0, x1);
-            mark(y1, x0);
-            mark(y1, x1);
-        }
-    }
-    blklist.clear();
-    for (size_t b = 0; b < n_blk; b++)
-        if (blkmap[b] == 0) {
-            blkmap[b] = (int)blklist.size();
-            blklist.push_back((int)b);
-        }
-}
-
 }  // namespace
 
 // pm_map_cube for host buffers, interpolation nearest / linear with NaN propagation (the default of
@@ -459,30 +519,51 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     const bool src_pinned = host_is_pinned(cube, cube_bytes);
     const bool dst_pinned = !device_out && host_is_pinned(out, out_bytes);
     const hipStream_t sk = ctx->stream;
-    // How a pinned cube is read (PM_OPT_ZERO_COPY): whole planes by DMA, the kernel gathering from
-    // host memory in place, or - what the library picks for a map that samples a plane sparsely -
-    // the blocks the map touches fetched once into a table in HBM.
-    bool gather = src_pinned && ctx->zero_copy == 1, blocks = false;
+    // How the cube crosses the link (PM_OPT_ZERO_COPY): whole planes by DMA (0); a pinned cube
+    // gathered in place by the kernel (1); the blocks the map samples - found once, by the sampling
+    // code itself (k_mark_blocks) - brought into a table in HBM, either fetched by the GPU from a
+    // pinned cube in 256-byte blocks (2) or collected by the copy threads in 16-byte blocks into
+    // pinned staging, chunk by chunk, and sent by DMA (3: any host memory). The library (-1) takes
+    // (3) when the table is well under half the size of the planes, else (0).
+    const int mode = ctx->zero_copy;
+    bool gather = src_pinned && mode == 1, blocks = false, host_blocks = false;
     std::vector<int> blkmap, blklist;
-    std::vector<double> hmaps;
-    if (src_pinned && (ctx->zero_copy < 0 || ctx->zero_copy == 2)) {
-        const double *hx = x_map, *hy = y_map;
-        if (device_out) {
-            hmaps.resize(2 * nmap);
-            PM_HIP(ctx, hipMemcpyAsync(hmaps.data(), x_map, nmap * sizeof(double), hipMemcpyDeviceToHost, sk));
-            PM_HIP(ctx, hipMemcpyAsync(hmaps.data() + nmap, y_map, nmap * sizeof(double), hipMemcpyDeviceToHost, sk));
+    int shift = 0;
+    if (mode < 0 || mode == 3 || (mode == 2 && src_pinned)) {
+        shift = mode == 2 ? pm::kBlkShiftFetch : pm::kBlkShiftHost;
+        const size_t n_blk = (j.plane_bytes + ((size_t)1 << shift) - 1) >> shift;
+        if (j.plane_bytes % ((size_t)1 << shift) == 0 && n_blk < ((size_t)1 << 31)) {
+            const size_t maps_bytes = (2 * nmap * sizeof(double) + 255) & ~(size_t)255;
+            rc = ensure_scratch(ctx, maps_bytes + n_blk);
+            if (rc != PM_OK) return rc;
+            pm::ReprojectArgs am = a;
+            unsigned char *dflags = (unsigned char *)ctx->scratch + maps_bytes;
+            if (device_out) {
+                am.x_map = x_map;
+                am.y_map = y_map;
+            } else {
+                double *dx = (double *)ctx->scratch;
+                PM_HIP(ctx, hipMemcpyAsync(dx, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+                PM_HIP(ctx, hipMemcpyAsync(dx + nmap, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+                am.x_map = dx;
+                am.y_map = dx + nmap;
+            }
+            PM_HIP(ctx, hipMemsetAsync(dflags, 0, n_blk, sk));
+            pm_launch_mark_blocks(am, dflags, shift, dtype, sk);
+            PM_HIP(ctx, hipGetLastError());
+            std::vector<unsigned char> hflags(n_blk);
+            PM_HIP(ctx, hipMemcpyAsync(hflags.data(), dflags, n_blk, hipMemcpyDeviceToHost, sk));
             PM_HIP(ctx, hipStreamSynchronize(sk));
-            hx = hmaps.data();
-            hy = hx + nmap;
+            blkmap.assign(n_blk, -1);
+            for (size_t q = 0; q < n_blk; q++)
+                if (hflags[q]) {
+                    blkmap[q] = (int)blklist.size();
+                    blklist.push_back((int)q);
+                }
+            const size_t table_bytes = blklist.size() << shift;
+            if (!blklist.empty() && (mode >= 2 || table_bytes * 5 < j.plane_bytes * 2)) (mode == 2 ? blocks : host_blocks) = true;
         }
-        list_blocks(j, hx, hy, blkmap, blklist);
-        const bool table_ok = j.plane_bytes % ((size_t)1 << pm::kBlkShift) == 0 && !blklist.empty();
-        const bool sparse = ((size_t)blklist.size() << pm::kBlkShift) * 5 < j.plane_bytes * 4;
-        if (table_ok && (sparse || ctx->zero_copy == 2))
-            blocks = true;
-        else if (sparse || ctx->zero_copy == 2)
-            gather = true;  // planes that do not split into whole blocks
-        // else: a dense map reads most of every plane - DMA of whole planes is the faster way
+        // (mode 2 / 3 on planes that do not split into whole blocks, or a map that samples nothing: whole planes)
     }
     const bool zero_copy = gather || blocks;  // no staging ring: the kernels read the caller's cube
 
@@ -490,10 +571,12 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
     chunk = std::min<size_t>(std::min<size_t>(chunk, (size_t)n_planes), 32768);
     if (zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, ((size_t)n_planes + 7) / 8), 32768);
-    const size_t table_row_bytes = (size_t)blklist.size() << pm::kBlkShift;  // one plane's rows of the block table
+    const size_t table_row_bytes = (size_t)blklist.size() << shift;  // one plane's rows of the block table
     if (blocks) chunk = std::max<size_t>(1, std::min<size_t>(chunk, ((size_t)256 << 20) / table_row_bytes));
+    if (host_blocks)  // chunks of the table, not of the cube
+        chunk = std::min<size_t>(std::max<size_t>(1, ctx->host_chunk_bytes / table_row_bytes), std::min<size_t>((size_t)n_planes, 32768));
     const size_t batch = std::min<size_t>((size_t)n_planes, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
-    const size_t slot_bytes = (chunk * j.plane_bytes + 255) & ~(size_t)255;
+    const size_t slot_bytes = ((host_blocks ? chunk * table_row_bytes : chunk * j.plane_bytes) + 255) & ~(size_t)255;
     // the kernel stores straight into the caller's array: device memory, or pinned memory next to a zero-copy cube
     const bool direct_out = device_out || (zero_copy && dst_pinned);
     size_t need = 2 * nmap * sizeof(double) + 256;
@@ -503,6 +586,7 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     const size_t blkmap_bytes = (blkmap.size() * sizeof(int) + 255) & ~(size_t)255;
     const size_t blklist_bytes = (blklist.size() * sizeof(int) + 255) & ~(size_t)255;
     if (blocks) need = blk_off + blkmap_bytes + blklist_bytes + chunk * table_row_bytes;
+    if (host_blocks) need = blk_off + blkmap_bytes;
     need = std::max(need, 2 * nmap * sizeof(double) + 512 + j.plane_bytes + nmap * sizeof(double));  // median redo
     rc = ensure_scratch(ctx, need);
     if (rc != PM_OK) return rc;
@@ -520,15 +604,23 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     }
 
     pm::BlockTable table{};
-    if (blocks) {
-        int *dmap = (int *)(base + blk_off), *dlist = (int *)(base + blk_off + blkmap_bytes);
+    if (blocks || host_blocks) {
+        int *dmap = (int *)(base + blk_off);
         PM_HIP(ctx, hipMemcpyAsync(dmap, blkmap.data(), blkmap.size() * sizeof(int), hipMemcpyHostToDevice, sk));
-        PM_HIP(ctx, hipMemcpyAsync(dlist, blklist.data(), blklist.size() * sizeof(int), hipMemcpyHostToDevice, sk));
         table.blkmap = dmap;
+        table.n_list = (unsigned)blklist.size();
+        table.shift = shift;
+        table.plane_bytes = j.plane_bytes;
+    }
+    if (blocks) {
+        int *dlist = (int *)(base + blk_off + blkmap_bytes);
+        PM_HIP(ctx, hipMemcpyAsync(dlist, blklist.data(), blklist.size() * sizeof(int), hipMemcpyHostToDevice, sk));
         table.blklist = dlist;
         table.table = base + blk_off + blkmap_bytes + blklist_bytes;
-        table.n_list = (unsigned)blklist.size();
-        table.plane_bytes = j.plane_bytes;
+    }
+    if (host_blocks) {
+        rc = ensure_in_stage(ctx, hp, slot_bytes);
+        if (rc != PM_OK) return rc;
     }
     const char *cube_dev = nullptr;  // zero copy: the device's view of the caller's pinned cube
     double *out_dev = nullptr;
@@ -553,8 +645,21 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
             b.n_planes = (int)np;
             b.plane_flags = ctx->flags + b0 + p0;
             b.out = direct_out ? out_dev + (b0 + p0) * nmap : dout_all + p0 * nmap;
+            pm::BlockTable tb = table;
             if (zero_copy) {
                 b.cube = cube_dev + (b0 + p0) * j.plane_bytes;
+            } else if (host_blocks) {
+                // the pool fills this slot's pinned buffer (free once the DMA of three chunks ago is
+                // done) while the DMA of the previous chunk runs
+                char *dslot = ring + (size_t)slot * slot_bytes;
+                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
+                hp->gather(hp->in_stage[slot], j.cube + (b0 + p0) * j.plane_bytes, j.plane_bytes, np, blklist.data(), blklist.size(), shift);
+                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
+                PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
+                PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
+                b.cube = nullptr;  // no plane to fall back on: see cleaned_value / BlockLoader
+                tb.table = dslot;
             } else {
                 char *dslot = ring + (size_t)slot * slot_bytes;
                 if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
@@ -564,8 +669,8 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
                 PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
                 b.cube = dslot;
             }
-            if (blocks)
-                pm_launch_reproject_blocks(b, table, dtype, sk);
+            if (blocks || host_blocks)
+                pm_launch_reproject_blocks(b, tb, dtype, sk, /*fetch=*/blocks);
             else
                 pm_launch_reproject(b, dtype, sk);
             PM_HIP(ctx, hipGetLastError());

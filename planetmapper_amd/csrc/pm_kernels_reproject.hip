@@ -31,6 +31,11 @@ __device__ __forceinline__ double cleaned_value(const T *img, double v, long i, 
                                                 bool &needs_median)
 {
     if (isfinite(v)) return v;
+    if (!img) {
+        // a block table filled by the host, no plane behind it: the plane is redone in full
+        needs_median = true;
+        return median;
+    }
     double sum = 0.0;
     int cnt = 0;
     for (long ii = (i > 0 ? i - 1 : 0); ii <= i + 1 && ii < ny; ii++)
@@ -150,15 +155,39 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 }
 
 // ------------------------------------------------------------------ sparse host path: block table
-// A cube in pinned HOST memory is sampled over PCIe, where what counts is how many bytes cross the
-// link and in which request sizes (tools/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of
-// 256 bytes and more 55 GB/s, and the gather of k_reproject - uncached, so neighbouring waves fetch
-// the same lines again - 32 GB/s of lines). A coarse map touches a fraction of each plane, the SAME
-// 256-byte blocks in every plane. So the host lists those blocks once per call (pm_hostpipe.hip),
-// k_fetch_blocks pulls exactly them, each once, 16 lanes on one block, into a dense table in HBM,
-// and k_reproject_blocks samples the table.
+// A cube in HOST memory mapped onto a coarse grid: what counts is how many bytes cross PCIe and in
+// which request sizes (tools/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of 256 bytes
+// and more 55 GB/s; the in-place gather of k_reproject - uncached, so neighbouring waves fetch the
+// same lines again - 32 GB/s of lines). The map touches a fraction of each plane, the SAME blocks in
+// every plane. k_mark_blocks runs the sampling arithmetic once and flags those blocks; the host
+// (pm_hostpipe.hip) numbers them; then either CPU threads collect the 16-byte blocks of each chunk
+// of planes into pinned staging and one DMA brings the dense table over, or k_fetch_blocks pulls
+// 256-byte blocks from pinned memory, each once, 16 lanes on one block; k_reproject_blocks samples
+// the table.
 
-// blockIdx.y = plane of the chunk; 16 lanes x 16 bytes per block, 4 blocks per wave
+// the "load" of the marking pass: flags the block of pixel i, returns a finite value (so that the
+// sampler takes its ordinary path and touches exactly the corners the real pass will load)
+template <typename T>
+struct MarkLoader {
+    unsigned char *flags;
+    int shift;
+    __device__ __forceinline__ double operator()(size_t i) const
+    {
+        flags[(i * sizeof(T)) >> shift] = 1;
+        return 0.0;
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mark_blocks(const ReprojectArgs a, unsigned char *flags, int shift)
+{
+    const int m = blockIdx.x * kBlock + threadIdx.x;
+    if (m >= a.n_map) return;
+    const double v = reproject_sample_from<T>(a, 0, (const T *)nullptr, MarkLoader<T>{flags, shift}, a.x_map[m], a.y_map[m]);
+    (void)v;
+}
+
+// blockIdx.y = plane of the chunk; 16 lanes x 16 bytes per 256-byte block, 4 blocks per wave
 __global__ __launch_bounds__(kBlock) void k_fetch_blocks(const char *__restrict__ cube, const BlockTable t)
 {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
@@ -166,21 +195,23 @@ __global__ __launch_bounds__(kBlock) void k_fetch_blocks(const char *__restrict_
     if (row >= t.n_list) return;
     const size_t pl = blockIdx.y;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 *src = (const u32x4 *)(cube + pl * t.plane_bytes + ((size_t)t.blklist[row] << kBlkShift)) + piece;
-    u32x4 *dst = (u32x4 *)(t.table + ((pl * t.n_list + row) << kBlkShift)) + piece;
+    const u32x4 *src = (const u32x4 *)(cube + pl * t.plane_bytes + ((size_t)t.blklist[row] << kBlkShiftFetch)) + piece;
+    u32x4 *dst = (u32x4 *)(t.table + ((pl * t.n_list + row) << kBlkShiftFetch)) + piece;
     *dst = *src;
 }
 
 template <typename T>
 struct BlockLoader {
-    const T *img;       // the plane in host memory (blocks the list does not hold)
+    const T *img;       // the plane in host memory (blocks the list does not hold), or null
     const int *blkmap;
     const char *rows;   // this plane's rows of the table
+    int shift;
     __device__ __forceinline__ double operator()(size_t i) const
     {
         const size_t byte = i * sizeof(T);
-        const int row = blkmap[byte >> kBlkShift];
-        const T *p = row >= 0 ? (const T *)(rows + ((size_t)row << kBlkShift) + (byte & ((1u << kBlkShift) - 1))) : img + i;
+        const int row = blkmap[byte >> shift];
+        if (row < 0 && !img) return __builtin_inf();  // (not reached: the marking pass ran this very code; inf has the plane redone)
+        const T *p = row >= 0 ? (const T *)(rows + ((size_t)row << shift) + (byte & ((1u << shift) - 1))) : img + i;
         return (double)*p;
     }
 };
@@ -191,8 +222,8 @@ __global__ __launch_bounds__(kBlock) void k_reproject_blocks(const ReprojectArgs
     const int m = blockIdx.x * kBlock + threadIdx.x;
     const int pl = blockIdx.y;
     if (m >= a.n_map) return;
-    const T *img = (const T *)a.cube + (size_t)pl * a.ny * a.nx;
-    const BlockLoader<T> ld{img, t.blkmap, t.table + (((size_t)pl * t.n_list) << kBlkShift)};
+    const T *img = a.cube ? (const T *)a.cube + (size_t)pl * a.ny * a.nx : nullptr;
+    const BlockLoader<T> ld{img, t.blkmap, t.table + (((size_t)pl * t.n_list) << t.shift), t.shift};
     a.out[(size_t)pl * a.n_map + m] = reproject_sample_from<T>(a, pl, img, ld, a.x_map[m], a.y_map[m]);
 }
 
@@ -849,10 +880,31 @@ static void launch_reproject_blocks_t(const pm::ReprojectArgs &a, const pm::Bloc
                        0, s, a, t);
 }
 
-void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s)
+template <typename T>
+static void launch_mark_blocks_t(const pm::ReprojectArgs &a, unsigned char *flags, int shift, hipStream_t s)
 {
-    hipLaunchKernelGGL(pm::k_fetch_blocks, dim3((t.n_list * 16 + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock), 0,
-                       s, (const char *)a.cube, t);
+    hipLaunchKernelGGL(pm::k_mark_blocks<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock), dim3(pm::kBlock), 0, s, a, flags, shift);
+}
+
+// flags[plane_bytes >> shift] (zeroed by the caller) <- 1 for every block the map samples
+void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int shift, int dtype, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_mark_blocks_t<double>(a, flags, shift, s); break;
+    case PM_F32: launch_mark_blocks_t<float>(a, flags, shift, s); break;
+    case PM_I16: launch_mark_blocks_t<int16_t>(a, flags, shift, s); break;
+    case PM_I32: launch_mark_blocks_t<int32_t>(a, flags, shift, s); break;
+    case PM_U8: launch_mark_blocks_t<uint8_t>(a, flags, shift, s); break;
+    case PM_U16: launch_mark_blocks_t<uint16_t>(a, flags, shift, s); break;
+    }
+}
+
+void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s, bool fetch)
+{
+    // (fetch == false: the host has filled the table, a.cube may be null)
+    if (fetch)
+        hipLaunchKernelGGL(pm::k_fetch_blocks, dim3((t.n_list * 16 + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
+                           0, s, (const char *)a.cube, t);
     switch (dtype) {
     case PM_F64: launch_reproject_blocks_t<double>(a, t, s); break;
     case PM_F32: launch_reproject_blocks_t<float>(a, t, s); break;

@@ -454,11 +454,17 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
             fin = np.isfinite(ref)
             assert np.max(np.abs(a[fin] - ref[fin])) <= 1e-11
             pc = engine.pinned_copy(cube)
+            # pageable cube: whole planes through the copy pipeline (0), block table collected by the
+            # copy threads (3; what the default picked above for this coarse map)
+            for zc in (0, 3):
+                engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+                assert np.array_equal(a, engine.map_cube(cube, xm, ym, interp, True), equal_nan=True), (interp, zc)
             engine.set_option(_lib.PM_OPT_ZERO_COPY, 0)
             b = engine.map_cube(pc, xm, ym, interp, True)
             assert np.array_equal(a, b, equal_nan=True), interp
-            # gathered in place (1), through the table of sampled 256-byte blocks (2), the library's choice (-1)
-            for zc in (1, 2, -1):
+            # gathered in place (1), through the table of sampled blocks fetched by the GPU (2) /
+            # collected by the copy threads (3), the library's choice (-1)
+            for zc in (1, 2, 3, -1):
                 engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
                 c = engine.map_cube(pc, xm, ym, interp, True)
                 assert np.array_equal(a, c, equal_nan=True), (interp, zc)
@@ -475,9 +481,11 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         engine.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, 32 << 20)
         ci = (rng.standard_normal((planes, sz, sz)) * 1000).astype(np.int16)
         pci = engine.pinned_copy(ci)
-        for zc in (-1, 0, 1, 2):
+        ri = engine.map_cube(ci, xm, ym)
+        for zc in (-1, 0, 1, 2, 3):
             engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
-            assert np.array_equal(engine.map_cube(ci, xm, ym), engine.map_cube(pci, xm, ym), equal_nan=True), zc
+            assert np.array_equal(ri, engine.map_cube(pci, xm, ym), equal_nan=True), zc
+            assert np.array_equal(ri, engine.map_cube(ci, xm, ym), equal_nan=True), zc
         engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
         assert np.max(np.abs(np.nan_to_num(engine.map_cube(ci, xm, ym) - oracle.map_cube(ci, xm, ym)))) <= 1e-9
         # planes that are not a whole number of 256-byte blocks (uint8, 250 x 250), and a map fine
@@ -489,15 +497,17 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         xmf, ymf = oracle.xy_map(jupiter, d, lonf, latf)
         p8, p6 = engine.pinned_copy(c8), engine.pinned_copy(cube[:6])
         fine = engine.map_cube(cube[:6], xmf, ymf)
-        for zc in (-1, 1, 2):
+        for zc in (-1, 1, 2, 3):
             engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
             assert np.array_equal(fine, engine.map_cube(p6, xmf, ymf), equal_nan=True), zc
+            assert np.array_equal(fine, engine.map_cube(cube[:6], xmf, ymf), equal_nan=True), zc
         engine.set_disc(124.5, 124.5, 110.0, 0.0, 250, 250, True)
         small = engine.map_cube(c8, xm8, ym8)
         assert np.max(np.abs(np.nan_to_num(small - oracle.map_cube(c8, xm8, ym8)))) <= 1e-11
-        for zc in (-1, 1, 2):
+        for zc in (-1, 1, 2, 3):
             engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
             assert np.array_equal(small, engine.map_cube(p8, xm8, ym8), equal_nan=True), zc
+            assert np.array_equal(small, engine.map_cube(c8, xm8, ym8), equal_nan=True), zc
         engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
         # frames: staged D2H into pageable arrays == DMA into pinned arrays
         names = ['LON-GRAPHIC', 'EMISSION', 'RA', 'RING-RADIUS']

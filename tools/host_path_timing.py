@@ -108,9 +108,15 @@ def cube(eng, g, planes, reps, chunks=(32,)):
     for chunk_mib in chunks:
         eng.set_option(_lib.PM_OPT_HOST_CHUNK_BYTES, chunk_mib << 20)
         eng.map_cube(pageable[:64], xm, ym, 'linear', True)  # (re)allocations of the ring
+        eng.set_option(_lib.PM_OPT_ZERO_COPY, 0)
         lo, med = best(lambda: run(pageable, 'pageable'), reps)
-        yield {'case': 'cube pageable -> pipelined copy', 'chunk_MiB': chunk_mib, 'planes': planes, 'ms_best': lo * 1e3,
+        yield {'case': 'cube pageable -> pipelined copy of whole planes', 'chunk_MiB': chunk_mib, 'planes': planes, 'ms_best': lo * 1e3,
                'ms_median': med * 1e3, 'cube_GBps': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
+        eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
+        lo, med = best(lambda: run(pageable, 'pageable_blocks'), reps)
+        yield {'case': 'cube pageable -> block table collected by the copy threads', 'chunk_MiB': chunk_mib, 'planes': planes,
+               'ms_best': lo * 1e3, 'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9,
+               'Mpix_s': planes * sz * sz / lo / 1e6}
         eng.set_option(_lib.PM_OPT_ZERO_COPY, 0)
         lo, med = best(lambda: run(pinned, 'pinned_copy'), reps)
         yield {'case': 'cube pinned -> pipelined DMA (zero copy off)', 'chunk_MiB': chunk_mib, 'planes': planes,
@@ -126,6 +132,10 @@ def cube(eng, g, planes, reps, chunks=(32,)):
     lo, med = best(lambda: run(pinned, 'blocks'), reps)
     yield {'case': 'cube pinned -> table of sampled 256-byte blocks', 'planes': planes, 'ms_best': lo * 1e3,
            'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
+    eng.set_option(_lib.PM_OPT_ZERO_COPY, 3)
+    lo, med = best(lambda: run(pinned, 'host_blocks'), reps)
+    yield {'case': 'cube pinned -> table of sampled 16-byte blocks collected by the copy threads', 'planes': planes,
+           'ms_best': lo * 1e3, 'ms_median': med * 1e3, 'cube_GBps_equivalent': nbytes / lo / 1e9, 'Mpix_s': planes * sz * sz / lo / 1e6}
     eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
     out_pinned = eng.pinned_empty((planes,) + xm.shape)
 
@@ -145,7 +155,7 @@ def cube(eng, g, planes, reps, chunks=(32,)):
                                         xm.shape[0], xm.shape[1], _lib.PM_INTERP_LINEAR, 1, out_arr.ctypes.data,
                                         _lib.PM_MEM_HOST))
 
-    for label, zc in (('DMA', 0), ('gather', 1), ('block table', 2)):
+    for label, zc in (('DMA', 0), ('gather', 1), ('fetched block table', 2), ('collected block table', 3)):
         eng.set_option(_lib.PM_OPT_ZERO_COPY, zc)
         for oname, oarr in (('reused pageable output', out_touched), ('pinned output', out_pinned)):
             lo, med = best(lambda: call(pinned, oarr), reps)
@@ -153,7 +163,7 @@ def cube(eng, g, planes, reps, chunks=(32,)):
         lo, med = best(lambda: call(pageable, out_pinned), reps)
         yield {'case': f'cube pageable -> pinned output (zero_copy={zc})', 'planes': planes, 'ms_best': lo * 1e3, 'ms_median': med * 1e3}
     eng.set_option(_lib.PM_OPT_ZERO_COPY, -1)
-    for k in ('pinned_copy', 'zero_copy', 'blocks'):
+    for k in ('pinned_copy', 'zero_copy', 'blocks', 'host_blocks', 'pageable_blocks'):
         assert np.array_equal(res[k], res['pageable'], equal_nan=True), k
     assert np.array_equal(out_pinned, res['pageable'], equal_nan=True)
 
@@ -164,9 +174,12 @@ def main():
     ap.add_argument('--planes', type=int, default=512)
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', choices=['frame', 'cube'])
+    ap.add_argument('--copy-threads', type=int, default=0, help='PM_OPT_HOST_COPY_THREADS (0: library default)')
     ap.add_argument('--chunks-mib', default='32', help='comma-separated PM_OPT_HOST_CHUNK_BYTES values to sweep (cube)')
     args = ap.parse_args()
     eng = Engine(0)
+    if args.copy_threads:
+        eng.set_option(_lib.PM_OPT_HOST_COPY_THREADS, args.copy_threads)
     g = load_scenario('jupiter_hst_2005')
     if args.only in (None, 'frame'):
         for r in frame(eng, g, args.size, args.reps):

@@ -212,7 +212,8 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           H2D copies, kernels and D2H copies of consecutive chunks overlap).
  *                           Default 32 MiB; clamped to [1 MiB, 1 GiB].
  *   PM_OPT_HOST_COPY_THREADS CPU threads that move pageable caller memory to / from the pinned
- *                           staging buffers. Default min(8, cores); 1..64.
+ *                           staging buffers. Default min(16, cores available to the process,
+ *                           divided by LOCAL_WORLD_SIZE when a launcher set it); 1..64.
  *   PM_OPT_ZERO_COPY        how the host cube of pm_map_cube (nearest / linear) crosses PCIe:
  *                           0 = whole planes by DMA;
  *                           1 = a PINNED cube (pm_host_alloc / pm_host_register) is gathered in

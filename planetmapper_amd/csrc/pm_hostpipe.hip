@@ -304,7 +304,17 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
             PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_stage[i], hipEventDisableTiming));
     }
     HostPipe *hp = ctx->pipe;
-    int threads = ctx->host_copy_threads > 0 ? ctx->host_copy_threads : std::min(8, usable_cores());
+    int threads = ctx->host_copy_threads;
+    if (threads <= 0) {
+        // the cores this process may count on: its share of the node when a launcher started one
+        // process per GPU (torchrun exports LOCAL_WORLD_SIZE)
+        int cores = usable_cores();
+        if (const char *lws = std::getenv("LOCAL_WORLD_SIZE")) {
+            const int n = std::atoi(lws);
+            if (n > 1) cores = std::max(2, cores / n);
+        }
+        threads = std::min(16, cores);
+    }
     hp->start_workers(threads);
     hp->start_retirer(ctx->device);
     *out = hp;

@@ -66,6 +66,16 @@ template <typename T>
 struct PlaneLoader {
     const T *img;
     __device__ __forceinline__ double operator()(size_t i) const { return (double)img[i]; }
+    // pixels i and i + 1 with ONE load instruction (element-aligned only; the hardware takes that)
+    __device__ __forceinline__ void pair(size_t i, double &lo, double &hi) const
+    {
+        struct P2 {
+            T a, b;
+        } v;
+        __builtin_memcpy(&v, img + i, sizeof(P2));
+        lo = (double)v.a;
+        hi = (double)v.b;
+    }
 };
 
 template <typename T, typename L>
@@ -107,10 +117,21 @@ __device__ __forceinline__ double reproject_sample_from(const ReprojectArgs &a, 
                 // _should_propagate_nan_to_map): one set of loads serves both.
                 const bool u00 = fx != 1.0 && fy != 1.0, u01 = fx != 0.0 && fy != 1.0;
                 const bool u10 = fx != 1.0 && fy != 0.0, u11 = fx != 0.0 && fy != 0.0;
-                const double r00 = u00 ? ld((size_t)y0 * nx + x0) : 0.0;
-                const double r01 = u01 ? ld((size_t)y0 * nx + x1) : 0.0;
-                const double r10 = u10 ? ld((size_t)y1 * nx + x0) : 0.0;
-                const double r11 = u11 ? ld((size_t)y1 * nx + x1) : 0.0;
+                // (the two pixels of a row are neighbours in memory: one load each row where both count)
+                double r00 = 0.0, r01 = 0.0, r10 = 0.0, r11 = 0.0;
+                const bool adj = x1 == x0 + 1;
+                if (u00 && u01 && adj) {
+                    ld.pair((size_t)y0 * nx + x0, r00, r01);
+                } else {
+                    if (u00) r00 = ld((size_t)y0 * nx + x0);
+                    if (u01) r01 = ld((size_t)y0 * nx + x1);
+                }
+                if (u10 && u11 && adj) {
+                    ld.pair((size_t)y1 * nx + x0, r10, r11);
+                } else {
+                    if (u10) r10 = ld((size_t)y1 * nx + x0);
+                    if (u11) r11 = ld((size_t)y1 * nx + x1);
+                }
                 if (a.propagate_nan && (isnan(r00) || isnan(r01) || isnan(r10) || isnan(r11))) {
                     skip = true;
                 } else {
@@ -176,6 +197,11 @@ struct MarkLoader {
         flags[(i * sizeof(T)) >> shift] = 1;
         return 0.0;
     }
+    __device__ __forceinline__ void pair(size_t i, double &lo, double &hi) const
+    {
+        lo = (*this)(i);
+        hi = (*this)(i + 1);
+    }
 };
 
 template <typename T>
@@ -213,6 +239,11 @@ struct BlockLoader {
         if (row < 0 && !img) return __builtin_inf();  // (not reached: the marking pass ran this very code; inf has the plane redone)
         const T *p = row >= 0 ? (const T *)(rows + ((size_t)row << shift) + (byte & ((1u << shift) - 1))) : img + i;
         return (double)*p;
+    }
+    __device__ __forceinline__ void pair(size_t i, double &lo, double &hi) const
+    {
+        lo = (*this)(i);
+        hi = (*this)(i + 1);
     }
 };
 

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
         // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
-        double lt = kp->g.lt_c, d = 0.0, k = 0.0, root = 0.0;
+        double lt = kp->g.lt_c, d = 0.0, k = 0.0, root = 0.0, inv_root = 0.0;
         V3 P = {0.0, 0.0, 0.0};
         // lanes still holding an intercept, as a wave-uniform mask in scalar registers (a
         // per-lane bool carried around the loop costs four VALU operations per evaluation)
@@ -344,13 +344,34 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double r2 = fmax((1.0 - p2) * ixx, 1e-300);
             // the first light time only seeds the next epoch (an error e in it moves the target
             // by VB e): 2^-45 relative is plenty there
-            root = first ? sqrt_seed_pos(r2) : sqrt_pos(r2);
+            if (first) {
+                // (sqrt_seed_pos, with its reciprocal-square-root estimate kept for the slope below)
+                inv_root = __builtin_amdgcn_rsq(r2);
+                const double g = r2 * inv_root;
+                root = fma(g, fma(-0.5 * inv_root, g, 0.5), g);
+            } else {
+                root = sqrt_pos(r2);
+            }
             return (-k - root) * kp->inv_c;
         };
         // The first evaluation, at t0 itself, is never the last: |lt - lt_c| would have to be
         // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
         // converged light time changes nothing. No test, no select after it.
         lt = evaluate(0.0, true);
+        if (!TRI) {
+            // One Newton-like step on that seed. The light time is a smooth function E(d) of the epoch
+            // offset d, and the fixed point lt = E((et - lt) - t0) is what the iteration below converges
+            // to. With the slope E'(0) = [VBs.X - (P.VBs) / root] / (X.X c) (the target's velocity along
+            // the ray and, through the shrinking chord, across it), lt1 + E' d / (1 + E') is within the
+            // stopping tolerance of the fixed point wherever the ray does not graze (the neglected
+            // E'' d^2 / 2 is ~2e-10 s / cos(emission) for Jupiter against a tolerance of 1.7e-9 s): the
+            // next evaluation then already confirms convergence, and most waves do two evaluations
+            // instead of three. Grazing lanes get a poor step and simply iterate on.
+            const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
+            const double ep = fma(-dot(P, vbs), inv_root, dot(vbs, X)) * ixx * kp->inv_c;
+            const double d0 = (kp->g.et - lt) - kp->t0;
+            lt = fma(ep * d0, 1.0 - ep, lt);
+        }
         // (a wave of the pre-mask annulus - candidates, but every ray misses - is done after that one
         //  evaluation: nothing is left to converge)
 #pragma unroll 1

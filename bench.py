@@ -72,6 +72,10 @@ def parse_args(argv=None):
     )  # fmt: skip
     ap.add_argument('--planes', type=int, default=512, help='cube workloads: total planes')
     ap.add_argument('--rehearse', action='store_true', help='CPU / gloo rehearsal of the N > 1 plumbing (no GPU work)')
+    ap.add_argument('--gather-mapped', action='store_true',
+                    help='headline at N > 1: also all-gather the N mapped planes every step (the frames are '
+                         'independent, so by default nothing is exchanged; the sharded-cube case with its RCCL '
+                         'all-gather is the cube_host section / --workload cube-host)')
     ap.add_argument('--side-stream', action='store_true',
                     help='frame workload: pm_mapped_data (and the all-gather) on a second engine context bound to a '
                     'side stream, next to the frame kernel (+1.7 % Mpix/s, but the frame kernel itself is timed 2.5 % '
@@ -587,8 +591,9 @@ def headline(args) -> None:
         # (the data plane and the lon/lat grids were written on the main stream before the first step
         #  and are only read: no ordering between the streams is needed inside the loop)
         # x/y map of the 1 deg grid + this rank's plane -> its slot (pm_mapped_data: the C form of
-        # get_mapped_data, one launch); slots exchanged by one RCCL all-gather (N > 1 only), left
-        # in flight so that it overlaps the next frame's backplane kernel. The data plane is finite
+        # get_mapped_data, one launch). Frames are independent of each other: nothing is exchanged
+        # between ranks (with --gather-mapped the N mapped planes are all-gathered over RCCL, left
+        # in flight so that the collective overlaps the next frame's backplane kernel). The data plane is finite
         # by construction (no +-inf: no plane needs its nanmedian), so the engine's flag check is
         # deferred to the closing synchronize(), which raises if that assumption were violated.
         k = counter[0] & 1
@@ -596,7 +601,7 @@ def headline(args) -> None:
         with torch.cuda.stream(side):
             pending[k] = map_cube_sharded_device(
                 eng_map, data, np.float64, 1, xm, ym, n0, n1, gathered[k], d.rank, 'linear', True, async_op=True,
-                previous=pending[k], defer_median_check=True, lonlat=(lon_d, lat_d),
+                previous=pending[k], defer_median_check=True, lonlat=(lon_d, lat_d), gather=args.gather_mapped,
             )  # fmt: skip
 
     def drain() -> None:
@@ -648,8 +653,9 @@ def headline(args) -> None:
                 'frame': [sz, sz],
                 'planes': len(HEADLINE),
                 'map': [n0, n1],
-                'parallelism': f'frames (and their mapped planes) sharded 1 per GPU x{d.world}'
-                + (', RCCL all-gather of mapped planes' if d.world > 1 else ''),
+                'parallelism': f'independent frames (and their mapped planes), 1 per GPU x{d.world}'
+                + ('' if d.world == 1 else (', RCCL all-gather of the mapped planes every step' if args.gather_mapped
+                                            else ', no collective (the sharded cube with its RCCL all-gather: cube_host)')),
                 'streams': 'one' if not args.side_stream else 'frame kernel on the main stream, get_mapped_data (+ all-gather) on a side stream',
                 'preheat_steps': args.preheat_steps,
             },

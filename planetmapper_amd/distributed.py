@@ -181,7 +181,8 @@ def backplanes_img_sharded(engine, names, ny: int, nx: int, *, alt: float = 0.0,
 
 def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_map, n0: int, n1: int,
                             gathered, rank: int, interpolation='linear', propagate_nan=True, group=None,
-                            async_op: bool = False, previous=None, defer_median_check: bool = False, lonlat=None):
+                            async_op: bool = False, previous=None, defer_median_check: bool = False, lonlat=None,
+                            gather: bool = True):
     """
     Device-resident variant used by the benchmark: this rank's `n_planes_local` planes
     (`cube`, a device tensor / pointer) are mapped straight into its slot of `gathered`
@@ -199,6 +200,8 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
     collective, so that peers never receive provisional values. `defer_median_check=True` skips
     that host round trip (fully asynchronous step) for data known to hold no such pixels; the
     caller's next `engine.synchronize()` still detects a violation and raises.
+
+    `gather=False` leaves the slots where they are (independent frames: nothing to exchange).
     """
     import torch.distributed as dist
 
@@ -214,7 +217,7 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
         engine.map_cube_device(cube, dtype, n_planes_local, x_map, y_map, n0, n1, mine, interpolation, propagate_nan)
     if not defer_median_check:
         engine.synchronize()
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if gather and dist.is_initialized() and dist.get_world_size(group) > 1:
         return dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group, async_op=async_op)
     return None
 

@@ -533,6 +533,58 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
 
 
+@pytest.mark.parametrize('dtype', [np.float64, np.float32, np.uint16])
+def test_host_cube_block_table_at_config5_plane_size(engine, oracle, jupiter, dtype):
+    """
+    BASELINE config 5 geometry (1024^2 planes, 1 deg map) with 24 planes from host memory: the default
+    route (table of the sampled 16-byte blocks, marked by k_mark_blocks, collected by the copy threads)
+    against whole planes by DMA and against the device-resident kernel - bit-identical - and against
+    the oracle on a few planes; NaN pixels, a -inf patch (plane redone with its nanmedian) and an
+    all-NaN plane included.
+    """
+    import torch
+
+    from planetmapper_amd import _lib
+
+    sz, planes = 1024, 24
+    x0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 1.0)
+    xm, ym = engine.xy_map(lon, lat)
+    rng = np.random.default_rng(512)
+    if np.issubdtype(dtype, np.floating):
+        cube = (rng.standard_normal((planes, sz, sz)) * 3 + 2).astype(dtype)
+        cube[rng.random(cube.shape) < 1e-3] = np.nan
+        cube[7][400:520, 380:640] = -np.inf
+        cube[19][:] = np.nan
+    else:
+        cube = rng.integers(0, 60000, (planes, sz, sz)).astype(dtype)
+    try:
+        for interp in ('linear', 'nearest'):
+            engine.set_option(_lib.PM_OPT_ZERO_COPY, 0)
+            whole = engine.map_cube(cube, xm, ym, interp, True)
+            for zc in (-1, 3):
+                engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+                assert np.array_equal(whole, engine.map_cube(cube, xm, ym, interp, True), equal_nan=True), (interp, zc)
+            n0, n1 = xm.shape
+            out = torch.empty((planes, n0, n1), dtype=torch.float64, device='cuda')
+            raw = cube.view(np.int16) if dtype == np.uint16 else cube  # (bytes only: torch need not know uint16)
+            dcube, dxm, dym = torch.from_numpy(raw).cuda(), torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+            torch.cuda.synchronize()
+            engine.map_cube_device(dcube, dtype, planes, dxm, dym, n0, n1, out, interp, True)
+            engine.synchronize()
+            assert np.array_equal(whole, out.cpu().numpy(), equal_nan=True), interp
+            pick = [0, 7, 19, 23]
+            ref = oracle.map_cube(cube[pick], xm, ym, interp, True)
+            got = whole[pick]
+            assert np.array_equal(np.isnan(got), np.isnan(ref)) and np.array_equal(np.isinf(got), np.isinf(ref))
+            fin = np.isfinite(ref)
+            assert np.max(np.abs(got[fin] - ref[fin])) <= 1e-9 * max(1.0, float(np.max(np.abs(ref[fin]))))
+    finally:
+        engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
+
+
 def test_c_abi_sharded_cube_with_an_rccl_communicator(engine, oracle, jupiter):
     """
     pm_comm_* / pm_map_cube_sharded (the C-ABI form of the plane sharding; multi-rank runs need a

@@ -366,11 +366,19 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // stopping tolerance of the fixed point wherever the ray does not graze (the neglected
             // E'' d^2 / 2 is ~2e-10 s / cos(emission) for Jupiter against a tolerance of 1.7e-9 s): the
             // next evaluation then already confirms convergence, and most waves do two evaluations
-            // instead of three. Grazing lanes get a poor step and simply iterate on.
+            // instead of three.
+            // Lanes near the limb keep the plain seed (|E'| >= 0.02, i.e. cos(emission) below ~0.005 for
+            // Jupiter): there E is a square root in d, a linear step overshoots, and - what matters -
+            // the reference decides hit or miss at EVERY evaluation of its own sequence of epochs
+            // (CSPICE sincpt: no intercept in any pass -> not found). A grazing ray (half chord of a few
+            // km) can hit with the target at one epoch of that sequence and miss at another, so those
+            // lanes must see exactly the reference's epochs. For the lanes that take the step the epoch
+            // error it leaves moves the target by ~E'^3 of the ray's margin to the limb: < 1e-5.
             const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
             const double ep = fma(-dot(P, vbs), inv_root, dot(vbs, X)) * ixx * kp->inv_c;
             const double d0 = (kp->g.et - lt) - kp->t0;
-            lt = fma(ep * d0, 1.0 - ep, lt);
+            const double stepped = fma(ep * d0, 1.0 - ep, lt);
+            lt = fabs(ep) < 0.02 ? stepped : lt;
         }
         // (a wave of the pre-mask annulus - candidates, but every ray misses - is done after that one
         //  evaluation: nothing is left to converge)

@@ -7,7 +7,7 @@ altitude offsets, with and without the radius pre-mask. For every frame: the NaN
 must be IDENTICAL (the limb decides hit or miss per pixel: this is where a changed light-time
 iteration would show first), and the values are held to the conditioned bars of tests/parity.py.
 
-    python tests/soak_parity.py [--frames 200] [--max-size 2048] [--seed 1]
+    python tests/soak_parity.py [--frames 200] [--max-size 2048] [--seed 1] [--general]
 
 One JSON line per frame, a summary line at the end; exit status 1 on any mismatch.
 """
@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--frames', type=int, default=200)
     ap.add_argument('--max-size', type=int, default=2048)
     ap.add_argument('--seed', type=int, default=1)
+    ap.add_argument('--general', action='store_true', help='force the general image kernel (PM_OPT_GENERAL_KERNEL)')
     args = ap.parse_args()
     from oracle import oracle
     from parity import compare_planes
@@ -58,7 +59,7 @@ def main():
     from planetmapper_amd.scenarios import load_scenario
 
     rng = np.random.default_rng(args.seed)
-    eng = Engine(0)
+    eng = Engine(0, general_kernel=True) if args.general else Engine(0)
     fixed = [load_scenario('jupiter_hst_2005'), load_scenario('saturn_earth_2005')]
     bad = 0
     t_start = time.time()

@@ -16,12 +16,12 @@
 //     read most of every plane): chunks of planes through a three-slot device ring - the H2D copy of
 //     chunk k + 1, the kernel of chunk k and the D2H copy of finished output overlap on three
 //     streams (4.3 GB cube: 89-94 ms, 46-48 GB/s sustained);
-//   * cube planes, sparse (the default for a coarse map - config 5's 1 deg map reads 12 % of each
+//   * cube planes, sparse (the default for a coarse map - config 5's 1 deg map reads 14 % of the 16-byte blocks of each
 //     plane): k_mark_blocks runs the sampling code once and flags the 16-byte blocks of a plane it
 //     loads from - the same in every plane; the copy threads collect those blocks of each chunk of
 //     planes into pinned staging (prefetching by hand: scattered reads defeat the hardware
 //     prefetchers) while the DMA of the previous chunk's table runs, and k_reproject_blocks samples
-//     the table: 0.7 GB cross the link instead of 4.3 GB (16-35 ms depending on the host, pageable
+//     the table: 0.59 GB cross the link instead of 4.3 GB (16-35 ms depending on the host, pageable
 //     or pinned cube alike);
 //   * a PINNED cube without CPU threads: the GPU fetches the 256-byte blocks the map samples, each
 //     once, into the table (PM_OPT_ZERO_COPY 2: 2.4 GB at the full PCIe rate, 47 ms), or the

@@ -14,7 +14,8 @@ import os
 from .geometry import PMDisc, PMGeometry
 
 LIB_NAME = 'libplanetmapper_hip.so'
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+# (PLANETMAPPER_HIP_LIB: another build of the library, e.g. for an A/B timing run)
+LIB_PATH = os.environ.get('PLANETMAPPER_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 NUM_PLANES = 26
 PLANE_NAMES = (

@@ -34,6 +34,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 
@@ -96,11 +97,25 @@ struct HostPipe {
     std::thread retirer;
     std::mutex rmu;
     std::condition_variable cv_piece, cv_slot;
-    int pieces_out = 0;  // issued and not yet retired (<= kSlots)
+    int pieces_out = 0;  // issued and not yet copied out (<= kSlots)
+    bool slot_busy[kSlots] = {};  // DMA in flight or being copied out (copy-outs may finish out of order)
     bool rstop = false;
     int device = 0;
     hipError_t rerror = hipSuccess;
 
+    void release_slot(int slot, hipError_t e)
+    {
+        {
+            std::lock_guard<std::mutex> lk(rmu);
+            if (e != hipSuccess && rerror == hipSuccess) rerror = e;
+            slot_busy[slot] = false;
+            pieces_out--;
+        }
+        cv_slot.notify_all();
+    }
+    // Waits for each DMA in turn and hands the piece to the pool WITHOUT waiting for the copy-out: while
+    // the pool copies piece k the thread is already waiting for the DMA of piece k + 1 (the wake-up
+    // latencies of an event wait and of a pool job, ~0.1 ms each, used to sit between any two pieces).
     void retire_main()
     {
         (void)hipSetDevice(device);
@@ -114,13 +129,10 @@ struct HostPipe {
                 inflight.pop_front();
             }
             const hipError_t e = hipEventSynchronize(ev_stage[pc.slot]);
-            if (e == hipSuccess) copy(pc.dst, stage[pc.slot], pc.bytes);
-            {
-                std::lock_guard<std::mutex> lk(rmu);
-                if (e != hipSuccess && rerror == hipSuccess) rerror = e;
-                pieces_out--;
-            }
-            cv_slot.notify_all();
+            if (e == hipSuccess)
+                copy_async(pc.dst, stage[pc.slot], pc.bytes, pc.slot);
+            else
+                release_slot(pc.slot, e);
         }
     }
     void start_retirer(int dev)
@@ -140,84 +152,107 @@ struct HostPipe {
         cv_piece.notify_all();
         retirer.join();
     }
-    // ---- copy pool
+    // ---- copy pool: a queue of jobs, each cut into parts that any pool thread takes; threads move on
+    // to the next job as soon as the parts of the front one are handed out
+    struct Job {
+        char *dst = nullptr;
+        const char *src = nullptr;
+        size_t total = 0, part = 0;  // units: bytes (copy) or blocks (gather)
+        // gather: block i of dst is block list[i % nlist] of source plane i / nlist
+        const int *list = nullptr;
+        size_t nlist = 0, plane_bytes = 0;
+        int shift = 0;  // log2 of the block size (>= 4)
+        size_t nparts = 0;
+        std::atomic<size_t> next{0}, finished{0};
+        int slot = -1;      // copy-out of a staged piece: the staging slot it frees
+        bool done = false;  // (under mu)
+    };
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
-    std::mutex job_mu;  // one job at a time (the retire thread and the calling thread both post jobs)
-    char *job_dst = nullptr;
-    const char *job_src = nullptr;
-    size_t job_bytes = 0, job_part = 0;  // units: bytes (copy) or blocks (gather)
-    // gather job: block i of the destination is block job_list[i % job_nlist] of source plane i / job_nlist
-    const int *job_list = nullptr;
-    size_t job_nlist = 0, job_plane_bytes = 0;
-    int job_shift = 0;  // log2 of the block size (>= 4)
-    std::atomic<size_t> job_next{0};
-    int job_active = 0;
-    uint64_t job_gen = 0;
+    std::deque<std::shared_ptr<Job>> queue;  // jobs that may still have parts to hand out
     bool stop = false;
 
-    void run_parts()
+    void run_part(const Job &j, size_t i)
+    {
+        const size_t a = i * j.part;
+        const size_t n = std::min(j.part, j.total - a);
+        if (!j.list) {
+            std::memcpy(j.dst + a, j.src + a, n);
+            return;
+        }
+        // Scattered small reads: the hardware prefetchers see no stream, so the cache line of the
+        // block `ahead` rows on is requested by hand (once per line); the table itself is written
+        // around the caches - it is read next by the DMA engine, not by this core.
+        const int sh = j.shift;
+        const size_t kB = (size_t)1 << sh;
+        const size_t ahead = PM_GATHER_AHEAD_BYTES >> sh;
+        size_t plane = a / j.nlist, row = a % j.nlist;
+        const char *src = j.src + plane * j.plane_bytes;
+        char *dst = j.dst + a * kB;
+        size_t last_line = ~(size_t)0;
+        for (size_t q = 0; q < n; q++, dst += kB) {
+            if (row + ahead < j.nlist) {
+                const size_t o = (size_t)j.list[row + ahead] << sh;
+                for (size_t l = o; l < o + kB; l += 64)
+                    if ((l >> 6) != last_line) {
+                        _mm_prefetch(src + l, PM_GATHER_HINT);
+                        last_line = l >> 6;
+                    }
+            }
+            const char *from = src + ((size_t)j.list[row] << sh);
+            for (size_t l = 0; l < kB; l += 16)
+                _mm_stream_si128((__m128i *)(dst + l), _mm_loadu_si128((const __m128i *)(from + l)));
+            if (++row == j.nlist) {
+                row = 0;
+                src += j.plane_bytes;
+            }
+        }
+        _mm_sfence();
+    }
+    void finish_part(const std::shared_ptr<Job> &j)
+    {
+        if (j->finished.fetch_add(1, std::memory_order_acq_rel) + 1 != j->nparts) return;
+        if (j->slot >= 0) release_slot(j->slot, hipSuccess);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            j->done = true;
+        }
+        cv_done.notify_all();
+    }
+    // parts of `j` until none is left to hand out
+    void take_parts(const std::shared_ptr<Job> &j)
     {
         for (;;) {
-            const size_t i = job_next.fetch_add(1, std::memory_order_relaxed);
-            const size_t a = i * job_part;
-            if (a >= job_bytes) break;
-            const size_t n = std::min(job_part, job_bytes - a);
-            if (!job_list) {
-                std::memcpy(job_dst + a, job_src + a, n);
-                continue;
-            }
-            // Scattered small reads: the hardware prefetchers see no stream, so the cache line of the
-            // block kAhead rows on is requested by hand (once per line); the table itself is written
-            // around the caches - it is read next by the DMA engine, not by this core.
-            const int sh = job_shift;
-            const size_t kB = (size_t)1 << sh;
-            const size_t ahead = PM_GATHER_AHEAD_BYTES >> sh;
-            size_t plane = a / job_nlist, row = a % job_nlist;
-            const char *src = job_src + plane * job_plane_bytes;
-            char *dst = job_dst + a * kB;
-            size_t last_line = ~(size_t)0;
-            for (size_t q = 0; q < n; q++, dst += kB) {
-                if (row + ahead < job_nlist) {
-                    const size_t o = (size_t)job_list[row + ahead] << sh;
-                    for (size_t l = o; l < o + kB; l += 64)
-                        if ((l >> 6) != last_line) {
-                            _mm_prefetch(src + l, PM_GATHER_HINT);
-                            last_line = l >> 6;
-                        }
-                }
-                const char *from = src + ((size_t)job_list[row] << sh);
-                for (size_t l = 0; l < kB; l += 16)
-                    _mm_stream_si128((__m128i *)(dst + l), _mm_loadu_si128((const __m128i *)(from + l)));
-                if (++row == job_nlist) {
-                    row = 0;
-                    src += job_plane_bytes;
-                }
-            }
-            _mm_sfence();
+            const size_t i = j->next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= j->nparts) return;
+            run_part(*j, i);
+            finish_part(j);
         }
     }
     void worker_main()
     {
-        uint64_t seen = 0;
         for (;;) {
+            std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv_work.wait(lk, [&] { return stop || job_gen != seen; });
-                if (stop) return;
-                seen = job_gen;
+                for (;;) {
+                    if (stop) return;
+                    while (!queue.empty() && queue.front()->next.load(std::memory_order_relaxed) >= queue.front()->nparts)
+                        queue.pop_front();
+                    if (!queue.empty()) {
+                        j = queue.front();
+                        break;
+                    }
+                    cv_work.wait(lk);
+                }
             }
-            run_parts();
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                if (--job_active == 0) cv_done.notify_all();
-            }
+            take_parts(j);
         }
     }
     void start_workers(int threads)
     {
-        const int want = std::max(0, threads - 1);  // the calling thread copies too
+        const int want = std::max(0, threads - 1);  // the calling thread works too
         if ((int)workers.size() == want) return;
         stop_workers();
         stop = false;
@@ -233,6 +268,35 @@ struct HostPipe {
         for (auto &t : workers) t.join();
         workers.clear();
     }
+    void post(const std::shared_ptr<Job> &j)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            queue.push_back(j);
+        }
+        cv_work.notify_all();
+    }
+    // post, work on it, return when it is complete
+    void run(const std::shared_ptr<Job> &j)
+    {
+        post(j);
+        take_parts(j);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return j->done; });
+    }
+    std::shared_ptr<Job> copy_job(char *dst, const char *src, size_t bytes)
+    {
+        auto j = std::make_shared<Job>();
+        j->dst = dst;
+        j->src = src;
+        j->total = bytes;
+        const size_t t = workers.size() + 1;
+        size_t part = (bytes + 2 * t - 1) / (2 * t);
+        part = std::max<size_t>(part, (size_t)1 << 20);
+        j->part = (part + 4095) & ~(size_t)4095;
+        j->nparts = (bytes + j->part - 1) / j->part;
+        return j;
+    }
     // dst <- src with every pool thread (and the caller) taking 1 MiB+ parts
     void copy(char *dst, const char *src, size_t bytes)
     {
@@ -240,50 +304,37 @@ struct HostPipe {
             std::memcpy(dst, src, bytes);
             return;
         }
-        std::lock_guard<std::mutex> jl(job_mu);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            job_dst = dst;
-            job_src = src;
-            job_bytes = bytes;
-            job_list = nullptr;
-            const size_t t = workers.size() + 1;
-            size_t part = (bytes + 2 * t - 1) / (2 * t);
-            part = std::max<size_t>(part, (size_t)1 << 20);
-            job_part = (part + 4095) & ~(size_t)4095;
-            job_next.store(0, std::memory_order_relaxed);
-            job_active = (int)workers.size();
-            job_gen++;
+        run(copy_job(dst, src, bytes));
+    }
+    // the same for a staged piece, without waiting: completion frees staging slot `slot`
+    void copy_async(char *dst, const char *src, size_t bytes, int slot)
+    {
+        if (bytes < ((size_t)1 << 20) || workers.empty()) {
+            std::memcpy(dst, src, bytes);
+            release_slot(slot, hipSuccess);
+            return;
         }
-        cv_work.notify_all();
-        run_parts();
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return job_active == 0; });
+        auto j = copy_job(dst, src, bytes);
+        j->slot = slot;
+        post(j);
     }
     // dst[plane][row] <- the (1 << shift)-byte block list[row] of source plane `plane`, for n_planes planes
     // plane_bytes apart: the rows of a block table (pm::BlockTable), collected by the pool
     void gather(char *dst, const char *src, size_t plane_bytes, size_t n_planes, const int *list, size_t n_list, int shift)
     {
-        std::lock_guard<std::mutex> jl(job_mu);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            job_dst = dst;
-            job_src = src;
-            job_bytes = n_planes * n_list;
-            job_list = list;
-            job_nlist = n_list;
-            job_plane_bytes = plane_bytes;
-            job_shift = shift;
-            const size_t t = workers.size() + 1;
-            job_part = std::max<size_t>((job_bytes + 4 * t - 1) / (4 * t), ((size_t)256 << 10) >> shift);
-            job_next.store(0, std::memory_order_relaxed);
-            job_active = (int)workers.size();
-            job_gen++;
-        }
-        cv_work.notify_all();
-        run_parts();
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return job_active == 0; });
+        auto j = std::make_shared<Job>();
+        j->dst = dst;
+        j->src = src;
+        j->total = n_planes * n_list;
+        j->list = list;
+        j->nlist = n_list;
+        j->plane_bytes = plane_bytes;
+        j->shift = shift;
+        const size_t t = workers.size() + 1;
+        j->part = std::max<size_t>((j->total + 4 * t - 1) / (4 * t), ((size_t)256 << 10) >> shift);
+        j->nparts = (j->total + j->part - 1) / j->part;
+        if (j->nparts == 0) return;
+        run(j);
     }
 };
 
@@ -414,20 +465,25 @@ int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_d
     if (rc != PM_OK) return rc;
     for (size_t off = 0; off < bytes; off += hp->stage_bytes) {
         const size_t n = std::min(hp->stage_bytes, bytes - off);
+        const int slot = hp->next_slot;
+        hp->next_slot = (slot + 1) % HostPipe::kSlots;
         {
             // the slot about to be reused is the oldest one out: wait until it has been copied out
             std::unique_lock<std::mutex> lk(hp->rmu);
-            hp->cv_slot.wait(lk, [&] { return hp->pieces_out < HostPipe::kSlots; });
+            hp->cv_slot.wait(lk, [&] { return !hp->slot_busy[slot]; });
             if (hp->rerror != hipSuccess) return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(hp->rerror));
+            hp->slot_busy[slot] = true;
+            hp->pieces_out++;
         }
-        const int slot = hp->next_slot;
-        hp->next_slot = (slot + 1) % HostPipe::kSlots;
-        PM_HIP(ctx, hipMemcpyAsync(hp->stage[slot], (const char *)src_dev + off, n, hipMemcpyDeviceToHost, stream));
-        PM_HIP(ctx, hipEventRecord(hp->ev_stage[slot], stream));
+        hipError_t e = hipMemcpyAsync(hp->stage[slot], (const char *)src_dev + off, n, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(hp->ev_stage[slot], stream);
+        if (e != hipSuccess) {
+            hp->release_slot(slot, hipSuccess);  // nothing will ever retire it
+            return fail(ctx, PM_ERR_HIP, "staged D2H copy failed: %s", hipGetErrorString(e));
+        }
         {
             std::lock_guard<std::mutex> lk(hp->rmu);
             hp->inflight.push_back({slot, (char *)dst_host + off, n});
-            hp->pieces_out++;
         }
         hp->cv_piece.notify_one();
     }

@@ -8,7 +8,8 @@
 // pinned memory, 49 GB/s each way in duplex):
 //
 //   * results -> pageable caller memory: DMA into a ring of pinned staging buffers; a retire thread
-//     waits for each DMA and a small pool of CPU threads copies the piece out while the next DMAs
+//     waits for each DMA and posts the copy-out to a pool of CPU threads (a queue of jobs: it does
+//     not wait for the copy, so the next DMA's completion is picked up at once) while the next DMAs
 //     run (fresh numpy arrays take their page faults on several cores at once: 74 GB/s with 8
 //     threads against 25 GB/s through the runtime's own pageable path); results -> pinned caller
 //     memory (pm_host_alloc / pm_host_register): one DMA;

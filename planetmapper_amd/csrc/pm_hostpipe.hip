@@ -271,6 +271,7 @@ struct HostPipe {
     }
     void post(const std::shared_ptr<Job> &j)
     {
+        if (workers.empty()) return;  // (a pool of one: the poster does all the parts itself, see run())
         {
             std::lock_guard<std::mutex> lk(mu);
             queue.push_back(j);

@@ -213,8 +213,9 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           Default 32 MiB; clamped to [1 MiB, 1 GiB].
  *   PM_OPT_HOST_COPY_THREADS CPU threads that move pageable caller memory to / from the pinned
  *                           staging buffers. Default min(16, cores available to the process,
- *                           divided by LOCAL_WORLD_SIZE when a launcher set it); 1..64.
- *   PM_OPT_ZERO_COPY        how the host cube of pm_map_cube (nearest / linear) crosses PCIe:
+ *                           divided by LOCAL_WORLD_SIZE when a launcher set it); 1..64, 0 = default.
+ *   PM_OPT_HOST_CUBE_ROUTE  (= PM_OPT_ZERO_COPY, its name when there were two routes)
+ *                           how the host cube of pm_map_cube (nearest / linear) crosses PCIe:
  *                           0 = whole planes by DMA;
  *                           1 = a PINNED cube (pm_host_alloc / pm_host_register) is gathered in
  *                               place by the reprojection kernel;
@@ -238,6 +239,7 @@ typedef enum pm_option {
     PM_OPT_HOST_CHUNK_BYTES = 2,
     PM_OPT_HOST_COPY_THREADS = 3,
     PM_OPT_ZERO_COPY = 4,
+    PM_OPT_HOST_CUBE_ROUTE = 4,
     PM_OPT_LAST_DISC_KERNEL = 5
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);
@@ -246,7 +248,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value);
 /*
  * Pinned (page-locked) host memory. PM_MEM_HOST calls accept any host pointer; buffers that
  * are pinned - allocated here or registered in place - are moved by DMA at the full PCIe rate
- * without the staging copy, and are the only ones PM_OPT_ZERO_COPY applies to. The reference
+ * without the staging copy, and are what routes 1 and 2 of PM_OPT_HOST_CUBE_ROUTE need. The reference
  * hands numpy arrays around (observation.py:240-318 loads the cube, body_xy.py:3166 makes the
  * planes); planetmapper_amd allocates those arrays from this pool.
  */

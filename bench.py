@@ -349,10 +349,23 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         d.barrier()
         return d.max_over_ranks(time.perf_counter() - t0) / steps
 
+    from planetmapper_amd import _lib
+
     t_res = run(False, steps_resident)
     ref = gathered.clone()
     t_fed = run(True, steps_fed)
     same = bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+    # the same step with the GPU fetching its blocks itself over its own PCIe link (route 2: no copy
+    # threads; slower on one GPU, but the leg that is private to each rank when N grows - the copy
+    # threads of the default route share the host's memory system)
+    t_fetch = None
+    if hasattr(eng, 'set_option'):
+        eng.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, 2)
+        try:
+            t_fetch = run(True, max(2, steps_fed // 4))
+            same = same and bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+        finally:
+            eng.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, -1)
     pix = planes * sz * sz
     block_bytes = mine_n * sz * sz * 8
     return {
@@ -364,6 +377,7 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         'planes_per_rank': per_rank,
         'ms_per_step_host_fed': round(t_fed * 1e3, 3),
         'ms_per_step_resident': round(t_res * 1e3, 4),
+        'ms_per_step_host_fed_gpu_fetch': None if t_fetch is None else round(t_fetch * 1e3, 3),
         'Mpix_s_host_fed': round(pix / t_fed / 1e6, 1),
         'Mpix_s_resident': round(pix / t_res / 1e6, 1),
         'host_feed_GBps_per_rank': round(block_bytes / t_fed / 1e9, 2),

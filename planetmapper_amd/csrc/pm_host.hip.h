@@ -29,6 +29,8 @@ void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int shift, int dtype, hipStream_t s);
+void pm_launch_number_blocks(const unsigned char *flags, size_t n_blk, int *tile_sums, int *blkmap, int *blklist, int *total,
+                             hipStream_t s);
 void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s, bool fetch);
 void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat, double *xo,
                            double *yo, int dtype, hipStream_t s);
@@ -97,7 +99,7 @@ struct pm_ctx {
     int last_disc_kernel = 0;     // PM_OPT_LAST_DISC_KERNEL
     // pipelined host path (pm_hostpipe.hip): options + lazily created state
     size_t host_chunk_bytes = (size_t)32 << 20;
-    int host_copy_threads = 0;   // 0: min(8, cores)
+    int host_copy_threads = 0;   // 0: the library's choice (pm_hostpipe.hip)
     int zero_copy = -1;          // PM_OPT_ZERO_COPY
     pmh::HostPipe *pipe = nullptr;
 };

@@ -81,6 +81,13 @@ struct HostPipe {
     // ---- pinned staging of the H2D leg of block tables collected by the pool (one per ring slot)
     char *in_stage[kRing] = {};
     size_t in_stage_bytes = 0;
+    // ---- bookkeeping of the block table (grow-only): flags / tile sums / block -> row / row -> block on
+    // the device, the x/y maps of a PM_MEM_HOST call, and the pinned host mirror of the count + list
+    unsigned char *d_flags = nullptr;
+    int *d_tiles = nullptr, *d_blkmap = nullptr, *d_blklist = nullptr;
+    double *d_maps = nullptr;
+    int *h_list = nullptr;  // [0] = count, [16 ...] = row -> block
+    size_t d_flags_cap = 0, d_tiles_cap = 0, d_blkmap_cap = 0, d_blklist_cap = 0, d_maps_cap = 0, h_list_cap = 0;
     // ---- pinned staging ring of the D2H leg
     static constexpr int kSlots = 4;
     char *stage[kSlots] = {};
@@ -384,6 +391,12 @@ void pipe_destroy(pm_ctx *ctx)
         if (hp->stage[i]) (void)hipHostFree(hp->stage[i]);
         if (hp->ev_stage[i]) (void)hipEventDestroy(hp->ev_stage[i]);
     }
+    if (hp->d_flags) (void)hipFree(hp->d_flags);
+    if (hp->d_tiles) (void)hipFree(hp->d_tiles);
+    if (hp->d_blkmap) (void)hipFree(hp->d_blkmap);
+    if (hp->d_blklist) (void)hipFree(hp->d_blklist);
+    if (hp->d_maps) (void)hipFree(hp->d_maps);
+    if (hp->h_list) (void)hipHostFree(hp->h_list);
     for (int i = 0; i < HostPipe::kRing; i++) {
         if (hp->in_stage[i]) (void)hipHostFree(hp->in_stage[i]);
         if (hp->ev_in[i]) (void)hipEventDestroy(hp->ev_in[i]);
@@ -428,6 +441,21 @@ static int ensure_stage(pm_ctx *ctx, HostPipe *hp)
         if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc of a %zu-byte staging buffer failed", want);
     }
     hp->stage_bytes = want;
+    return PM_OK;
+}
+
+// grow-only buffer of the pipe (device memory, or pinned host memory); contents are not kept
+template <typename T>
+static int grow(pm_ctx *ctx, T **p, size_t *cap, size_t bytes, bool host)
+{
+    if (*p && *cap >= bytes) return PM_OK;
+    if (*p) PM_HIP(ctx, host ? hipHostFree(*p) : hipFree(*p));
+    *p = nullptr;
+    *cap = 0;
+    const size_t want = bytes + bytes / 4 + 256;
+    const hipError_t e = host ? hipHostMalloc((void **)p, want, hipHostMallocDefault) : hipMalloc((void **)p, want);
+    if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "allocation of %zu bytes for the block table failed", want);
+    *cap = want;
     return PM_OK;
 }
 
@@ -595,41 +623,48 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     // (3) when the table is well under half the size of the planes, else (0).
     const int mode = ctx->zero_copy;
     bool gather = src_pinned && mode == 1, blocks = false, host_blocks = false;
-    std::vector<int> blkmap, blklist;
+    size_t n_list = 0;
     int shift = 0;
+    // the x/y maps on the device: the caller's (PM_MEM_HOST_CUBE) or a copy
+    const double *dxm = x_map, *dym = y_map;
+    if (!device_out) {
+        rc = grow(ctx, &hp->d_maps, &hp->d_maps_cap, 2 * nmap * sizeof(double), false);
+        if (rc != PM_OK) return rc;
+        PM_HIP(ctx, hipMemcpyAsync(hp->d_maps, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+        PM_HIP(ctx, hipMemcpyAsync(hp->d_maps + nmap, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
+        dxm = hp->d_maps;
+        dym = hp->d_maps + nmap;
+    }
     if (mode < 0 || mode == 3 || (mode == 2 && src_pinned)) {
         shift = mode == 2 ? pm::kBlkShiftFetch : pm::kBlkShiftHost;
         const size_t n_blk = (j.plane_bytes + ((size_t)1 << shift) - 1) >> shift;
         if (j.plane_bytes % ((size_t)1 << shift) == 0 && n_blk < ((size_t)1 << 31)) {
-            const size_t maps_bytes = (2 * nmap * sizeof(double) + 255) & ~(size_t)255;
-            rc = ensure_scratch(ctx, maps_bytes + n_blk);
-            if (rc != PM_OK) return rc;
+            // flag the blocks the map samples (the sampling code itself, once, on plane geometry only),
+            // number them on the device; the host needs the count (and, to collect them, the list)
+            const size_t n_tiles = (n_blk + 4095) / 4096, n_pad = n_tiles * 4096;
+            if ((rc = grow(ctx, &hp->d_flags, &hp->d_flags_cap, n_pad, false)) != PM_OK) return rc;
+            if ((rc = grow(ctx, &hp->d_tiles, &hp->d_tiles_cap, (n_tiles + 1) * sizeof(int), false)) != PM_OK) return rc;
+            if ((rc = grow(ctx, &hp->d_blkmap, &hp->d_blkmap_cap, n_blk * sizeof(int), false)) != PM_OK) return rc;
+            if ((rc = grow(ctx, &hp->d_blklist, &hp->d_blklist_cap, n_blk * sizeof(int), false)) != PM_OK) return rc;
+            if ((rc = grow(ctx, &hp->h_list, &hp->h_list_cap, 64, true)) != PM_OK) return rc;
             pm::ReprojectArgs am = a;
-            unsigned char *dflags = (unsigned char *)ctx->scratch + maps_bytes;
-            if (device_out) {
-                am.x_map = x_map;
-                am.y_map = y_map;
-            } else {
-                double *dx = (double *)ctx->scratch;
-                PM_HIP(ctx, hipMemcpyAsync(dx, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
-                PM_HIP(ctx, hipMemcpyAsync(dx + nmap, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
-                am.x_map = dx;
-                am.y_map = dx + nmap;
-            }
-            PM_HIP(ctx, hipMemsetAsync(dflags, 0, n_blk, sk));
-            pm_launch_mark_blocks(am, dflags, shift, dtype, sk);
+            am.x_map = dxm;
+            am.y_map = dym;
+            int *d_total = hp->d_tiles + n_tiles;
+            PM_HIP(ctx, hipMemsetAsync(hp->d_flags, 0, n_pad, sk));
+            pm_launch_mark_blocks(am, hp->d_flags, shift, dtype, sk);
+            pm_launch_number_blocks(hp->d_flags, n_blk, hp->d_tiles, hp->d_blkmap, hp->d_blklist, d_total, sk);
             PM_HIP(ctx, hipGetLastError());
-            std::vector<unsigned char> hflags(n_blk);
-            PM_HIP(ctx, hipMemcpyAsync(hflags.data(), dflags, n_blk, hipMemcpyDeviceToHost, sk));
+            PM_HIP(ctx, hipMemcpyAsync(hp->h_list, d_total, sizeof(int), hipMemcpyDeviceToHost, sk));
             PM_HIP(ctx, hipStreamSynchronize(sk));
-            blkmap.assign(n_blk, -1);
-            for (size_t q = 0; q < n_blk; q++)
-                if (hflags[q]) {
-                    blkmap[q] = (int)blklist.size();
-                    blklist.push_back((int)q);
-                }
-            const size_t table_bytes = blklist.size() << shift;
-            if (!blklist.empty() && (mode >= 2 || table_bytes * 5 < j.plane_bytes * 2)) (mode == 2 ? blocks : host_blocks) = true;
+            n_list = (size_t)hp->h_list[0];
+            const size_t table_bytes = n_list << shift;
+            if (n_list > 0 && (mode >= 2 || table_bytes * 5 < j.plane_bytes * 2)) (mode == 2 ? blocks : host_blocks) = true;
+            if (host_blocks) {
+                if ((rc = grow(ctx, &hp->h_list, &hp->h_list_cap, 64 + n_list * sizeof(int), true)) != PM_OK) return rc;
+                PM_HIP(ctx, hipMemcpyAsync(hp->h_list + 16, hp->d_blklist, n_list * sizeof(int), hipMemcpyDeviceToHost, sk));
+                PM_HIP(ctx, hipStreamSynchronize(sk));
+            }
         }
         // (mode 2 / 3 on planes that do not split into whole blocks, or a map that samples nothing: whole planes)
     }
@@ -639,9 +674,9 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
     chunk = std::min<size_t>(std::min<size_t>(chunk, (size_t)n_planes), 32768);
     if (zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, ((size_t)n_planes + 7) / 8), 32768);
-    const size_t table_row_bytes = (size_t)blklist.size() << shift;  // one plane's rows of the block table
+    const size_t table_row_bytes = n_list << shift;  // one plane's rows of the block table
     if (blocks) chunk = std::max<size_t>(1, std::min<size_t>(chunk, ((size_t)256 << 20) / table_row_bytes));
-    if (host_blocks)  // chunks of the table, not of the cube
+    if (host_blocks)  // chunks of the table, not of the cube (smaller chunks for short cubes: no gain, measured)
         chunk = std::min<size_t>(std::max<size_t>(1, ctx->host_chunk_bytes / table_row_bytes), std::min<size_t>((size_t)n_planes, 32768));
     const size_t batch = std::min<size_t>((size_t)n_planes, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
     const size_t slot_bytes = ((host_blocks ? chunk * table_row_bytes : chunk * j.plane_bytes) + 255) & ~(size_t)255;
@@ -650,42 +685,25 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
     size_t need = 2 * nmap * sizeof(double) + 256;
     if (!zero_copy) need += HostPipe::kRing * slot_bytes;
     if (!direct_out) need += batch * nmap * sizeof(double);
-    const size_t blk_off = (need + 255) & ~(size_t)255;  // block map, block list, table
-    const size_t blkmap_bytes = (blkmap.size() * sizeof(int) + 255) & ~(size_t)255;
-    const size_t blklist_bytes = (blklist.size() * sizeof(int) + 255) & ~(size_t)255;
-    if (blocks) need = blk_off + blkmap_bytes + blklist_bytes + chunk * table_row_bytes;
-    if (host_blocks) need = blk_off + blkmap_bytes;
+    const size_t blk_off = (need + 255) & ~(size_t)255;  // the table of a GPU-fetched chunk
+    if (blocks) need = blk_off + chunk * table_row_bytes;
     need = std::max(need, 2 * nmap * sizeof(double) + 512 + j.plane_bytes + nmap * sizeof(double));  // median redo
     rc = ensure_scratch(ctx, need);
     if (rc != PM_OK) return rc;
     char *base = (char *)ctx->scratch;
-    double *dxm = (double *)base;
-    double *dym = dxm + nmap;
     char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
     double *dout_all = (double *)(ring + (zero_copy ? 0 : HostPipe::kRing * slot_bytes));
-    if (device_out) {
-        dxm = const_cast<double *>(x_map);
-        dym = const_cast<double *>(y_map);
-    } else {
-        PM_HIP(ctx, hipMemcpyAsync(dxm, x_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
-        PM_HIP(ctx, hipMemcpyAsync(dym, y_map, nmap * sizeof(double), hipMemcpyHostToDevice, sk));
-    }
 
     pm::BlockTable table{};
     if (blocks || host_blocks) {
-        int *dmap = (int *)(base + blk_off);
-        PM_HIP(ctx, hipMemcpyAsync(dmap, blkmap.data(), blkmap.size() * sizeof(int), hipMemcpyHostToDevice, sk));
-        table.blkmap = dmap;
-        table.n_list = (unsigned)blklist.size();
+        table.blkmap = hp->d_blkmap;
+        table.blklist = hp->d_blklist;
+        table.n_list = (unsigned)n_list;
         table.shift = shift;
         table.plane_bytes = j.plane_bytes;
     }
-    if (blocks) {
-        int *dlist = (int *)(base + blk_off + blkmap_bytes);
-        PM_HIP(ctx, hipMemcpyAsync(dlist, blklist.data(), blklist.size() * sizeof(int), hipMemcpyHostToDevice, sk));
-        table.blklist = dlist;
-        table.table = base + blk_off + blkmap_bytes + blklist_bytes;
-    }
+    if (blocks) table.table = base + blk_off;
+    const int *hlist = hp->h_list ? hp->h_list + 16 : nullptr;
     if (host_blocks) {
         rc = ensure_in_stage(ctx, hp, slot_bytes);
         if (rc != PM_OK) return rc;
@@ -721,7 +739,7 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
                 // done) while the DMA of the previous chunk runs
                 char *dslot = ring + (size_t)slot * slot_bytes;
                 if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
-                hp->gather(hp->in_stage[slot], j.cube + (b0 + p0) * j.plane_bytes, j.plane_bytes, np, blklist.data(), blklist.size(), shift);
+                hp->gather(hp->in_stage[slot], j.cube + (b0 + p0) * j.plane_bytes, j.plane_bytes, np, hlist, n_list, shift);
                 if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
                 PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
                 PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));

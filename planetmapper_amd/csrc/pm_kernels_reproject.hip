@@ -180,8 +180,8 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 // which request sizes (tools/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of 256 bytes
 // and more 55 GB/s; the in-place gather of k_reproject - uncached, so neighbouring waves fetch the
 // same lines again - 32 GB/s of lines). The map touches a fraction of each plane, the SAME blocks in
-// every plane. k_mark_blocks runs the sampling arithmetic once and flags those blocks; the host
-// (pm_hostpipe.hip) numbers them; then either CPU threads collect the 16-byte blocks of each chunk
+// every plane. k_mark_blocks runs the sampling arithmetic once and flags those blocks; k_blocks_*
+// number them (block <-> row of the table); then either CPU threads collect the 16-byte blocks of each chunk
 // of planes into pinned staging and one DMA brings the dense table over, or k_fetch_blocks pulls
 // 256-byte blocks from pinned memory, each once, 16 lanes on one block; k_reproject_blocks samples
 // the table.
@@ -211,6 +211,81 @@ __global__ __launch_bounds__(kBlock) void k_mark_blocks(const ReprojectArgs a, u
     if (m >= a.n_map) return;
     const double v = reproject_sample_from<T>(a, 0, (const T *)nullptr, MarkLoader<T>{flags, shift}, a.x_map[m], a.y_map[m]);
     (void)v;
+}
+
+// ---- numbering the flagged blocks (block -> row of the table, row -> block), on the device: the
+// host only needs the count. A tile is 4096 flags: 256 lanes x 16 flags (flags are 0 / 1 bytes, read
+// as four 32-bit words; the flag array is padded with zeros to whole tiles).
+constexpr int kNumberTile = 4096;
+
+__device__ __forceinline__ int flags16(const unsigned char *flags, size_t tile, unsigned lane, uint4 &w)
+{
+    w = *(const uint4 *)(flags + tile * kNumberTile + (size_t)lane * 16);
+    return __builtin_popcount(w.x) + __builtin_popcount(w.y) + __builtin_popcount(w.z) + __builtin_popcount(w.w);
+}
+
+// inclusive prefix sum of v over the 256 lanes of the workgroup (wave shuffles + one LDS hop)
+__device__ __forceinline__ int block_inclusive_scan(int v, int *wave_tot /* LDS, 4 ints */)
+{
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(v, d, 64);
+        if (lane >= (unsigned)d) v += up;
+    }
+    if (lane == 63u) wave_tot[wave] = v;
+    __syncthreads();
+    int base = 0;
+    for (unsigned w = 0; w < wave; w++) base += wave_tot[w];
+    __syncthreads();
+    return v + base;
+}
+
+__global__ __launch_bounds__(kBlock) void k_blocks_count(const unsigned char *__restrict__ flags, int *__restrict__ tile_sums)
+{
+    __shared__ int wave_tot[4];
+    uint4 w;
+    const int c = flags16(flags, blockIdx.x, threadIdx.x, w);
+    const int incl = block_inclusive_scan(c, wave_tot);
+    if (threadIdx.x == kBlock - 1) tile_sums[blockIdx.x] = incl;
+}
+
+// one workgroup: tile_sums -> exclusive offsets (in place), *total = number of flagged blocks
+__global__ __launch_bounds__(kBlock) void k_blocks_offsets(int *__restrict__ tile_sums, int n_tiles, int *__restrict__ total)
+{
+    __shared__ int wave_tot[4];
+    __shared__ int carry_s;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < n_tiles; t0 += kBlock) {
+        const int i = t0 + (int)threadIdx.x;
+        const int v = i < n_tiles ? tile_sums[i] : 0;
+        const int incl = block_inclusive_scan(v, wave_tot);
+        const int carry = carry_s;
+        if (i < n_tiles) tile_sums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) carry_s = carry + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = carry_s;
+}
+
+__global__ __launch_bounds__(kBlock) void k_blocks_number(const unsigned char *__restrict__ flags, const int *__restrict__ tile_offsets,
+                                                          size_t n_blk, int *__restrict__ blkmap, int *__restrict__ blklist)
+{
+    __shared__ int wave_tot[4];
+    uint4 w;
+    const int c = flags16(flags, blockIdx.x, threadIdx.x, w);
+    int row = tile_offsets[blockIdx.x] + block_inclusive_scan(c, wave_tot) - c;
+    const size_t first = (size_t)blockIdx.x * kNumberTile + (size_t)threadIdx.x * 16;
+    const unsigned words[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const size_t i = first + k;
+        if (i >= n_blk) break;
+        const bool set = (words[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+        blkmap[i] = set ? row : -1;
+        if (set) blklist[row++] = (int)i;
+    }
 }
 
 // blockIdx.y = plane of the chunk; 16 lanes x 16 bytes per 256-byte block, 4 blocks per wave
@@ -928,6 +1003,16 @@ void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int
     case PM_U8: launch_mark_blocks_t<uint8_t>(a, flags, shift, s); break;
     case PM_U16: launch_mark_blocks_t<uint16_t>(a, flags, shift, s); break;
     }
+}
+
+// flags (n_pad = whole tiles of 4096, zero beyond n_blk) -> blkmap[n_blk], blklist[*total], *total
+void pm_launch_number_blocks(const unsigned char *flags, size_t n_blk, int *tile_sums, int *blkmap, int *blklist, int *total,
+                             hipStream_t s)
+{
+    const unsigned n_tiles = (unsigned)((n_blk + pm::kNumberTile - 1) / pm::kNumberTile);
+    hipLaunchKernelGGL(pm::k_blocks_count, dim3(n_tiles), dim3(pm::kBlock), 0, s, flags, tile_sums);
+    hipLaunchKernelGGL(pm::k_blocks_offsets, dim3(1), dim3(pm::kBlock), 0, s, tile_sums, (int)n_tiles, total);
+    hipLaunchKernelGGL(pm::k_blocks_number, dim3(n_tiles), dim3(pm::kBlock), 0, s, flags, tile_sums, n_blk, blkmap, blklist);
 }
 
 void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s, bool fetch)

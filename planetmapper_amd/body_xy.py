@@ -333,48 +333,50 @@ class BodyXY:
         self.set_rotation(-self.north_pole_angle())
         self.set_disc_method('rotate_north_to_top')
 
+    def _reframe(self, size, zoom: float, shift: float) -> None:
+        """New frame size with the disc kept on the same piece of sky: centre -> centre * zoom + shift."""
+        self.set_img_size(*size)
+        if zoom != 1.0:
+            self.set_r0(self.get_r0() * zoom)
+        for get, put in ((self.get_x0, self.set_x0), (self.get_y0, self.set_y0)):
+            put(get() * zoom + shift)
+
     def scale_img_size(self, factor: float, *, allow_rounding: bool = False) -> None:
         """body_xy.py:973-1023: multiply nx, ny by `factor`, keeping the disc where it is"""
         if factor <= 0:
             raise ValueError('Scaling factor must be greater than zero')
-        nx, ny = self.get_img_size()
-        nx_f, ny_f = nx * factor, ny * factor
-        nx_c, ny_c = math.ceil(nx_f), math.ceil(ny_f)
-        if not allow_rounding and (nx_c != nx_f or ny_c != ny_f):
+        old = self.get_img_size()
+        exact = tuple(n * factor for n in old)
+        whole = tuple(math.ceil(v) for v in exact)
+        if whole != exact and not allow_rounding:
             raise ValueError(
-                f'Image size ({nx}, {ny}) cannot be exactly scaled by {factor} to an integer number of '
-                f'pixels: new size would be ({nx_f}, {ny_f}). Use `allow_rounding=True` to allow rounding '
-                'of the image size.'
+                f'Image size {old} cannot be exactly scaled by {factor} to an integer number of pixels: new size '
+                f'would be {exact}. Use `allow_rounding=True` to allow rounding of the image size.'
             )
-        self.set_img_size(nx_c, ny_c)
-        self.set_r0(self.get_r0() * factor)
-        offset = (factor - 1) / 2  # the pixel grid runs from -0.5 to n - 0.5
-        self.set_x0(self.get_x0() * factor + offset)
-        self.set_y0(self.get_y0() * factor + offset)
+        # pixel edges sit at -0.5 and n - 0.5: a zoom about the lower left EDGE moves a centre c to
+        # c * factor + (factor - 1) / 2
+        self._reframe(whole, factor, (factor - 1) / 2)
 
     def add_img_border(self, border: int) -> None:
         """body_xy.py:1025-1058: grow (or crop, if negative) the frame by `border` pixels per side"""
-        border = int(border)
-        nx, ny = self.get_img_size()
-        self.set_img_size(nx + 2 * border, ny + 2 * border)
-        self.set_x0(self.get_x0() + border)
-        self.set_y0(self.get_y0() + border)
+        pad = int(border)
+        self._reframe(tuple(n + 2 * pad for n in self.get_img_size()), 1.0, pad)
 
     def add_arcsec_offset(self, dra_arcsec: float = 0, ddec_arcsec: float = 0) -> None:
         """body_xy.py:1088-1103: shift (x0, y0) by an offset given in RA/Dec arcseconds"""
-        ra0, dec0 = self.xy2radec(0, 0)
-        dx, dy = self.radec2xy(ra0 + dra_arcsec / 3600, dec0 + ddec_arcsec / 3600)
-        self.adjust_disc_params(dx=dx, dy=dy)
+        origin = self.xy2radec(0, 0)
+        moved = self.radec2xy(origin[0] + dra_arcsec / 3600, origin[1] + ddec_arcsec / 3600)
+        self.adjust_disc_params(dx=moved[0], dy=moved[1])
 
     def _get_img_limits(self, func):
-        """body_xy.py:1106-1120: extremes over the four outer pixel corners"""
-        corners = [(-0.5, -0.5), (-0.5, self._ny - 0.5), (self._nx - 0.5, -0.5), (self._nx - 0.5, self._ny - 0.5)]
-        pts = [func(x, y) for x, y in corners]
-        return (min(p[0] for p in pts), max(p[0] for p in pts)), (min(p[1] for p in pts), max(p[1] for p in pts))
+        """body_xy.py:1106-1120: extremes of `func` over the four outer pixel corners"""
+        edges_x, edges_y = (-0.5, self._nx - 0.5), (-0.5, self._ny - 0.5)
+        u, v = zip(*(func(x, y) for x in edges_x for y in edges_y))
+        return (min(u), max(u)), (min(v), max(v))
 
     def get_img_limits_radec(self):
-        xlim, ylim = self._get_img_limits(self.xy2radec)
-        return (xlim[1], xlim[0]), ylim  # RA increases to the left
+        (ra_lo, ra_hi), dec = self._get_img_limits(self.xy2radec)
+        return (ra_hi, ra_lo), dec  # RA increases to the left
 
     def get_img_limits_km(self):
         return self._get_img_limits(self.xy2km)

@@ -202,39 +202,42 @@ class Observation(BodyXY):
                 x0, y0, r0, rotation = body.get_disc_params()
         return x0, y0, r0, rotation
 
+    # which of (x0, y0, r0, rotation) each *_from_wcs method takes over, and the disc method it records
+    _WCS_PARTS = {
+        'wcs': (0, 1, 2, 3),
+        'wcs_position': (0, 1),
+        'wcs_rotation': (3,),
+        'wcs_plate_scale': (2,),
+    }
+
+    def _adopt_wcs(self, method: str, *args, **kwargs) -> None:
+        found = self._get_disc_params_from_wcs(*args, **kwargs)
+        setters = (self.set_x0, self.set_y0, self.set_r0, self.set_rotation)
+        for k in self._WCS_PARTS[method]:
+            setters[k](found[k])
+        self.set_disc_method(method)
+
     def disc_from_wcs(self, suppress_warnings: bool = False, validate: bool = True, use_header_offsets: bool = True,
                       distortion_warning_threshold: float | None = 0.25) -> None:
         """observation.py:502-558"""
-        x0, y0, r0, rotation = self._get_disc_params_from_wcs(
-            suppress_warnings, validate, use_header_offsets, distortion_warning_threshold
-        )
-        self.set_x0(x0)
-        self.set_y0(y0)
-        self.set_r0(r0)
-        self.set_rotation(rotation)
-        self.set_disc_method('wcs')
+        self._adopt_wcs('wcs', suppress_warnings, validate, use_header_offsets, distortion_warning_threshold)
 
     def position_from_wcs(self, *args, **kwargs) -> None:
         """observation.py:560-577"""
-        x0, y0, _, _ = self._get_disc_params_from_wcs(*args, **kwargs)
-        self.set_x0(x0)
-        self.set_y0(y0)
-        self.set_disc_method('wcs_position')
+        self._adopt_wcs('wcs_position', *args, **kwargs)
 
     def rotation_from_wcs(self, *args, **kwargs) -> None:
         """observation.py:579-594"""
-        self.set_rotation(self._get_disc_params_from_wcs(*args, **kwargs)[3])
-        self.set_disc_method('wcs_rotation')
+        self._adopt_wcs('wcs_rotation', *args, **kwargs)
 
     def plate_scale_from_wcs(self, *args, **kwargs) -> None:
         """observation.py:596-612"""
-        self.set_r0(self._get_disc_params_from_wcs(*args, **kwargs)[2])
-        self.set_disc_method('wcs_plate_scale')
+        self._adopt_wcs('wcs_plate_scale', *args, **kwargs)
 
     def get_wcs_offset(self, *args, **kwargs) -> tuple[float, float, float, float]:
         """(dx, dy, dr, drotation) of the current disc from the WCS one. observation.py:614-668"""
-        x0, y0, r0, rotation = self._get_disc_params_from_wcs(*args, **kwargs)
-        return self.get_x0() - x0, self.get_y0() - y0, self.get_r0() - r0, (self.get_rotation() - rotation) % 360
+        dx, dy, dr, drot = (mine - theirs for mine, theirs in zip(self.get_disc_params(), self._get_disc_params_from_wcs(*args, **kwargs)))
+        return dx, dy, dr, drot % 360
 
     def get_wcs_arcsec_offset(self, *args, check_is_position_offset_only: bool = True, **kwargs) -> tuple[float, float]:
         """(dra_arcsec, ddec_arcsec) of the current disc from the WCS one. observation.py:670-748"""

@@ -230,6 +230,12 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                               the size of the planes, else 0.
  *                           (1 and 2 on pageable memory, 2 and 3 on planes that are not a whole
  *                           number of blocks: as 0.)
+ *   PM_OPT_SPARSE_FRAME     image planes into host memory (pm_backplanes_img, PM_MEM_HOST): the planes of
+ *                           the disc are NaN outside the radius pre-mask of optimize_speed; 1 = only
+ *                           bands of rows around that circle cross PCIe (as rectangles) and the copy
+ *                           threads write the NaN around them; 0 = whole planes; -1 (default) = 1 for
+ *                           planes of 64 MiB and more of which the circle covers under 85 % (smaller
+ *                           planes gain nothing: measured).
  *   PM_OPT_LAST_DISC_KERNEL read-only (pm_get_option): which kernel the latest image-plane call
  *                           dispatched for the planes that need the intercept: 0 none yet,
  *                           1 spheroid fast path, 2 its triaxial variant, 3 general kernel.
@@ -240,7 +246,8 @@ typedef enum pm_option {
     PM_OPT_HOST_COPY_THREADS = 3,
     PM_OPT_ZERO_COPY = 4,
     PM_OPT_HOST_CUBE_ROUTE = 4,
-    PM_OPT_LAST_DISC_KERNEL = 5
+    PM_OPT_LAST_DISC_KERNEL = 5,
+    PM_OPT_SPARSE_FRAME = 6
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);
 int pm_get_option(pm_ctx *ctx, int option, int64_t *value);

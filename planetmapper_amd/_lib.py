@@ -66,6 +66,7 @@ PM_OPT_HOST_COPY_THREADS = 3
 PM_OPT_ZERO_COPY = 4
 PM_OPT_HOST_CUBE_ROUTE = 4  # the same option under the name that says what it selects
 PM_OPT_LAST_DISC_KERNEL = 5
+PM_OPT_SPARSE_FRAME = 6
 
 
 class LibraryNotBuiltError(ImportError):

@@ -388,6 +388,10 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         if (value < -1 || value > 3) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1 .. 3");
         ctx->zero_copy = (int)value;
         return PM_OK;
+    case PM_OPT_SPARSE_FRAME:
+        if (value < -1 || value > 1) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SPARSE_FRAME takes -1, 0 or 1");
+        ctx->sparse_frame = (int)value;
+        return PM_OK;
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
 }
@@ -400,6 +404,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_HOST_CHUNK_BYTES: *value = (int64_t)ctx->host_chunk_bytes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS: *value = ctx->host_copy_threads; return PM_OK;
     case PM_OPT_ZERO_COPY: *value = ctx->zero_copy; return PM_OK;
+    case PM_OPT_SPARSE_FRAME: *value = ctx->sparse_frame; return PM_OK;
     case PM_OPT_LAST_DISC_KERNEL: *value = ctx->last_disc_kernel; return PM_OK;
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -601,9 +606,19 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
 
     if (mem != PM_MEM_DEVICE) {
         // results -> caller memory at the rate of the link (pm_hostpipe.hip)
+        // Planes of the disc (not the ring planes, which every pixel has) are NaN outside the radius
+        // pre-mask: when that circle leaves a good part of the frame empty only bands around it are
+        // copied and the copy threads write the NaN (PM_OPT_SPARSE_FRAME).
+        const uint64_t nan_outside = d.optimize_speed ? (kDiscBits & ~kRingBits) : 0;
+        const double circle = 3.14159265358979323846 * p.r2 / ((double)d.nx * (double)n_rows);
+        const bool sparse = ctx->sparse_frame != 0 && (size_t)d.nx * sizeof(double) <= ((size_t)1 << 20) &&
+                            (ctx->sparse_frame > 0 || (npx * sizeof(double) >= ((size_t)64 << 20) && circle < 0.85));
         for (int i = 0; i < PM_NUM_PLANES; i++)
             if ((plane_mask >> i) & 1) {
-                rc = d2h_issue(ctx, ctx->stream, out[i], p.out[i], npx * sizeof(double));
+                if (sparse && ((nan_outside >> i) & 1))
+                    rc = d2h_issue_disc(ctx, ctx->stream, out[i], p.out[i], (size_t)d.nx, (size_t)n_rows, (double)row_begin, p.x0, p.y0, p.r2);
+                else
+                    rc = d2h_issue(ctx, ctx->stream, out[i], p.out[i], npx * sizeof(double));
                 if (rc != PM_OK) return rc;
             }
         return d2h_finish(ctx, ctx->stream);

@@ -101,6 +101,7 @@ struct pm_ctx {
     size_t host_chunk_bytes = (size_t)32 << 20;
     int host_copy_threads = 0;   // 0: the library's choice (pm_hostpipe.hip)
     int zero_copy = -1;          // PM_OPT_ZERO_COPY
+    int sparse_frame = -1;       // PM_OPT_SPARSE_FRAME
     pmh::HostPipe *pipe = nullptr;
 };
 
@@ -137,6 +138,9 @@ bool host_is_pinned(const void *p, size_t bytes);
 // dst_host <- src_dev on `stream` (staged through pinned buffers + copy threads for pageable
 // destinations); d2h_finish completes every issued copy and synchronises the stream
 int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_dev, size_t bytes);
+// the same for a frame plane that is NaN outside a circle: only bands around the circle are copied
+int d2h_issue_disc(pm_ctx *ctx, hipStream_t stream, double *dst_host, const double *src_dev, size_t nx, size_t n_rows, double y_first,
+                   double x0, double y0, double r2);
 int d2h_finish(pm_ctx *ctx, hipStream_t stream);
 int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
                             const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out);

@@ -93,10 +93,16 @@ struct HostPipe {
     char *stage[kSlots] = {};
     size_t stage_bytes = 0;
     hipEvent_t ev_stage[kSlots] = {};
+    // rows of a frame plane of which only the columns [xa, xb) hold anything but NaN (d2h_issue_disc)
+    struct Rows {
+        size_t nx = 0, n = 0;  // row length (pixels), rows
+        size_t xa = 0, xb = 0;
+    };
     struct Piece {
         int slot;
         char *dst;
         size_t bytes;
+        Rows rows;  // rows.n != 0: the staged piece is the rectangle rows.n x (xb - xa), dst the first row
     };
     // pieces whose DMA has been enqueued, oldest first; the retire thread waits for each DMA and has
     // the pool copy the piece out, so the calling thread stays free to feed the next chunk
@@ -111,12 +117,13 @@ struct HostPipe {
     int device = 0;
     hipError_t rerror = hipSuccess;
 
+    // (slot < 0: an asynchronous job that holds no staging slot, counted in pieces_out all the same)
     void release_slot(int slot, hipError_t e)
     {
         {
             std::lock_guard<std::mutex> lk(rmu);
             if (e != hipSuccess && rerror == hipSuccess) rerror = e;
-            slot_busy[slot] = false;
+            if (slot >= 0) slot_busy[slot] = false;
             pieces_out--;
         }
         cv_slot.notify_all();
@@ -137,10 +144,12 @@ struct HostPipe {
                 inflight.pop_front();
             }
             const hipError_t e = hipEventSynchronize(ev_stage[pc.slot]);
-            if (e == hipSuccess)
-                copy_async(pc.dst, stage[pc.slot], pc.bytes, pc.slot);
-            else
+            if (e != hipSuccess)
                 release_slot(pc.slot, e);
+            else if (pc.rows.n)
+                rows_async(pc.dst, stage[pc.slot], pc.rows, pc.slot);
+            else
+                copy_async(pc.dst, stage[pc.slot], pc.bytes, pc.slot);
         }
     }
     void start_retirer(int dev)
@@ -173,7 +182,11 @@ struct HostPipe {
         size_t nparts = 0;
         std::atomic<size_t> next{0}, finished{0};
         int slot = -1;      // copy-out of a staged piece: the staging slot it frees
+        bool counted = false;  // an asynchronous job without a slot: completion decrements pieces_out
         bool done = false;  // (under mu)
+        // rows job (units: rows): row r of dst (rows.nx doubles) <- NaN | row r of the staged rectangle | NaN;
+        // src == nullptr: the columns [xa, xb) are left alone (a DMA writes them) or do not exist
+        Rows rows;
     };
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -185,6 +198,18 @@ struct HostPipe {
     {
         const size_t a = i * j.part;
         const size_t n = std::min(j.part, j.total - a);
+        if (j.rows.n) {
+            const Rows &rw = j.rows;
+            const uint64_t nan_bits = 0x7ff8000000000000ull;  // the quiet NaN the kernels store
+            const size_t w = rw.xb - rw.xa;
+            for (size_t r = a; r < a + n; r++) {
+                uint64_t *row = (uint64_t *)(j.dst + r * rw.nx * sizeof(double));
+                for (size_t x = 0; x < rw.xa; x++) row[x] = nan_bits;
+                if (j.src && w) std::memcpy(row + rw.xa, j.src + r * w * sizeof(double), w * sizeof(double));
+                for (size_t x = rw.xb; x < rw.nx; x++) row[x] = nan_bits;
+            }
+            return;
+        }
         if (!j.list) {
             std::memcpy(j.dst + a, j.src + a, n);
             return;
@@ -221,7 +246,7 @@ struct HostPipe {
     void finish_part(const std::shared_ptr<Job> &j)
     {
         if (j->finished.fetch_add(1, std::memory_order_acq_rel) + 1 != j->nparts) return;
-        if (j->slot >= 0) release_slot(j->slot, hipSuccess);
+        if (j->slot >= 0 || j->counted) release_slot(j->slot, hipSuccess);
         {
             std::lock_guard<std::mutex> lk(mu);
             j->done = true;
@@ -325,6 +350,31 @@ struct HostPipe {
         }
         auto j = copy_job(dst, src, bytes);
         j->slot = slot;
+        post(j);
+    }
+    // rows of a frame plane, asynchronously: NaN outside [xa, xb), the staged rectangle (or nothing) inside.
+    // slot >= 0: the staging slot to free on completion; otherwise the job is counted in pieces_out here.
+    void rows_async(char *dst, const char *src, const Rows &rw, int slot)
+    {
+        auto j = std::make_shared<Job>();
+        j->dst = dst;
+        j->src = src;
+        j->rows = rw;
+        j->total = rw.n;
+        const size_t t = workers.size() + 1;
+        const size_t row_bytes = std::max<size_t>(rw.nx * sizeof(double), 1);
+        j->part = std::max<size_t>(std::max<size_t>((rw.n + 2 * t - 1) / (2 * t), ((size_t)512 << 10) / row_bytes), 1);
+        j->nparts = (rw.n + j->part - 1) / j->part;
+        j->slot = slot;
+        if (slot < 0) {
+            j->counted = true;
+            std::lock_guard<std::mutex> lk(rmu);
+            pieces_out++;
+        }
+        if (workers.empty()) {
+            take_parts(j);
+            return;
+        }
         post(j);
     }
     // dst[plane][row] <- the (1 << shift)-byte block list[row] of source plane `plane`, for n_planes planes
@@ -513,7 +563,76 @@ int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_d
         }
         {
             std::lock_guard<std::mutex> lk(hp->rmu);
-            hp->inflight.push_back({slot, (char *)dst_host + off, n});
+            hp->inflight.push_back({slot, (char *)dst_host + off, n, HostPipe::Rows{}});
+        }
+        hp->cv_piece.notify_one();
+    }
+    return PM_OK;
+}
+
+// A frame plane that is NaN outside the circle (x - x0)^2 + (y - y0)^2 <= r2 (the image kernels' radius
+// pre-mask, y counted from `y_first` for the plane's first row): only bands of rows around that circle
+// cross the link, as rectangles; the copy threads write the NaN of everything else. The spans are
+// taken a pixel wider than the circle, so no rounding of this arithmetic decides a pixel.
+int d2h_issue_disc(pm_ctx *ctx, hipStream_t stream, double *dst_host, const double *src_dev, size_t nx, size_t n_rows, double y_first,
+                   double x0, double y0, double r2)
+{
+    HostPipe *hp;
+    int rc = pipe_get(ctx, &hp);
+    if (rc != PM_OK) return rc;
+    const bool pinned = host_is_pinned(dst_host, nx * n_rows * sizeof(double));
+    if (!pinned) {
+        rc = ensure_stage(ctx, hp);
+        if (rc != PM_OK) return rc;
+    }
+    const size_t band = std::max<size_t>(1, std::min<size_t>(256, hp->stage_bytes ? hp->stage_bytes / (nx * sizeof(double)) : 256));
+    const double rr = std::sqrt(std::fmax(r2, 0.0));
+    for (size_t r0 = 0; r0 < n_rows; r0 += band) {
+        const size_t nr = std::min(band, n_rows - r0);
+        // widest span of the circle over the rows of the band (dy closest to 0), one pixel of margin
+        const double ya = y_first + (double)r0 - y0, yb = y_first + (double)(r0 + nr - 1) - y0;
+        const double dy = (ya <= 0.0 && yb >= 0.0) ? 0.0 : std::fmin(std::fabs(ya), std::fabs(yb));
+        HostPipe::Rows rw;
+        rw.nx = nx;
+        rw.n = nr;
+        char *dst = (char *)(dst_host + r0 * nx);
+        const double reach = dy - 0.5 <= rr ? std::sqrt(std::fmax(rr * rr - std::fmax(dy - 0.5, 0.0) * std::fmax(dy - 0.5, 0.0), 0.0)) : -1.0;
+        double fa = std::floor(x0 - reach) - 1.0, fb = std::ceil(x0 + reach) + 2.0;
+        if (reach < 0.0 || fb <= 0.0 || fa >= (double)nx) {
+            rw.xa = rw.xb = 0;  // nothing of the circle in these rows: all NaN
+            hp->rows_async(dst, nullptr, rw, -1);
+            continue;
+        }
+        rw.xa = (size_t)std::fmax(fa, 0.0);
+        rw.xb = (size_t)std::fmin(fb, (double)nx);
+        const size_t w = rw.xb - rw.xa;
+        const double *src = src_dev + r0 * nx + rw.xa;
+        if (pinned) {
+            // the DMA writes the rectangle in place, the pool the NaN around it
+            PM_HIP(ctx, hipMemcpy2DAsync(dst_host + r0 * nx + rw.xa, nx * sizeof(double), src, nx * sizeof(double), w * sizeof(double), nr,
+                                         hipMemcpyDeviceToHost, stream));
+            hp->rows_async(dst, nullptr, rw, -1);
+            continue;
+        }
+        const int slot = hp->next_slot;
+        hp->next_slot = (slot + 1) % HostPipe::kSlots;
+        {
+            std::unique_lock<std::mutex> lk(hp->rmu);
+            hp->cv_slot.wait(lk, [&] { return !hp->slot_busy[slot]; });
+            if (hp->rerror != hipSuccess) return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(hp->rerror));
+            hp->slot_busy[slot] = true;
+            hp->pieces_out++;
+        }
+        hipError_t e = hipMemcpy2DAsync(hp->stage[slot], w * sizeof(double), src, nx * sizeof(double), w * sizeof(double), nr,
+                                        hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(hp->ev_stage[slot], stream);
+        if (e != hipSuccess) {
+            hp->release_slot(slot, hipSuccess);
+            return fail(ctx, PM_ERR_HIP, "staged D2H copy failed: %s", hipGetErrorString(e));
+        }
+        {
+            std::lock_guard<std::mutex> lk(hp->rmu);
+            hp->inflight.push_back({slot, dst, w * nr * sizeof(double), rw});
         }
         hp->cv_piece.notify_one();
     }

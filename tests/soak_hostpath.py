@@ -85,7 +85,8 @@ def main():
         eng.map_cube_device(dcube, cube.dtype, planes, dxm, dym, n0, n1, dout, interp, True)
         eng.synchronize()
         same_cube = bool(np.array_equal(out, dout.cpu().numpy(), equal_nan=True))
-        # a frame into fresh numpy arrays against device buffers
+        # a frame into fresh numpy arrays against device buffers (sparse / whole / the library's choice)
+        eng.set_option(_lib.PM_OPT_SPARSE_FRAME, int(rng.integers(-1, 2)))
         fresh = eng.backplanes_img(names)
         dev = {n: torch.empty((ny, nx), dtype=torch.float64, device='cuda') for n in names}
         eng.backplanes_img_device(dev)

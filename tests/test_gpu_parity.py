@@ -533,6 +533,61 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
 
 
+def test_sparse_frame_transfer_equals_the_whole_planes(engine, jupiter, saturn):
+    """
+    Image planes into host memory (pm_hostpipe.hip, PM_OPT_SPARSE_FRAME): the disc planes are NaN
+    outside the radius pre-mask, so only bands of rows around that circle are copied (rectangles) and the
+    copy threads write the NaN - bit-identical to whole-plane copies and to the device buffers, for discs
+    in the middle of, on the edge of and outside the frame, row blocks, pinned and pageable arrays, with
+    planes that are NOT NaN outside the circle (RA, ring radius) in the same call.
+    """
+    import ctypes
+
+    import torch
+
+    from planetmapper_amd import _lib
+    from planetmapper_amd.engine import PLANE_INDEX, plane_mask
+
+    names = ['LON-GRAPHIC', 'EMISSION', 'DISTANCE', 'RA', 'RING-RADIUS', 'LIMB-DISTANCE', 'LOCAL-SOLAR-TIME']
+    cases = [  # nx, ny, x0, y0, r0
+        (2048, 2048, 1023.5, 1023.5, 700.0), (1800, 1300, 400.0, 900.0, 350.0), (1500, 1100, -200.0, 500.0, 400.0),
+        (1400, 1200, 700.0, 1600.0, 300.0), (1300, 1024, 3000.0, 3000.0, 100.0), (900, 1700, 450.0, 850.0, 40.0),
+        (1024, 1024, 511.5, 511.5, 3000.0),
+    ]  # fmt: skip
+    try:
+        for k, (nx, ny, x0, y0, r0) in enumerate(cases):
+            engine.set_geometry(saturn if k % 3 == 2 else jupiter)
+            engine.set_disc(x0, y0, r0, 0.3 * k, nx, ny, True)
+            dev = {n: torch.empty((ny, nx), dtype=torch.float64, device='cuda') for n in names}
+            engine.backplanes_img_device(dev)
+            engine.synchronize()
+            ref = {n: dev[n].cpu().numpy() for n in names}
+            for mode in (1, 0, -1):
+                engine.set_option(_lib.PM_OPT_SPARSE_FRAME, mode)
+                got = engine.backplanes_img(names)
+                for n in names:
+                    assert np.array_equal(got[n], ref[n], equal_nan=True), (k, mode, n)
+            # pinned arrays, and a block of rows
+            engine.set_option(_lib.PM_OPT_SPARSE_FRAME, 1)
+            pin = {n: engine.pinned_empty((ny, nx)) for n in names}
+            ptrs = (ctypes.c_void_p * _lib.NUM_PLANES)()
+            for n, arr in pin.items():
+                arr[...] = -7.0
+                ptrs[PLANE_INDEX[n]] = arr.ctypes.data
+            engine._check(engine._lib.pm_backplanes_img(engine._ctx, plane_mask(names), 0.0, ptrs, _lib.PM_MEM_HOST))
+            for n in names:
+                assert np.array_equal(pin[n], ref[n], equal_nan=True), (k, 'pinned', n)
+            r_lo, r_n = ny // 3, ny // 2
+            blk = {n: np.full((r_n, nx), -7.0) for n in names}
+            for n, arr in blk.items():
+                ptrs[PLANE_INDEX[n]] = arr.ctypes.data
+            engine._check(engine._lib.pm_backplanes_img_rows(engine._ctx, plane_mask(names), 0.0, r_lo, r_n, ptrs, _lib.PM_MEM_HOST))
+            for n in names:
+                assert np.array_equal(blk[n], ref[n][r_lo : r_lo + r_n], equal_nan=True), (k, 'rows', n)
+    finally:
+        engine.set_option(_lib.PM_OPT_SPARSE_FRAME, -1)
+
+
 @pytest.mark.parametrize('dtype', [np.float64, np.float32, np.uint16])
 def test_host_cube_block_table_at_config5_plane_size(engine, oracle, jupiter, dtype):
     """

@@ -13,12 +13,15 @@
 //     run (fresh numpy arrays take their page faults on several cores at once: 74 GB/s with 8
 //     threads against 25 GB/s through the runtime's own pageable path); results -> pinned caller
 //     memory (pm_host_alloc / pm_host_register): one DMA;
+//   * large image planes of the disc (NaN outside the radius pre-mask): only bands of rows around that
+//     circle are copied, as rectangles, and the pool writes the NaN of everything else (d2h_issue_disc:
+//     74 % of the bytes of the headline frame; 12.0 -> 9.9 ms into pinned arrays);
 //   * cube planes, whole (PM_OPT_ZERO_COPY 0, and what the library picks for a map fine enough to
 //     read most of every plane): chunks of planes through a three-slot device ring - the H2D copy of
 //     chunk k + 1, the kernel of chunk k and the D2H copy of finished output overlap on three
 //     streams (4.3 GB cube: 89-94 ms, 46-48 GB/s sustained);
-//   * cube planes, sparse (the default for a coarse map - config 5's 1 deg map reads 14 % of the 16-byte blocks of each
-//     plane): k_mark_blocks runs the sampling code once and flags the 16-byte blocks of a plane it
+//   * cube planes, sparse (the default for a coarse map - config 5's 1 deg map reads 14 % of the
+//     16-byte blocks of each plane): k_mark_blocks runs the sampling code once and flags the 16-byte blocks of a plane it
 //     loads from - the same in every plane; the copy threads collect those blocks of each chunk of
 //     planes into pinned staging (prefetching by hand: scattered reads defeat the hardware
 //     prefetchers) while the DMA of the previous chunk's table runs, and k_reproject_blocks samples
@@ -29,7 +32,8 @@
 //     reprojection kernel gathers from host memory in place (1: uncached 128-byte line requests that
 //     neighbouring waves repeat, 68-71 ms; the result can be stored straight into a pinned output).
 //
-// No compute happens on the CPU here: the threads move bytes.
+// No compute happens on the CPU here: the threads move bytes (and write the constant NaN where the
+// kernels' own pre-mask says nothing else can be).
 #include <emmintrin.h>
 
 #include <atomic>

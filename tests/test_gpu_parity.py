@@ -533,7 +533,7 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         engine.set_option(_lib.PM_OPT_ZERO_COPY, -1)
 
 
-def test_sparse_frame_transfer_equals_the_whole_planes(engine, jupiter, saturn):
+def test_sparse_frame_transfer_equals_the_whole_planes(engine_fg, jupiter, saturn):
     """
     Image planes into host memory (pm_hostpipe.hip, PM_OPT_SPARSE_FRAME): the disc planes are NaN
     outside the radius pre-mask, so only bands of rows around that circle are copied (rectangles) and the
@@ -541,6 +541,7 @@ def test_sparse_frame_transfer_equals_the_whole_planes(engine, jupiter, saturn):
     in the middle of, on the edge of and outside the frame, row blocks, pinned and pageable arrays, with
     planes that are NOT NaN outside the circle (RA, ring radius) in the same call.
     """
+    engine = engine_fg  # both image kernels: the pre-mask is theirs
     import ctypes
 
     import torch
@@ -548,7 +549,7 @@ def test_sparse_frame_transfer_equals_the_whole_planes(engine, jupiter, saturn):
     from planetmapper_amd import _lib
     from planetmapper_amd.engine import PLANE_INDEX, plane_mask
 
-    names = ['LON-GRAPHIC', 'EMISSION', 'DISTANCE', 'RA', 'RING-RADIUS', 'LIMB-DISTANCE', 'LOCAL-SOLAR-TIME']
+    names = ['LON-GRAPHIC', 'EMISSION', 'AZIMUTH', 'DISTANCE', 'DOPPLER', 'RA', 'RING-RADIUS', 'LIMB-DISTANCE', 'LOCAL-SOLAR-TIME']
     cases = [  # nx, ny, x0, y0, r0
         (2048, 2048, 1023.5, 1023.5, 700.0), (1800, 1300, 400.0, 900.0, 350.0), (1500, 1100, -200.0, 500.0, 400.0),
         (1400, 1200, 700.0, 1600.0, 300.0), (1300, 1024, 3000.0, 3000.0, 100.0), (900, 1700, 450.0, 850.0, 40.0),

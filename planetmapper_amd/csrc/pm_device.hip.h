@@ -395,6 +395,10 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
 {
     const double d = dot(u, v);
     const bool mid = fabs(d) < 0.5;
+    // Neighbouring pixels have neighbouring angles: most waves sit wholly inside (or wholly outside)
+    // the 60..120 deg band, and then the half-chord, its square root and every select below are dead
+    // weight. Same operations on the same operands as the general form: the same bits.
+    if (__all(mid)) return kHalfPi - asin_half(d);
     // sin^2 of half the angle to the nearer of v and -v: |u -+ v|^2 / 4 = (1 - |u . v|) / 2 for unit
     // vectors. The short form loses relative accuracy as the angle closes (the 1e-16 of the dot
     // product against 1 - |d|): it is taken while 1 - |d| > 1e-4 in every lane of the wave (angles
@@ -408,6 +412,10 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
         const double sg = (d > 0.0) ? -1.0 : 1.0;
         const V3 w = {fma(sg, v.x, u.x), fma(sg, v.y, u.y), fma(sg, v.z, u.z)};
         s = 0.5 * sqrt_fast(dot(w, w));
+    }
+    if (!__any(mid)) {
+        const double r = asin_half(s);
+        return d > 0.0 ? 2.0 * r : kPi - 2.0 * r;
     }
     const double r = asin_half(mid ? d : s);
     return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);

@@ -175,6 +175,7 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
 {
     const double d = n.z;
     const bool mid = fabs(d) < 0.5;
+    if (__all(mid)) return asin_half(d);  // a wave wholly within 30 deg of the equator (see vsep_fast)
     // (half-chord to the nearer pole: (1 - |n.z|) / 2 while that keeps its accuracy, see vsep_fast)
     const double h = fma(-0.5, fabs(d), 0.5);
     double s;
@@ -183,6 +184,10 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
     } else {
         const double wz = d + ((d > 0.0) ? -1.0 : 1.0);
         s = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
+    }
+    if (!__any(mid)) {
+        const double r = asin_half(s);
+        return d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi);
     }
     const double r = asin_half(mid ? d : s);
     return mid ? r : (d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi));

@@ -8,10 +8,12 @@ One step = one frame through the hot path, everything resident in HBM:
   2. pm_mapped_data      x/y map of the 1 deg rectangular grid (180 x 360) + bilinear reprojection of
                          1 data plane onto it = get_mapped_data (kernel k_mapped_data<f64>; the same
                          results as pm_xy_map + pm_map_cube, kernels k_map_xy + k_reproject)
-With N > 1 GPUs every rank processes its own frame (weak scaling, no data-path collective in
-the backplane stage) and the reprojected planes - one per rank, i.e. the wavelength planes of
-`Observation.get_mapped_data` sharded one per GPU - are combined by ONE RCCL all-gather, the
-only exchange step the path has.
+With N > 1 GPUs every rank processes its own frame and maps its own data plane (weak scaling).
+Frames are independent units: by default NOTHING is exchanged between the ranks in the headline
+step (`config.gather_mapped` false; `--gather-mapped` adds an RCCL all-gather of the N mapped planes
+per step for whoever wants to price it - numbers with and without it are not comparable). The
+collective the north star names belongs to the plane-sharded cube, which is the `cube_host` section
+below: that section, not the headline, is the strong-scaling figure of record.
 
 Beside the headline line the same JSON object carries (rank 0, after the timed region):
   roofline / step_roofline / fp64   the dominant kernel and the whole step against the HBM peak,
@@ -681,6 +683,7 @@ def headline(args) -> None:
                 'parallelism': f'independent frames (and their mapped planes), 1 per GPU x{d.world}'
                 + ('' if d.world == 1 else (', RCCL all-gather of the mapped planes every step' if args.gather_mapped
                                             else ', no collective (the sharded cube with its RCCL all-gather: cube_host)')),
+                'gather_mapped': bool(args.gather_mapped),
                 'streams': 'one' if not args.side_stream else 'frame kernel on the main stream, get_mapped_data (+ all-gather) on a side stream',
                 'preheat_steps': args.preheat_steps,
             },

@@ -270,6 +270,22 @@ int check_ready(pm_ctx *ctx, bool need_disc)
     return PM_OK;
 }
 
+// error return of a host-buffer call that may have copies in flight: drain them first (pm_hostpipe.hip)
+int host_fail(pm_ctx *ctx, int rc)
+{
+    pipe_abort(ctx);
+    return rc;
+}
+
+// `mem` of an entry point: PM_MEM_HOST and PM_MEM_DEVICE everywhere, PM_MEM_HOST_CUBE only where a
+// cube is the one host buffer of the call (pm_map_cube, pm_mapped_data, pm_map_cube_sharded)
+int check_mem(pm_ctx *ctx, int mem, bool host_cube_ok)
+{
+    if (mem == PM_MEM_HOST || mem == PM_MEM_DEVICE || (host_cube_ok && mem == PM_MEM_HOST_CUBE)) return PM_OK;
+    if (mem == PM_MEM_HOST_CUBE) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_MEM_HOST_CUBE applies to cube mapping calls only");
+    return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown mem value %d", mem);
+}
+
 }  // namespace
 
 extern "C" {
@@ -525,6 +541,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
 {
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
+    if ((rc = check_mem(ctx, mem, false)) != PM_OK) return rc;
     if (!out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "out is NULL");
     if (plane_mask & ~kAllBits) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown plane bit in mask");
     if (!std::isfinite(alt)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "alt must be finite");
@@ -619,7 +636,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
                     rc = d2h_issue_disc(ctx, ctx->stream, out[i], p.out[i], (size_t)d.nx, (size_t)n_rows, (double)row_begin, p.x0, p.y0, p.r2);
                 else
                     rc = d2h_issue(ctx, ctx->stream, out[i], p.out[i], npx * sizeof(double));
-                if (rc != PM_OK) return rc;
+                if (rc != PM_OK) return host_fail(ctx, rc);
             }
         return d2h_finish(ctx, ctx->stream);
     }
@@ -631,6 +648,7 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, c
 {
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
+    if ((rc = check_mem(ctx, mem, false)) != PM_OK) return rc;
     if (!out || !lon_deg || !lat_deg) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (plane_mask & ~kAllBits) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown plane bit in mask");
     if (n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative map shape");
@@ -675,7 +693,7 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, c
         for (int i = 0; i < PM_NUM_PLANES; i++)
             if ((plane_mask >> i) & 1) {
                 rc = d2h_issue(ctx, ctx->stream, out[i], p.out[i], n * sizeof(double));
-                if (rc != PM_OK) return rc;
+                if (rc != PM_OK) return host_fail(ctx, rc);
             }
         return d2h_finish(ctx, ctx->stream);
     }
@@ -687,6 +705,7 @@ int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a, con
 {
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
+    if ((rc = check_mem(ctx, mem, false)) != PM_OK) return rc;
     if (from < 0 || from > PM_COORD_LONLAT || to < 0 || to > PM_COORD_LONLAT)
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown coordinate system");
     if (n == 0) return PM_OK;
@@ -727,7 +746,7 @@ int pm_transform(pm_ctx *ctx, int from, int to, uint64_t n, const double *a, con
     PM_HIP(ctx, hipGetLastError());
     rc = d2h_issue(ctx, ctx->stream, out_a, t.oa, n * sizeof(double));
     if (rc == PM_OK) rc = d2h_issue(ctx, ctx->stream, out_b, t.ob, n * sizeof(double));
-    if (rc != PM_OK) return rc;
+    if (rc != PM_OK) return host_fail(ctx, rc);
     return d2h_finish(ctx, ctx->stream);
 }
 
@@ -736,6 +755,7 @@ int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *
 {
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
+    if ((rc = check_mem(ctx, mem, false)) != PM_OK) return rc;
     if (n == 0) return PM_OK;
     if (!ra_deg || !dec_deg || !out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (n > 0xffffffffull * 256ull) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "too many points");
@@ -756,7 +776,7 @@ int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *
     pm_launch_radec_query(p, base, base + n, n, ring_only_visible, base + 2 * n, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
     rc = d2h_issue(ctx, ctx->stream, out, base + 2 * n, n * 8 * sizeof(double));
-    if (rc != PM_OK) return rc;
+    if (rc != PM_OK) return host_fail(ctx, rc);
     return d2h_finish(ctx, ctx->stream);
 }
 
@@ -775,6 +795,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
 {
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
+    if ((rc = check_mem(ctx, mem, true)) != PM_OK) return rc;
     if (!cube || !x_map || !y_map || !out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
     size_t esz = dtype_size(dtype);
     if (esz == 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown dtype %d", dtype);
@@ -941,7 +962,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
         if (rc != PM_OK) return rc;
         rc = d2h_issue(ctx, ctx->stream, out + p0 * nmap, dout, np * nmap * sizeof(double));
         if (rc == PM_OK) rc = d2h_finish(ctx, ctx->stream);
-        if (rc != PM_OK) return rc;
+        if (rc != PM_OK) return host_fail(ctx, rc);
     }
     return PM_OK;
 }
@@ -952,6 +973,7 @@ int pm_mapped_data(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const
 {
     int rc = check_ready(ctx, true);
     if (rc != PM_OK) return rc;
+    if ((rc = check_mem(ctx, mem, true)) != PM_OK) return rc;
     if (!cube || !lon_deg || !lat_deg || !x_map || !y_map || !out) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (!std::isfinite(alt)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "alt must be finite");
     const size_t esz = dtype_size(dtype);
@@ -964,7 +986,8 @@ int pm_mapped_data(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const
     const bool fused = mem == PM_MEM_DEVICE && simple && n_planes >= 1 && n_planes <= 8 && d.nx >= 1 && d.ny >= 1 &&
                        (size_t)n0 * n1 > 0 && !ctx->force_general;
     if (!fused) {
-        rc = pm_xy_map(ctx, lon_deg, lat_deg, n0, n1, alt, x_map, y_map, mem);
+        // (PM_MEM_HOST_CUBE: only the cube is a host buffer - the grids and the maps are device pointers)
+        rc = pm_xy_map(ctx, lon_deg, lat_deg, n0, n1, alt, x_map, y_map, mem == PM_MEM_HOST_CUBE ? PM_MEM_DEVICE : mem);
         if (rc != PM_OK) return rc;
         return pm_map_cube(ctx, cube, dtype, n_planes, x_map, y_map, n0, n1, interpolation, propagate_nan, out, mem);
     }

@@ -38,12 +38,19 @@ Rccl *rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        // PM_RCCL_LIBRARY names the library to bind instead of the default sonames (a site with its own
+        // RCCL build; the tests use it to rehearse the machine without RCCL)
+        const char *override_name = std::getenv("PM_RCCL_LIBRARY");
+        std::string tried;
+        for (const char *name : {override_name, override_name ? nullptr : "librccl.so.1", override_name ? nullptr : "librccl.so"}) {
+            if (!name) continue;
             r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.handle) break;
+            const char *e = dlerror();  // (one call: dlerror() clears the message it returns)
+            if (tried.empty()) tried = e ? e : (std::string(name) + " not found");
         }
         if (!r.handle) {
-            r.error = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "librccl.so.1 not found");
+            r.error = "cannot load RCCL: " + (tried.empty() ? std::string("librccl.so.1 not found") : tried);
             return;
         }
         auto sym = [&](const char *n) {

@@ -397,21 +397,23 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
     const bool mid = fabs(d) < 0.5;
     // Neighbouring pixels have neighbouring angles: most waves sit wholly inside (or wholly outside)
     // the 60..120 deg band, and then the half-chord, its square root and every select below are dead
-    // weight. Same operations on the same operands as the general form: the same bits.
+    // weight. Same operations on the same operands as the general form: the same bits whatever the
+    // wave's other lanes hold (the wave votes below only skip work, they never change a lane's result).
     if (__all(mid)) return kHalfPi - asin_half(d);
     // sin^2 of half the angle to the nearer of v and -v: |u -+ v|^2 / 4 = (1 - |u . v|) / 2 for unit
     // vectors. The short form loses relative accuracy as the angle closes (the 1e-16 of the dot
-    // product against 1 - |d|): it is taken while 1 - |d| > 1e-4 in every lane of the wave (angles
-    // beyond 0.8 deg from 0 / 180: the error stays below 2e-14 rad), the difference form of
-    // CSPICE's vsep_c otherwise.
+    // product against 1 - |d|): a lane takes it while its own 1 - |d| > 1e-4 (angles beyond 0.8 deg
+    // from 0 / 180: the error stays below 2e-14 rad) and the difference form of CSPICE's vsep_c
+    // otherwise. The choice is PER LANE - a point's bits do not depend on which points share its
+    // wave; the difference form is only evaluated in waves where some lane needs it.
     const double h = fma(-0.5, fabs(d), 0.5);
-    double s;
-    if (__all(mid || h > 5e-5)) {
-        s = sqrt_fast(h);
-    } else {
+    const bool close = !mid && !(h > 5e-5);
+    double s = sqrt_fast(h);
+    if (__any(close)) {
         const double sg = (d > 0.0) ? -1.0 : 1.0;
         const V3 w = {fma(sg, v.x, u.x), fma(sg, v.y, u.y), fma(sg, v.z, u.z)};
-        s = 0.5 * sqrt_fast(dot(w, w));
+        const double sd = 0.5 * sqrt_fast(dot(w, w));
+        s = close ? sd : s;
     }
     if (!__any(mid)) {
         const double r = asin_half(s);

@@ -142,6 +142,8 @@ int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_d
 int d2h_issue_disc(pm_ctx *ctx, hipStream_t stream, double *dst_host, const double *src_dev, size_t nx, size_t n_rows, double y_first,
                    double x0, double y0, double r2);
 int d2h_finish(pm_ctx *ctx, hipStream_t stream);
+// after an error in the middle of a host-buffer call: waits until nothing of it is running any more
+void pipe_abort(pm_ctx *ctx);
 int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
                             const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out);
 

@@ -274,13 +274,15 @@ struct HostPipe {
             {
                 std::unique_lock<std::mutex> lk(mu);
                 for (;;) {
-                    if (stop) return;
                     while (!queue.empty() && queue.front()->next.load(std::memory_order_relaxed) >= queue.front()->nparts)
                         queue.pop_front();
                     if (!queue.empty()) {
                         j = queue.front();
                         break;
                     }
+                    // (only with nothing left to hand out: a queued copy-out owns a staging slot that
+                    //  nobody else would ever release)
+                    if (stop) return;
                     cv_work.wait(lk);
                 }
             }
@@ -643,6 +645,25 @@ int d2h_issue_disc(pm_ctx *ctx, hipStream_t stream, double *dst_host, const doub
     return PM_OK;
 }
 
+// An error return in the middle of a pipelined call: nothing of it may still be running when the
+// caller gets its arrays back. Waits for every issued piece (DMA, retire thread, pool jobs) and for the
+// three streams; errors met on the way are dropped - the call already reports one.
+void pipe_abort(pm_ctx *ctx)
+{
+    HostPipe *hp = ctx->pipe;
+    if (hp) {
+        {
+            std::unique_lock<std::mutex> lk(hp->rmu);
+            hp->cv_slot.wait(lk, [&] { return hp->pieces_out == 0; });
+            hp->rerror = hipSuccess;
+        }
+        if (hp->s_in) (void)hipStreamSynchronize(hp->s_in);
+        if (hp->s_out) (void)hipStreamSynchronize(hp->s_out);
+    }
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipGetLastError();
+}
+
 int d2h_finish(pm_ctx *ctx, hipStream_t stream)
 {
     HostPipe *hp = ctx->pipe;
@@ -708,8 +729,19 @@ int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &plan
 // pm_map_cube for host buffers, interpolation nearest / linear with NaN propagation (the default of
 // Observation.get_mapped_data). Caller has validated the arguments and sized ctx->flags.
 // `device_out`: x_map / y_map / out are DEVICE pointers (PM_MEM_HOST_CUBE): only the cube travels.
+static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
+                                        const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out);
+
 int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
                             const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
+{
+    const int rc = map_cube_host_pipelined_impl(ctx, cube, dtype, n_planes, x_map, y_map, nmap, a, out, device_out);
+    if (rc != PM_OK) pipe_abort(ctx);  // (copies / jobs of the failed call must not outlive it)
+    return rc;
+}
+
+static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
+                                        const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
 {
     HostPipe *hp;
     int rc = pipe_get(ctx, &hp);

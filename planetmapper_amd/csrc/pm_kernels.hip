@@ -176,14 +176,14 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
     const double d = n.z;
     const bool mid = fabs(d) < 0.5;
     if (__all(mid)) return asin_half(d);  // a wave wholly within 30 deg of the equator (see vsep_fast)
-    // (half-chord to the nearer pole: (1 - |n.z|) / 2 while that keeps its accuracy, see vsep_fast)
+    // (half-chord to the nearer pole: (1 - |n.z|) / 2 while that keeps its accuracy, chosen per lane: see vsep_fast)
     const double h = fma(-0.5, fabs(d), 0.5);
-    double s;
-    if (__all(mid || h > 5e-5)) {
-        s = sqrt_fast(h);
-    } else {
+    const bool close = !mid && !(h > 5e-5);
+    double s = sqrt_fast(h);
+    if (__any(close)) {
         const double wz = d + ((d > 0.0) ? -1.0 : 1.0);
-        s = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
+        const double sd = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
+        s = close ? sd : s;
     }
     if (!__any(mid)) {
         const double r = asin_half(s);

@@ -74,3 +74,26 @@ def test_c_shard_bounds_equal_the_python_ones():
                 assert lib.pm_shard_bounds(n, world, rank, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)) == 0
                 assert (a.value, b.value, c.value) == shard_bounds(n, world, rank)
     assert lib.pm_shard_bounds(4, 2, 2, None, None, None) == _lib.PM_ERR_INVALID_ARGUMENT
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash():
+    """
+    A box without RCCL: pm_comm_unique_id must return PM_ERR_UNSUPPORTED (the path that used to call
+    dlerror() twice and build a std::string from NULL). Forced with PM_RCCL_LIBRARY, in a child
+    process because the binding is resolved once per process.
+    """
+    import subprocess
+    import sys
+
+    code = (
+        'import ctypes, sys\n'
+        f'sys.path.insert(0, {REPO!r})\n'
+        'from planetmapper_amd import _lib\n'
+        'lib = _lib.load()\n'
+        'buf = ctypes.create_string_buffer(128)\n'
+        'print("rc", lib.pm_comm_unique_id(buf))\n'
+    )
+    env = dict(os.environ, PM_RCCL_LIBRARY='/nonexistent/librccl-missing.so')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert f'rc {_lib.PM_ERR_UNSUPPORTED}' in r.stdout

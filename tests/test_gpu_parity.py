@@ -1551,3 +1551,73 @@ def test_random_geometries_fuzz(engine, oracle):
             _compare(om, rm, oracle.PLANE_NAMES, g, r0=r0)
         except AssertionError as e:
             raise AssertionError(f'case {i} (map): distance {dist:.4g} km, shape {shape}, alt {alt}: {e}') from e
+
+
+def test_mem_argument_is_validated_by_every_entry_point(engine, jupiter):
+    """
+    PM_MEM_HOST_CUBE is meaningful for cube mapping only (the cube is the one host buffer); every
+    other entry point must refuse it - and any unknown value - instead of treating it as PM_MEM_HOST
+    (which would hand device pointers to the CPU copy threads).
+    """
+    import ctypes
+
+    from planetmapper_amd import _lib
+    from planetmapper_amd.engine import plane_mask
+
+    engine.set_geometry(jupiter)
+    engine.set_disc(3.5, 3.5, 3.0, 0.0, 8, 8, True)
+    lib, ctx = engine._lib, engine._ctx
+    buf = np.zeros((4, 64))
+    ptrs = (ctypes.c_void_p * _lib.NUM_PLANES)()
+    ptrs[0] = buf[0].ctypes.data
+    p = lambda k: buf[k].ctypes.data  # noqa: E731
+    for bad in (_lib.PM_MEM_HOST_CUBE, 7, -1):
+        assert lib.pm_backplanes_img(ctx, plane_mask(['LON-GRAPHIC']), 0.0, ptrs, bad) == _lib.PM_ERR_INVALID_ARGUMENT
+        assert lib.pm_backplanes_img_rows(ctx, plane_mask(['LON-GRAPHIC']), 0.0, 0, 8, ptrs, bad) == _lib.PM_ERR_INVALID_ARGUMENT
+        assert lib.pm_backplanes_map(ctx, plane_mask(['LON-GRAPHIC']), p(1), p(2), 8, 8, 0.0, ptrs, bad) == _lib.PM_ERR_INVALID_ARGUMENT
+        assert lib.pm_xy_map(ctx, p(1), p(2), 8, 8, 0.0, p(0), p(3), bad) == _lib.PM_ERR_INVALID_ARGUMENT
+        assert lib.pm_transform(ctx, 0, 1, 64, p(1), p(2), 0.0, 0, p(0), p(3), bad) == _lib.PM_ERR_INVALID_ARGUMENT
+        assert lib.pm_radec_query(ctx, 8, p(1), p(2), 0.0, 1, p(0), bad) == _lib.PM_ERR_INVALID_ARGUMENT
+        with pytest.raises(ValueError):
+            engine._check(lib.pm_transform(ctx, 0, 1, 64, p(1), p(2), 0.0, 0, p(0), p(3), bad))
+    for bad in (7, -1):
+        assert lib.pm_map_cube(ctx, p(0), 0, 1, p(1), p(2), 8, 8, 1, 1, p(3), bad) == _lib.PM_ERR_INVALID_ARGUMENT
+    # the engine still works after the refusals
+    assert np.isfinite(engine.backplanes_img(['LON-GRAPHIC'])['LON-GRAPHIC']).any()
+
+
+def test_a_point_alone_equals_the_same_point_inside_an_array(engine, oracle, jupiter):
+    """
+    Wave votes in the kernels (`__all` / `__any`) may skip work but never decide a lane's result in
+    the vsep / latitude helpers: the incidence / emission / latitude of one map point must come out
+    bit-identical whether it is evaluated alone, in a full wave of neighbours, or next to points on
+    the other side of the body (other tiers of the elementary functions are wave-uniform by design and
+    are held to 2e-13 deg here: pm_fastmath.hip.h sincos_auto).
+    """
+    engine.set_geometry(jupiter)
+    engine.set_disc(140.5, 90.25, 80.0, 0.3, 300, 200, True)
+    rng = np.random.default_rng(12345)
+    names = ['LAT-GRAPHIC', 'INCIDENCE', 'EMISSION', 'PHASE', 'PIXEL-X', 'PIXEL-Y']
+    lon = rng.uniform(0, 360, 512)
+    lat = rng.uniform(-90, 90, 512)
+    # a few points hard against the poles / the sub-observer point: the branch lanes
+    lat[:8] = [89.9999, -89.9999, 89.5, -89.5, 60.0, -60.0, 30.0, -30.0]
+    whole = engine.backplanes_map(names, lon[None, :], lat[None, :])
+    order = rng.permutation(512)
+    shuffled = engine.backplanes_map(names, lon[order][None, :], lat[order][None, :])
+    for i in range(0, 512, 37):
+        alone = engine.backplanes_map(names, lon[i : i + 1][None, :], lat[i : i + 1][None, :])
+        for n in names:
+            a, w = alone[n][0, 0], whole[n][0, i]
+            assert (np.isnan(a) and np.isnan(w)) or abs(a - w) <= 2e-13, (n, i, a, w)
+    inv = np.argsort(order)
+    for n in names:
+        a, b = whole[n][0], shuffled[n][0][inv]
+        assert np.array_equal(np.isnan(a), np.isnan(b)), n
+        assert np.nanmax(np.abs(a - b), initial=0.0) <= 2e-13, n
+    # the image kernel: a 1-row frame through the disc centre against the same row of the full frame
+    engine.set_disc(140.5, 90.0, 80.0, 0.0, 300, 181, True)
+    full = engine.backplanes_img(['LAT-GRAPHIC', 'INCIDENCE', 'EMISSION'])
+    rows = engine.backplanes_img_rows(['LAT-GRAPHIC', 'INCIDENCE', 'EMISSION'], 90, 1)
+    for n in rows:
+        assert np.array_equal(full[n][90], rows[n][0], equal_nan=True), n

@@ -304,9 +304,12 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     BASELINE config 5 as the reference runs it (observation.py:876-905 maps a HOST cube): P x 1024^2
     f64 planes in host memory, contiguous blocks of ceil(P / N) planes per rank
     (`distributed.shard_bounds`), each rank feeding its block from its own pinned host buffer over
-    its own PCIe link (`PM_MEM_HOST_CUBE`: only the 16-byte blocks the map samples cross it), ONE RCCL
-    all-gather of the mapped planes. Returns step times with the host feed and with the block
-    already resident in HBM, max over ranks.
+    its own PCIe link (`PM_MEM_HOST_CUBE`, by the route the library measured fastest on that rank), the
+    mapped planes all-gathered exchange by exchange behind the mapping, a closing agreement on success
+    (`distributed.map_cube_sharded_pipelined`). Returns step times with the host feed and with the block
+    already resident in HBM (mean of the timed region, max over ranks; rank 0's own per-step median /
+    min / max beside it) and, at N = 1, `shard_proxy`: rank 0's step of a 2 / 4 / 8-rank run measured on
+    this GPU, with the scaling it predicts.
     """
     torch = d.torch
     from planetmapper_amd.distributed import shard_bounds
@@ -329,68 +332,152 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     t_pin = time.perf_counter() - t
     torch.from_numpy(cube_h).copy_(cube_d)
     gathered = torch.full((d.world, per_rank, n0, n1), float('nan'), dtype=torch.float64, device=d.dev)
-    mine = gathered[d.rank][:mine_n] if mine_n else None
+
+    from planetmapper_amd.distributed import exchange_planes, map_cube_sharded_pipelined
 
     def step(fed: bool):
+        # the x/y map of the grid, then this rank's planes exchange by exchange: each one mapped,
+        # finished (flag check) and its all-gather started while the next is collected / copied / mapped;
+        # a closing 4-byte agreement on success (distributed.map_cube_sharded_pipelined)
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-        if mine_n:
-            if fed:
-                eng.map_cube_host_to_device(cube_h[:mine_n], xm, ym, n0, n1, mine)
-            else:
-                eng.map_cube_device(cube_d, np.float64, mine_n, xm, ym, n0, n1, mine)
-            eng.synchronize()  # finished (flag check) before peers see it
-        d.all_gather(gathered, gathered[d.rank])
+        map_cube_sharded_pipelined(eng, cube_h if fed else cube_d, np.float64, planes, xm, ym, n0, n1, gathered, d.rank, d.world,
+                                   host_cube=fed)
 
-    def run(fed: bool, steps: int) -> float:
+    def run(fed: bool, steps: int):
         for _ in range(2):
             step(fed)
         d.barrier()
+        own = []
         t0 = time.perf_counter()
         for _ in range(steps):
+            t = time.perf_counter()
             step(fed)
+            d.sync()
+            own.append(time.perf_counter() - t)
         d.barrier()
-        return d.max_over_ranks(time.perf_counter() - t0) / steps
+        return d.max_over_ranks(time.perf_counter() - t0) / steps, own
+
+    def spread(ts) -> dict:
+        return {'median': round(float(np.median(ts)) * 1e3, 3), 'min': round(min(ts) * 1e3, 3), 'max': round(max(ts) * 1e3, 3),
+                'reps': len(ts)}
 
     from planetmapper_amd import _lib
 
-    t_res = run(False, steps_resident)
+    real = hasattr(eng, 'set_option')  # (the CPU rehearsal's engine double has no options)
+    t_res, own_res = run(False, steps_resident)
     ref = gathered.clone()
-    t_fed = run(True, steps_fed)
+    t_fed, own_fed = run(True, steps_fed)
     same = bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+    route = eng.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) if real else None
+    route_ns = {str(r): eng.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(4)} if real else None
+    table_hits = eng.get_option(_lib.PM_OPT_BLOCK_TABLE_HITS) if real else None
     # the same step with the GPU fetching its blocks itself over its own PCIe link (route 2: no copy
     # threads; slower on one GPU, but the leg that is private to each rank when N grows - the copy
     # threads of the default route share the host's memory system)
-    t_fetch = None
-    if hasattr(eng, 'set_option'):
+    t_fetch = own_fetch = None
+    if real:
         eng.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, 2)
         try:
-            t_fetch = run(True, max(2, steps_fed // 4))
+            t_fetch, own_fetch = run(True, max(3, steps_fed // 2))
             same = same and bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
         finally:
             eng.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, -1)
     pix = planes * sz * sz
     block_bytes = mine_n * sz * sz * 8
-    return {
+    sec = {
         'workload': f'host-resident IFU cube {planes}x{sz}x{sz} f64 -> 1 deg map ({n0}x{n1}), bilinear, '
-        f'{per_rank} planes per rank from pinned host memory, RCCL all-gather of the mapped planes'
-        + ('' if d.world > 1 else ' (skipped at N=1)'),
+        f'{per_rank} planes per rank from pinned host memory, pipelined RCCL all-gather of the mapped planes '
+        f'({exchange_planes(per_rank, n0, n1)} planes per exchange) + agreement on success'
+        + ('' if d.world > 1 else ' (no collective at N=1)'),
         'rccl_ranks': d.world,
         'planes': planes,
         'planes_per_rank': per_rank,
         'ms_per_step_host_fed': round(t_fed * 1e3, 3),
         'ms_per_step_resident': round(t_res * 1e3, 4),
         'ms_per_step_host_fed_gpu_fetch': None if t_fetch is None else round(t_fetch * 1e3, 3),
+        'rank0_step_ms_host_fed': spread(own_fed),
+        'rank0_step_ms_resident': spread(own_res),
+        'rank0_step_ms_host_fed_gpu_fetch': None if own_fetch is None else spread(own_fetch),
         'Mpix_s_host_fed': round(pix / t_fed / 1e6, 1),
         'Mpix_s_resident': round(pix / t_res / 1e6, 1),
         'host_feed_GBps_per_rank': round(block_bytes / t_fed / 1e9, 2),
-        'host_feed': 'sparse: the 16-byte blocks of each plane that the map samples (flagged once by the sampling '
-        'kernel) are collected by the copy threads into pinned staging, sent by DMA chunk by chunk and sampled '
-        'from the table in HBM (PM_OPT_ZERO_COPY default)',
+        'host_feed': 'the route the library measured fastest on this rank (PM_OPT_HOST_CUBE_ROUTE -1: three short chunks '
+        'through each candidate on the first call, then the fastest): 3 = the 16-byte blocks of each plane that the map '
+        'samples, collected by the copy threads into pinned staging and sent by DMA; 0 = whole planes by DMA; 2 = 256-byte '
+        'blocks fetched by the GPU itself; block table cached across calls by map fingerprint',
+        'route_chosen': route,
+        'route_ns_per_plane': route_ns,
+        'block_table_cache_hits': table_hits,
         'fed_equals_resident': same,
         'all_gather_bytes_per_rank': per_rank * n0 * n1 * 8,
         'pinned_alloc_ms': round(t_pin * 1e3, 1),
         'scaling': 'strong',
     }
+    if real and d.world == 1 and mine_n >= 16:
+        sec['shard_proxy'] = shard_proxy(eng, step_fed_n=lambda n_local, n_total: _proxy_step(
+            eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local, n_total, gathered), planes=planes, n0=n0, n1=n1, t_n1=t_fed,
+            t_n1_median=float(np.median(own_fed)))
+    return sec
+
+
+def _proxy_step(eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local: int, n_total: int, gathered) -> None:
+    """rank 0's step of an N-rank run on this one GPU: its block, exchange by exchange, no collective"""
+    from planetmapper_amd.distributed import map_cube_sharded_pipelined
+
+    world = -(-n_total // n_local)
+    eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
+    slots = gathered.reshape(-1, n0, n1)[: world * n_local].reshape(world, n_local, n0, n1)
+    map_cube_sharded_pipelined(eng, cube_h[:n_local], np.float64, n_total, xm, ym, n0, n1, slots, 0, world, host_cube=True,
+                               pipeline_chunks=True)
+
+
+def shard_proxy(eng, step_fed_n, planes: int, n0: int, n1: int, t_n1: float, t_n1_median: float) -> dict:
+    """
+    What the sharded host-fed cube would cost rank 0 of an N-GPU run, measured on THIS box: its block of
+    ceil(P / N) planes, cut into the exchanges of the real protocol, fed with the copy threads such a rank
+    gets - (a) cores / N, the library's own rule under a launcher (`LOCAL_WORLD_SIZE`) when the CPU quota
+    of the job does NOT grow with the GPUs, and (b) all of this box's cores, when every rank brings its
+    own quota. Each case lets the library measure its routes afresh (two warm-up steps), then times 7
+    steps. The collective cannot be measured on one GPU: its EXPOSED part - the last exchange only, the
+    others travel behind the mapping - is priced at an ASSUMED 50 GB/s per xGMI link (a third of the
+    153 GB/s link figure of MI355X_MICROARCH.md) + 30 us. Not shared in this proxy: the host's memory
+    system, which N ranks collecting at once would share - that is what the real N = 2, 4, 8 runs add.
+    """
+    from planetmapper_amd import _lib
+    from planetmapper_amd.distributed import exchange_planes
+
+    cores = host_cores()
+    out = {'cores_this_box': cores, 'n1_ms_mean': round(t_n1 * 1e3, 3), 'n1_ms_median': round(t_n1_median * 1e3, 3),
+           'assumed_xgmi_GBps_per_link': 50.0, 'cases': []}
+    try:
+        for n in (2, 4, 8):
+            per = -(-planes // n)
+            for label, threads in (('cores/N', max(2, cores // n)), ('cores', min(16, cores))):
+                eng.set_option(_lib.PM_OPT_HOST_COPY_THREADS, threads)
+                eng.set_option(_lib.PM_OPT_ROUTE_EXPLORE, 1)  # forget what another thread count measured
+                for _ in range(2):
+                    step_fed_n(per, planes)
+                ts = []
+                for _ in range(7):
+                    t = time.perf_counter()
+                    step_fed_n(per, planes)
+                    eng.synchronize()
+                    ts.append(time.perf_counter() - t)
+                k = exchange_planes(per, n0, n1)
+                exposed = k * n0 * n1 * 8 / 50e9 + 30e-6
+                t_med = float(np.median(ts))
+                out['cases'].append({
+                    'N': n, 'planes_per_rank': per, 'copy_threads': threads, 'threads_rule': label,
+                    'route_chosen': eng.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE),
+                    'rank0_ms': {'median': round(t_med * 1e3, 3), 'min': round(min(ts) * 1e3, 3), 'max': round(max(ts) * 1e3, 3)},
+                    'exposed_allgather_ms_assumed': round(exposed * 1e3, 3),
+                    'predicted_step_ms': round((t_med + exposed) * 1e3, 3),
+                    'predicted_scaling': round(t_n1_median / (t_med + exposed), 2),
+                })
+    finally:
+        eng.set_option(_lib.PM_OPT_HOST_COPY_THREADS, 0)
+        eng.set_option(_lib.PM_OPT_ROUTE_EXPLORE, 1)
+    return out
 
 
 def host_path_section(eng, g, sz: int) -> dict:
@@ -406,16 +493,20 @@ def host_path_section(eng, g, sz: int) -> dict:
     nbytes = len(HEADLINE) * sz * sz * 8
     eng.backplanes_img(HEADLINE)
 
-    def best(fn, reps=3):
+    def timed(fn, reps=7):
         ts = []
         for _ in range(reps):
             t = time.perf_counter()
             r = fn()
             ts.append(time.perf_counter() - t)
             del r
-        return min(ts)
+        return ts
 
-    t_fresh = best(lambda: eng.backplanes_img(HEADLINE))
+    def ms(ts) -> dict:
+        return {'median': round(float(np.median(ts)) * 1e3, 2), 'min': round(min(ts) * 1e3, 2), 'max': round(max(ts) * 1e3, 2),
+                'reps': len(ts)}
+
+    t_fresh = timed(lambda: eng.backplanes_img(HEADLINE))
     pinned = {n: eng.pinned_empty((sz, sz)) for n in HEADLINE}
     ptrs = (ctypes.c_void_p * _lib.NUM_PLANES)()
     for n, arr in pinned.items():
@@ -424,26 +515,27 @@ def host_path_section(eng, g, sz: int) -> dict:
     def into_pinned():
         eng._check(eng._lib.pm_backplanes_img(eng._ctx, plane_mask(HEADLINE), 0.0, ptrs, _lib.PM_MEM_HOST))
 
-    t_pin = best(into_pinned)
+    t_pin = timed(into_pinned)
     eng.set_option(_lib.PM_OPT_SPARSE_FRAME, 0)
     try:
-        t_pin_whole = best(into_pinned)
-        t_fresh_whole = best(lambda: eng.backplanes_img(HEADLINE))
+        t_pin_whole = timed(into_pinned, 5)
+        t_fresh_whole = timed(lambda: eng.backplanes_img(HEADLINE), 5)
     finally:
         eng.set_option(_lib.PM_OPT_SPARSE_FRAME, -1)
+    med = lambda ts: float(np.median(ts))  # noqa: E731
     return {
         'frame': f'{sz}x{sz} x {len(HEADLINE)} planes = {nbytes / 1e6:.0f} MB to host',
-        'ms_fresh_numpy_arrays': round(t_fresh * 1e3, 2),
-        'GBps_fresh_numpy_arrays': round(nbytes / t_fresh / 1e9, 1),
-        'ms_pinned_arrays': round(t_pin * 1e3, 2),
-        'GBps_pinned_arrays': round(nbytes / t_pin / 1e9, 1),
+        'ms_fresh_numpy_arrays': ms(t_fresh),
+        'GBps_fresh_numpy_arrays_median': round(nbytes / med(t_fresh) / 1e9, 1),
+        'ms_pinned_arrays': ms(t_pin),
+        'GBps_pinned_arrays_median': round(nbytes / med(t_pin) / 1e9, 1),
         'pcie_gen5_x16_spec_GBps': 63.0,
-        'Mpix_s_fresh_numpy_arrays': round(sz * sz / t_fresh / 1e6, 1),
-        'ms_fresh_numpy_arrays_whole_planes': round(t_fresh_whole * 1e3, 2),
-        'ms_pinned_arrays_whole_planes': round(t_pin_whole * 1e3, 2),
-        'note': 'default transfer: only bands of rows around the radius pre-mask circle cross PCIe (74 % of the bytes of '
-        'this frame), the copy threads write the NaN outside them; the GB/s figures count the bytes DELIVERED, '
-        'so they can exceed the link rate; *_whole_planes = PM_OPT_SPARSE_FRAME 0',
+        'Mpix_s_fresh_numpy_arrays_median': round(sz * sz / med(t_fresh) / 1e6, 1),
+        'ms_fresh_numpy_arrays_whole_planes': ms(t_fresh_whole),
+        'ms_pinned_arrays_whole_planes': ms(t_pin_whole),
+        'note': 'default transfer: only the spans of rows inside the radius pre-mask circle cross PCIe, the copy threads write '
+        'the NaN outside them; the GB/s figures count the bytes DELIVERED, so they can exceed the link rate; '
+        '*_whole_planes = PM_OPT_SPARSE_FRAME 0',
     }
 
 
@@ -724,7 +816,7 @@ def headline(args) -> None:
     if not args.no_extras:
         if d.world == 1 and d.rank == 0:
             line['host_path'] = host_path_section(eng, g, sz)
-        sec = cube_host_section(d, eng, g, args.planes, steps_fed=5, steps_resident=50)
+        sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50)
         if d.rank == 0:
             line['cube_host'] = sec
     if d.rank == 0:

@@ -42,7 +42,8 @@ typedef enum pm_status {
     PM_ERR_HIP = -3,              /* a HIP call failed; see pm_last_error */
     PM_ERR_STATE = -4,            /* geometry or disc not set yet */
     PM_ERR_ALLOC = -5,
-    PM_ERR_UNSUPPORTED = -6       /* valid in the reference, not implemented here yet */
+    PM_ERR_UNSUPPORTED = -6,      /* valid in the reference, not implemented here yet */
+    PM_ERR_PEER = -7              /* pm_map_cube_sharded: another rank failed; the gathered result is not valid */
 } pm_status;
 
 /* PM_MEM_HOST_CUBE (pm_map_cube only): `cube` is a HOST pointer, x_map / y_map / out are DEVICE
@@ -226,8 +227,14 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           3 = the same table in 16-byte blocks, collected by the copy threads
  *                               into pinned staging and sent by DMA - any host memory; the link
  *                               carries little more than the sampled pixels;
- *                          -1 (default) = the library chooses: 3 when the table is under 40 % of
- *                               the size of the planes, else 0.
+ *                          -1 (default) = the library chooses, per context (i.e. per rank of a sharded
+ *                               cube), the route that MEASURED fastest on the problem at hand: the first
+ *                               call with enough planes feeds three short chunks through each candidate
+ *                               (3, 0, and 2 for a pinned cube), times them, and maps the rest - and
+ *                               every later call on the same plane size / map / memory kind / thread
+ *                               count - by the fastest (results are bit-identical whatever the route).
+ *                               Until then: 3 when the table is under 40 % of the size of the planes,
+ *                               else 0.
  *                           (1 and 2 on pageable memory, 2 and 3 on planes that are not a whole
  *                           number of blocks: as 0.)
  *   PM_OPT_SPARSE_FRAME     image planes into host memory (pm_backplanes_img, PM_MEM_HOST): the planes of
@@ -236,6 +243,22 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           threads write the NaN around them; 0 = whole planes; -1 (default) = 1 for
  *                           planes of 64 MiB and more of which the circle covers under 85 % (smaller
  *                           planes gain nothing: measured).
+ *   PM_OPT_BLOCK_TABLE_CACHE 1 (default): the block table of routes 2 / 3 (which blocks of a plane the map
+ *                           samples, their numbering, the list the copy threads walk) is kept in the
+ *                           context and reused by later calls with the same x/y map (compared by a 128-bit
+ *                           fingerprint computed on the GPU), plane shape, element size and sampling mode -
+ *                           as the reference keeps its x/y map between planes (body_xy.py:3478). 0: rebuilt
+ *                           by every call.
+ *   PM_OPT_BLOCK_TABLE_HITS read-only: calls that reused the cached table since the context was created.
+ *   PM_OPT_ROUTE_EXPLORE    1 (default): measure the candidate routes as described under
+ *                           PM_OPT_HOST_CUBE_ROUTE -1; 0: choose by table size only. Setting it (to either
+ *                           value) forgets what has been measured.
+ *   PM_OPT_LAST_CUBE_ROUTE  read-only: the route (0..3) the latest host-cube call ended on, -1 none yet.
+ *   PM_OPT_LAST_REDO_PLANES read-only: how many planes of the latest FINISHED nearest / linear pm_map_cube were
+ *                           mapped a second time with their nanmedian (the values the first pass stored for
+ *                           them were provisional).
+ *   PM_OPT_ROUTE_NS_PER_PLANE + r  read-only: measured cost of route r on the current problem, ns per plane of
+ *                           the whole pipeline (0: not measured).
  *   PM_OPT_LAST_DISC_KERNEL read-only (pm_get_option): which kernel the latest image-plane call
  *                           dispatched for the planes that need the intercept: 0 none yet,
  *                           1 spheroid fast path, 2 its triaxial variant, 3 general kernel.
@@ -247,10 +270,30 @@ typedef enum pm_option {
     PM_OPT_ZERO_COPY = 4,
     PM_OPT_HOST_CUBE_ROUTE = 4,
     PM_OPT_LAST_DISC_KERNEL = 5,
-    PM_OPT_SPARSE_FRAME = 6
+    PM_OPT_SPARSE_FRAME = 6,
+    PM_OPT_BLOCK_TABLE_CACHE = 7,
+    PM_OPT_BLOCK_TABLE_HITS = 8,
+    PM_OPT_ROUTE_EXPLORE = 9,
+    PM_OPT_LAST_CUBE_ROUTE = 10,
+    PM_OPT_LAST_REDO_PLANES = 11,
+    PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..3 */
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);
 int pm_get_option(pm_ctx *ctx, int option, int64_t *value);
+
+/*
+ * Progress of a nearest / linear pm_map_cube (no reference counterpart: the reference's plane loop,
+ * observation.py:892-904, reports through its progress hook, base.py:773-783). `cb(user, first, n)` is
+ * called ON THE CALLING THREAD, inside pm_map_cube, each time the kernels of planes [first, first + n)
+ * have been enqueued on the context stream - planes arrive in order, once each - so that a caller can
+ * queue work behind them (an event on pm_stream(), then a collective on another stream) while later
+ * planes are still being collected and copied in. What those kernels store is provisional for planes that
+ * turn out to need their nanmedian: after the call has finished (pm_synchronize() for device buffers)
+ * PM_OPT_LAST_REDO_PLANES says whether any were redone. cb = NULL removes the callback. The callback must
+ * not call back into the same context.
+ */
+typedef void (*pm_chunk_callback)(void *user, int first_plane, int n_planes);
+int pm_set_chunk_callback(pm_ctx *ctx, pm_chunk_callback cb, void *user);
 
 /*
  * Pinned (page-locked) host memory. PM_MEM_HOST calls accept any host pointer; buffers that
@@ -402,12 +445,24 @@ int pm_mapped_data(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const
  * with mem = PM_MEM_HOST_CUBE - each rank feeds its block over its own PCIe link - or HBM with
  * PM_MEM_DEVICE); x_map / y_map / out_all are device pointers; out_all has room for
  * world * per_rank * n0 * n1 doubles, block r at out_all + r * per_rank * n0 * n1 (planes beyond P
- * are NaN padding). With gather != 0 the all-gather is enqueued on the context stream
- * (pm_synchronize() waits for it); with gather == 0, or comm == NULL (single process), only this
- * rank's block is written - no collective (each rank keeps / writes its slice).
+ * are NaN padding). With gather != 0 the block is cut into exchanges of
+ * pm_exchange_planes(per_rank, n0, n1) planes (a function of shapes only: every rank issues the same
+ * sequence): each exchange is mapped, finished (flag check / nanmedian replay) and then sent to / received
+ * from every peer on the communicator's own stream (ncclSend / ncclRecv in one group: an all-gather
+ * whose pieces land rank-major), so exchange k crosses xGMI while exchange k + 1 is collected, copied
+ * and mapped. A rank whose mapping fails still takes part in every exchange, and a closing 4-byte
+ * all-reduce of the ranks' status codes makes every rank return an error if any rank had one (its own
+ * code, PM_ERR_PEER for a failure elsewhere): no rank is left waiting in a collective and the gathered
+ * cube is valid everywhere or nowhere. The call returns when out_all is complete on this rank.
+ * With gather == 0, or comm == NULL (single process), only this rank's block is written - no
+ * collective (each rank keeps / writes its slice). mem = PM_MEM_HOST (gather == 0 only):
+ * everything is host memory and out_all is the caller's whole (P, n0, n1) array, e.g. ONE array in
+ * shared memory for all ranks - this rank writes planes [start, stop) of it and nothing else.
  */
 typedef struct pm_comm pm_comm; /* opaque */
 int pm_shard_bounds(int n_planes, int world, int rank, int *start, int *stop, int *per_rank);
+/* planes per exchange of the pipelined all-gather (>= 1; at most 8 exchanges of at least 4 MiB each) */
+int pm_exchange_planes(int per_rank, int n0, int n1);
 int pm_comm_unique_id(void *id128);
 int pm_comm_create(pm_ctx *ctx, int world, int rank, const void *id128, pm_comm **comm);
 int pm_comm_destroy(pm_comm *comm);

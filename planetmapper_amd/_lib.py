@@ -35,6 +35,7 @@ PM_ERR_HIP = -3
 PM_ERR_STATE = -4
 PM_ERR_ALLOC = -5
 PM_ERR_UNSUPPORTED = -6
+PM_ERR_PEER = -7
 
 PM_MEM_HOST = 0
 PM_MEM_DEVICE = 1
@@ -57,7 +58,7 @@ EXPORTS = (
     'pm_set_smooth_options', 'pm_backplanes_img_rows', 'pm_set_spline_smoothing', 'pm_radec_query',
     'pm_set_option', 'pm_get_option', 'pm_host_alloc', 'pm_host_free', 'pm_host_register',
     'pm_host_unregister', 'pm_shard_bounds', 'pm_comm_unique_id', 'pm_comm_create', 'pm_comm_destroy',
-    'pm_map_cube_sharded', 'pm_mapped_data',
+    'pm_map_cube_sharded', 'pm_mapped_data', 'pm_exchange_planes', 'pm_set_chunk_callback',
 )  # fmt: skip
 
 PM_OPT_GENERAL_KERNEL = 1
@@ -67,6 +68,16 @@ PM_OPT_ZERO_COPY = 4
 PM_OPT_HOST_CUBE_ROUTE = 4  # the same option under the name that says what it selects
 PM_OPT_LAST_DISC_KERNEL = 5
 PM_OPT_SPARSE_FRAME = 6
+PM_OPT_BLOCK_TABLE_CACHE = 7
+PM_OPT_BLOCK_TABLE_HITS = 8
+PM_OPT_ROUTE_EXPLORE = 9
+PM_OPT_LAST_CUBE_ROUTE = 10
+PM_OPT_LAST_REDO_PLANES = 11
+PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..3
+
+
+# pm_chunk_callback: void (*)(void *user, int first_plane, int n_planes)
+CHUNK_CALLBACK = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 
 
 class LibraryNotBuiltError(ImportError):
@@ -83,6 +94,10 @@ class EngineError(RuntimeError):
 
 class UnsupportedError(NotImplementedError):
     pass
+
+
+class PeerFailedError(EngineError):
+    """A sharded call failed on ANOTHER rank: the gathered result is not valid on this one either."""
 
 
 _lib = None
@@ -156,6 +171,8 @@ def load() -> ctypes.CDLL:
     lib.pm_host_unregister.argtypes = [vp, vp]
     ip = ctypes.POINTER(c_int)
     lib.pm_shard_bounds.argtypes = [c_int, c_int, c_int, ip, ip, ip]
+    lib.pm_exchange_planes.argtypes = [c_int, c_int, c_int]
+    lib.pm_set_chunk_callback.argtypes = [vp, vp, vp]
     lib.pm_comm_unique_id.argtypes = [vp]
     lib.pm_comm_create.argtypes = [vp, c_int, c_int, vp, ctypes.POINTER(vp)]
     lib.pm_comm_destroy.argtypes = [vp]

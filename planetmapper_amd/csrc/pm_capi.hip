@@ -408,8 +408,28 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         if (value < -1 || value > 1) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SPARSE_FRAME takes -1, 0 or 1");
         ctx->sparse_frame = (int)value;
         return PM_OK;
+    case PM_OPT_BLOCK_TABLE_CACHE:
+        ctx->table_cache = value != 0;
+        return PM_OK;
+    case PM_OPT_ROUTE_EXPLORE:
+        ctx->route_explore = value != 0;
+        pipe_reset_route_stats(ctx);  // (what was measured is forgotten: the next large call measures again)
+        return PM_OK;
+    case PM_OPT_BLOCK_TABLE_HITS:
+    case PM_OPT_LAST_CUBE_ROUTE:
+    case PM_OPT_LAST_REDO_PLANES:
+    case PM_OPT_LAST_DISC_KERNEL:
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "option %d is read-only", option);
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
+}
+
+int pm_set_chunk_callback(pm_ctx *ctx, pm_chunk_callback cb, void *user)
+{
+    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
+    ctx->chunk_cb = cb;
+    ctx->chunk_user = cb ? user : nullptr;
+    return PM_OK;
 }
 
 int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
@@ -422,6 +442,15 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_ZERO_COPY: *value = ctx->zero_copy; return PM_OK;
     case PM_OPT_SPARSE_FRAME: *value = ctx->sparse_frame; return PM_OK;
     case PM_OPT_LAST_DISC_KERNEL: *value = ctx->last_disc_kernel; return PM_OK;
+    case PM_OPT_BLOCK_TABLE_CACHE: *value = ctx->table_cache; return PM_OK;
+    case PM_OPT_BLOCK_TABLE_HITS: *value = pipe_table_hits(ctx); return PM_OK;
+    case PM_OPT_ROUTE_EXPLORE: *value = ctx->route_explore; return PM_OK;
+    case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
+    case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
+    }
+    if (option >= PM_OPT_ROUTE_NS_PER_PLANE && option < PM_OPT_ROUTE_NS_PER_PLANE + 4) {
+        *value = pipe_route_ns_per_plane(ctx, option - PM_OPT_ROUTE_NS_PER_PLANE);
+        return PM_OK;
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
 }

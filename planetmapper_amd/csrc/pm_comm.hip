@@ -21,14 +21,20 @@ typedef struct ncclComm *ncclComm_t;
 struct ncclUniqueId {
     char internal[128];
 };
-enum { ncclSuccess = 0, ncclFloat64 = 8 };
+enum { ncclSuccess = 0, ncclInt32 = 2, ncclFloat64 = 8, ncclSum = 0 };
 
 struct Rccl {
     void *handle = nullptr;
     int (*GetUniqueId)(ncclUniqueId *) = nullptr;
     int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     int (*CommDestroy)(ncclComm_t) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -61,7 +67,13 @@ Rccl *rccl()
         r.GetUniqueId = (int (*)(ncclUniqueId *))sym("ncclGetUniqueId");
         r.CommInitRank = (int (*)(ncclComm_t *, int, ncclUniqueId, int))sym("ncclCommInitRank");
         r.CommDestroy = (int (*)(ncclComm_t))sym("ncclCommDestroy");
+        r.CommAbort = (int (*)(ncclComm_t))sym("ncclCommAbort");
         r.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t, hipStream_t))sym("ncclAllGather");
+        r.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclAllReduce");
+        r.Send = (int (*)(const void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclSend");
+        r.Recv = (int (*)(void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclRecv");
+        r.GroupStart = (int (*)())sym("ncclGroupStart");
+        r.GroupEnd = (int (*)())sym("ncclGroupEnd");
         r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
     });
     return &r;
@@ -73,7 +85,39 @@ struct pm_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
     pm_ctx *ctx = nullptr;
+    // the exchange runs on its own stream, next to the mapping of the following chunk
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done = nullptr;
+    int *d_status = nullptr;  // [0..1] this rank's (failed, redone) flags, [2..3] their sums over the ranks
+    int *h_status = nullptr;  // pinned mirror
+    bool broken = false;      // a collective failed: the communicator has been aborted
 };
+
+namespace {
+
+// planes per exchange of the pipelined all-gather: a function of the block size and the map size ONLY,
+// so that every rank issues the same sequence of collectives whatever its own block, memory or route
+int exchange_planes(int per_rank, size_t nmap)
+{
+    if (per_rank <= 0) return 1;
+    const size_t by_count = ((size_t)per_rank + 7) / 8;                               // at most 8 exchanges
+    const size_t by_bytes = (((size_t)4 << 20) + nmap * sizeof(double) - 1) / std::max<size_t>(nmap * sizeof(double), 1);  // of >= 4 MiB
+    return (int)std::min<size_t>((size_t)per_rank, std::max<size_t>(std::max(by_count, by_bytes), 1));
+}
+
+int nccl_fail(pm_ctx *ctx, pm_comm *comm, const char *what, int nrc)
+{
+    Rccl *r = rccl();
+    // peers blocked in the same collective are released by tearing the communicator down
+    if (comm && comm->comm && r->CommAbort && !comm->broken) {
+        (void)r->CommAbort(comm->comm);
+        comm->comm = nullptr;
+        comm->broken = true;
+    }
+    return pmh::fail(ctx, PM_ERR_HIP, "%s failed: %s", what, r->GetErrorString ? r->GetErrorString(nrc) : "?");
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -87,6 +131,12 @@ int pm_shard_bounds(int n_planes, int world, int rank, int *start, int *stop, in
     if (stop) *stop = (int)b;
     if (per_rank) *per_rank = pr;
     return PM_OK;
+}
+
+int pm_exchange_planes(int per_rank, int n0, int n1)
+{
+    if (per_rank < 0 || n0 < 0 || n1 < 0) return PM_ERR_INVALID_ARGUMENT;
+    return exchange_planes(per_rank, (size_t)n0 * n1);
 }
 
 int pm_comm_unique_id(void *id128)
@@ -118,6 +168,14 @@ int pm_comm_create(pm_ctx *ctx, int world, int rank, const void *id128, pm_comm 
     c->world = world;
     c->rank = rank;
     c->ctx = ctx;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&c->d_status, 4 * sizeof(int)) != hipSuccess ||
+        hipHostMalloc((void **)&c->h_status, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        pm_comm_destroy(c);
+        return pmh::fail(ctx, PM_ERR_HIP, "could not create the exchange stream of the communicator");
+    }
     *comm = c;
     return PM_OK;
 }
@@ -130,48 +188,174 @@ int pm_comm_destroy(pm_comm *comm)
         (void)hipSetDevice(comm->ctx->device);
         (void)hipStreamSynchronize(comm->ctx->stream);
     }
+    if (comm->stream) (void)hipStreamSynchronize(comm->stream);
     if (comm->comm && r->CommDestroy) (void)r->CommDestroy(comm->comm);
+    if (comm->ev_ready) (void)hipEventDestroy(comm->ev_ready);
+    if (comm->ev_done) (void)hipEventDestroy(comm->ev_done);
+    if (comm->d_status) (void)hipFree(comm->d_status);
+    if (comm->h_status) (void)hipHostFree(comm->h_status);
+    if (comm->stream) (void)hipStreamDestroy(comm->stream);
     delete comm;
     return PM_OK;
 }
 
+}  // extern "C"
+
+namespace {
+
+// the exchanges of one pm_map_cube_sharded call: issued in order, each as soon as the kernels of its
+// planes are on the context stream (pm_set_chunk_callback), on the communicator's own stream
+struct Exchanger {
+    pm_ctx *ctx;
+    pm_comm *comm;
+    double *out_all, *mine;
+    size_t nmap;
+    int per_rank, mine_n, step;
+    int next_e0 = 0;  // first plane of the next exchange to issue
+    int nrc = ncclSuccess;
+    hipError_t herr = hipSuccess;
+
+    bool failed() const { return nrc != ncclSuccess || herr != hipSuccess; }
+    // one group of sends / receives: planes [e0, e1) of every rank's block, behind the context stream
+    void issue(int e0, int e1)
+    {
+        if (failed()) return;
+        Rccl *r = rccl();
+        herr = hipEventRecord(comm->ev_ready, ctx->stream);
+        if (herr == hipSuccess) herr = hipStreamWaitEvent(comm->stream, comm->ev_ready, 0);
+        if (herr != hipSuccess) return;
+        const size_t count = (size_t)(e1 - e0) * nmap;
+        nrc = r->GroupStart();
+        for (int peer = 0; peer < comm->world && nrc == ncclSuccess; peer++) {
+            if (peer == comm->rank) continue;
+            nrc = r->Send(mine + (size_t)e0 * nmap, count, ncclFloat64, peer, comm->comm, comm->stream);
+            if (nrc == ncclSuccess)
+                nrc = r->Recv(out_all + ((size_t)peer * per_rank + e0) * nmap, count, ncclFloat64, peer, comm->comm, comm->stream);
+        }
+        const int erc = r->GroupEnd();
+        if (nrc == ncclSuccess) nrc = erc;
+    }
+    // planes [0, done) of this rank's block have their kernels enqueued: issue what has become ready
+    void progress(int done)
+    {
+        while (next_e0 < per_rank) {
+            const int e1 = std::min(next_e0 + step, per_rank);
+            if (std::min(e1, mine_n) > done) break;  // (planes beyond mine_n are padding, written up front)
+            issue(next_e0, e1);
+            next_e0 = e1;
+        }
+    }
+    static void on_chunk(void *user, int first, int n) { ((Exchanger *)user)->progress(first + n); }
+};
+
+}  // namespace
+
+extern "C" {
+
+// The sharded form of Observation._get_mapped_data (observation.py:876-905). Protocol with gather != 0
+// and more than one rank - the same sequence of collectives on every rank whatever happens on it:
+//   1. the block is cut into exchanges of pm_exchange_planes(per_rank, n0, n1) planes (a function of
+//      shapes only);
+//   2. ONE pm_map_cube maps the block (its own pipeline - collecting / copying in chunk k + 1 while chunk
+//      k is mapped - stays whole); each time the kernels of further planes are on the context stream
+//      (pm_set_chunk_callback) the exchanges they complete are issued on the communicator's own stream:
+//      one group of ncclSend / ncclRecv with every peer (an all-gather whose pieces land rank-major in
+//      out_all), so exchange k crosses xGMI while the planes of exchange k + 1 are still on their way in;
+//   3. when the mapping has finished (flag check, nanmedian replay) any exchange not yet issued - a rank
+//      without planes, a rank whose mapping FAILED - is issued all the same: nobody is left waiting;
+//   4. one 8-byte all-reduce closes the call: (ranks that failed, ranks that had to redo planes with their
+//      nanmedian after those planes had been sent). Any failure: every rank returns an error (its own
+//      code, PM_ERR_PEER for a failure elsewhere) - the gathered cube is valid on all ranks or on none.
+//      Any redo (rare: +-inf pixels): every rank sends its whole block once more.
 int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int dtype, int n_planes_total,
                         const double *x_map, const double *y_map, int n0, int n1, int interpolation, int propagate_nan,
                         double *out_all, int mem, int gather)
 {
     if (!ctx || !out_all) return PM_ERR_INVALID_ARGUMENT;
-    if (mem != PM_MEM_DEVICE && mem != PM_MEM_HOST_CUBE)
-        return pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT, "pm_map_cube_sharded takes PM_MEM_DEVICE or PM_MEM_HOST_CUBE");
     const int world = comm ? comm->world : 1, rank = comm ? comm->rank : 0;
     if (comm && comm->ctx != ctx) return pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT, "communicator belongs to another context");
+    if (comm && comm->broken) return pmh::fail(ctx, PM_ERR_STATE, "the communicator was aborted by an earlier failure");
+    const bool exchange = gather && world > 1 && comm;
+    // (argument errors every rank sees alike are returned at once; what can differ between ranks goes
+    //  through the agreement below)
+    if (mem != PM_MEM_DEVICE && mem != PM_MEM_HOST_CUBE && !(mem == PM_MEM_HOST && !gather))
+        return pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT,
+                         "pm_map_cube_sharded takes PM_MEM_DEVICE or PM_MEM_HOST_CUBE (PM_MEM_HOST with gather = 0 only)");
     int a = 0, b = 0, per_rank = 0;
     if (pm_shard_bounds(n_planes_total, world, rank, &a, &b, &per_rank) != PM_OK || n0 < 0 || n1 < 0)
         return pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT, "invalid shard request");
     const size_t nmap = (size_t)n0 * n1;
     if (n_planes_total == 0 || nmap == 0) return PM_OK;
-    double *mine = out_all + (size_t)rank * per_rank * nmap;
-    if (b > a) {
+    const int mine_n = b - a;
+    if (mem == PM_MEM_HOST) {
+        // every rank writes its planes into the caller's (P, n0, n1) host array - e.g. one array in shared
+        // memory for all ranks: no collective at all (SURVEY 8e "each rank copies its slice")
+        if (mine_n == 0) return PM_OK;
         if (!local_cube) return pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT, "local_cube is NULL but this rank owns planes");
-        int rc = pm_map_cube(ctx, local_cube, dtype, b - a, x_map, y_map, n0, n1, interpolation, propagate_nan, mine, mem);
-        if (rc != PM_OK) return rc;
+        return pm_map_cube(ctx, local_cube, dtype, mine_n, x_map, y_map, n0, n1, interpolation, propagate_nan,
+                           out_all + (size_t)a * nmap, PM_MEM_HOST);
     }
+    double *mine = out_all + (size_t)rank * per_rank * nmap;
+    Rccl *r = rccl();
     // planes of a short last block: NaN padding, so that the gathered buffer is defined everywhere
-    if (b - a < per_rank) {
-        const size_t pad = (size_t)(per_rank - (b - a)) * nmap;
+    if (mine_n < per_rank) {
+        const size_t pad = (size_t)(per_rank - mine_n) * nmap;
         std::vector<double> nanrow(std::min<size_t>(pad, nmap), std::nan(""));
         for (size_t off = 0; off < pad; off += nanrow.size())
-            PM_HIP(ctx, hipMemcpyAsync(mine + (size_t)(b - a) * nmap + off, nanrow.data(),
-                                       std::min(nanrow.size(), pad - off) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            PM_HIP(ctx, hipMemcpyAsync(mine + (size_t)mine_n * nmap + off, nanrow.data(), std::min(nanrow.size(), pad - off) * sizeof(double),
+                                       hipMemcpyHostToDevice, ctx->stream));
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     }
-    // the mapped planes are final only after the flag check / nanmedian replay: finish before peers see them
-    int rc = pm_synchronize(ctx);
-    if (rc != PM_OK) return rc;
-    if (!gather || world == 1 || !comm) return PM_OK;
-    Rccl *r = rccl();
-    const int nrc = r->AllGather(mine, out_all, (size_t)per_rank * nmap, ncclFloat64, comm->comm, ctx->stream);
-    if (nrc != ncclSuccess)
-        return pmh::fail(ctx, PM_ERR_HIP, "ncclAllGather failed: %s", r->GetErrorString ? r->GetErrorString(nrc) : "?");
+    Exchanger ex{ctx, comm, out_all, mine, nmap, per_rank, mine_n, exchange ? exchange_planes(per_rank, nmap) : std::max(per_rank, 1)};
+    int status = PM_OK;
+    if (mine_n > 0) {
+        if (!local_cube) {
+            status = pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT, "local_cube is NULL but this rank owns planes");
+        } else {
+            void (*saved_cb)(void *, int, int) = ctx->chunk_cb;
+            void *saved_user = ctx->chunk_user;
+            if (exchange) {
+                ctx->chunk_cb = &Exchanger::on_chunk;
+                ctx->chunk_user = &ex;
+            }
+            status = pm_map_cube(ctx, local_cube, dtype, mine_n, x_map, y_map, n0, n1, interpolation, propagate_nan, mine, mem);
+            ctx->chunk_cb = saved_cb;
+            ctx->chunk_user = saved_user;
+            // the mapped planes are final only after the flag check / nanmedian replay
+            if (status == PM_OK) status = pm_synchronize(ctx);
+        }
+    }
+    const std::string first_error = status != PM_OK ? ctx->error : std::string();
+    if (!exchange) return status;
+    ex.progress(per_rank);  // whatever has not been sent yet (no planes here, or a failed mapping)
+    if (ex.herr != hipSuccess) return pmh::fail(ctx, PM_ERR_HIP, "ordering the exchange failed: %s", hipGetErrorString(ex.herr));
+    if (ex.nrc != ncclSuccess) return nccl_fail(ctx, comm, "exchange of mapped planes (ncclSend / ncclRecv)", ex.nrc);
+    // the agreement: (failed ranks, ranks that redid planes after sending them)
+    comm->h_status[0] = status != PM_OK ? 1 : 0;
+    comm->h_status[1] = (status == PM_OK && mine_n > 0 && ctx->last_redo_planes > 0) ? 1 : 0;
+    PM_HIP(ctx, hipMemcpyAsync(comm->d_status, comm->h_status, 2 * sizeof(int), hipMemcpyHostToDevice, comm->stream));
+    int nrc = r->AllReduce(comm->d_status, comm->d_status + 2, 2, ncclInt32, ncclSum, comm->comm, comm->stream);
+    if (nrc != ncclSuccess) return nccl_fail(ctx, comm, "ncclAllReduce of the ranks' status", nrc);
+    PM_HIP(ctx, hipMemcpyAsync(comm->h_status + 2, comm->d_status + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, comm->stream));
+    PM_HIP(ctx, hipStreamSynchronize(comm->stream));
+    const int n_failed = comm->h_status[2], n_redo = comm->h_status[3];
+    if (n_failed == 0 && n_redo > 0) {
+        // somebody's planes changed after they had been sent: everybody sends the whole block again
+        ex.nrc = ncclSuccess;
+        ex.issue(0, per_rank);
+        if (ex.herr != hipSuccess) return pmh::fail(ctx, PM_ERR_HIP, "ordering the exchange failed: %s", hipGetErrorString(ex.herr));
+        if (ex.nrc != ncclSuccess) return nccl_fail(ctx, comm, "second exchange of mapped planes", ex.nrc);
+    }
+    // pm_synchronize() / later work on the context stream waits for the exchange; so does this call
+    PM_HIP(ctx, hipEventRecord(comm->ev_done, comm->stream));
+    PM_HIP(ctx, hipStreamWaitEvent(ctx->stream, comm->ev_done, 0));
+    PM_HIP(ctx, hipStreamSynchronize(comm->stream));
+    if (status != PM_OK) {
+        ctx->error = first_error;
+        return status;
+    }
+    if (n_failed > 0)
+        return pmh::fail(ctx, PM_ERR_PEER, "%d other rank(s) failed to map their planes: the gathered cube is not valid", n_failed);
     return PM_OK;
 }
 

@@ -31,6 +31,7 @@ void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int shift, int dtype, hipStream_t s);
 void pm_launch_number_blocks(const unsigned char *flags, size_t n_blk, int *tile_sums, int *blkmap, int *blklist, int *total,
                              hipStream_t s);
+void pm_launch_hash_maps(const double *x_map, const double *y_map, int n, unsigned long long *out, hipStream_t s);
 void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s, bool fetch);
 void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat, double *xo,
                            double *yo, int dtype, hipStream_t s);
@@ -102,6 +103,14 @@ struct pm_ctx {
     int host_copy_threads = 0;   // 0: the library's choice (pm_hostpipe.hip)
     int zero_copy = -1;          // PM_OPT_ZERO_COPY
     int sparse_frame = -1;       // PM_OPT_SPARSE_FRAME
+    int table_cache = 1;         // PM_OPT_BLOCK_TABLE_CACHE
+    int route_explore = 1;       // PM_OPT_ROUTE_EXPLORE
+    int last_cube_route = -1;    // PM_OPT_LAST_CUBE_ROUTE
+    int last_redo_planes = 0;    // PM_OPT_LAST_REDO_PLANES: planes of the latest finished pm_map_cube redone with their nanmedian
+    // pm_set_chunk_callback: told, on the calling thread, each time the kernels of further planes of a
+    // nearest / linear pm_map_cube have been ENQUEUED on the context stream (planes arrive in order)
+    void (*chunk_cb)(void *, int, int) = nullptr;
+    void *chunk_user = nullptr;
     pmh::HostPipe *pipe = nullptr;
 };
 
@@ -134,6 +143,10 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
 
 // pm_hostpipe.hip: the host <-> HBM leg of PM_MEM_HOST calls
 void pipe_destroy(pm_ctx *ctx);
+// counters / measurements of the host pipe for pm_get_option (0 when the pipe does not exist yet)
+long pipe_table_hits(const pm_ctx *ctx);
+long pipe_route_ns_per_plane(const pm_ctx *ctx, int route);
+void pipe_reset_route_stats(pm_ctx *ctx);
 bool host_is_pinned(const void *p, size_t bytes);
 // dst_host <- src_dev on `stream` (staged through pinned buffers + copy threads for pageable
 // destinations); d2h_finish completes every issued copy and synchronises the stream

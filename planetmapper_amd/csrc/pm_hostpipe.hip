@@ -37,6 +37,7 @@
 #include <emmintrin.h>
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -85,13 +86,36 @@ struct HostPipe {
     // ---- pinned staging of the H2D leg of block tables collected by the pool (one per ring slot)
     char *in_stage[kRing] = {};
     size_t in_stage_bytes = 0;
-    // ---- bookkeeping of the block table (grow-only): flags / tile sums / block -> row / row -> block on
-    // the device, the x/y maps of a PM_MEM_HOST call, and the pinned host mirror of the count + list
-    unsigned char *d_flags = nullptr;
-    int *d_tiles = nullptr, *d_blkmap = nullptr, *d_blklist = nullptr;
-    double *d_maps = nullptr;
-    int *h_list = nullptr;  // [0] = count, [16 ...] = row -> block
-    size_t d_flags_cap = 0, d_tiles_cap = 0, d_blkmap_cap = 0, d_blklist_cap = 0, d_maps_cap = 0, h_list_cap = 0;
+    // ---- how a host cube crosses the link (PM_OPT_HOST_CUBE_ROUTE)
+    enum Route : int { kWhole = 0, kInPlace = 1, kFetch = 2, kCollect = 3 };
+    // ---- a block table's bookkeeping (grow-only buffers): flags / tile sums / block -> row / row -> block
+    // on the device, the pinned host mirror of the count + list - and what they currently describe: the
+    // table is kept between calls and reused while the x/y map (by fingerprint), the plane geometry and
+    // the sampling mode are the same
+    struct Table {
+        unsigned char *d_flags = nullptr;
+        int *d_tiles = nullptr, *d_blkmap = nullptr, *d_blklist = nullptr;
+        int *h_list = nullptr;  // [0] = count, [16 ...] = row -> block
+        size_t d_flags_cap = 0, d_tiles_cap = 0, d_blkmap_cap = 0, d_blklist_cap = 0, h_list_cap = 0;
+        bool valid = false, have_list = false;
+        unsigned long long hash[2] = {0, 0};
+        size_t n_map = 0, plane_bytes = 0, esz = 0, n_list = 0;
+        int shift = 0, ny = 0, nx = 0, interpolation = 0, propagate_nan = 0;
+    };
+    Table tab[2];  // [0]: 16-byte blocks (collected by the pool), [1]: 256-byte blocks (fetched by the GPU)
+    unsigned long long *d_hash = nullptr, *h_hash = nullptr;
+    long table_hits = 0, table_builds = 0;
+    // ---- what each route has cost on the problem at hand (ns per plane, whole pipeline), measured
+    struct RouteStats {
+        size_t plane_bytes = 0, n_list16 = 0, esz = 0;
+        bool pinned = false, device_out = false;
+        int threads = 0;
+        double ns_per_plane[4] = {0.0, 0.0, 0.0, 0.0};  // 0: not measured yet
+        int committed = -1;
+    };
+    RouteStats rstats;
+    double *d_maps = nullptr;  // the x/y maps of a PM_MEM_HOST call
+    size_t d_maps_cap = 0;
     // ---- pinned staging ring of the D2H leg
     static constexpr int kSlots = 4;
     char *stage[kSlots] = {};
@@ -447,12 +471,16 @@ void pipe_destroy(pm_ctx *ctx)
         if (hp->stage[i]) (void)hipHostFree(hp->stage[i]);
         if (hp->ev_stage[i]) (void)hipEventDestroy(hp->ev_stage[i]);
     }
-    if (hp->d_flags) (void)hipFree(hp->d_flags);
-    if (hp->d_tiles) (void)hipFree(hp->d_tiles);
-    if (hp->d_blkmap) (void)hipFree(hp->d_blkmap);
-    if (hp->d_blklist) (void)hipFree(hp->d_blklist);
+    for (auto &t : hp->tab) {
+        if (t.d_flags) (void)hipFree(t.d_flags);
+        if (t.d_tiles) (void)hipFree(t.d_tiles);
+        if (t.d_blkmap) (void)hipFree(t.d_blkmap);
+        if (t.d_blklist) (void)hipFree(t.d_blklist);
+        if (t.h_list) (void)hipHostFree(t.h_list);
+    }
+    if (hp->d_hash) (void)hipFree(hp->d_hash);
+    if (hp->h_hash) (void)hipHostFree(hp->h_hash);
     if (hp->d_maps) (void)hipFree(hp->d_maps);
-    if (hp->h_list) (void)hipHostFree(hp->h_list);
     for (int i = 0; i < HostPipe::kRing; i++) {
         if (hp->in_stage[i]) (void)hipHostFree(hp->in_stage[i]);
         if (hp->ev_in[i]) (void)hipEventDestroy(hp->ev_in[i]);
@@ -463,6 +491,17 @@ void pipe_destroy(pm_ctx *ctx)
     if (hp->s_out) (void)hipStreamDestroy(hp->s_out);
     delete hp;
     ctx->pipe = nullptr;
+}
+
+long pipe_table_hits(const pm_ctx *ctx) { return ctx->pipe ? ctx->pipe->table_hits : 0; }
+long pipe_route_ns_per_plane(const pm_ctx *ctx, int route)
+{
+    if (!ctx->pipe || route < 0 || route > 3) return 0;
+    return (long)ctx->pipe->rstats.ns_per_plane[route];
+}
+void pipe_reset_route_stats(pm_ctx *ctx)
+{
+    if (ctx->pipe) ctx->pipe->rstats = HostPipe::RouteStats{};
 }
 
 // Is [p, p + bytes) page-locked host memory the GPU can address (hipHostMalloc / hipHostRegister)?
@@ -724,14 +763,234 @@ int redo_with_median(pm_ctx *ctx, const CubeJob &j, const std::vector<int> &plan
     return PM_OK;
 }
 
+double now_ns()
+{
+    return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// 128-bit fingerprint of the device-resident x/y maps (k_hash_maps): 16 bytes and one host round trip
+int maps_fingerprint(pm_ctx *ctx, HostPipe *hp, const double *dxm, const double *dym, size_t nmap, unsigned long long h[2])
+{
+    if (!hp->d_hash) PM_HIP(ctx, hipMalloc((void **)&hp->d_hash, 2 * sizeof(unsigned long long)));
+    if (!hp->h_hash) PM_HIP(ctx, hipHostMalloc((void **)&hp->h_hash, 2 * sizeof(unsigned long long), hipHostMallocDefault));
+    const hipStream_t sk = ctx->stream;
+    PM_HIP(ctx, hipMemsetAsync(hp->d_hash, 0, 2 * sizeof(unsigned long long), sk));
+    pm_launch_hash_maps(dxm, dym, (int)nmap, hp->d_hash, sk);
+    PM_HIP(ctx, hipGetLastError());
+    PM_HIP(ctx, hipMemcpyAsync(hp->h_hash, hp->d_hash, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, sk));
+    PM_HIP(ctx, hipStreamSynchronize(sk));
+    h[0] = hp->h_hash[0];
+    h[1] = hp->h_hash[1];
+    return PM_OK;
+}
+
+// The block table of shift `shift` for this map and plane geometry: the one the pipe holds (the reference
+// keeps its x/y map between calls, body_xy.py:3478 - a cube mapped plane block by plane block, or frame
+// after frame with the same navigation, meets the same table every time) or a fresh one: k_mark_blocks runs
+// the sampling code itself over the map once and flags the blocks it loads from, k_blocks_* number them;
+// the host reads the count and, when it is the one that collects (want_list), the list.
+int table_get(pm_ctx *ctx, HostPipe *hp, HostPipe::Table &t, int shift, const pm::ReprojectArgs &am, int dtype, size_t plane_bytes,
+              size_t esz, bool have_hash, const unsigned long long hash[2], bool want_list)
+{
+    const hipStream_t sk = ctx->stream;
+    const size_t n_blk = (plane_bytes + ((size_t)1 << shift) - 1) >> shift;
+    const bool hit = have_hash && t.valid && t.shift == shift && t.hash[0] == hash[0] && t.hash[1] == hash[1] &&
+                     t.n_map == (size_t)am.n_map && t.plane_bytes == plane_bytes && t.ny == am.ny && t.nx == am.nx && t.esz == esz &&
+                     t.interpolation == am.interpolation && t.propagate_nan == am.propagate_nan;
+    int rc;
+    if (!hit) {
+        t.valid = false;
+        t.have_list = false;
+        const size_t n_tiles = (n_blk + 4095) / 4096, n_pad = n_tiles * 4096;
+        if ((rc = grow(ctx, &t.d_flags, &t.d_flags_cap, n_pad, false)) != PM_OK) return rc;
+        if ((rc = grow(ctx, &t.d_tiles, &t.d_tiles_cap, (n_tiles + 1) * sizeof(int), false)) != PM_OK) return rc;
+        if ((rc = grow(ctx, &t.d_blkmap, &t.d_blkmap_cap, n_blk * sizeof(int), false)) != PM_OK) return rc;
+        if ((rc = grow(ctx, &t.d_blklist, &t.d_blklist_cap, n_blk * sizeof(int), false)) != PM_OK) return rc;
+        if ((rc = grow(ctx, &t.h_list, &t.h_list_cap, 64, true)) != PM_OK) return rc;
+        int *d_total = t.d_tiles + n_tiles;
+        PM_HIP(ctx, hipMemsetAsync(t.d_flags, 0, n_pad, sk));
+        pm_launch_mark_blocks(am, t.d_flags, shift, dtype, sk);
+        pm_launch_number_blocks(t.d_flags, n_blk, t.d_tiles, t.d_blkmap, t.d_blklist, d_total, sk);
+        PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(t.h_list, d_total, sizeof(int), hipMemcpyDeviceToHost, sk));
+        PM_HIP(ctx, hipStreamSynchronize(sk));
+        t.n_list = (size_t)t.h_list[0];
+        t.shift = shift;
+        t.n_map = (size_t)am.n_map;
+        t.plane_bytes = plane_bytes;
+        t.ny = am.ny;
+        t.nx = am.nx;
+        t.esz = esz;
+        t.interpolation = am.interpolation;
+        t.propagate_nan = am.propagate_nan;
+        if (have_hash) {
+            t.hash[0] = hash[0];
+            t.hash[1] = hash[1];
+            t.valid = true;
+        }
+        hp->table_builds++;
+    } else {
+        hp->table_hits++;
+    }
+    if (want_list && !t.have_list && t.n_list > 0) {
+        // (the first 64 bytes of h_list hold the count; a regrown buffer gets it back)
+        if ((rc = grow(ctx, &t.h_list, &t.h_list_cap, 64 + t.n_list * sizeof(int), true)) != PM_OK) return rc;
+        t.h_list[0] = (int)t.n_list;
+        PM_HIP(ctx, hipMemcpyAsync(t.h_list + 16, t.d_blklist, t.n_list * sizeof(int), hipMemcpyDeviceToHost, sk));
+        PM_HIP(ctx, hipStreamSynchronize(sk));
+        t.have_list = true;
+    }
+    return PM_OK;
+}
+
+// One stretch of planes of a call, fed by one route (HostPipe::Route). A call is one segment - or, the
+// first time the library is left to choose for a problem, a few short ones, one per candidate route,
+// timed, and the rest by the fastest.
+struct Segment {
+    int route;
+    size_t p0, n;       // planes [p0, p0 + n) of the call
+    size_t chunk;       // planes per chunk of the pipeline (0: the route's default)
+    bool probe;         // timed for the route statistics
+};
+
+struct SegLayout {
+    size_t chunk, batch, slot_bytes, table_row_bytes, blk_off, need;
+    bool zero_copy, direct_out;
+};
+
+SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, size_t n_list, int shift, bool dst_pinned)
+{
+    SegLayout L{};
+    const size_t nmap = j.nmap;
+    const bool gather = sg.route == HostPipe::kInPlace, blocks = sg.route == HostPipe::kFetch, host_blocks = sg.route == HostPipe::kCollect;
+    L.zero_copy = gather || blocks;  // no staging ring: the kernels read the caller's cube
+    L.table_row_bytes = (blocks || host_blocks) ? n_list << shift : 0;  // one plane's rows of the block table
+    size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
+    chunk = std::min<size_t>(std::min<size_t>(chunk, sg.n), 32768);
+    if (L.zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, (sg.n + 7) / 8), 32768);
+    if (blocks) chunk = std::max<size_t>(1, std::min<size_t>(chunk, ((size_t)256 << 20) / L.table_row_bytes));
+    if (host_blocks)  // chunks of the table, not of the cube (smaller chunks for short cubes: no gain, measured)
+        chunk = std::min<size_t>(std::max<size_t>(1, ctx->host_chunk_bytes / L.table_row_bytes), std::min<size_t>(sg.n, 32768));
+    if (sg.chunk) chunk = std::min<size_t>(sg.chunk, sg.n);
+    L.chunk = chunk;
+    L.batch = std::min<size_t>(sg.n, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
+    L.slot_bytes = ((host_blocks ? chunk * L.table_row_bytes : chunk * j.plane_bytes) + 255) & ~(size_t)255;
+    // the kernel stores straight into the caller's array: device memory, or pinned memory next to a zero-copy cube
+    L.direct_out = j.device_out || (L.zero_copy && dst_pinned);
+    size_t need = 2 * nmap * sizeof(double) + 256;
+    if (!L.zero_copy) need += HostPipe::kRing * L.slot_bytes;
+    if (!L.direct_out) need += L.batch * nmap * sizeof(double);
+    L.blk_off = (need + 255) & ~(size_t)255;  // the table of a GPU-fetched chunk
+    if (blocks) need = L.blk_off + chunk * L.table_row_bytes;
+    L.need = need;
+    return L;
+}
+
+// the pipeline over one segment: H2D of chunk k + 1 (whole planes, or the block table the pool has
+// collected), kernel of chunk k and the staged D2H of finished output overlap on three streams
+int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, const SegLayout &L, const HostPipe::Table *tab,
+                const double *dxm, const double *dym, const char *cube_dev, double *out_dev)
+{
+    const hipStream_t sk = ctx->stream;
+    const size_t nmap = j.nmap;
+    const bool blocks = sg.route == HostPipe::kFetch, host_blocks = sg.route == HostPipe::kCollect;
+    char *base = (char *)ctx->scratch;
+    char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
+    double *dout_all = (double *)(ring + (L.zero_copy ? 0 : HostPipe::kRing * L.slot_bytes));
+    pm::BlockTable table{};
+    if (blocks || host_blocks) {
+        table.blkmap = tab->d_blkmap;
+        table.blklist = tab->d_blklist;
+        table.n_list = (unsigned)tab->n_list;
+        table.shift = tab->shift;
+        table.plane_bytes = j.plane_bytes;
+    }
+    if (blocks) table.table = base + L.blk_off;
+    const int *hlist = (host_blocks && tab->h_list) ? tab->h_list + 16 : nullptr;
+    int rc;
+    // s_out drains finished output while later chunks are still being copied in / mapped
+    size_t c = 0;  // running chunk number of the segment (ring slot = c % kRing)
+    for (size_t b0 = 0; b0 < sg.n; b0 += L.batch) {
+        const size_t nb = std::min(L.batch, sg.n - b0);
+        size_t drained = 0;  // planes of this batch already handed to the D2H leg
+        size_t launched = 0;
+        for (size_t q0 = 0; q0 < nb; q0 += L.chunk, c++) {
+            const size_t np = std::min(L.chunk, nb - q0);
+            const size_t pl = sg.p0 + b0 + q0;  // first plane of the chunk within the call
+            const int slot = (int)(c % HostPipe::kRing);
+            pm::ReprojectArgs b = j.a;
+            b.x_map = dxm;
+            b.y_map = dym;
+            b.n_planes = (int)np;
+            b.plane_flags = ctx->flags + pl;
+            b.out = L.direct_out ? out_dev + pl * nmap : dout_all + q0 * nmap;
+            pm::BlockTable tb = table;
+            if (L.zero_copy) {
+                b.cube = cube_dev + pl * j.plane_bytes;
+            } else if (host_blocks) {
+                // the pool fills this slot's pinned buffer (free once the DMA of three chunks ago is
+                // done) while the DMA of the previous chunk runs
+                char *dslot = ring + (size_t)slot * L.slot_bytes;
+                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
+                hp->gather(hp->in_stage[slot], j.cube + pl * j.plane_bytes, j.plane_bytes, np, hlist, tab->n_list, tab->shift);
+                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * L.table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
+                PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
+                PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
+                b.cube = nullptr;  // no plane to fall back on: see cleaned_value / BlockLoader
+                tb.table = dslot;
+            } else {
+                char *dslot = ring + (size_t)slot * L.slot_bytes;
+                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                PM_HIP(ctx, hipMemcpyAsync(dslot, j.cube + pl * j.plane_bytes, np * j.plane_bytes, hipMemcpyHostToDevice, hp->s_in));
+                PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
+                PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
+                b.cube = dslot;
+            }
+            if (blocks || host_blocks)
+                pm_launch_reproject_blocks(b, tb, j.dtype, sk, /*fetch=*/blocks);
+            else
+                pm_launch_reproject(b, j.dtype, sk);
+            PM_HIP(ctx, hipGetLastError());
+            PM_HIP(ctx, hipEventRecord(hp->ev_k[slot], sk));
+            if (ctx->chunk_cb) ctx->chunk_cb(ctx->chunk_user, (int)pl, (int)np);
+            launched = q0 + np;
+            // hand finished output to the D2H leg in pieces worth a DMA
+            if (!L.direct_out && (launched - drained) * nmap * sizeof(double) >= ((size_t)8 << 20)) {
+                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_k[slot], 0));
+                rc = d2h_issue(ctx, hp->s_out, j.out + (sg.p0 + b0 + drained) * nmap, dout_all + drained * nmap,
+                               (launched - drained) * nmap * sizeof(double));
+                if (rc != PM_OK) return rc;
+                drained = launched;
+            }
+        }
+        if (!L.direct_out) {
+            if (launched > drained) {
+                PM_HIP(ctx, hipEventRecord(hp->ev_tmp, sk));
+                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_tmp, 0));
+                rc = d2h_issue(ctx, hp->s_out, j.out + (sg.p0 + b0 + drained) * nmap, dout_all + drained * nmap,
+                               (launched - drained) * nmap * sizeof(double));
+                if (rc != PM_OK) return rc;
+            }
+            // the next batch reuses dout_all
+            rc = d2h_finish(ctx, hp->s_out);
+            if (rc != PM_OK) return rc;
+        }
+    }
+    // the ring and the events are free for the next segment / the flag check
+    PM_HIP(ctx, hipStreamSynchronize(sk));
+    PM_HIP(ctx, hipStreamSynchronize(hp->s_in));
+    return PM_OK;
+}
+
 }  // namespace
+
+static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
+                                        const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out);
 
 // pm_map_cube for host buffers, interpolation nearest / linear with NaN propagation (the default of
 // Observation.get_mapped_data). Caller has validated the arguments and sized ctx->flags.
 // `device_out`: x_map / y_map / out are DEVICE pointers (PM_MEM_HOST_CUBE): only the cube travels.
-static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
-                                        const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out);
-
 int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
                             const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
 {
@@ -770,16 +1029,6 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     const bool src_pinned = host_is_pinned(cube, cube_bytes);
     const bool dst_pinned = !device_out && host_is_pinned(out, out_bytes);
     const hipStream_t sk = ctx->stream;
-    // How the cube crosses the link (PM_OPT_ZERO_COPY): whole planes by DMA (0); a pinned cube
-    // gathered in place by the kernel (1); the blocks the map samples - found once, by the sampling
-    // code itself (k_mark_blocks) - brought into a table in HBM, either fetched by the GPU from a
-    // pinned cube in 256-byte blocks (2) or collected by the copy threads in 16-byte blocks into
-    // pinned staging, chunk by chunk, and sent by DMA (3: any host memory). The library (-1) takes
-    // (3) when the table is well under half the size of the planes, else (0).
-    const int mode = ctx->zero_copy;
-    bool gather = src_pinned && mode == 1, blocks = false, host_blocks = false;
-    size_t n_list = 0;
-    int shift = 0;
     // the x/y maps on the device: the caller's (PM_MEM_HOST_CUBE) or a copy
     const double *dxm = x_map, *dym = y_map;
     if (!device_out) {
@@ -790,153 +1039,159 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         dxm = hp->d_maps;
         dym = hp->d_maps + nmap;
     }
-    if (mode < 0 || mode == 3 || (mode == 2 && src_pinned)) {
-        shift = mode == 2 ? pm::kBlkShiftFetch : pm::kBlkShiftHost;
-        const size_t n_blk = (j.plane_bytes + ((size_t)1 << shift) - 1) >> shift;
-        if (j.plane_bytes % ((size_t)1 << shift) == 0 && n_blk < ((size_t)1 << 31)) {
-            // flag the blocks the map samples (the sampling code itself, once, on plane geometry only),
-            // number them on the device; the host needs the count (and, to collect them, the list)
-            const size_t n_tiles = (n_blk + 4095) / 4096, n_pad = n_tiles * 4096;
-            if ((rc = grow(ctx, &hp->d_flags, &hp->d_flags_cap, n_pad, false)) != PM_OK) return rc;
-            if ((rc = grow(ctx, &hp->d_tiles, &hp->d_tiles_cap, (n_tiles + 1) * sizeof(int), false)) != PM_OK) return rc;
-            if ((rc = grow(ctx, &hp->d_blkmap, &hp->d_blkmap_cap, n_blk * sizeof(int), false)) != PM_OK) return rc;
-            if ((rc = grow(ctx, &hp->d_blklist, &hp->d_blklist_cap, n_blk * sizeof(int), false)) != PM_OK) return rc;
-            if ((rc = grow(ctx, &hp->h_list, &hp->h_list_cap, 64, true)) != PM_OK) return rc;
-            pm::ReprojectArgs am = a;
-            am.x_map = dxm;
-            am.y_map = dym;
-            int *d_total = hp->d_tiles + n_tiles;
-            PM_HIP(ctx, hipMemsetAsync(hp->d_flags, 0, n_pad, sk));
-            pm_launch_mark_blocks(am, hp->d_flags, shift, dtype, sk);
-            pm_launch_number_blocks(hp->d_flags, n_blk, hp->d_tiles, hp->d_blkmap, hp->d_blklist, d_total, sk);
-            PM_HIP(ctx, hipGetLastError());
-            PM_HIP(ctx, hipMemcpyAsync(hp->h_list, d_total, sizeof(int), hipMemcpyDeviceToHost, sk));
-            PM_HIP(ctx, hipStreamSynchronize(sk));
-            n_list = (size_t)hp->h_list[0];
-            const size_t table_bytes = n_list << shift;
-            if (n_list > 0 && (mode >= 2 || table_bytes * 5 < j.plane_bytes * 2)) (mode == 2 ? blocks : host_blocks) = true;
-            if (host_blocks) {
-                if ((rc = grow(ctx, &hp->h_list, &hp->h_list_cap, 64 + n_list * sizeof(int), true)) != PM_OK) return rc;
-                PM_HIP(ctx, hipMemcpyAsync(hp->h_list + 16, hp->d_blklist, n_list * sizeof(int), hipMemcpyDeviceToHost, sk));
-                PM_HIP(ctx, hipStreamSynchronize(sk));
-            }
-        }
-        // (mode 2 / 3 on planes that do not split into whole blocks, or a map that samples nothing: whole planes)
+    // How the cube crosses the link (PM_OPT_HOST_CUBE_ROUTE): whole planes by DMA (0); a pinned cube
+    // gathered in place by the kernel (1); the blocks the map samples brought into a table in HBM,
+    // either fetched by the GPU from a pinned cube in 256-byte blocks (2) or collected by the copy
+    // threads in 16-byte blocks into pinned staging, chunk by chunk, and sent by DMA (3: any host
+    // memory). Left to the library (-1) the route is the one that MEASURED fastest for this problem on
+    // this context (below); until enough planes have come by to measure, (3) when the table is well
+    // under half the size of the planes, else (0).
+    const int mode = ctx->zero_copy;
+    pm::ReprojectArgs am = a;
+    am.x_map = dxm;
+    am.y_map = dym;
+    auto splits = [&](int shift) { return j.plane_bytes % ((size_t)1 << shift) == 0 && (j.plane_bytes >> shift) < ((size_t)1 << 31); };
+    const bool can_collect = splits(pm::kBlkShiftHost), can_fetch = src_pinned && splits(pm::kBlkShiftFetch);
+    unsigned long long hash[2] = {0, 0};
+    bool have_hash = false;
+    const bool want16 = (mode < 0 || mode == HostPipe::kCollect) && can_collect;
+    const bool want256 = mode == HostPipe::kFetch && can_fetch;
+    bool have256 = false;  // the 256-byte table describes THIS call's map
+    if ((want16 || want256) && ctx->table_cache) {
+        if ((rc = maps_fingerprint(ctx, hp, dxm, dym, nmap, hash)) != PM_OK) return rc;
+        have_hash = true;
     }
-    const bool zero_copy = gather || blocks;  // no staging ring: the kernels read the caller's cube
+    HostPipe::Table &t16 = hp->tab[0], &t256 = hp->tab[1];
+    if (want16 && (rc = table_get(ctx, hp, t16, pm::kBlkShiftHost, am, dtype, j.plane_bytes, j.esz, have_hash, hash, /*want_list=*/true)) != PM_OK)
+        return rc;
+    if (want256) {
+        if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
+        have256 = t256.n_list > 0;
+    }
 
-    // planes per chunk of the copy pipeline; per batch of the output buffer
-    size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
-    chunk = std::min<size_t>(std::min<size_t>(chunk, (size_t)n_planes), 32768);
-    if (zero_copy) chunk = std::min<size_t>(std::max<size_t>(chunk, ((size_t)n_planes + 7) / 8), 32768);
-    const size_t table_row_bytes = n_list << shift;  // one plane's rows of the block table
-    if (blocks) chunk = std::max<size_t>(1, std::min<size_t>(chunk, ((size_t)256 << 20) / table_row_bytes));
-    if (host_blocks)  // chunks of the table, not of the cube (smaller chunks for short cubes: no gain, measured)
-        chunk = std::min<size_t>(std::max<size_t>(1, ctx->host_chunk_bytes / table_row_bytes), std::min<size_t>((size_t)n_planes, 32768));
-    const size_t batch = std::min<size_t>((size_t)n_planes, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
-    const size_t slot_bytes = ((host_blocks ? chunk * table_row_bytes : chunk * j.plane_bytes) + 255) & ~(size_t)255;
-    // the kernel stores straight into the caller's array: device memory, or pinned memory next to a zero-copy cube
-    const bool direct_out = device_out || (zero_copy && dst_pinned);
-    size_t need = 2 * nmap * sizeof(double) + 256;
-    if (!zero_copy) need += HostPipe::kRing * slot_bytes;
-    if (!direct_out) need += batch * nmap * sizeof(double);
-    const size_t blk_off = (need + 255) & ~(size_t)255;  // the table of a GPU-fetched chunk
-    if (blocks) need = blk_off + chunk * table_row_bytes;
-    need = std::max(need, 2 * nmap * sizeof(double) + 512 + j.plane_bytes + nmap * sizeof(double));  // median redo
+    // ---- the plan: segments of planes, each fed by one route
+    std::vector<Segment> plan;
+    const size_t P = (size_t)n_planes;
+    HostPipe::RouteStats &rs = hp->rstats;
+    bool exploring = false;
+    if (mode == HostPipe::kInPlace && src_pinned) {
+        plan.push_back({HostPipe::kInPlace, 0, P, 0, false});
+    } else if (mode == HostPipe::kFetch && have256) {
+        plan.push_back({HostPipe::kFetch, 0, P, 0, false});
+    } else if (mode == HostPipe::kCollect && want16 && t16.n_list > 0) {
+        plan.push_back({HostPipe::kCollect, 0, P, 0, false});
+    } else if (mode < 0 && want16 && t16.n_list > 0) {
+        // The library chooses, per context (= per rank), from what it has measured on this very problem:
+        // the routes differ in which resource they lean on - the copy threads and the host's memory
+        // system (3), the PCIe link alone (0), the GPU's own reads over the link (2) - and how those
+        // compare depends on the box, on how many ranks share the host and on the threads this rank
+        // was given, none of which the size of the table knows.
+        const int threads = (int)hp->workers.size() + 1;
+        if (rs.plane_bytes != j.plane_bytes || rs.n_list16 != t16.n_list || rs.pinned != src_pinned || rs.threads != threads ||
+            rs.device_out != device_out || rs.esz != j.esz) {
+            rs = HostPipe::RouteStats{};
+            rs.plane_bytes = j.plane_bytes;
+            rs.n_list16 = t16.n_list;
+            rs.pinned = src_pinned;
+            rs.threads = threads;
+            rs.device_out = device_out;
+            rs.esz = j.esz;
+        }
+        const size_t row16 = t16.n_list << pm::kBlkShiftHost;
+        const int by_size = row16 * 5 < j.plane_bytes * 2 ? HostPipe::kCollect : HostPipe::kWhole;
+        // probe segments: three short chunks each, so that the pipeline's fill is a third of the figure
+        const size_t c3 = std::max<size_t>(1, std::min<size_t>(8, ((size_t)8 << 20) / std::max<size_t>(row16, 1)));
+        const size_t c0 = std::max<size_t>(1, ((size_t)32 << 20) / j.plane_bytes);
+        const size_t c2 = c3;
+        const size_t need_planes = 3 * c3 + 3 * c0 + (can_fetch ? 3 * c2 : 0);
+        if (rs.committed == HostPipe::kFetch && can_fetch) {
+            if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
+            have256 = t256.n_list > 0;
+        }
+        if (rs.committed >= 0 && (rs.committed != HostPipe::kFetch || have256)) {
+            plan.push_back({rs.committed, 0, P, 0, false});
+        } else if (ctx->route_explore && P > need_planes) {
+            exploring = true;
+            size_t at = 0;
+            plan.push_back({HostPipe::kCollect, at, 3 * c3, c3, true});
+            at += 3 * c3;
+            plan.push_back({HostPipe::kWhole, at, 3 * c0, c0, true});
+            at += 3 * c0;
+            if (can_fetch) {
+                if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
+                have256 = t256.n_list > 0;
+                if (have256) {
+                    plan.push_back({HostPipe::kFetch, at, 3 * c2, c2, true});
+                    at += 3 * c2;
+                }
+            }
+            plan.push_back({-1, at, P - at, 0, false});  // route filled in once the probes are in
+        } else {
+            plan.push_back({by_size, 0, P, 0, false});
+        }
+    } else {
+        // whole planes (asked for, or a route that does not apply: pageable memory for 1 / 2, planes that do
+        // not split into whole blocks, a map that samples nothing)
+        plan.push_back({HostPipe::kWhole, 0, P, 0, false});
+    }
+
+    // ---- device scratch for the largest segment, staging for the collected tables
+    std::vector<SegLayout> lay(plan.size());
+    size_t need = 2 * nmap * sizeof(double) + 512 + j.plane_bytes + nmap * sizeof(double);  // median redo
+    size_t in_stage_need = 0;
+    for (size_t i = 0; i < plan.size(); i++) {
+        // (the remainder of an exploring call may take any route: size it for the most demanding)
+        const int routes[3] = {HostPipe::kCollect, HostPipe::kWhole, HostPipe::kFetch};
+        for (int r = 0; r < (plan[i].route < 0 ? 3 : 1); r++) {
+            Segment sg = plan[i];
+            if (sg.route < 0) sg.route = routes[r];
+            if (sg.route == HostPipe::kFetch && !have256) continue;
+            const HostPipe::Table &tt = sg.route == HostPipe::kFetch ? t256 : t16;
+            const SegLayout L = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned);
+            need = std::max(need, L.need);
+            if (sg.route == HostPipe::kCollect) in_stage_need = std::max(in_stage_need, L.slot_bytes);
+            if (plan[i].route >= 0) lay[i] = L;
+        }
+    }
     rc = ensure_scratch(ctx, need);
     if (rc != PM_OK) return rc;
-    char *base = (char *)ctx->scratch;
-    char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
-    double *dout_all = (double *)(ring + (zero_copy ? 0 : HostPipe::kRing * slot_bytes));
-
-    pm::BlockTable table{};
-    if (blocks || host_blocks) {
-        table.blkmap = hp->d_blkmap;
-        table.blklist = hp->d_blklist;
-        table.n_list = (unsigned)n_list;
-        table.shift = shift;
-        table.plane_bytes = j.plane_bytes;
-    }
-    if (blocks) table.table = base + blk_off;
-    const int *hlist = hp->h_list ? hp->h_list + 16 : nullptr;
-    if (host_blocks) {
-        rc = ensure_in_stage(ctx, hp, slot_bytes);
+    if (in_stage_need) {
+        rc = ensure_in_stage(ctx, hp, in_stage_need);
         if (rc != PM_OK) return rc;
     }
     const char *cube_dev = nullptr;  // zero copy: the device's view of the caller's pinned cube
     double *out_dev = nullptr;
-    if (zero_copy) PM_HIP(ctx, hipHostGetDevicePointer((void **)&cube_dev, (void *)cube, 0));
+    bool dev_view = false;  // some segment has the GPU read the caller's cube in place
+    for (const Segment &sg : plan) dev_view = dev_view || sg.route == HostPipe::kInPlace || sg.route == HostPipe::kFetch || (sg.route < 0 && have256);
+    if (dev_view) PM_HIP(ctx, hipHostGetDevicePointer((void **)&cube_dev, (void *)cube, 0));
     if (device_out)
         out_dev = out;
-    else if (direct_out)
+    else if (dst_pinned)
         PM_HIP(ctx, hipHostGetDevicePointer((void **)&out_dev, (void *)out, 0));
 
-    // s_out drains finished output while later chunks are still being copied in / mapped
-    size_t c = 0;  // running chunk number (ring slot = c % kRing)
-    for (size_t b0 = 0; b0 < (size_t)n_planes; b0 += batch) {
-        const size_t nb = std::min(batch, (size_t)n_planes - b0);
-        size_t drained = 0;  // planes of this batch already handed to the D2H leg
-        size_t launched = 0;
-        for (size_t p0 = 0; p0 < nb; p0 += chunk, c++) {
-            const size_t np = std::min(chunk, nb - p0);
-            const int slot = (int)(c % HostPipe::kRing);
-            pm::ReprojectArgs b = a;
-            b.x_map = dxm;
-            b.y_map = dym;
-            b.n_planes = (int)np;
-            b.plane_flags = ctx->flags + b0 + p0;
-            b.out = direct_out ? out_dev + (b0 + p0) * nmap : dout_all + p0 * nmap;
-            pm::BlockTable tb = table;
-            if (zero_copy) {
-                b.cube = cube_dev + (b0 + p0) * j.plane_bytes;
-            } else if (host_blocks) {
-                // the pool fills this slot's pinned buffer (free once the DMA of three chunks ago is
-                // done) while the DMA of the previous chunk runs
-                char *dslot = ring + (size_t)slot * slot_bytes;
-                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
-                hp->gather(hp->in_stage[slot], j.cube + (b0 + p0) * j.plane_bytes, j.plane_bytes, np, hlist, n_list, shift);
-                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
-                PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
-                PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
-                PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
-                b.cube = nullptr;  // no plane to fall back on: see cleaned_value / BlockLoader
-                tb.table = dslot;
-            } else {
-                char *dslot = ring + (size_t)slot * slot_bytes;
-                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
-                PM_HIP(ctx, hipMemcpyAsync(dslot, j.cube + (b0 + p0) * j.plane_bytes, np * j.plane_bytes, hipMemcpyHostToDevice,
-                                           hp->s_in));
-                PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
-                PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
-                b.cube = dslot;
-            }
-            if (blocks || host_blocks)
-                pm_launch_reproject_blocks(b, tb, dtype, sk, /*fetch=*/blocks);
-            else
-                pm_launch_reproject(b, dtype, sk);
-            PM_HIP(ctx, hipGetLastError());
-            PM_HIP(ctx, hipEventRecord(hp->ev_k[slot], sk));
-            launched = p0 + np;
-            // hand finished output to the D2H leg in pieces worth a DMA
-            if (!direct_out && (launched - drained) * nmap * sizeof(double) >= ((size_t)8 << 20)) {
-                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_k[slot], 0));
-                rc = d2h_issue(ctx, hp->s_out, out + (b0 + drained) * nmap, dout_all + drained * nmap,
-                               (launched - drained) * nmap * sizeof(double));
-                if (rc != PM_OK) return rc;
-                drained = launched;
-            }
+    for (size_t i = 0; i < plan.size(); i++) {
+        Segment &sg = plan[i];
+        if (sg.n == 0) continue;
+        if (sg.route < 0) {
+            // the probes are in: the rest of this call, and every later call on this problem, by the fastest
+            int best = -1;
+            for (int r = 0; r < 4; r++)
+                if (rs.ns_per_plane[r] > 0.0 && (best < 0 || rs.ns_per_plane[r] < rs.ns_per_plane[best])) best = r;
+            rs.committed = best < 0 ? HostPipe::kCollect : best;
+            sg.route = rs.committed;
+            const HostPipe::Table &tt = sg.route == HostPipe::kFetch ? t256 : t16;
+            lay[i] = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned);
         }
-        if (!direct_out) {
-            if (launched > drained) {
-                PM_HIP(ctx, hipEventRecord(hp->ev_tmp, sk));
-                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_tmp, 0));
-                rc = d2h_issue(ctx, hp->s_out, out + (b0 + drained) * nmap, dout_all + drained * nmap,
-                               (launched - drained) * nmap * sizeof(double));
-                if (rc != PM_OK) return rc;
-            }
-            // the next batch reuses dout_all
-            rc = d2h_finish(ctx, hp->s_out);
-            if (rc != PM_OK) return rc;
+        const HostPipe::Table *tt = sg.route == HostPipe::kFetch ? &t256 : &t16;
+        const double t_begin = now_ns();
+        rc = run_segment(ctx, hp, j, sg, lay[i], tt, dxm, dym, cube_dev, out_dev);
+        if (rc != PM_OK) return rc;
+        const double per_plane = (now_ns() - t_begin) / (double)sg.n;
+        ctx->last_cube_route = sg.route;
+        if (mode < 0 && sg.route >= 0 && sg.route < 4 && (sg.probe || !exploring) && sg.n >= 3) {
+            // (a running mean once committed: the figure pm_get_option reports follows the box)
+            double &v = rs.ns_per_plane[sg.route];
+            v = (v > 0.0 && !sg.probe) ? 0.75 * v + 0.25 * per_plane : per_plane;
         }
     }
     // per-plane flags of the whole call: one read-back
@@ -948,8 +1203,10 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     std::vector<int> redo;
     for (int p = 0; p < n_planes; p++)
         if (hflags[(size_t)p] == a.seq) redo.push_back(p);
+    ctx->last_redo_planes = (int)redo.size();
     if (!redo.empty()) {
-        char *dplane = ring;  // scratch was sized for one plane + one mapped plane behind the maps
+        char *base = (char *)ctx->scratch;
+        char *dplane = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);  // scratch was sized for one plane + one mapped plane behind the maps
         double *dout1 = (double *)(dplane + ((j.plane_bytes + 255) & ~(size_t)255));
         rc = redo_with_median(ctx, j, redo, dxm, dym, dplane, dout1);
         if (rc != PM_OK) return rc;

@@ -288,6 +288,36 @@ __global__ __launch_bounds__(kBlock) void k_blocks_number(const unsigned char *_
     }
 }
 
+// 128-bit fingerprint of an x/y map (the key under which a context keeps its block table between
+// calls, as the reference keeps _get_xy_map, body_xy.py:3478): two independent sums of a 64-bit
+// finaliser over (bits of x, bits of y, cell index). out[2] is zeroed by the caller.
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z)
+{
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(kBlock) void k_hash_maps(const double *__restrict__ x_map, const double *__restrict__ y_map, int n,
+                                                      unsigned long long *__restrict__ out)
+{
+    unsigned long long h0 = 0, h1 = 0;
+    for (int m = blockIdx.x * kBlock + threadIdx.x; m < n; m += gridDim.x * kBlock) {
+        const unsigned long long bx = (unsigned long long)__double_as_longlong(x_map[m]);
+        const unsigned long long by = (unsigned long long)__double_as_longlong(y_map[m]);
+        const unsigned long long i = (unsigned long long)m;
+        h0 += mix64(bx + 0x9e3779b97f4a7c15ull * (2 * i + 1)) ^ mix64(by ^ (0xd1b54a32d192ed03ull * (i + 1)));
+        h1 += mix64((bx ^ 0x8cb92ba72f3d8dd7ull) * (2 * i + 3) + by) + mix64(by + (i << 32 | (i >> 3)) + 0x2545f4914f6cdd1dull);
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        h0 += __shfl_down(h0, d, 64);
+        h1 += __shfl_down(h1, d, 64);
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        atomicAdd(out, h0);
+        atomicAdd(out + 1, h1);
+    }
+}
+
 // blockIdx.y = plane of the chunk; 16 lanes x 16 bytes per 256-byte block, 4 blocks per wave
 __global__ __launch_bounds__(kBlock) void k_fetch_blocks(const char *__restrict__ cube, const BlockTable t)
 {
@@ -1003,6 +1033,13 @@ void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int
     case PM_U8: launch_mark_blocks_t<uint8_t>(a, flags, shift, s); break;
     case PM_U16: launch_mark_blocks_t<uint16_t>(a, flags, shift, s); break;
     }
+}
+
+// out[0..1] (zeroed) <- 128-bit fingerprint of the two maps
+void pm_launch_hash_maps(const double *x_map, const double *y_map, int n, unsigned long long *out, hipStream_t s)
+{
+    const unsigned blocks = (unsigned)std::min<size_t>(((size_t)n + pm::kBlock - 1) / pm::kBlock, 256);
+    hipLaunchKernelGGL(pm::k_hash_maps, dim3(blocks ? blocks : 1), dim3(pm::kBlock), 0, s, x_map, y_map, n, out);
 }
 
 // flags (n_pad = whole tiles of 4096, zero beyond n_blk) -> blkmap[n_blk], blklist[*total], *total

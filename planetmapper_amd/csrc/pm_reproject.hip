@@ -629,11 +629,14 @@ int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype)
                                ctx->stream));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     bool any = false, stale = false;
+    int n_redo = 0;
     for (int f : hflags) {
         any = any || (f == a.seq);
+        n_redo += (f == a.seq);
         stale = stale || (f > ctx->checked_seq && f < a.seq);
     }
     ctx->checked_seq = a.seq;
+    ctx->last_redo_planes = n_redo;
     if (stale)
         return fail(ctx, PM_ERR_STATE,
                     "an earlier asynchronous pm_map_cube call sampled pixels that need the plane nanmedian (+-inf "
@@ -677,6 +680,7 @@ int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_no
         pm_launch_reproject(b, dtype, ctx->stream);
     }
     PM_HIP(ctx, hipGetLastError());
+    if (ctx->chunk_cb) ctx->chunk_cb(ctx->chunk_user, 0, a.n_planes);
     if (sync_now) return finish_reproject(ctx, a, dtype);
     ctx->pending = true;
     ctx->pending_args = a;

@@ -31,6 +31,45 @@ def shard_bounds(n_planes: int, world_size: int, rank: int) -> tuple[int, int, i
     return start, stop, per_rank
 
 
+def exchange_planes(per_rank: int, n0: int, n1: int) -> int:
+    """
+    Planes per exchange of the pipelined all-gather (`pm_exchange_planes` of the C ABI): at most 8
+    exchanges per block, each of at least 4 MiB of mapped planes. A function of shapes only, so every
+    rank issues the same sequence of collectives whatever happens on it.
+    """
+    if per_rank < 0 or n0 < 0 or n1 < 0:
+        raise ValueError('negative shape')
+    if per_rank == 0:
+        return 1
+    nmap_bytes = max(n0 * n1 * 8, 1)
+    by_count = -(-per_rank // 8)
+    by_bytes = -(-(4 << 20) // nmap_bytes)
+    return min(per_rank, max(by_count, by_bytes, 1))
+
+
+class PeerFailedError(RuntimeError):
+    """A sharded call failed on ANOTHER rank: the gathered result is not valid on this rank either."""
+
+
+def agree_on_success(error: BaseException | None, group=None) -> None:
+    """
+    The closing agreement of a sharded call: every rank contributes whether its part worked, one tiny
+    all-reduce (MIN) spreads the verdict, and EVERY rank raises if any rank failed - its own exception
+    where there is one, `PeerFailedError` elsewhere. A rank must reach this call even when its own
+    work failed (catch, participate, then raise): leaving early would strand its peers in the next
+    collective.
+    """
+    import torch
+    import torch.distributed as dist
+
+    ok = torch.tensor([0 if error is None else -1], dtype=torch.int32, device=_group_device(group))
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if error is not None:
+        raise error
+    if int(ok.item()) != 0:
+        raise PeerFailedError('another rank failed in this sharded call: the gathered result is not valid')
+
+
 def _group_device(group):
     import torch
     import torch.distributed as dist
@@ -87,6 +126,7 @@ def get_mapped_data_sharded(
     local_planes: np.ndarray | None = None,
     n_planes: int | None = None,
     gather: bool = True,
+    out: np.ndarray | None = None,
     **map_kwargs,
 ) -> np.ndarray:
     """
@@ -105,7 +145,14 @@ def get_mapped_data_sharded(
       * `gather=True`: the full (P, n0, n1) float64 result on every rank (one all-gather, RCCL over
         xGMI for the nccl backend);
       * `gather=False`: this rank's (stop - start, n0, n1) block only, no collective at all (SURVEY
-        8e: "otherwise none - each rank keeps / writes its slice").
+        8e: "otherwise none - each rank keeps / writes its slice");
+      * `gather=False, out=<(P, n0, n1) float64 array>`: the block is written into `out[start:stop]` and
+        `out` is returned - with ONE array in shared memory (`multiprocessing.shared_memory`, a
+        memory-mapped file) handed to every rank the whole result assembles in the caller's array
+        without any collective.
+
+    A rank whose mapping raises does not leave its peers waiting: with `gather=True` every rank first
+    agrees on success (`agree_on_success`: a 4-byte all-reduce) and all of them raise if one failed.
 
     The interpolation arguments are those of `map_img` (body_xy.py:1414-1429).
     """
@@ -136,11 +183,24 @@ def get_mapped_data_sharded(
         raise ValueError(
             f'rank {rank} of {world} owns planes [{start}, {stop}) of {n_planes} but was given {local_planes.shape[0]}'
         )
-    x_map = obs.get_x_map(**map_kwargs)
-    n0, n1 = x_map.shape
-    mine = obs.map_img(local_planes, **interp, **map_kwargs) if stop > start else np.empty((0, n0, n1))
+    error, mine, shape = None, None, None
+    try:
+        x_map = obs.get_x_map(**map_kwargs)
+        shape = x_map.shape
+        mine = obs.map_img(local_planes, **interp, **map_kwargs) if stop > start else np.empty((0,) + shape)
+    except Exception as e:  # noqa: BLE001 - reported through the agreement below
+        if not gather:
+            raise
+        error = e
     if not gather:
-        return mine
+        if out is None:
+            return mine
+        if out.shape != (int(n_planes),) + shape or out.dtype != np.float64:
+            raise ValueError(f'out must be a float64 array of shape {(int(n_planes),) + shape}')
+        out[start:stop] = mine
+        return out
+    agree_on_success(error, group)
+    n0, n1 = shape
     if n_planes == 0:
         return np.empty((0, n0, n1))
     local = np.full((per_rank, n0, n1), np.nan)
@@ -220,6 +280,118 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
     if gather and dist.is_initialized() and dist.get_world_size(group) > 1:
         return dist.all_gather_into_tensor(gathered.view(-1), mine.reshape(-1), group=group, async_op=async_op)
     return None
+
+
+def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x_map, y_map, n0: int, n1: int, gathered,
+                               rank: int, world: int, *, interpolation='linear', propagate_nan=True, group=None,
+                               host_cube: bool = False, gather: bool = True, pipeline_chunks: bool | None = None) -> None:
+    """
+    The plane-sharded cube with the collective PIPELINED behind the mapping - the torch.distributed
+    form of `pm_map_cube_sharded` (same protocol, include/planetmapper_hip.h):
+
+      1. this rank's block (`local_cube`: its planes `shard_bounds(n_planes_total, world, rank)` only - a
+         device tensor / pointer, or a numpy array in host memory with `host_cube=True`) is cut into
+         exchanges of `exchange_planes(per_rank, n0, n1)` planes - a function of shapes only;
+      2. ONE engine call maps the block into this rank's slot of `gathered` ((world, per_rank, n0, n1)
+         float64 on the group's device), so the engine's own pipeline (collecting / copying chunk k + 1
+         while chunk k is mapped) stays whole; each time the kernels of further planes are on the
+         engine's stream (`Engine.set_chunk_callback`) the all-gathers of the exchanges they complete are
+         started asynchronously: exchange k crosses xGMI while later planes are still on their way in;
+      3. after the call has been FINISHED (`engine.synchronize()`: flag check / nanmedian replay) any
+         exchange not started yet - a rank without planes, a rank whose mapping raised - is started all
+         the same: no peer is left waiting in a collective;
+      4. one small all-reduce closes the call: (ranks that failed, ranks that redid planes with their
+         nanmedian after those planes had been sent). Any failure: EVERY rank raises (its own exception,
+         `PeerFailedError` elsewhere). Any redo (rare: +-inf pixels): every rank gathers the block once more.
+
+    `gather=False`: only this rank's slot is written, no collective, errors raise at once.
+    `pipeline_chunks=True` keeps the exchange bookkeeping running even when nothing is exchanged (a
+    single process timing what one rank of N would do: bench.py's shard proxy).
+    """
+    import torch
+    import torch.distributed as dist
+
+    start, stop, per_rank = shard_bounds(int(n_planes_total), int(world), int(rank))
+    mine_n = stop - start
+    exchange = gather and dist.is_initialized() and dist.get_world_size(group) > 1
+    chunked = exchange or bool(pipeline_chunks)
+    step = exchange_planes(per_rank, n0, n1) if chunked else max(per_rank, 1)
+    slot = gathered[rank]
+    if mine_n < per_rank:
+        slot[mine_n:].fill_(float('nan'))  # planes of a short last block
+    works, state = [], {'next': 0, 'error': None}
+    ext = None
+    if exchange and dist.get_backend(group) == 'nccl' and getattr(engine, 'stream', 0):
+        # collectives are ordered behind torch's CURRENT stream: make that the engine's stream while they are queued
+        ext = torch.cuda.ExternalStream(engine.stream, device=slot.device)
+
+    def issue(e0: int, e1: int) -> None:
+        if not exchange:
+            return
+        outs = [gathered[r, e0:e1] for r in range(world)]
+        if ext is not None:
+            with torch.cuda.stream(ext):
+                works.append(dist.all_gather(outs, slot[e0:e1], group=group, async_op=True))
+        else:
+            works.append(dist.all_gather(outs, slot[e0:e1], group=group, async_op=True))
+
+    def progress(done: int) -> None:
+        # planes [0, done) of the block have their kernels enqueued: start what has become ready
+        while state['next'] < per_rank:
+            e1 = min(state['next'] + step, per_rank)
+            if min(e1, mine_n) > done:
+                break
+            issue(state['next'], e1)
+            state['next'] = e1
+
+    def on_chunk(first: int, n: int) -> None:
+        try:
+            if state['error'] is None:
+                progress(first + n)
+        except Exception as e:  # noqa: BLE001 - must not unwind through the C frames
+            state['error'] = e
+
+    redone = 0
+    if mine_n > 0:
+        if chunked:
+            engine.set_chunk_callback(on_chunk)
+        try:
+            if host_cube:
+                engine.map_cube_host_to_device(local_cube[:mine_n], x_map, y_map, n0, n1, slot[:mine_n], interpolation, propagate_nan)
+            else:
+                engine.map_cube_device(local_cube[:mine_n], dtype, mine_n, x_map, y_map, n0, n1, slot[:mine_n], interpolation,
+                                       propagate_nan)
+            engine.synchronize()  # final: flag check / nanmedian replay
+            redone = int(engine.last_redo_planes())
+        except Exception as e:  # noqa: BLE001 - reported through the agreement
+            if not exchange:
+                raise
+            state['error'] = state['error'] or e
+        finally:
+            if chunked:
+                engine.set_chunk_callback(None)
+    if not exchange:
+        if state['error'] is not None:
+            raise state['error']
+        return
+    error = state['error']
+    try:
+        progress(per_rank)  # whatever has not been started yet
+    except Exception as e:  # noqa: BLE001
+        error = error or e
+    for w in works:
+        w.wait()
+    verdict = torch.tensor([0 if error is None else 1, 1 if (error is None and redone > 0) else 0], dtype=torch.int32,
+                           device=_group_device(group))
+    dist.all_reduce(verdict, op=dist.ReduceOp.SUM, group=group)
+    n_failed, n_redo = (int(v) for v in verdict.tolist())
+    if n_failed == 0 and n_redo > 0:
+        # somebody's planes changed after they had been sent: everybody gathers the whole block again
+        dist.all_gather([gathered[r] for r in range(world)], slot, group=group)
+    if error is not None:
+        raise error
+    if n_failed > 0:
+        raise PeerFailedError(f'{n_failed} other rank(s) failed in this sharded call: the gathered cube is not valid')
 
 
 class Comm:

@@ -126,6 +126,8 @@ class Engine:
             raise _lib.UnsupportedError(msg)
         if rc == _lib.PM_ERR_ALLOC:
             raise MemoryError(msg)
+        if rc == _lib.PM_ERR_PEER:
+            raise _lib.PeerFailedError(msg)
         raise _lib.EngineError(f'{msg} (status {rc})')
 
     def synchronize(self) -> None:
@@ -139,6 +141,25 @@ class Engine:
         v = ctypes.c_int64(0)
         self._check(self._lib.pm_get_option(self._ctx, int(option), ctypes.byref(v)))
         return int(v.value)
+
+    def last_redo_planes(self) -> int:
+        """planes of the latest finished nearest / linear map_cube that were redone with their nanmedian"""
+        return self.get_option(_lib.PM_OPT_LAST_REDO_PLANES)
+
+    def set_chunk_callback(self, fn) -> None:
+        """
+        `pm_set_chunk_callback`: `fn(first_plane, n_planes)` is called on the calling thread, inside a
+        nearest / linear `map_cube*` call, each time the kernels of further planes have been enqueued
+        on the engine's stream (planes arrive in order); None removes it. An exception raised by `fn`
+        cannot cross the C frames: catch inside `fn`.
+        """
+        if fn is None:
+            self._check(self._lib.pm_set_chunk_callback(self._ctx, None, None))
+            self._chunk_cb = None
+            return
+        cb = _lib.CHUNK_CALLBACK(lambda _user, first, n: fn(int(first), int(n)))
+        self._check(self._lib.pm_set_chunk_callback(self._ctx, ctypes.cast(cb, ctypes.c_void_p), None))
+        self._chunk_cb = cb  # (the C side holds a bare pointer: keep the thunk alive)
 
     @property
     def stream(self) -> int:

@@ -18,6 +18,22 @@ class OracleEngine:
         self.calls = []  # (kind, names) log, used to assert caching behaviour
 
     device = 0
+    _chunk_cb = None
+    redo_planes = 0  # what last_redo_planes() reports (tests set it to rehearse the second gather)
+
+    def set_chunk_callback(self, fn):
+        self._chunk_cb = fn
+
+    def last_redo_planes(self):
+        return self.redo_planes
+
+    def _report_chunks(self, n_planes):
+        """like the library: planes arrive in order, in a few pieces"""
+        if self._chunk_cb is None:
+            return
+        piece = max(1, n_planes // 3)
+        for first in range(0, n_planes, piece):
+            self._chunk_cb(first, min(piece, n_planes - first))
 
     def synchronize(self):
         self.calls.append(('sync',))
@@ -64,6 +80,7 @@ class OracleEngine:
 
         res = self.map_cube(cube.numpy()[:n_planes], x_map.numpy(), y_map.numpy(), interpolation, propagate_nan)
         out.reshape(n_planes, n0, n1).copy_(torch.from_numpy(res))
+        self._report_chunks(n_planes)
 
     def mapped_data_device(self, cube, dtype, n_planes, lon, lat, n0, n1, x_map, y_map, out, interpolation='linear',
                            propagate_nan=True, alt=0.0):
@@ -93,6 +110,7 @@ class OracleEngine:
         out.reshape(cube.shape[0], n0, n1).copy_(
             torch.from_numpy(oracle.map_cube(cube, x_map.numpy(), y_map.numpy(), interpolation, propagate_nan))
         )
+        self._report_chunks(cube.shape[0])
 
     def radec_query(self, ra, dec, *, alt=0.0, ring_only_visible=True):
         ra, dec = np.broadcast_arrays(np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64))

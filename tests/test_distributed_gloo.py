@@ -247,3 +247,136 @@ def test_bench_cube_host_section_world_size_2(tmp_path, planes):
     world = 2
     mp.spawn(_cube_host_worker, args=(world, _free_port(), planes, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def _protocol_worker(rank: int, world: int, port: int, tmpdir: str) -> None:
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from oracle import oracle
+        from oracle_engine import OracleEngine
+        import planetmapper_amd.distributed as D
+        from planetmapper_amd import Observation
+        from planetmapper_amd.scenarios import load_scenario
+
+        g = load_scenario('jupiter_hst_2005')
+        eng = OracleEngine()
+        eng.set_geometry(g)
+        eng.set_disc(9.5, 12.0, 8.0, 0.5, 20, 24, True)
+        lon, lat = oracle.rectangular_grid(g, 15.0)
+        o = eng.backplanes_map(['PIXEL-X', 'PIXEL-Y'], lon, lat)
+        xm, ym = torch.from_numpy(o['PIXEL-X'].copy()), torch.from_numpy(o['PIXEL-Y'].copy())
+        n0, n1 = lon.shape
+        planes = 11  # 6 + 5: the second rank's last exchange is half padding
+        rng = np.random.default_rng(77)
+        cube = rng.standard_normal((planes, 24, 20))
+        cube[rng.random(cube.shape) < 0.02] = np.nan
+        a, b, per_rank = D.shard_bounds(planes, world, rank)
+        expect = oracle.map_cube(cube, xm.numpy(), ym.numpy())
+
+        # ---- (b) several exchanges per block: the all-gathers of finished exchanges are in flight while
+        # the next one is mapped; the pieces land rank-major
+        real_exchange = D.exchange_planes
+        D.exchange_planes = lambda per, n0_, n1_: 2  # (the real rule gives one exchange for a map this small)
+        try:
+            for host_cube in (True, False):
+                gathered = torch.full((world, per_rank, n0, n1), -7.0, dtype=torch.float64)
+                local = cube[a:b].copy() if host_cube else torch.from_numpy(cube[a:b].copy())
+                eng.calls.clear()
+                D.map_cube_sharded_pipelined(eng, local, np.float64, planes, xm, ym, n0, n1, gathered, rank, world,
+                                             host_cube=host_cube)
+                got = gathered.reshape(world * per_rank, n0, n1).numpy()
+                assert np.array_equal(got[:planes], expect, equal_nan=True)
+                assert np.isnan(got[planes:]).all()  # padding of the short block
+                kinds = [c[0] for c in eng.calls]
+                # ONE engine call per block (its own pipeline stays whole), finished before the closing agreement
+                assert kinds == ['host_cube' if host_cube else 'cube', 'sync']
+            # planes redone with their nanmedian after they were sent: everybody gathers once more
+            eng.redo_planes = 1 if rank == 0 else 0
+            gathered = torch.full((world, per_rank, n0, n1), -7.0, dtype=torch.float64)
+            D.map_cube_sharded_pipelined(eng, cube[a:b].copy(), np.float64, planes, xm, ym, n0, n1, gathered, rank, world,
+                                         host_cube=True)
+            eng.redo_planes = 0
+            assert np.array_equal(gathered.reshape(-1, n0, n1).numpy()[:planes], expect, equal_nan=True)
+            # ---- (e) a rank whose mapping raises: nobody hangs, every rank raises
+            class Boom(RuntimeError):
+                pass
+
+            def failing(*args, **kw):
+                raise Boom('injected')
+
+            eng_bad = OracleEngine()
+            eng_bad.set_geometry(g)
+            eng_bad.set_disc(9.5, 12.0, 8.0, 0.5, 20, 24, True)
+            if rank == 1:
+                eng_bad.map_cube_host_to_device = failing
+            gathered = torch.zeros((world, per_rank, n0, n1), dtype=torch.float64)
+            with pytest.raises(Boom if rank == 1 else D.PeerFailedError):
+                D.map_cube_sharded_pipelined(eng_bad, cube[a:b].copy(), np.float64, planes, xm, ym, n0, n1, gathered, rank, world,
+                                             host_cube=True)
+            # the group is still usable afterwards
+            D.map_cube_sharded_pipelined(eng, cube[a:b].copy(), np.float64, planes, xm, ym, n0, n1, gathered, rank, world,
+                                         host_cube=True)
+            assert np.array_equal(gathered.reshape(-1, n0, n1).numpy()[:planes], expect, equal_nan=True)
+        finally:
+            D.exchange_planes = real_exchange
+
+        # ---- (e) the numpy-level API: agreement before the all-gather
+        obs = Observation(data=cube, geometry=g, engine=OracleEngine())
+        obs.set_disc_params(9.5, 12.0, 8.0, 30.0)
+        full = obs.get_mapped_data(degree_interval=15)
+        obs_bad = Observation(data=cube, geometry=g, engine=OracleEngine())
+        obs_bad.set_disc_params(9.5, 12.0, 8.0, 30.0)
+        if rank == 0:
+            def bad_map_img(*args, **kw):
+                raise ValueError('injected on rank 0')
+
+            obs_bad.map_img = bad_map_img
+        with pytest.raises(ValueError if rank == 0 else D.PeerFailedError):
+            D.get_mapped_data_sharded(obs_bad, degree_interval=15)
+        assert np.array_equal(D.get_mapped_data_sharded(obs, degree_interval=15), full, equal_nan=True)
+
+        # ---- no collective at all: every rank writes its planes into ONE shared array
+        shared = np.lib.format.open_memmap(os.path.join(tmpdir, 'shared.npy'), mode='r+')
+        out = D.get_mapped_data_sharded(obs, gather=False, out=shared, degree_interval=15)
+        assert out is shared
+        shared.flush()
+        dist.barrier()
+        again = np.load(os.path.join(tmpdir, 'shared.npy'))
+        assert np.array_equal(again, full, equal_nan=True)
+        with pytest.raises(ValueError):
+            D.get_mapped_data_sharded(obs, gather=False, out=np.zeros((1, 2, 3)), degree_interval=15)
+        open(os.path.join(tmpdir, f'ok{rank}'), 'w').close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_exchange_failure_agreement_and_shared_output_world_size_2(tmp_path):
+    """
+    The protocol of the sharded cube (distributed.map_cube_sharded_pipelined = pm_map_cube_sharded):
+    several exchanges per block with their all-gathers started behind the mapping, a failing rank that
+    keeps its peers from hanging (every rank raises), and the collective-free form where every rank
+    writes its planes into one shared (P, n0, n1) array.
+    """
+    world = 2
+    np.lib.format.open_memmap(os.path.join(tmp_path, 'shared.npy'), mode='w+', dtype=np.float64, shape=(11, 12, 24))[...] = -1.0
+    mp.spawn(_protocol_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f'ok{r}') for r in range(world))
+
+
+def test_exchange_planes_rule_equals_the_c_one():
+    import ctypes  # noqa: F401
+
+    from planetmapper_amd import _lib
+    from planetmapper_amd.distributed import exchange_planes
+
+    lib = _lib.load()
+    for per in (0, 1, 2, 7, 8, 9, 64, 65, 256, 512, 4096):
+        for n0, n1 in ((180, 360), (6, 12), (1, 1), (1800, 3600), (0, 5)):
+            assert lib.pm_exchange_planes(per, n0, n1) == exchange_planes(per, n0, n1), (per, n0, n1)
+    assert exchange_planes(64, 180, 360) == 9 and exchange_planes(512, 180, 360) == 64

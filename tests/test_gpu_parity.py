@@ -1621,3 +1621,154 @@ def test_a_point_alone_equals_the_same_point_inside_an_array(engine, oracle, jup
     rows = engine.backplanes_img_rows(['LAT-GRAPHIC', 'INCIDENCE', 'EMISSION'], 90, 1)
     for n in rows:
         assert np.array_equal(full[n][90], rows[n][0], equal_nan=True), n
+
+
+def test_block_table_cache_routes_measured_and_chunk_callback(engine, oracle, jupiter):
+    """
+    The per-context state of the host-cube path (round 3): (a) the block table is reused by later calls
+    with the same x/y map and rebuilt when the map (one cell!), the disc or the dtype changes, and can be
+    switched off; (b) left to itself the library feeds three short chunks through each candidate route
+    on the first large call, commits to the fastest, and every route gives the same bits;
+    (c) the chunk callback reports every plane once, in order, and the number of planes redone.
+    """
+    import torch
+
+    from planetmapper_amd import _lib
+
+    sz, planes = 512, 200
+    x0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 1.0)
+    xm, ym = engine.xy_map(lon, lat)
+    n0, n1 = xm.shape
+    rng = np.random.default_rng(99)
+    cube = engine.pinned_empty((planes, sz, sz))
+    cube[...] = rng.standard_normal((planes, sz, sz))
+    cube[rng.random(cube.shape) < 1e-3] = np.nan
+    dxm, dym = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+    out = torch.empty((planes, n0, n1), dtype=torch.float64, device='cuda')
+    ref = torch.empty_like(out)
+    engine.map_cube_device(torch.from_numpy(cube).cuda(), np.float64, planes, dxm, dym, n0, n1, ref)
+    engine.synchronize()
+    ref = ref.cpu().numpy()
+    hits = lambda: engine.get_option(_lib.PM_OPT_BLOCK_TABLE_HITS)  # noqa: E731
+
+    def fed(c=cube, xm_=dxm, ym_=dym, o=out):
+        engine.map_cube_host_to_device(c, xm_, ym_, n0, n1, o[: c.shape[0]])
+        engine.synchronize()
+        return o[: c.shape[0]].cpu().numpy()
+
+    try:
+        # ---- (b) first call: exploration, then committed
+        engine.set_option(_lib.PM_OPT_ROUTE_EXPLORE, 1)
+        assert np.array_equal(fed(), ref, equal_nan=True)
+        ns = {r: engine.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(4)}
+        assert ns[0] > 0 and ns[2] > 0 and ns[3] > 0 and ns[1] == 0, ns  # pinned cube: three candidates were timed
+        best = min((v, r) for r, v in ns.items() if v > 0)[1]
+        assert engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) == best
+        h0 = hits()
+        assert np.array_equal(fed(), ref, equal_nan=True)  # committed route, cached table
+        assert engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) == best and hits() > h0
+        # a pageable copy of the cube is another problem (no GPU fetch possible): measured afresh, same bits
+        pageable = np.array(cube)
+        assert np.array_equal(fed(pageable), ref, equal_nan=True)
+        ns2 = {r: engine.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(4)}
+        assert ns2[0] > 0 and ns2[3] > 0 and ns2[2] == 0, ns2
+        # every explicit route: the same bits
+        for route in (0, 1, 2, 3):
+            engine.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, route)
+            assert np.array_equal(fed(), ref, equal_nan=True), route
+            assert engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) in ((route,) if route != 1 else (1, -1, best, 0, 2, 3))
+        engine.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, 3)
+        # ---- (a) cache: hit on an identical map, miss when ONE cell moves (and the moved map's result is right)
+        h0 = hits()
+        fed(cube[:16])
+        assert hits() == h0 + 1
+        xm2 = xm.copy()
+        k = np.flatnonzero(np.isfinite(xm2))[1234]
+        xm2.flat[k] += 2.75
+        dxm2 = torch.from_numpy(xm2).cuda()
+        got2 = fed(cube[:16], dxm2)
+        assert hits() == h0 + 1  # rebuilt
+        want2 = torch.empty((16, n0, n1), dtype=torch.float64, device='cuda')
+        engine.map_cube_device(torch.from_numpy(cube[:16]).cuda(), np.float64, 16, dxm2, dym, n0, n1, want2)
+        engine.synchronize()
+        assert np.array_equal(got2, want2.cpu().numpy(), equal_nan=True)
+        assert not np.array_equal(got2, ref[:16], equal_nan=True)
+        fed(cube[:16], dxm2)
+        assert hits() == h0 + 2
+        # another dtype with the same map: its own table
+        c32 = cube[:16].astype(np.float32)
+        got32 = fed(c32, dxm2)
+        assert hits() == h0 + 2
+        engine.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, 0)
+        assert np.array_equal(got32, fed(c32, dxm2), equal_nan=True)
+        engine.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, 3)
+        # switched off: never a hit, same results
+        engine.set_option(_lib.PM_OPT_BLOCK_TABLE_CACHE, 0)
+        h1 = hits()
+        assert np.array_equal(fed(cube[:16]), ref[:16], equal_nan=True) and np.array_equal(fed(cube[:16]), ref[:16], equal_nan=True)
+        assert hits() == h1
+        engine.set_option(_lib.PM_OPT_BLOCK_TABLE_CACHE, 1)
+        # ---- (c) chunk callback: every plane once, in order; redone planes counted
+        for route in (0, 2, 3, -1):
+            engine.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, route)
+            seen = []
+            engine.set_chunk_callback(lambda first, n: seen.append((first, n)))
+            try:
+                fed()
+            finally:
+                engine.set_chunk_callback(None)
+            assert seen and seen[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(seen, seen[1:])), (route, seen[:4])
+            assert seen[-1][0] + seen[-1][1] == planes
+            assert engine.last_redo_planes() == 0
+        seen = []
+        engine.set_chunk_callback(lambda first, n: seen.append((first, n)))
+        try:
+            dirty = np.array(cube[:12])
+            dirty[5][200:300, 200:330] = np.inf
+            dirty[9][100:140, 250:300] = -np.inf
+            fed(dirty)
+            assert engine.last_redo_planes() == 2 and seen[-1][0] + seen[-1][1] == 12
+            seen.clear()
+            engine.map_cube_device(torch.from_numpy(dirty).cuda(), np.float64, 12, dxm, dym, n0, n1, out[:12])
+            assert seen == [(0, 12)]
+            engine.synchronize()
+            assert engine.last_redo_planes() == 2
+        finally:
+            engine.set_chunk_callback(None)
+    finally:
+        engine.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, -1)
+        engine.set_option(_lib.PM_OPT_BLOCK_TABLE_CACHE, 1)
+        engine.set_option(_lib.PM_OPT_ROUTE_EXPLORE, 1)
+
+
+def test_c_abi_sharded_cube_into_one_host_array_without_a_collective(engine, oracle, jupiter):
+    """pm_map_cube_sharded(mem = PM_MEM_HOST, gather = 0): the ranks of a job write their planes into ONE
+    (P, n0, n1) host array - rehearsed here as the 3 'ranks' of a communicator-less call, one after the other."""
+    import ctypes
+
+    from planetmapper_amd import _lib
+    from planetmapper_amd.distributed import shard_bounds
+
+    sz, planes = 96, 7
+    x0 = (sz - 1) / 2
+    engine.set_geometry(jupiter)
+    engine.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+    lon, lat = oracle.rectangular_grid(jupiter, 10.0)
+    xm, ym = engine.xy_map(lon, lat)
+    n0, n1 = xm.shape
+    rng = np.random.default_rng(8)
+    cube = rng.standard_normal((planes, sz, sz))
+    whole = engine.map_cube(cube, xm, ym)
+    out = np.full((planes, n0, n1), -5.0)
+    lib, ctx = engine._lib, engine._ctx
+    # (comm = NULL is a single rank: it owns every plane)
+    engine._check(lib.pm_map_cube_sharded(ctx, None, cube.ctypes.data, 0, planes, xm.ctypes.data, ym.ctypes.data, n0, n1, 1, 1,
+                                          out.ctypes.data, _lib.PM_MEM_HOST, 0))
+    assert np.array_equal(out, whole, equal_nan=True)
+    with pytest.raises(ValueError):
+        engine._check(lib.pm_map_cube_sharded(ctx, None, cube.ctypes.data, 0, planes, xm.ctypes.data, ym.ctypes.data, n0, n1, 1, 1,
+                                              out.ctypes.data, _lib.PM_MEM_HOST, 1))
+    assert shard_bounds(planes, 3, 2) == (6, 7, 3)

@@ -83,6 +83,7 @@ struct HostPipe {
     static constexpr int kRing = 3;
     hipEvent_t ev_in[kRing] = {}, ev_k[kRing] = {};
     hipEvent_t ev_tmp = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // (with timing: stage times of a probe chunk)
     // ---- pinned staging of the H2D leg of block tables collected by the pool (one per ring slot)
     char *in_stage[kRing] = {};
     size_t in_stage_bytes = 0;
@@ -440,6 +441,8 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
             PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_k[i], hipEventDisableTiming));
         }
         PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_tmp, hipEventDisableTiming));
+        PM_HIP(ctx, hipEventCreate(&hp->ev_t0));
+        PM_HIP(ctx, hipEventCreate(&hp->ev_t1));
         for (int i = 0; i < HostPipe::kSlots; i++)
             PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_stage[i], hipEventDisableTiming));
     }
@@ -487,6 +490,8 @@ void pipe_destroy(pm_ctx *ctx)
         if (hp->ev_k[i]) (void)hipEventDestroy(hp->ev_k[i]);
     }
     if (hp->ev_tmp) (void)hipEventDestroy(hp->ev_tmp);
+    if (hp->ev_t0) (void)hipEventDestroy(hp->ev_t0);
+    if (hp->ev_t1) (void)hipEventDestroy(hp->ev_t1);
     if (hp->s_in) (void)hipStreamDestroy(hp->s_in);
     if (hp->s_out) (void)hipStreamDestroy(hp->s_out);
     delete hp;
@@ -888,9 +893,15 @@ SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, siz
 
 // the pipeline over one segment: H2D of chunk k + 1 (whole planes, or the block table the pool has
 // collected), kernel of chunk k and the staged D2H of finished output overlap on three streams
+// `stage_ns` (probe segments: ONE chunk): the time of the route's slowest pipeline stage for that chunk -
+// what a long run of such chunks costs per chunk once the stages overlap: the copy threads' collection
+// against the DMA of the table (3), the DMA of the planes (0), the GPU's own fetch over the link (2).
+// (The wall time of a lone chunk would add the stages up and charge the pipeline's fill to the route.)
 int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, const SegLayout &L, const HostPipe::Table *tab,
-                const double *dxm, const double *dym, const char *cube_dev, double *out_dev)
+                const double *dxm, const double *dym, const char *cube_dev, double *out_dev, double *stage_ns)
 {
+    double cpu_stage_ns = 0.0;
+    bool timed_events = false;
     const hipStream_t sk = ctx->stream;
     const size_t nmap = j.nmap;
     const bool blocks = sg.route == HostPipe::kFetch, host_blocks = sg.route == HostPipe::kCollect;
@@ -914,6 +925,10 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
         const size_t nb = std::min(L.batch, sg.n - b0);
         size_t drained = 0;  // planes of this batch already handed to the D2H leg
         size_t launched = 0;
+        // (Tried: ramping the chunks of a collected table up and down - c/8, c/4 ... c ... halves of the rest -
+        //  to shorten the pipeline's fill and drain for short blocks. Same-box A/B, 64 and 512 planes, three
+        //  process pairs: 2.26-2.86 vs 2.17-2.52 ms and 11.9-16.3 vs 13.0-14.6 ms - inside the run-to-run
+        //  spread of the collecting threads' placement; not kept.)
         for (size_t q0 = 0; q0 < nb; q0 += L.chunk, c++) {
             const size_t np = std::min(L.chunk, nb - q0);
             const size_t pl = sg.p0 + b0 + q0;  // first plane of the chunk within the call
@@ -932,9 +947,16 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 // done) while the DMA of the previous chunk runs
                 char *dslot = ring + (size_t)slot * L.slot_bytes;
                 if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
+                const double tg = stage_ns ? now_ns() : 0.0;
                 hp->gather(hp->in_stage[slot], j.cube + pl * j.plane_bytes, j.plane_bytes, np, hlist, tab->n_list, tab->shift);
+                if (stage_ns) cpu_stage_ns += now_ns() - tg;
                 if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                if (stage_ns && c == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
                 PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * L.table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
+                if (stage_ns && c == 0) {
+                    PM_HIP(ctx, hipEventRecord(hp->ev_t1, hp->s_in));
+                    timed_events = true;
+                }
                 PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
                 PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
                 b.cube = nullptr;  // no plane to fall back on: see cleaned_value / BlockLoader
@@ -942,15 +964,28 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
             } else {
                 char *dslot = ring + (size_t)slot * L.slot_bytes;
                 if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                if (stage_ns && c == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
+                const double tc = stage_ns ? now_ns() : 0.0;
                 PM_HIP(ctx, hipMemcpyAsync(dslot, j.cube + pl * j.plane_bytes, np * j.plane_bytes, hipMemcpyHostToDevice, hp->s_in));
+                if (stage_ns) cpu_stage_ns += now_ns() - tc;  // (pageable planes: the runtime stages them inside the call)
+                if (stage_ns && c == 0) {
+                    PM_HIP(ctx, hipEventRecord(hp->ev_t1, hp->s_in));
+                    timed_events = true;
+                }
                 PM_HIP(ctx, hipEventRecord(hp->ev_in[slot], hp->s_in));
                 PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
                 b.cube = dslot;
             }
+            const bool time_kernel = stage_ns && c == 0 && L.zero_copy;  // (the GPU's reads over the link ARE the stage)
+            if (time_kernel) PM_HIP(ctx, hipEventRecord(hp->ev_t0, sk));
             if (blocks || host_blocks)
                 pm_launch_reproject_blocks(b, tb, j.dtype, sk, /*fetch=*/blocks);
             else
                 pm_launch_reproject(b, j.dtype, sk);
+            if (time_kernel) {
+                PM_HIP(ctx, hipEventRecord(hp->ev_t1, sk));
+                timed_events = true;
+            }
             PM_HIP(ctx, hipGetLastError());
             PM_HIP(ctx, hipEventRecord(hp->ev_k[slot], sk));
             if (ctx->chunk_cb) ctx->chunk_cb(ctx->chunk_user, (int)pl, (int)np);
@@ -980,6 +1015,11 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
     // the ring and the events are free for the next segment / the flag check
     PM_HIP(ctx, hipStreamSynchronize(sk));
     PM_HIP(ctx, hipStreamSynchronize(hp->s_in));
+    if (stage_ns) {
+        float ms = 0.0f;
+        if (timed_events) PM_HIP(ctx, hipEventElapsedTime(&ms, hp->ev_t0, hp->ev_t1));
+        *stage_ns = std::max(cpu_stage_ns, (double)ms * 1e6);
+    }
     return PM_OK;
 }
 
@@ -1002,6 +1042,8 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
 static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
                                         const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
 {
+    static const bool trace = std::getenv("PM_HOSTPIPE_TRACE") != nullptr;  // stage times of every call on stderr
+    const double t_call = trace ? now_ns() : 0.0;
     HostPipe *hp;
     int rc = pipe_get(ctx, &hp);
     if (rc != PM_OK) return rc;
@@ -1069,6 +1111,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         have256 = t256.n_list > 0;
     }
 
+    const double t_tables = trace ? now_ns() : 0.0;
     // ---- the plan: segments of planes, each fed by one route
     std::vector<Segment> plan;
     const size_t P = (size_t)n_planes;
@@ -1099,11 +1142,11 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         }
         const size_t row16 = t16.n_list << pm::kBlkShiftHost;
         const int by_size = row16 * 5 < j.plane_bytes * 2 ? HostPipe::kCollect : HostPipe::kWhole;
-        // probe segments: three short chunks each, so that the pipeline's fill is a third of the figure
-        const size_t c3 = std::max<size_t>(1, std::min<size_t>(8, ((size_t)8 << 20) / std::max<size_t>(row16, 1)));
-        const size_t c0 = std::max<size_t>(1, ((size_t)32 << 20) / j.plane_bytes);
-        const size_t c2 = c3;
-        const size_t need_planes = 3 * c3 + 3 * c0 + (can_fetch ? 3 * c2 : 0);
+        // probe segments: ONE chunk of the route's usual size each, judged by its slowest stage (run_segment)
+        const size_t c3 = std::max<size_t>(1, std::min<size_t>(ctx->host_chunk_bytes / std::max<size_t>(row16, 1), 32768));
+        const size_t c0 = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
+        const size_t c2 = std::max<size_t>(1, std::min<size_t>(c3, ((size_t)64 << 20) / j.plane_bytes));
+        const size_t need_planes = c3 + c0 + (can_fetch ? c2 : 0);
         if (rs.committed == HostPipe::kFetch && can_fetch) {
             if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
             have256 = t256.n_list > 0;
@@ -1113,16 +1156,16 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         } else if (ctx->route_explore && P > need_planes) {
             exploring = true;
             size_t at = 0;
-            plan.push_back({HostPipe::kCollect, at, 3 * c3, c3, true});
-            at += 3 * c3;
-            plan.push_back({HostPipe::kWhole, at, 3 * c0, c0, true});
-            at += 3 * c0;
+            plan.push_back({HostPipe::kCollect, at, c3, c3, true});
+            at += c3;
+            plan.push_back({HostPipe::kWhole, at, c0, c0, true});
+            at += c0;
             if (can_fetch) {
                 if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
                 have256 = t256.n_list > 0;
                 if (have256) {
-                    plan.push_back({HostPipe::kFetch, at, 3 * c2, c2, true});
-                    at += 3 * c2;
+                    plan.push_back({HostPipe::kFetch, at, c2, c2, true});
+                    at += c2;
                 }
             }
             plan.push_back({-1, at, P - at, 0, false});  // route filled in once the probes are in
@@ -1169,6 +1212,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     else if (dst_pinned)
         PM_HIP(ctx, hipHostGetDevicePointer((void **)&out_dev, (void *)out, 0));
 
+    const double t_plan = trace ? now_ns() : 0.0;
     for (size_t i = 0; i < plan.size(); i++) {
         Segment &sg = plan[i];
         if (sg.n == 0) continue;
@@ -1184,16 +1228,22 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         }
         const HostPipe::Table *tt = sg.route == HostPipe::kFetch ? &t256 : &t16;
         const double t_begin = now_ns();
-        rc = run_segment(ctx, hp, j, sg, lay[i], tt, dxm, dym, cube_dev, out_dev);
+        double stage = 0.0;
+        rc = run_segment(ctx, hp, j, sg, lay[i], tt, dxm, dym, cube_dev, out_dev, sg.probe ? &stage : nullptr);
         if (rc != PM_OK) return rc;
-        const double per_plane = (now_ns() - t_begin) / (double)sg.n;
+        const double wall = now_ns() - t_begin;
         ctx->last_cube_route = sg.route;
-        if (mode < 0 && sg.route >= 0 && sg.route < 4 && (sg.probe || !exploring) && sg.n >= 3) {
-            // (a running mean once committed: the figure pm_get_option reports follows the box)
+        if (trace) std::fprintf(stderr, "[pm hostpipe] segment route %d planes %zu+%zu: %.3f ms%s (stage %.3f ms)\n", sg.route, sg.p0, sg.n,
+                                wall * 1e-6, sg.probe ? " probe" : "", stage * 1e-6);
+        if (mode < 0 && sg.route >= 0 && sg.route < 4) {
             double &v = rs.ns_per_plane[sg.route];
-            v = (v > 0.0 && !sg.probe) ? 0.75 * v + 0.25 * per_plane : per_plane;
+            if (sg.probe)
+                v = stage / (double)sg.n;
+            else if (!exploring && sg.n >= 3 * lay[i].chunk)  // (a running mean once committed, from calls long enough to be pipelines)
+                v = v > 0.0 ? 0.75 * v + 0.25 * wall / (double)sg.n : wall / (double)sg.n;
         }
     }
+    const double t_segs = trace ? now_ns() : 0.0;
     // per-plane flags of the whole call: one read-back
     std::vector<int> hflags((size_t)n_planes);
     PM_HIP(ctx, hipMemcpyAsync(hflags.data(), ctx->flags, (size_t)n_planes * sizeof(int), hipMemcpyDeviceToHost, sk));
@@ -1204,6 +1254,9 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     for (int p = 0; p < n_planes; p++)
         if (hflags[(size_t)p] == a.seq) redo.push_back(p);
     ctx->last_redo_planes = (int)redo.size();
+    if (trace)
+        std::fprintf(stderr, "[pm hostpipe] call %d planes: setup+tables %.3f ms, plan+scratch %.3f ms, segments %.3f ms, flags %.3f ms\n", n_planes,
+                     (t_tables - t_call) * 1e-6, (t_plan - t_tables) * 1e-6, (t_segs - t_plan) * 1e-6, (now_ns() - t_segs) * 1e-6);
     if (!redo.empty()) {
         char *base = (char *)ctx->scratch;
         char *dplane = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);  // scratch was sized for one plane + one mapped plane behind the maps

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 1
+#define PM_ABI_VERSION 2 /* 2: pm_geometry.DVT, DAT */
 
 typedef enum pm_status {
     PM_OK = 0,
@@ -108,14 +108,22 @@ typedef struct pm_geometry {
     double radii[3];    /* Body.radii (a, b, c) WITHOUT altitude adjustment */
 
     double T0[3];       /* Body._target_obsvec: target centre at t0 wrt observer at et */
-    double VT[3];       /* SSB velocity of target centre at t0 */
-    double AT[3];       /* SSB acceleration of target centre at t0 */
+    double VT[3];       /* d/dt of the SSB position of the target centre at t0 (see DVT) */
+    double AT[3];       /* d2/dt2 of it */
     double VO[3];       /* SSB velocity of observer at et (radial velocity only) */
+    double DVT[3];      /* what a STATE of the target centre at t0 (spkezr: Body._state_from_targvec,
+                           body.py:2830-2845) adds to VT. VT / AT are the derivatives of the target's
+                           POSITION with respect to time - what re-evaluating the ephemeris at et - lt, as
+                           CSPICE does at every light-time pass, amounts to; a segment that carries its
+                           own velocity polynomial (SPK type 3: Jupiter wrt its barycentre in jup120)
+                           gives a state velocity 2e-6 km/s away from that. Radial velocity only; 0 for
+                           type 2 chains. */
+    double DAT[3];      /* the same for the acceleration: d/dt of the state velocity minus AT (7e-9 km/s^2) */
 
     double ts0;         /* epoch at which S0/VS/AS are evaluated (~ t0 - Sun light time) */
     double S0[3];       /* P_sun(ts0) - P_T(t0) */
-    double VS[3];       /* SSB velocity of the Sun at ts0 */
-    double AS[3];       /* SSB acceleration of the Sun at ts0 */
+    double VS[3];       /* d/dt of the SSB position of the Sun at ts0 */
+    double AS[3];       /* d2/dt2 of it */
 
     double R0[9];       /* pxform(J2000 -> target frame) at t0 */
     double wdot;        /* spin rate about body +z, rad/s (dW/dt of the IAU model) */

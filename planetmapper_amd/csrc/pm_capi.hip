@@ -189,6 +189,12 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     rot(g.VS, p.VSB, 1.0);
     rot(g.AS, p.ASB, 1.0);
     rot(g.VO, p.VOB, 1.0);
+    {
+        const double vst[3] = {g.VT[0] + g.DVT[0], g.VT[1] + g.DVT[1], g.VT[2] + g.DVT[2]};
+        rot(vst, p.VSB_state, 1.0);
+        const double ast[3] = {g.AT[0] + g.DAT[0], g.AT[1] + g.DAT[1], g.AT[2] + g.DAT[2]};
+        rot(ast, p.ASB_state, 1.0);
+    }
     rot(g.ring_n, p.ring_nb, 1.0);
     rot(g.sub_obsvec, p.sub_obs_b, 1.0);
     rot(g.sub_ray, p.sub_ray_b, 1.0);

@@ -494,8 +494,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             }
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
-                const V3 vp = {fma(kp->AB[0], d, kp->VB[0]) - kp->g.wdot * sp0.y, fma(kp->AB[1], d, kp->VB[1]) + kp->g.wdot * sp0.x,
-                               fma(kp->AB[2], d, kp->VB[2])};
+                const V3 vp = {fma(kp->ASB_state[0], d, kp->VSB_state[0]) - kp->g.wdot * sp0.y,
+                               fma(kp->ASB_state[1], d, kp->VSB_state[1]) + kp->g.wdot * sp0.x, fma(kp->ASB_state[2], d, kp->VSB_state[2])};
                 const V3 vo = v3(kp->VOB[0], kp->VOB[1], kp->VOB[2]);
                 const double dlt = (dot(u, vp - vo) * kp->inv_c) / (1.0 + dot(u, vp) * kp->inv_c);
                 const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;

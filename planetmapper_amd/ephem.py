@@ -229,11 +229,53 @@ class RotationModel:
             @ rotate(math.pi / 2.0 + ra, 3)
         )
 
-    def spin_rate(self, et: float, h: float = 16.0) -> float:
-        """dW/dt in rad/s (nutation terms included, by central difference)."""
-        _, _, w1 = self.euler_deg(et + h)
-        _, _, w0 = self.euler_deg(et - h)
-        return math.radians(w1 - w0) / (2.0 * h)
+    def spin_rate(self, et: float) -> float:
+        """
+        dW/dt in rad/s, the derivative of the model taken term by term (nutation terms included). (A
+        central difference of W itself, 1.6e6 deg for Jupiter in 2005, carries the rounding of W divided
+        by the step: 1.7e-13 rad/s - as much as the whole rotation budget over a light-time span.)
+        """
+        t_cent = et / JULIAN_CENTURY_S
+        d_days = et / SPD
+        rate = 0.0  # deg / s
+        for k, ck in enumerate(self.pm):
+            if k >= 1:
+                rate += k * ck * d_days ** (k - 1) / SPD
+        for i in range(min(len(self.nut_prec_pm), len(self.nut_prec_angles) // 2)):
+            theta = math.radians(self.nut_prec_angles[2 * i] + self.nut_prec_angles[2 * i + 1] * t_cent)
+            theta_dot = math.radians(self.nut_prec_angles[2 * i + 1]) / JULIAN_CENTURY_S  # rad / s
+            rate += self.nut_prec_pm[i] * math.cos(theta) * theta_dot
+        return math.radians(rate)
+
+    def pole_rates(self, et: float) -> tuple[float, float]:
+        """(d RA / dt, d DEC / dt) of the pole in rad/s, term by term."""
+        t_cent = et / JULIAN_CENTURY_S
+        ra = dec = 0.0  # deg / century
+        for k, ck in enumerate(self.pole_ra):
+            if k >= 1:
+                ra += k * ck * t_cent ** (k - 1)
+        for k, ck in enumerate(self.pole_dec):
+            if k >= 1:
+                dec += k * ck * t_cent ** (k - 1)
+        for i in range(len(self.nut_prec_angles) // 2):
+            theta = math.radians(self.nut_prec_angles[2 * i] + self.nut_prec_angles[2 * i + 1] * t_cent)
+            rate = math.radians(self.nut_prec_angles[2 * i + 1])  # rad / century
+            if i < len(self.nut_prec_ra):
+                ra += self.nut_prec_ra[i] * math.cos(theta) * rate
+            if i < len(self.nut_prec_dec):
+                dec -= self.nut_prec_dec[i] * math.sin(theta) * rate
+        return math.radians(ra) / JULIAN_CENTURY_S, math.radians(dec) / JULIAN_CENTURY_S
+
+    def body_z_rate(self, et: float) -> float:
+        """
+        Angular velocity of the body-fixed frame about its own +z axis, rad/s: dW/dt plus the component of
+        the pole's precession along the pole, d RA / dt * sin(DEC) (W is counted from the node of the
+        equator, which moves with the pole: Saturn 2e-13 rad/s). R(t0 + d) = Rz(body_z_rate * d) R(t0) up
+        to the TRANSVERSE motion of the pole (Jupiter 1e-14, Saturn 2e-14, Mars 5e-13 rad/s).
+        """
+        ra_dot, _ = self.pole_rates(et)
+        dec = math.radians(self.euler_deg(et)[1])
+        return self.spin_rate(et) + ra_dot * math.sin(dec)
 
 
 # ----------------------------------------------------------------------------------
@@ -309,6 +351,23 @@ class ChebySegment:
                 v, dv, _ = _cheby_eval(c, s)
                 vel[i] = v
                 acc[i] = dv / radius
+        return pos, vel, acc
+
+    def motion(self, et: float) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """
+        (position, d/dt position, d2/dt2 position): the derivatives of the POSITION series itself, also
+        for type 3 - whose separate velocity polynomial (`state`) is a fit of its own, a few 1e-6 km/s
+        away from this. What evaluating the position at neighbouring epochs amounts to.
+        """
+        rec = self._record(et)
+        mid, radius = rec[0], rec[1]
+        ncomp = 3 if self.spk_type == 2 else 6
+        n = (len(rec) - 2) // ncomp
+        s = (et - mid) / radius
+        pos, vel, acc = np.empty(3), np.empty(3), np.empty(3)
+        for i in range(3):
+            p, dp, ddp = _cheby_eval(rec[2 + i * n : 2 + (i + 1) * n], s)
+            pos[i], vel[i], acc[i] = p, dp / radius, ddp / (radius * radius)
         return pos, vel, acc
 
     def trimmed(self, et_lo: float, et_hi: float) -> 'ChebySegment':
@@ -450,6 +509,24 @@ class Ephemeris:
             if seg.frame != 1:
                 raise ValueError('only J2000 (frame 1) segments are supported')
             p, v, a = seg.state(et)
+            pos += p
+            vel += v
+            acc += a
+            cur = seg.center
+            hops += 1
+            if hops > 8:
+                raise RuntimeError('ephemeris chain too long')
+        return pos, vel, acc
+
+    def ssb_motion(self, body: int, et: float):
+        """(pos, d pos / dt, d2 pos / dt2) of `body` wrt the SSB: `ChebySegment.motion` along the chain."""
+        pos, vel, acc = np.zeros(3), np.zeros(3), np.zeros(3)
+        cur, hops = body, 0
+        while cur != 0:
+            seg = self._find(cur, et)
+            if seg.frame != 1:
+                raise ValueError('only J2000 (frame 1) segments are supported')
+            p, v, a = seg.motion(et)
             pos += p
             vel += v
             acc += a

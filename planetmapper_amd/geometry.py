@@ -36,6 +36,8 @@ class PMGeometry(ctypes.Structure):
         ('VT', _D3),
         ('AT', _D3),
         ('VO', _D3),
+        ('DVT', _D3),
+        ('DAT', _D3),
         ('ts0', ctypes.c_double),
         ('S0', _D3),
         ('VS', _D3),
@@ -59,7 +61,7 @@ class PMGeometry(ctypes.Structure):
     ]
 
     _VEC_FIELDS = (
-        'radii', 'T0', 'VT', 'AT', 'VO', 'S0', 'VS', 'AS', 'R0',
+        'radii', 'T0', 'VT', 'AT', 'VO', 'DVT', 'DAT', 'S0', 'VS', 'AS', 'R0',
         'sub_sp', 'sub_ray', 'sub_obsvec', 'ring_n', 'M',
     )
 
@@ -249,11 +251,18 @@ class GeometryBuilder:
                 else np.asarray(observer_velocity, dtype=float)
             )
         g.lt_c = lt
-        p_t0, v_t0, a_t0 = eph.ssb_state(self.target_id, t0)
+        # The kernels propagate the target as T0 + VT d + AT d^2 / 2 where the reference has CSPICE
+        # re-evaluate its POSITION at et - lt: VT / AT are the time derivatives of the position series.
+        # A state (spkezr, for the radial velocity) takes its velocity from the segment's own velocity
+        # polynomial where there is one (SPK type 3): DVT is the difference (2e-6 km/s for 599 in jup120).
+        p_t0, v_state, a_state = eph.ssb_state(self.target_id, t0)
+        _, v_t0, a_t0 = eph.ssb_motion(self.target_id, t0)
         for i in range(3):
             g.T0[i] = T0[i]
             g.VT[i] = v_t0[i]
             g.AT[i] = a_t0[i]
+            g.DVT[i] = v_state[i] - v_t0[i]
+            g.DAT[i] = a_state[i] - a_t0[i]
             g.VO[i] = v_obs[i]
 
         # --- Sun as seen from the target centre at t0 (one-way light time)
@@ -265,7 +274,7 @@ class GeometryBuilder:
                 break
             lts = new
         ts0 = t0 - lts
-        p_s, v_s, a_s = eph.ssb_state(self.sun_id, ts0)
+        p_s, v_s, a_s = eph.ssb_motion(self.sun_id, ts0)  # (positions only are ever asked of the Sun)
         g.ts0 = ts0
         for i in range(3):
             g.S0[i] = p_s[i] - p_t0[i]
@@ -274,7 +283,7 @@ class GeometryBuilder:
 
         # --- orientation
         R0 = rot.matrix(t0)
-        wdot = rot.spin_rate(t0)
+        wdot = rot.body_z_rate(t0)  # (dW/dt + the pole's precession along the pole: what pxform at t0 + d amounts to)
         for i in range(9):
             g.R0[i] = R0.flat[i]
         g.wdot = wdot

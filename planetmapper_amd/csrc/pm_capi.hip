@@ -231,7 +231,14 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         p.ph[3] = -0.5 * c0 * i1 * i2;
         p.ph[4] = -(1.0 + 2.0 * c0 * c0) * i1 * i2 * i2 / 6.0;
         p.ph[5] = -c0 * (9.0 + 6.0 * c0 * c0) * i1 * i2 * i2 * i2 / 24.0;
-        p.pad2_ = 0;
+    }
+    {
+        // one quantum of the epoch et - lt, as an angle on the body: beyond 1e-9 deg the fast path keeps to
+        // the reference's own sequence of epochs (Params::plain_lt)
+        const double quantum = std::nextafter(std::fabs(p.t0), INFINITY) - std::fabs(p.t0);
+        const double vt = std::sqrt(g.VT[0] * g.VT[0] + g.VT[1] * g.VT[1] + g.VT[2] * g.VT[2]);
+        const double rmin_ = std::fmin(p.radii[0], std::fmin(p.radii[1], p.radii[2]));
+        p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_) ? 1 : 0;
     }
     for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
     {

@@ -124,7 +124,13 @@ struct Params {
     // guard that decides whether it applies): ph[0] = c0, ph[1] = g0, ph[2..5] = acos^(n)(c0) / n!
     double ph[6];
     int32_t phase_series;  // 1: the series holds to < 1e-15 rad over this frame's disc
-    int32_t pad2_;
+    // 1: the spheroid fast path walks the reference's own sequence of light-time epochs (no Newton step on
+    // the seed). Epochs et - lt are doubles: one quantum of them (6e-8 s at et = 3.8e8 s) moves the target
+    // by |VT| ulp(t0), and two light times 1e-10 s apart round to different quanta in 0.1 % of the pixels.
+    // Where that jump is visible on the body (Mars seen from Earth in 2012: 2.4e-8 deg per quantum) only the
+    // reference's own iterates reproduce its choice of quantum; where it is not (Jupiter 2005: 3e-10 deg),
+    // the shorter sequence is taken. Host: pm_capi.hip fill_params.
+    int32_t plain_lt;
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

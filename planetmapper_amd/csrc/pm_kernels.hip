@@ -363,7 +363,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
         // converged light time changes nothing. No test, no select after it.
         lt = evaluate(0.0, true);
-        if (!TRI) {
+        if (!TRI && !kp->plain_lt) {  // (kernel-argument flag: a scalar branch)
             // One Newton-like step on that seed. The light time is a smooth function E(d) of the epoch
             // offset d, and the fixed point lt = E((et - lt) - t0) is what the iteration below converges
             // to. With the slope E'(0) = [VBs.X - (P.VBs) / root] / (X.X c) (the target's velocity along

@@ -122,11 +122,15 @@ def _pixels(sz: int, x0: float, r_pix: float, n: int, seed: int):
     return np.unique(px, axis=0)
 
 
-def _compare_with_exact(planes: dict, exact: dict, px, g, label: str) -> dict:
-    """block-model planes (full frames) against the exact-ephemeris values at `px`; returns worst errors"""
+def _compare_with_exact(planes: dict, exact: dict, px, g, label: str, slack: float = 1.0) -> dict:
+    """block-model planes (full frames) against the exact-ephemeris values at `px`; returns worst errors.
+    `slack` widens the conditioned bars (the HIP planes carry their own rounding next to that of the direct
+    evaluation of 1e8-km vectors here: two independent sources against one bar)"""
     from parity import base_deg
 
     bar = base_deg(g)
+    t0 = abs(g.et - g.lt_c)
+    quantum_deg = float(np.rad2deg(np.linalg.norm(g.VT[:]) * np.spacing(t0) / min(g.radii[:])))
     ce = np.clip(np.cos(np.deg2rad(exact['EMISSION'])), 1e-7, None)
     cl = np.clip(np.cos(np.deg2rad(exact['LAT-GRAPHIC'])), 1e-7, None)
     report = {}
@@ -153,7 +157,17 @@ def _compare_with_exact(planes: dict, exact: dict, px, g, label: str) -> dict:
             tol = bar + np.rad2deg(1e-4 / np.clip(np.abs(exact['RING-RADIUS']), 1.0, None))
         else:  # ring radius / distance [km]: 1e-13 of 1e9 km, more towards the ring-plane horizon
             tol = 1e-4 + 2e-12 * np.abs(exact['RING-DISTANCE'])
+        tol = tol * slack
         bad = fin & (dd > tol)
+        if n in ('LON-GRAPHIC', 'LAT-GRAPHIC', 'INCIDENCE', 'EMISSION') and quantum_deg > 0.3 * bar:
+            # Epochs et - lt are doubles. One quantum of them moves the target by |VT| ulp(t0): 2.4e-8 deg on Mars
+            # in 2012 (3e-10 deg on Jupiter in 2005). Two evaluations whose light times differ in the last digits
+            # round to neighbouring quanta in ~1e-4 of the pixels - so would CSPICE against itself on another
+            # machine: a few pixels one quantum (conditioned like everything else) away are not a discrepancy.
+            k = (1.0 / (ce * cl)) if n == 'LON-GRAPHIC' else 1.0 / ce
+            flipped = bad & (dd <= tol + 1.5 * quantum_deg * k)
+            assert flipped.sum() <= max(2, 2e-3 * fin.sum()), (label, n, int(flipped.sum()))
+            bad = bad & ~flipped
         assert not bad.any(), (label, n, float(np.nanmax(dd / tol)), px[np.nanargmax(np.where(fin, dd / tol, 0))])
         report[n] = {'max': float(np.nanmax(dd)), 'inside_flat_bar': float(np.mean(dd[fin] <= bar))}
     return report
@@ -217,6 +231,6 @@ def test_hip_against_the_exact_ephemeris_mode(name):
             planes = eng.backplanes_img(list(exact))
         finally:
             eng.close()
-        rep = _compare_with_exact(planes, exact, px, g, f'{name} general={general}')
+        rep = _compare_with_exact(planes, exact, px, g, f'{name} general={general}', slack=2.0)
         assert rep['PHASE']['max'] < 1e-11 or name == 'jupiter_near_field', rep['PHASE']
         assert rep['LAT-GRAPHIC']['inside_flat_bar'] > 0.97 and rep['EMISSION']['inside_flat_bar'] > 0.95, rep

@@ -34,3 +34,21 @@ def jupiter_info():
     from planetmapper_amd.scenarios import scenario_info
 
     return scenario_info('jupiter_hst_2005')
+
+
+def fresh_seed(test_name: str) -> int:
+    """
+    Seed of the per-run leg of a fuzz test: from PM_FUZZ_SEED if set (to replay a failure), else from the
+    clock. Printed (pytest -s / the failure report shows it) and appended to gpurun_out/fuzz_seeds.log.
+    """
+    import time
+
+    env = os.environ.get('PM_FUZZ_SEED')
+    seed = int(env) if env else int(time.time_ns() % (2**32))
+    line = f'{test_name}: PM_FUZZ_SEED={seed}'
+    print('\n[fuzz] ' + line)
+    out = os.path.join(REPO, 'gpurun_out')
+    if os.path.isdir(out):
+        with open(os.path.join(out, 'fuzz_seeds.log'), 'a') as f:
+            f.write(line + '\n')
+    return seed

@@ -18,9 +18,23 @@ Bars (BASELINE.json north_star):
 
 from __future__ import annotations
 
+import json
+import os
+
 import numpy as np
 
 BASE_DEG = 1e-9
+# The conditioned bar is COND x 1e-9 deg x condition number: the north star's own number times 1 / cos(emission)
+# (and 1 / cos(latitude) for longitudes). 3.0 until round 3; measured over the whole GPU suite with
+# PM_PARITY_REPORT=1 (profiles/r03_parity_margins.json: every frame of every test, both image kernels, the map
+# kernels, the random-seed legs) the worst pixel sits at 0.72 of this bar (limb planes; the disc planes at 0.57).
+COND = 1.0
+# Share of on-disc pixels inside the FLAT bar (frames of more than 5000 on-disc pixels). Measured HIP vs oracle:
+# headline frame (Jupiter 4096^2) LON 99.46 %, LAT 99.998 %, INC / EMI 99.79 %, PHASE 100 % - asserted at those
+# levels by the headline test itself; lowest over every frame of the suite (Saturn, tilted 27 deg: more of its
+# disc at high latitude, where the longitude's 1 / cos(lat) works): LON 98.2 %, LAT 99.58 %, INC / EMI 99.44 %.
+MIN_FLAT = {'LON-GRAPHIC': 0.98, 'LAT-GRAPHIC': 0.995, 'PHASE': 0.9999, 'INCIDENCE': 0.993, 'EMISSION': 0.993}
+_REPORT = os.environ.get('PM_PARITY_REPORT')
 
 
 def base_deg(g) -> float:
@@ -52,8 +66,8 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
     coslat = ones
     if 'LAT-GRAPHIC' in ref:
         coslat = np.clip(np.cos(np.deg2rad(ref['LAT-GRAPHIC'])), 1e-7, None)
-    lat_t = 3.0 * BASE_DEG * kappa
-    lon_t = 3.0 * BASE_DEG * kappa / coslat
+    lat_t = COND * BASE_DEG * kappa
+    lon_t = COND * BASE_DEG * kappa / coslat
     for n in ('LAT-GRAPHIC', 'LAT-CENTRIC', 'INCIDENCE', 'EMISSION'):
         tol[n] = lat_t
     for n in ('LON-GRAPHIC', 'LON-CENTRIC'):
@@ -92,8 +106,8 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
         k = np.maximum(1.0, r_eq / rho)
         llat = ref.get('LIMB-LAT-GRAPHIC', np.zeros_like(rho))
         cl = np.clip(np.cos(np.deg2rad(llat)), 1e-7, None)
-        tol['LIMB-LAT-GRAPHIC'] = 3.0 * BASE_DEG * k
-        tol['LIMB-LON-GRAPHIC'] = 3.0 * BASE_DEG * k / cl
+        tol['LIMB-LAT-GRAPHIC'] = COND * BASE_DEG * k
+        tol['LIMB-LON-GRAPHIC'] = COND * BASE_DEG * k / cl
         # |surface point| varies by (r_eq - r_polar) with the (ill-conditioned) direction
         tol['LIMB-DISTANCE'] = 1e-5 + np.minimum(r_eq - r_polar, (r_eq - r_polar) * 2e-6 / rho)
     else:
@@ -108,21 +122,26 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
     ring_pos = max(2e-5, 10 * 1.11e-16 * dist / sin_b)
     if 'RING-RADIUS' in ref:
         rad = np.abs(ref['RING-RADIUS'])
-        tol['RING-RADIUS'] = ring_pos + 1e-11 * rad
-        tol['RING-LON-GRAPHIC'] = BASE_DEG + np.rad2deg(ring_pos / np.clip(rad, 1.0, None))
+        # (relative part: a ray nearly parallel to the plane meets it 1e9 km away with n.u ~ 1e-5: 1e-16 / 1e-5)
+        tol['RING-RADIUS'] = ring_pos + 3e-11 * rad
+        # a ray near the ring plane's horizon meets it 1e10 km away: the 3e-11 of that distance is seconds of
+        # light time, over which PM's transform (body.py:972-1006) spins the body by wdot dt (seed 3276483807 of
+        # the fuzz test: at 1.8e10 km the binary64 ORACLE is 0.37 km and 1.3e-8 deg from the binary128 truth)
+        tol['RING-LON-GRAPHIC'] = (BASE_DEG + np.rad2deg(ring_pos / np.clip(rad, 1.0, None))
+                                   + np.rad2deg(abs(g.wdot) * 3e-11 * rad / g.clight))
     else:
         tol['RING-RADIUS'] = 1e-3
         tol['RING-LON-GRAPHIC'] = 1e-7
     if 'RING-DISTANCE' in ref:
         rd = ref['RING-DISTANCE']
         rd_min = np.nanmin(rd) if np.isfinite(rd).any() else 0.0
-        tol['RING-DISTANCE'] = 10 * ring_pos + 1e-11 * np.abs(rd - rd_min)
+        tol['RING-DISTANCE'] = 10 * ring_pos + 3e-11 * np.abs(rd - rd_min)
     else:
         tol['RING-DISTANCE'] = 1e-3
     return tol
 
 
-def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=0.98, plate_scale_arcsec=None) -> dict:
+def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate_scale_arcsec=None) -> dict:
     """
     Assert parity of `out` (HIP) with `ref` (oracle). Returns statistics
     {name: (max_abs_diff, fraction within the flat bar `base_deg(g)`)}.
@@ -151,6 +170,11 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=0.98, plate
             continue
         t = tol[n]
         bad = d > t
+        if _REPORT:
+            worst = float(np.nanmax(np.where(fin, d / np.maximum(t, 1e-300), 0.0)))
+            with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'parity_ratios.jsonl'), 'a') as f:
+                f.write(json.dumps({'test': os.environ.get('PYTEST_CURRENT_TEST', ''), 'plane': n, 'worst_over_bar': worst,
+                                    'pixels': int(fin.sum()), 'flat': float(np.mean(d[fin] <= flat_bar))}) + '\n')
         if np.any(bad & fin):
             i = np.unravel_index(np.nanargmax(np.where(fin, d / np.maximum(t, 1e-300), 0)), d.shape)
             raise AssertionError(
@@ -159,6 +183,6 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=0.98, plate
             )
         flat = float(np.mean(d[fin] <= flat_bar))
         stats[n] = (float(np.nanmax(d)), flat)
-        if n in ('LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION') and fin.sum() > 5000:
-            assert flat >= min_flat_fraction, (n, flat)
+        if n in MIN_FLAT and fin.sum() > 5000:
+            assert flat >= (MIN_FLAT[n] if min_flat_fraction is None else min_flat_fraction), (n, flat)
     return stats

@@ -56,6 +56,26 @@ def _compare(out, ref, names, g, r0=None):
     return compare_planes(out, ref, names, g, plate_scale_arcsec=ps)
 
 
+def _check_golden(out, gold, names):
+    """
+    HIP against the reference's golden planes DIRECTLY: NaN masks identical, the reference's own comparison
+    rule (tests/test_observation.py:1255: atol 1e-6, rtol 1e-5) and the tight bars the CPU oracle is held to
+    against the same files (tests/test_oracle_golden.py TIGHT: 1e-8 deg, 1e-5 km, 1e-9 km/s ...).
+    """
+    from test_oracle_golden import TIGHT
+
+    for n in names:
+        a, b = out[n], np.asarray(gold[n], dtype=float)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), n
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True), n
+        if np.isfinite(b).any():
+            d = np.abs(a - b)
+            if 'LON' in n or n == 'RA':
+                d = np.minimum(d, 360.0 - d)
+            rel = 1e-11 * np.nanmax(np.abs(b)) if n in ('RING-RADIUS', 'RING-DISTANCE', 'DISTANCE') else 0.0
+            assert np.nanmax(d) <= TIGHT[n] + rel, (n, float(np.nanmax(d)))
+
+
 def _golden_setup(engine, g):
     engine.set_geometry(g)
     engine.set_disc(2.5, 3.1, 3.9, float(np.deg2rad(123.456) % (2 * np.pi)), 7, 10, True)
@@ -66,9 +86,7 @@ def test_golden_nav_all_planes(engine, oracle, jupiter):
     gold = np.load(os.path.join(GOLDEN, 'golden_test_nav.npz'))
     _golden_setup(engine, jupiter)
     out = engine.backplanes_img(oracle.PLANE_NAMES)
-    for n in oracle.PLANE_NAMES:
-        assert np.array_equal(np.isnan(out[n]), np.isnan(gold[n])), n
-        assert np.allclose(out[n], gold[n], rtol=1e-5, atol=1e-6, equal_nan=True), n
+    _check_golden(out, gold, oracle.PLANE_NAMES)
     ref = oracle.backplanes_img(jupiter, oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10), oracle.PLANE_NAMES)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter)
 
@@ -77,9 +95,7 @@ def test_golden_nav_alt(engine, oracle, jupiter):
     gold = np.load(os.path.join(GOLDEN, 'golden_test_nav_alt.npz'))
     _golden_setup(engine, jupiter)
     out = engine.backplanes_img(oracle.PLANE_NAMES, alt=34567.8912)
-    for n in oracle.PLANE_NAMES:
-        assert np.array_equal(np.isnan(out[n]), np.isnan(gold[n])), n
-        assert np.allclose(out[n], gold[n], rtol=1e-5, atol=1e-6, equal_nan=True), n
+    _check_golden(out, gold, oracle.PLANE_NAMES)
 
 
 @pytest.mark.parametrize(
@@ -96,9 +112,7 @@ def test_golden_maps(engine, oracle, jupiter, name, interp, alt):
     _golden_setup(engine, jupiter)
     lon, lat = gold['LON-GRAPHIC'], gold['LAT-GRAPHIC']
     out = engine.backplanes_map(oracle.PLANE_NAMES, lon, lat, alt=alt)
-    for n in oracle.PLANE_NAMES:
-        assert np.array_equal(np.isnan(out[n]), np.isnan(gold[n])), n
-        assert np.allclose(out[n], gold[n], rtol=1e-5, atol=1e-6, equal_nan=True), n
+    _check_golden(out, gold, oracle.PLANE_NAMES)
     disc = oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10)
     ref = oracle.backplanes_map(jupiter, disc, oracle.PLANE_NAMES, lon, lat, alt=alt)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter, r0=3.9)
@@ -234,8 +248,10 @@ def test_headline_frame_4096_vs_oracle_and_round_trip(engine, oracle, jupiter):
     stats = _compare(out, ref, HEADLINE, jupiter)
     print('\n4096^2 HIP vs oracle (max |diff| deg, fraction within flat 1e-9 deg):', stats)
     assert int(np.isfinite(out['LON-GRAPHIC']).sum()) == int(np.isfinite(ref['LON-GRAPHIC']).sum())
+    # share of on-disc pixels inside the flat 1e-9 deg (measured: LON 99.46 %, LAT 99.998 %, INC / EMI 99.79 %, PHASE 100 %)
+    floor = {'LON-GRAPHIC': 0.99, 'LAT-GRAPHIC': 0.999, 'PHASE': 1.0, 'INCIDENCE': 0.995, 'EMISSION': 0.995}
     for n in HEADLINE:
-        assert stats[n][1] > 0.98, (n, stats[n])
+        assert stats[n][1] >= floor[n], (n, stats[n])
     # round trip on a band of rows through the disc (emission < 85 deg: well conditioned)
     rows = slice(2040, 2056)
     lon, lat, emi = out['LON-GRAPHIC'][rows], out['LAT-GRAPHIC'][rows], out['EMISSION'][rows]
@@ -1230,6 +1246,63 @@ def test_config4_saturn_rings_full_size(engine_fg, oracle, saturn):
     assert np.isfinite(out['RING-RADIUS']).mean() > 0.5
 
 
+@pytest.mark.parametrize('case', ['edge_on', 'observer_in_ring_plane', 'disc_partly_off_frame'])
+def test_saturn_rings_special_geometries_full_size(engine_fg, oracle, saturn, case):
+    """
+    The divergent paths of config 4 at 4096^2: rings seen (nearly) edge-on - the ring plane's horizon crosses
+    the frame, most rays meet the plane at grazing angles or not at all - the observer IN the ring plane
+    (plane constant 0: every ray that is not parallel to the plane 'hits' it at distance 0, CSPICE's inrypl_c
+    rule), and a disc half out of the frame. Masks bit-exact, values inside the bars.
+    """
+    from planetmapper_amd.geometry import PMGeometry  # noqa: F401
+
+    sz = 4096
+    g = saturn.copy()
+    x0 = y0 = (sz - 1) / 2
+    r0 = 800.0
+    if case != 'disc_partly_off_frame':
+        # tilt the ring plane until the observer is `b` above it: rotate its normal about the axis
+        # perpendicular to the normal and the line of sight
+        n = np.array(g.ring_n[:])
+        t0 = np.array(g.T0[:])
+        los = t0 / np.linalg.norm(t0)
+        axis = np.cross(n, los)
+        axis /= np.linalg.norm(axis)
+        b_now = np.arcsin(float(n @ los))
+        b_new = 0.0 if case == 'observer_in_ring_plane' else np.deg2rad(0.02)
+        ang = b_now - b_new
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        Rm = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        n2 = Rm @ n
+        if case == 'observer_in_ring_plane':
+            n2 = n2 - (n2 @ los) * los  # exactly perpendicular to the line of sight: plane constant 0
+            n2 /= np.linalg.norm(n2)
+        k2 = float(n2 @ t0)
+        if k2 < 0:
+            n2, k2 = -n2, -k2
+        for i in range(3):
+            g.ring_n[i] = n2[i]
+        g.ring_k = 0.0 if case == 'observer_in_ring_plane' else k2
+    else:
+        x0, y0 = 150.0, sz - 300.0
+    engine_fg.set_geometry(g)
+    engine_fg.set_disc(x0, y0, r0, float(np.deg2rad(20.0)), sz, sz, True)
+    names = HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']
+    out = engine_fg.backplanes_img(names)
+    oracle.set_num_threads(16)
+    ref = oracle.backplanes_img(g, oracle.make_disc(x0, y0, r0, 20.0, sz, sz), names)
+    for n in names:
+        assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (case, n)
+    _compare(out, ref, names, g, r0=r0)
+    frac_ring = np.isfinite(out['RING-RADIUS']).mean()
+    if case == 'edge_on':
+        assert 0.05 < frac_ring < 0.97  # both sides of the plane's horizon are in the frame
+    elif case == 'observer_in_ring_plane':
+        assert np.nanmax(np.abs(out['RING-DISTANCE'])) == 0.0 or frac_ring == 0.0
+    else:
+        assert 0.02 < np.isfinite(out['LON-GRAPHIC']).mean() < 0.08
+
+
 def test_config3_cube_2048_full_size(engine, oracle, jupiter):
     """
     BASELINE config 3 at its full size (SURVEY 8d recipe): P = 8 planes of 2048^2 f64 - limb-darkened
@@ -1318,13 +1391,18 @@ def test_config5_cube_512_planes_properties(engine, oracle, jupiter):
     assert torch.equal(torch.nan_to_num(out2), torch.nan_to_num(out))
 
 
-def test_random_discs_and_frames_fuzz(engine_fg, oracle, jupiter, saturn):
+@pytest.mark.parametrize('leg', ['fixed_seed', 'fresh_seed'])
+def test_random_discs_and_frames_fuzz(engine_fg, oracle, jupiter, saturn, leg):
     """
-    Seeded sweep over frame shapes (1 x 1 up to ragged 200-pixel sides), disc positions inside,
+    Sweep over frame shapes (1 x 1 up to ragged 200-pixel sides), disc positions inside,
     on the edge of and outside the frame, radii from sub-pixel to frame-filling, any rotation,
     with and without the radius pre-mask and altitude offsets: all 26 planes, masks bit-exact.
+    Once with a fixed seed, once with a seed of this run (logged: conftest.fresh_seed).
     """
-    rng = np.random.default_rng(20260101)
+    from conftest import fresh_seed
+
+    seed = 20260101 if leg == 'fixed_seed' else fresh_seed('test_random_discs_and_frames_fuzz')
+    rng = np.random.default_rng(seed)
     cases = [(1, 1, 0.0, 0.0, 0.6, 0.0), (2, 1, 0.5, 0.0, 5.0, 1.0), (64, 1, 31.5, 0.0, 40.0, 3.0), (1, 70, 0.0, 30.0, 25.0, 5.9)]
     for _ in range(26):
         nx, ny = int(rng.integers(3, 200)), int(rng.integers(3, 200))
@@ -1342,17 +1420,25 @@ def test_random_discs_and_frames_fuzz(engine_fg, oracle, jupiter, saturn):
         out = engine_fg.backplanes_img(oracle.PLANE_NAMES, alt=alt)
         ref = oracle.backplanes_img(g, d, oracle.PLANE_NAMES, alt=alt)
         for n in oracle.PLANE_NAMES:
-            assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (i, n, nx, ny, x0, y0, r0, rot)
-        _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)
+            assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (seed, i, n, nx, ny, x0, y0, r0, rot)
+        try:
+            _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)
+        except AssertionError as e:
+            raise AssertionError(f'seed {seed} case {i} {(nx, ny, x0, y0, r0, rot, opt, alt)}: {e}') from e
 
 
-def test_random_reprojection_fuzz(engine, oracle, jupiter):
+@pytest.mark.parametrize('leg', ['fixed_seed', 'fresh_seed'])
+def test_random_reprojection_fuzz(engine, oracle, jupiter, leg):
     """
-    Seeded sweep over small frames, discs, NaN / inf patterns, dtypes and every interpolation mode
+    Sweep over small frames, discs, NaN / inf patterns, dtypes and every interpolation mode
     of map_img (both NaN policies), on rectangular maps of random resolution: mapped planes against
     the oracle on the GPU's own x/y maps (NaN masks identical, values to 1e-9 of the data scale).
+    Once with a fixed seed, once with a seed of this run (logged: conftest.fresh_seed).
     """
-    rng = np.random.default_rng(77)
+    from conftest import fresh_seed
+
+    seed = 77 if leg == 'fixed_seed' else fresh_seed('test_random_reprojection_fuzz')
+    rng = np.random.default_rng(seed)
     modes = ['nearest', 'linear', 'quadratic', 'cubic', (1, 3), (4, 2), 'smooth']
     for i in range(14):
         nx, ny = int(rng.integers(7, 60)), int(rng.integers(7, 60))
@@ -1376,11 +1462,11 @@ def test_random_reprojection_fuzz(engine, oracle, jupiter):
             for prop in (True, False):
                 a = engine.map_cube(cube, xm, ym, interp, prop)
                 b = oracle.map_cube(cube, xm, ym, interp, prop)
-                assert np.array_equal(np.isnan(a), np.isnan(b)), (i, nx, ny, interp, prop)
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (seed, i, nx, ny, interp, prop)
                 fin = np.isfinite(b)
                 if fin.any():
                     scale = max(1.0, float(np.abs(b[fin]).max()))
-                    assert np.max(np.abs(a[fin] - b[fin])) <= 1e-9 * scale, (i, nx, ny, interp, prop)
+                    assert np.max(np.abs(a[fin] - b[fin])) <= 1e-9 * scale, (seed, i, nx, ny, interp, prop)
 
 
 def test_transforms_with_non_finite_inputs(engine, oracle, jupiter):
@@ -1484,9 +1570,11 @@ def test_radec_query_vs_oracle_and_kats(engine, oracle, jupiter, saturn):
             assert fin[0].sum() > 100 and fin[2].sum() > 1000
 
 
-def test_random_geometries_fuzz(engine, oracle):
+@pytest.mark.parametrize('leg', ['fixed_seed', 'fresh_seed'])
+def test_random_geometries_fuzz(engine, oracle, leg):
     """
-    Seeded sweep over observers: distances from 2.6 radii to 30 au (across the thresholds at
+    (Once with a fixed seed, once with a seed of this run - logged: conftest.fresh_seed.)
+    Sweep over observers: distances from 2.6 radii to 30 au (across the thresholds at
     which the launcher leaves the spheroid fast path: observer within two radii of the surface,
     spin angle over a light-time span, acceleration term), any aspect angle, observer velocities
     up to 60 km/s, oblate / nearly spherical / triaxial shapes, both longitude conventions,
@@ -1500,7 +1588,10 @@ def test_random_geometries_fuzz(engine, oracle):
     d = _load_json('jupiter_hst_2005')
     gb = GeometryBuilder(Ephemeris.from_json(d['ephemeris']), RotationModel.from_json(d['pck']), d['target_id'])
     h = d['header']
-    rng = np.random.default_rng(314159)
+    from conftest import fresh_seed
+
+    seed = 314159 if leg == 'fixed_seed' else fresh_seed('test_random_geometries_fuzz')
+    rng = np.random.default_rng(seed)
     r_eq = 71492.0
     dists = [2.6 * r_eq, 2.95 * r_eq, 3.05 * r_eq, 5.0 * r_eq] + list(10 ** rng.uniform(5.6, 9.65, 16))
     for i, dist in enumerate(dists):
@@ -1538,11 +1629,11 @@ def test_random_geometries_fuzz(engine, oracle):
         out = engine.backplanes_img(oracle.PLANE_NAMES, alt=alt)
         ref = oracle.backplanes_img(g, dd, oracle.PLANE_NAMES, alt=alt)
         for n in oracle.PLANE_NAMES:
-            assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (i, n, dist)
+            assert np.array_equal(np.isnan(out[n]), np.isnan(ref[n])), (seed, i, n, dist)
         try:
             _compare(out, ref, oracle.PLANE_NAMES, g, r0=r0)
         except AssertionError as e:
-            raise AssertionError(f'case {i}: distance {dist:.4g} km, shape {shape}, alt {alt}: {e}') from e
+            raise AssertionError(f'seed {seed} case {i}: distance {dist:.4g} km, shape {shape}, alt {alt}: {e}') from e
         assert np.isfinite(out['LON-GRAPHIC']).sum() > 500, (i, dist)
         lon, lat = oracle.rectangular_grid(g, 10.0)
         om = engine.backplanes_map(oracle.PLANE_NAMES, lon, lat, alt=alt)
@@ -1550,7 +1641,7 @@ def test_random_geometries_fuzz(engine, oracle):
         try:
             _compare(om, rm, oracle.PLANE_NAMES, g, r0=r0)
         except AssertionError as e:
-            raise AssertionError(f'case {i} (map): distance {dist:.4g} km, shape {shape}, alt {alt}: {e}') from e
+            raise AssertionError(f'seed {seed} case {i} (map): distance {dist:.4g} km, shape {shape}, alt {alt}: {e}') from e
 
 
 def test_mem_argument_is_validated_by_every_entry_point(engine, jupiter):

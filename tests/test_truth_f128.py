@@ -133,11 +133,13 @@ def test_hip_is_as_close_to_the_truth_as_the_binary64_oracle(jupiter):
         report[n] = {'hip_vs_truth': sh, 'oracle64_vs_truth': so}
         # HIP is no further from the exact value of the formulation than a strict binary64
         # evaluation of it is (factor 2: the worst limb pixel of two roundings of the same ray)
-        assert sh['max'] <= 2.0 * so['max'] + 1e-10, (n, sh, so)
-        assert sh['p999'] <= 2.0 * so['p999'] + 1e-10, (n, sh, so)
-        assert sh['p99'] <= 1.5 * so['p99'] + 5e-11, (n, sh, so)
-        assert sh['inside_1e-9'] >= so['inside_1e-9'] - 0.01, (n, sh, so)
-        assert sh['inside_1e-9'] >= 0.98, (n, sh)
+        # (measured, round 2: HIP / oracle64 = 0.78 ... 1.04 on max, 0.88 ... 0.93 on p999 and p99 of the planes near
+        #  the bar; the phase angle, four orders of magnitude inside it, carries one ulp of its cosine: floors)
+        assert sh['max'] <= 1.25 * so['max'] + 1e-11, (n, sh, so)
+        assert sh['p999'] <= 1.25 * so['p999'] + 2e-13, (n, sh, so)
+        assert sh['p99'] <= 1.25 * so['p99'] + 2e-13, (n, sh, so)
+        assert sh['inside_1e-9'] >= so['inside_1e-9'] - 0.003, (n, sh, so)
+        assert sh['inside_1e-9'] >= {'LON-GRAPHIC': 0.985, 'INCIDENCE': 0.99, 'EMISSION': 0.99}.get(n, 0.999), (n, sh)
     out = os.path.join(REPO, 'gpurun_out')
     if os.path.isdir(out):
         with open(os.path.join(out, 'truth_f128_report.json'), 'w') as f:

@@ -68,8 +68,9 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline line only: no host_path / cube_host sections')
     ap.add_argument(
-        '--workload', default='frame', choices=['frame', 'saturn', 'cube', 'cube-host'],
-        help='frame: BASELINE headline (default); saturn: config 4 (Saturn + rings, 8 planes); cube: config 5 with '
+        '--workload', default='frame', choices=['frame', 'saturn', 'all26', 'cube', 'cube-host'],
+        help='frame: BASELINE headline (default); saturn: config 4 (Saturn + rings, 8 planes); all26: every default '
+        'backplane of a 4096^2 frame (what save_observation asks for); cube: config 5 with '
         'the cube resident in HBM; cube-host: config 5 fed from host memory (planes sharded over the GPUs)',
     )  # fmt: skip
     ap.add_argument('--planes', type=int, default=512, help='cube workloads: total planes')
@@ -565,7 +566,28 @@ def other_workloads(args) -> None:
         eng.close()
         return
 
-    if args.workload == 'saturn':
+    if args.workload == 'all26':
+        # what save_observation asks for (observation.py:1269-1279): all 26 default backplanes of one frame
+        from planetmapper_amd._lib import PLANE_NAMES
+
+        sz = args.size
+        names = list(PLANE_NAMES)
+        g = load_scenario('jupiter_hst_2005')
+        eng.set_geometry(g)
+        x0 = (sz - 1) / 2
+        eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+        planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=d.dev) for n in names}
+
+        def work():
+            eng.backplanes_img_device(planes)
+
+        units = sz * sz
+        metric = 'Mpix/s all 26 default backplanes (save_observation set), 4096^2 frame'
+        workload = (f'Jupiter/HST 2005-01-01 geometry, {sz}x{sz}, centred disc, all {len(names)} planes: 15 of the intercept '
+                    '(k_disc_sph<7, false>) + 11 every pixel has (k_sky<true>)')
+        alg = sz * sz * 8 * len(names)
+        scaling = 'weak'
+    elif args.workload == 'saturn':
         # Saturn-like spheroid, 4096^2, r0 = 800 px, rotation 20 deg
         sz = args.size
         names = HEADLINE + ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']

@@ -262,6 +262,13 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           PM_OPT_HOST_CUBE_ROUTE -1; 0: choose by table size only. Setting it (to either
  *                           value) forgets what has been measured.
  *   PM_OPT_LAST_CUBE_ROUTE  read-only: the route (0..3) the latest host-cube call ended on, -1 none yet.
+ *   PM_OPT_FUSE_PLANES      1: an image-plane request that holds planes of the intercept AND planes every pixel
+ *                           has (RA / Dec, pixel x / y, km, angular, limb) runs as ONE launch on the spheroid
+ *                           fast path (k_disc_sph<FLAGS, TRI, SKY>); 0 (default): one launch per group. The same
+ *                           device code either way - bit-identical planes. Default 0 because it measured faster:
+ *                           all 26 planes of a 4096^2 frame 0.654 ms in two launches against 0.698 ms in one (the
+ *                           sky planes stream at 7 TB/s from k_sky's 256-thread workgroups, at 5 TB/s from the
+ *                           one-wave workgroups the intercept kernel is built around).
  *   PM_OPT_LAST_REDO_PLANES read-only: how many planes of the latest FINISHED nearest / linear pm_map_cube were
  *                           mapped a second time with their nanmedian (the values the first pass stored for
  *                           them were provisional).
@@ -284,6 +291,7 @@ typedef enum pm_option {
     PM_OPT_ROUTE_EXPLORE = 9,
     PM_OPT_LAST_CUBE_ROUTE = 10,
     PM_OPT_LAST_REDO_PLANES = 11,
+    PM_OPT_FUSE_PLANES = 12,
     PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..3 */
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);

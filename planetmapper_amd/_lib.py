@@ -73,6 +73,7 @@ PM_OPT_BLOCK_TABLE_HITS = 8
 PM_OPT_ROUTE_EXPLORE = 9
 PM_OPT_LAST_CUBE_ROUTE = 10
 PM_OPT_LAST_REDO_PLANES = 11
+PM_OPT_FUSE_PLANES = 12
 PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..3
 
 

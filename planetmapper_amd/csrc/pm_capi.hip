@@ -58,7 +58,6 @@ void set_row_order(pm::Params &p, int rows)
     p.row_magic = mod_magic((uint32_t)rows);
     p.col_blocks = (uint32_t)((p.nx + pm::kSphBlock - 1) / pm::kSphBlock);
     p.col_magic = mod_magic(p.col_blocks);
-    p.pad_ = 0;
 }
 
 int ensure_scratch(pm_ctx *ctx, size_t bytes)
@@ -152,6 +151,7 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
                 amax = std::fmax(amax, std::fabs(p.Ar[3] * fx + p.Ar[4] * fy + p.Ar[5]));
             }
         p.view_tiny = (amax <= 1e-3) ? 1 : 0;  // NaN compares false
+        p.view_direct = (amax <= 1.5) ? 1u : 0u;
         p.lon_k[0] = g.west_positive ? -1.0 : 1.0;
         p.lon_k[1] = p.lon_k[0] * g.wdot;
     }
@@ -343,6 +343,7 @@ pm_ctx *pm_create(int device, int *status)
     ctx->own_stream = true;
     const char *fg = std::getenv("PM_FORCE_GENERAL");
     ctx->force_general = fg && fg[0] == '1';
+    if (const char *fp = std::getenv("PM_FUSE_PLANES")) ctx->fuse_planes = fp[0] != '0';  // (A/B runs of tools / bench)
     set(PM_OK);
     return ctx;
 }
@@ -424,6 +425,9 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_BLOCK_TABLE_CACHE:
         ctx->table_cache = value != 0;
         return PM_OK;
+    case PM_OPT_FUSE_PLANES:
+        ctx->fuse_planes = value != 0;
+        return PM_OK;
     case PM_OPT_ROUTE_EXPLORE:
         ctx->route_explore = value != 0;
         pipe_reset_route_stats(ctx);  // (what was measured is forgotten: the next large call measures again)
@@ -456,6 +460,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_SPARSE_FRAME: *value = ctx->sparse_frame; return PM_OK;
     case PM_OPT_LAST_DISC_KERNEL: *value = ctx->last_disc_kernel; return PM_OK;
     case PM_OPT_BLOCK_TABLE_CACHE: *value = ctx->table_cache; return PM_OK;
+    case PM_OPT_FUSE_PLANES: *value = ctx->fuse_planes; return PM_OK;
     case PM_OPT_BLOCK_TABLE_HITS: *value = pipe_table_hits(ctx); return PM_OK;
     case PM_OPT_ROUTE_EXPLORE: *value = ctx->route_explore; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
@@ -622,6 +627,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
             if ((plane_mask >> i) & 1) p.out[i] = (double *)ctx->scratch + (size_t)(k++) * npx;
     }
 
+    bool fused_sky = false;
     if (plane_mask & kDiscBits) {
         int flags = 0;
         if (plane_mask & kIllumBits) flags |= 1;
@@ -650,13 +656,19 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         // a triaxial body is turned by its spin angle per light-time evaluation with a short series
         const bool small_spin = std::fabs(ctx->geometry.wdot) * span < 1e-3;
         const bool spheroid = y2 > 4.0 && slow && small_spin && !ctx->force_general;
+        // every plane of the frame from one launch (PM_OPT_FUSE_PLANES): the sky / limb planes ride along
+        fused_sky = spheroid && ctx->fuse_planes && (plane_mask & kSkyBits);
+        if (fused_sky) {
+            pd.mask = plane_mask;
+            flags |= (plane_mask & kLimbBits) ? (2 << 3) : (1 << 3);
+        }
         if (spheroid)
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else
             pm_launch_disc(pd, flags, ctx->stream);
         ctx->last_disc_kernel = spheroid ? (pd.radii[0] != pd.radii[1] ? 2 : 1) : 3;
     }
-    if (plane_mask & kSkyBits) {
+    if ((plane_mask & kSkyBits) && !fused_sky) {
         pm::Params ps = p;
         ps.mask = plane_mask & kSkyBits;
         pm_launch_sky(ps, (plane_mask & kLimbBits) != 0, ctx->stream);

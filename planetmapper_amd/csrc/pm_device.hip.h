@@ -115,7 +115,7 @@ struct Params {
     // n mod d on the scalar unit: q = umulhi(n, ceil(2^32 / d)) is the quotient or one more
     uint32_t row_magic;  // d = rows
     uint32_t col_blocks, col_magic;  // d = column blocks of the spheroid kernel, ceil(nx / kSphBlock)
-    uint32_t pad_;
+    uint32_t view_direct;  // every view angle of the frame is below 1.5 rad: recrad(radrec(angles)) = angles (sky_block)
     double ring_nb[3], sub_obs_b[3], sub_ray_b[3];  // R0 ring_n, R0 sub_obsvec, R0 sub_ray: ring block in B0
     double lt_tol;       // CSPICE's light-time stopping rule: 1e-17 |et - lt|  (lt varies by 1e-9 relative over a disc)
     // Phase angle of the spheroid fast path as a series in the cosine: over a disc seen from afar the
@@ -793,6 +793,30 @@ __device__ __forceinline__ double azimuth_deg(double ph_deg, double in_deg, doub
     return (kPi - acos(a / b)) * kDeg;
 }
 
+// acos(x) for |x| <= 1 with asin on |x| <= 0.5 only (vsep_fast's scheme): pi/2 - asin(x) in the middle, the
+// half-angle form 2 asin(sqrt((1 - |x|) / 2)) towards the ends (1 - |x| is exact there)
+__device__ __forceinline__ double acos_fast(double x)
+{
+    const bool mid = fabs(x) <= 0.5;
+    const double s = sqrt_fast(fma(-0.5, fabs(x), 0.5));
+    const double r = asin_half(mid ? x : s);
+    return mid ? kHalfPi - r : (x > 0.0 ? 2.0 * r : kPi - 2.0 * r);
+}
+
+// Body._azimuth_angle_from_gie_radians body.py:2319-2332 from the COSINES of the three angles - the dot
+// products the angles themselves were taken from - instead of cos() of the angles: pi - acos(q) = acos(-q),
+// q = (cos g - cos e cos i) / (sin e sin i). NaN where the reference's arccos is: |q| > 1 or 0 / 0.
+// (Three libm cosines, an arccos, two square roots and an IEEE division cost this one plane 0.09 ms of a
+//  4096^2 frame - two thirds of the whole headline set.)
+__device__ __forceinline__ double azimuth_from_cosines(double cg, double ci, double ce)
+{
+    const double a = fma(-ce, ci, cg);
+    const double b2 = fma(-ce, ce, 1.0) * fma(-ci, ci, 1.0);
+    const double q = a * rsqrt_fast(fmax(b2, 1e-300));
+    const double az = acos_fast(-fmax(-1.0, fmin(1.0, q)));
+    return (fabs(q) <= 1.0 && b2 > 0.0) ? az * kDeg : __builtin_nan("");
+}
+
 // spkcpt_c velocity with the light-time rate; Body._radial_velocity_from_state body.py:2847
 __device__ __forceinline__ double radial_velocity(const Params &p, V3 sp, double lt, V3 pos, const M3 &R)
 {
@@ -939,20 +963,30 @@ __device__ __forceinline__ void limb_coords_f(const Params &p, V3 ray, double &l
 }
 
 // Body.local_solar_time_from_lon body.py:2376-2398 (et2lst_c, truncated to whole seconds)
+// fmod(x, 86400) for |x| < 3 * 86400 is at most two exact subtractions (Sterbenz), the divisions are
+// div_fast (agrees with the IEEE quotient in every probed sample): the libm fmod and five IEEE divisions of
+// the plain form cost this plane a fifth of the whole headline set.
 __device__ __forceinline__ double local_solar_time(const Params &p, double lon_deg)
 {
     if (!isfinite(lon_deg)) return __builtin_nan("");
     double lon = lon_deg * kRad;
     double le = p.g.west_positive ? -lon : lon;
     double angle = le - p.g.lst_sun_lon;
-    double frac = angle / kTwoPi + 0.5;
-    double secnds = fmod(86400.0 * frac, 86400.0);
+    double frac = div_fast(angle, kTwoPi) + 0.5;
+    double secnds = 86400.0 * frac;  // |angle| < 4 pi: |secnds| < 3 * 86400
+    if (!(fabs(secnds) < 259200.0)) {
+        secnds = fmod(secnds, 86400.0);
+    } else {
+        const double m = fabs(secnds);
+        const double r = m >= 172800.0 ? m - 172800.0 : (m >= 86400.0 ? m - 86400.0 : m);
+        secnds = secnds < 0.0 ? -r : r;
+    }
     if (secnds < 0.0) secnds += 86400.0;
-    double hr = floor(secnds / 3600.0);
+    double hr = floor(div_fast(secnds, 3600.0));
     double rem = secnds - 3600.0 * hr;
-    double mn = floor(rem / 60.0);
+    double mn = floor(div_fast(rem, 60.0));
     double sc = floor(rem - 60.0 * mn);
-    return hr + mn / 60.0 + sc / 3600.0;
+    return hr + div_fast(mn, 60.0) + div_fast(sc, 3600.0);
 }
 
 // pixel -> unit ray: BodyXY._xy2obsvec_norm body_xy.py:375 -> Body._angular2obsvec_norm body.py:1363

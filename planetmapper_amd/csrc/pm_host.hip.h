@@ -104,6 +104,7 @@ struct pm_ctx {
     int zero_copy = -1;          // PM_OPT_ZERO_COPY
     int sparse_frame = -1;       // PM_OPT_SPARSE_FRAME
     int table_cache = 1;         // PM_OPT_BLOCK_TABLE_CACHE
+    int fuse_planes = 0;         // PM_OPT_FUSE_PLANES
     int route_explore = 1;       // PM_OPT_ROUTE_EXPLORE
     int last_cube_route = -1;    // PM_OPT_LAST_CUBE_ROUTE
     int last_redo_planes = 0;    // PM_OPT_LAST_REDO_PLANES: planes of the latest finished pm_map_cube redone with their nanmedian

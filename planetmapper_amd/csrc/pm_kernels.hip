@@ -193,11 +193,121 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
     return mid ? r : (d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi));
 }
 
+// pixel -> unit vector in the angular frame (BodyXY._xy2obsvec_norm body_xy.py:375: radrec of the view
+// angles; the ray is M^T of it in J2000, C of it in B0). The affine map is taken in radians: folding
+// arcsec -> rad into its six constants moves an angle of 1e-4 rad by 1 ulp.
+__device__ __forceinline__ V3 pixel_va(const Params &p, const int x, const int y)
+{
+    const double fx = (double)x, fy = (double)y;
+    const double ra = fma(p.Ar[0], fx, fma(p.Ar[1], fy, p.Ar[2]));
+    const double de = fma(p.Ar[3], fx, fma(p.Ar[4], fy, p.Ar[5]));
+    double sr, cr, sd, cd;
+    if (p.view_tiny) {  // kernel-argument flag: a scalar branch, no wave vote
+        sincos_tiny(ra, sr, cr);
+        sincos_tiny(de, sd, cd);
+    } else {
+        sincos_auto(ra, sr, cr);
+        sincos_auto(de, sd, cd);
+    }
+    return v3(cr * cd, sr * cd, sd);
+}
+
+// Reference loops fused here: BodyXY._get_radec_img body_xy.py:3409, get_x_img :3494,
+// get_y_img :3519, _get_km_xy_img :3545, get_angular_x_img :3610,
+// _get_limb_coordinate_imgs :3964. One pixel's planes from its angular-frame unit vector `va`; shared by
+// k_sky (these planes alone) and by the SKY variants of k_disc_sph (every plane of a frame from one
+// launch): the same code on the same `va`, the same bits.
+// Constants through the laundered kernel-argument pointer: loaded here, not at kernel entry.
+template <bool LIMB>
+__device__ __forceinline__ void sky_block(const V3 va, const int x, const int y, const size_t row_base, const unsigned lane_off)
+{
+    const Params &p = *(const Params *)kernarg_params();
+    if (PM_WANT(PM_RA) || PM_WANT(PM_DEC)) {
+        double ra, dec;
+        recrad_f(mtxv(p.g.M, va), ra, dec);  // the ray in J2000 (finite, non-zero for every pixel)
+        PM_PUT_ROW(PM_RA, ra * kDeg);
+        PM_PUT_ROW(PM_DEC, dec * kDeg);
+    }
+    PM_PUT_ROW(PM_PIXEL_X, (double)x);
+    PM_PUT_ROW(PM_PIXEL_Y, (double)y);
+    if (PM_WANT(PM_KM_X) || PM_WANT(PM_KM_Y) || PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y)) {
+        // The reference takes each pixel's RA / Dec (in degrees) back to a ray and to angular coordinates
+        // (radec2km, body_xy.py:3545-3552; Body._obsvec2angular body.py:1345): recrad of the vector the
+        // view angles were turned into - i.e. the view angles themselves, the affine map of the pixel, as
+        // long as they stay inside (-pi, pi) x (-pi/2, pi/2) (host: Params::view_direct; the round trip
+        // through two sincos, a 3 x 3 product and two atan2 returns them to 1e-16 rad = 2e-11 arcsec).
+        double ax, ay;
+        if (p.view_direct) {
+            ax = fma(p.A[0], (double)x, fma(p.A[1], (double)y, p.A[2]));
+            ay = fma(p.A[3], (double)x, fma(p.A[4], (double)y, p.A[5]));
+        } else {
+            obsvec2angular_f(p, mtxv(p.g.M, va), ax, ay);
+        }
+        const double kx = fma(p.K[0], ax, p.K[1] * ay), ky = fma(p.K[2], ax, p.K[3] * ay);
+        PM_PUT_ROW(PM_KM_X, kx);
+        PM_PUT_ROW(PM_KM_Y, ky);
+        if (PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y)) {
+            const double ik = rcp_fast(p.g.km_per_arcsec);
+            const double qx = kx * ik, qy = ky * ik;
+            PM_PUT_ROW(PM_ANGULAR_X, fma(fma(-p.g.km_per_arcsec, qx, kx), ik, qx));
+            PM_PUT_ROW(PM_ANGULAR_Y, fma(fma(-p.g.km_per_arcsec, qy, ky), ik, qy));
+        }
+    }
+    if (LIMB) {
+        // Body._limb_coordinates_from_obsvec body.py:2081-2110 in B0, like the ring block of k_disc_sph:
+        // the point of the ray nearest the body centre, PM's _obsvec2targvec of it (R(t) off =
+        // Rz_frame(wdot (t - t0)) (R0 off), lengths are rotation invariant), the surface point under it
+        // (surfpt_c from the centre = tv / |tv / radii|) and recpgr_c there.
+        const V3 u = mxv(p.C, va);  // the ray in B0 (unit to 1e-16)
+        const V3 o0 = v3(p.O0[0], p.O0[1], p.O0[2]);  // -R0 T0
+        const double k = -div_fast(dot(o0, u), dot(u, u));
+        const V3 nb = {fma(k, u.x, o0.x), fma(k, u.y, o0.y), fma(k, u.z, o0.z)};  // near point - T0, in B0
+        const double nd = norm_f(nb);
+        const V3 ob = {fma(k, u.x, -p.sub_obs_b[0]), fma(k, u.y, -p.sub_obs_b[1]), fma(k, u.z, -p.sub_obs_b[2])};
+        const V3 w = ob - ld3(p.sub_ray_b);
+        const double dd = norm_f(w) - p.g.sub_dist;
+        const double t = p.g.sub_et - dd * p.inv_c;
+        const double ang = p.g.wdot * (t - p.t0);
+        double sa, ca;
+        if (__all(fabs(ang) <= 1e-3)) {
+            sincos_tiny(ang, sa, ca);
+        } else {
+            sincos_auto(ang, sa, ca);
+        }
+        const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1], ob.z + p.g.sub_sp[2]};
+        const V3 X = {tv.x * p.ir[0], tv.y * p.ir[1], tv.z * p.ir[2]};
+        const double sc = rsqrt_fast(dot(X, X));
+        const V3 sfc = sc * tv;
+        const double nx = sfc.x * p.limb_n[0], ny = sfc.y * p.limb_n[0], nz = sfc.z * p.limb_n[1];
+        const double lat = atan2_fast(nz, sqrt_fast(fma(nx, nx, ny * ny)));
+        double l = atan2_fast(sfc.y, sfc.x);
+        if (p.g.west_positive) l = -l;
+        if (l < 0.0) l += kTwoPi;
+        PM_PUT_ROW(PM_LIMB_LON_GRAPHIC, l * kDeg);
+        PM_PUT_ROW(PM_LIMB_LAT_GRAPHIC, lat * kDeg);
+        PM_PUT_ROW(PM_LIMB_DISTANCE, nd - norm_f(sfc));
+    }
+}
+
+template <bool LIMB>
+__global__ __launch_bounds__(kBlock) void k_sky(const Params p_)
+{
+    const Params &p = *(const Params *)kernarg_params();
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int y = p.y_off + (int)blockIdx.y;
+    if (x >= p.nx) return;
+    sky_block<LIMB>(pixel_va(p, x, y), x, y, (size_t)blockIdx.y * p.nx, (unsigned)x * 8u);  // (row base wave-uniform: saddr stores)
+}
+
 // TRI: triaxial ellipsoid (a != b). The shape is no longer invariant under the spin, so each
 // light-time evaluation first turns ray and observer by the spin angle of its epoch (a few
 // 1e-5 rad: series) into the body-fixed frame and rescales the ray; the intercept is then
 // body-fixed, and is turned back to B0 for the illumination geometry.
-template <int FLAGS, bool TRI>
+// SKY: 0 = the planes of the intercept only; 1 / 2 = the planes every pixel has as well (sky_block without /
+// with the limb planes): all 26 planes of a frame from ONE launch, what save_observation asks for
+// (observation.py:1269-1279). The sky planes go first: a wave issues their stores and computes its intercept
+// while they drain.
+template <int FLAGS, bool TRI, int SKY = 0>
 __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 {
     // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8); with a row-major grid
@@ -225,23 +335,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 
     const bool any_cand = __any(cand);
     V3 va = {0.0, 0.0, 0.0};  // unit vector of the pixel in the angular frame
-    if (any_cand || (FLAGS & DF_RING)) {
-        // pixel -> unit ray (BodyXY._xy2obsvec_norm body_xy.py:375)
-        // (the affine map is taken in radians: folding arcsec -> rad into its six constants moves
-        //  an angle of 1e-4 rad by 1 ulp)
-        const double fx = (double)x, fy = (double)y;
-        const double ra = fma(p.Ar[0], fx, fma(p.Ar[1], fy, p.Ar[2]));
-        const double de = fma(p.Ar[3], fx, fma(p.Ar[4], fy, p.Ar[5]));
-        double sr, cr, sd, cd;
-        if (p.view_tiny) {  // kernel-argument flag: a scalar branch, no wave vote
-            sincos_tiny(ra, sr, cr);
-            sincos_tiny(de, sd, cd);
-        } else {
-            sincos_auto(ra, sr, cr);
-            sincos_auto(de, sd, cd);
-        }
-        va = v3(cr * cd, sr * cd, sd);
-    }
+    if (any_cand || (FLAGS & DF_RING) || SKY != 0) va = pixel_va(p, x, y);
+    // the planes every pixel has first: the wave issues their stores and computes its intercept while they drain
+    if (SKY != 0 && inside) sky_block<SKY == 2>(va, x, y, row_base, lane_off);
 
     // the ray in B0 (both the ring and the disc block work there)
     V3 u = {0.0, 0.0, 0.0};
@@ -489,7 +585,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     PM_PUT_ROW(PM_PHASE, ph);
                     PM_PUT_ROW(PM_INCIDENCE, in);
                     PM_PUT_ROW(PM_EMISSION, em);
-                    if (PM_WANT(PM_AZIMUTH)) PM_PUT_ROW(PM_AZIMUTH, azimuth_deg(ph, in, em));
+                    if (PM_WANT(PM_AZIMUTH)) PM_PUT_ROW(PM_AZIMUTH, azimuth_from_cosines(dot(sunb, ob), dot(n, sunb), dot(n, ob)) + miss);
                 }
             }
             if (FLAGS & DF_STATE) {
@@ -499,11 +595,11 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 const V3 vo = v3(kp->VOB[0], kp->VOB[1], kp->VOB[2]);
                 const double dlt = (dot(u, vp - vo) * kp->inv_c) / (1.0 + dot(u, vp) * kp->inv_c);
                 const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;
-                const double beta = rv / kp->g.clight;
+                const double beta = rv * kp->inv_c;  // SpiceBase.calculate_doppler_factor base.py:550
                 if (inside) {
                     PM_PUT_ROW(PM_DISTANCE, dist_lt);
                     PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);
-                    PM_PUT_ROW(PM_DOPPLER, sqrt((1.0 + beta) / (1.0 - beta)));
+                    PM_PUT_ROW(PM_DOPPLER, sqrt_fast(div_fast(1.0 + beta, 1.0 - beta)));
                 }
             }
         }
@@ -535,59 +631,6 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         PM_PUT_ROW(PM_RING_RADIUS, rr);
         PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
         PM_PUT_ROW(PM_RING_DISTANCE, rd);
-    }
-}
-
-// Reference loops fused here: BodyXY._get_radec_img body_xy.py:3409, get_x_img :3494,
-// get_y_img :3519, _get_km_xy_img :3545, get_angular_x_img :3610,
-// _get_limb_coordinate_imgs :3964.
-template <bool LIMB>
-__global__ __launch_bounds__(kBlock) void k_sky(const Params p)
-{
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int y = p.y_off + (int)blockIdx.y;
-    if (x >= p.nx) return;
-    const size_t row_base = (size_t)blockIdx.y * p.nx;  // wave-uniform: stores use the saddr form
-    const unsigned lane_off = (unsigned)x * 8u;
-    // xy2ray with the fast elementary functions (rays are finite for every pixel)
-    const double xd = (double)x, yd = (double)y;
-    const double ax0 = fma(p.A[0], xd, fma(p.A[1], yd, p.A[2]));
-    const double ay0 = fma(p.A[3], xd, fma(p.A[4], yd, p.A[5]));
-    V3 ray = mtxv(p.g.M, radrec_f(-(div_fast(ax0, 3600.0) * kRad), div_fast(ay0, 3600.0) * kRad));
-    if (PM_WANT(PM_RA) || PM_WANT(PM_DEC)) {
-        double ra, dec;
-        recrad_f(ray, ra, dec);
-        PM_PUT_ROW(PM_RA, ra * kDeg);
-        PM_PUT_ROW(PM_DEC, dec * kDeg);
-    }
-    PM_PUT_ROW(PM_PIXEL_X, xd);
-    PM_PUT_ROW(PM_PIXEL_Y, yd);
-    const bool km = PM_WANT(PM_KM_X) || PM_WANT(PM_KM_Y) || PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y);
-    if (km || LIMB) {
-        // The reference rebuilds the ray from RA/Dec in degrees (radec2obsvec_norm, body_xy.py:3262);
-        // that round trip moves it by < 1 ulp - below the rounding of the ray itself, 1e4 times
-        // below the parity bar after the D/R amplification - and is not replayed.
-        const V3 ray2 = ray;
-        if (km) {
-            double ax, ay;
-            obsvec2angular_f(p, ray2, ax, ay);
-            double kx = fma(p.K[0], ax, p.K[1] * ay), ky = fma(p.K[2], ax, p.K[3] * ay);
-            PM_PUT_ROW(PM_KM_X, kx);
-            PM_PUT_ROW(PM_KM_Y, ky);
-            if (PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y)) {
-                const double ik = rcp_fast(p.g.km_per_arcsec);
-                const double qx = kx * ik, qy = ky * ik;
-                PM_PUT_ROW(PM_ANGULAR_X, fma(fma(-p.g.km_per_arcsec, qx, kx), ik, qx));
-                PM_PUT_ROW(PM_ANGULAR_Y, fma(fma(-p.g.km_per_arcsec, qy, ky), ik, qy));
-            }
-        }
-        if (LIMB) {
-            double ll, lb, ld;
-            limb_coords_f(p, ray2, ll, lb, ld);
-            PM_PUT_ROW(PM_LIMB_LON_GRAPHIC, ll);
-            PM_PUT_ROW(PM_LIMB_LAT_GRAPHIC, lb);
-            PM_PUT_ROW(PM_LIMB_DISTANCE, ld);
-        }
     }
 }
 
@@ -938,15 +981,21 @@ void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
     }
 }
 
+// flags: DiscFlags in bits 0..2; bits 3..4: 0 = intercept planes only, 1 / 2 = + the sky planes (/ + limb planes)
 void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 {
     dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
     dim3 block(pm::kSphBlock);
     const bool tri = p.radii[0] != p.radii[1];
-#define PM_SPH_CASE(F)                                                                  \
-    case F:                                                                             \
-        if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, true>), grid, block, 0, s, p);   \
-        else hipLaunchKernelGGL((pm::k_disc_sph<F, false>), grid, block, 0, s, p);      \
+    const int sky = (flags >> 3) & 3;
+#define PM_SPH_CASE(F)                                                                                          \
+    case F:                                                                                                     \
+        if (tri && sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, true, 0>), grid, block, 0, s, p);            \
+        else if (tri && sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, true, 1>), grid, block, 0, s, p);       \
+        else if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, true, 2>), grid, block, 0, s, p);                   \
+        else if (sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, false, 0>), grid, block, 0, s, p);             \
+        else if (sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, false, 1>), grid, block, 0, s, p);             \
+        else hipLaunchKernelGGL((pm::k_disc_sph<F, false, 2>), grid, block, 0, s, p);                           \
         break;
     switch (flags & 7) {
         PM_SPH_CASE(0)

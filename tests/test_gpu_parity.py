@@ -1863,3 +1863,43 @@ def test_c_abi_sharded_cube_into_one_host_array_without_a_collective(engine, ora
         engine._check(lib.pm_map_cube_sharded(ctx, None, cube.ctypes.data, 0, planes, xm.ctypes.data, ym.ctypes.data, n0, n1, 1, 1,
                                               out.ctypes.data, _lib.PM_MEM_HOST, 1))
     assert shard_bounds(planes, 3, 2) == (6, 7, 3)
+
+
+@pytest.mark.parametrize('which', ['jupiter', 'saturn'])
+def test_all_planes_from_one_launch_equal_the_launch_per_group(engine, oracle, jupiter, saturn, which):
+    """
+    save_observation's request (observation.py:1269-1279): all 26 planes of a frame. With PM_OPT_FUSE_PLANES
+    the spheroid path computes them in ONE launch (k_disc_sph<FLAGS, TRI, SKY>: the sky / limb
+    planes ride along with the intercept planes); without, one launch per group as before. The same code
+    runs in both: every plane bit-identical - ragged frame, row block, subsets of planes - and inside the
+    bars against the oracle.
+    """
+    from planetmapper_amd import _lib
+
+    g, sz_x, sz_y, r0, rot = (jupiter, 517, 389, 170.0, 0.58) if which == 'jupiter' else (saturn, 700, 640, 120.0, 0.35)
+    engine.set_geometry(g)
+    engine.set_disc(sz_x / 2.1, sz_y / 1.9, r0, rot, sz_x, sz_y, True)
+    subsets = [oracle.PLANE_NAMES, ['LON-GRAPHIC', 'RA', 'PIXEL-Y'], ['EMISSION', 'LIMB-DISTANCE', 'KM-X', 'RING-RADIUS'],
+               ['DISTANCE', 'ANGULAR-X', 'LIMB-LAT-GRAPHIC', 'DEC']]  # fmt: skip
+    was_general = engine.get_option(_lib.PM_OPT_GENERAL_KERNEL)  # (the module's engine may be inside an engine_fg leg)
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
+    try:
+        for names in subsets:
+            engine.set_option(_lib.PM_OPT_FUSE_PLANES, 1)
+            one = engine.backplanes_img(names)
+            assert engine.get_option(_lib.PM_OPT_LAST_DISC_KERNEL) == 1
+            rows_one = engine.backplanes_img_rows(names, 101, 57)
+            engine.set_option(_lib.PM_OPT_FUSE_PLANES, 0)
+            per_group = engine.backplanes_img(names)
+            rows_group = engine.backplanes_img_rows(names, 101, 57)
+            for n in names:
+                assert np.array_equal(one[n], per_group[n], equal_nan=True), (which, n)
+                assert np.array_equal(rows_one[n], rows_group[n], equal_nan=True), (which, n)
+                assert np.array_equal(rows_one[n], one[n][101:158], equal_nan=True), (which, n)
+        engine.set_option(_lib.PM_OPT_FUSE_PLANES, 1)
+        d = oracle.make_disc(sz_x / 2.1, sz_y / 1.9, r0, 0.0, sz_x, sz_y)
+        d.rotation_rad = rot
+        _compare(engine.backplanes_img(oracle.PLANE_NAMES), oracle.backplanes_img(g, d, oracle.PLANE_NAMES), oracle.PLANE_NAMES, g, r0=r0)
+    finally:
+        engine.set_option(_lib.PM_OPT_FUSE_PLANES, 0)
+        engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, was_general)

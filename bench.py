@@ -119,21 +119,34 @@ def rectangular_grid(west_positive: bool, degree_interval: float = 1.0):
     return np.ascontiguousarray(lon % 360), np.ascontiguousarray(lat)
 
 
-def profile_record(kernel_prefix: str) -> dict:
+def library_sha256() -> str:
+    import hashlib
+
+    from planetmapper_amd import _lib
+
+    with open(_lib.LIB_PATH, 'rb') as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def profile_record(kernel_prefix: str) -> tuple[dict, bool]:
     """
     Per-launch PMC figures of a kernel from the separate rocprofv3 --pmc passes of
     tools/pmc_profile.sh (profiles/traffic.json: WRITE_SIZE + FETCH_SIZE bytes, FP64 operations).
-    PMC counters cannot be collected inside this process, so the last profiled values are reported.
+    PMC counters cannot be collected inside this process, so the last profiled values are reported -
+    but only while they belong to THIS build: the file carries the sha256 of the library it was measured
+    on. Returns (record, stale): stale = the file exists but was measured on another build (record empty).
     """
     try:
         with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
             t = json.load(f)
-        for k, v in t.items():
-            if k.startswith(kernel_prefix):
-                return v
-    except (OSError, ValueError, KeyError):
-        pass
-    return {}
+    except (OSError, ValueError):
+        return {}, False
+    if t.get('_library_sha256') != library_sha256():
+        return {}, True
+    for k, v in t.items():
+        if k.startswith(kernel_prefix) and isinstance(v, dict):
+            return v, False
+    return {}, False
 
 
 def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
@@ -771,7 +784,7 @@ def headline(args) -> None:
         alg = algorithmic_bytes(sz, sz, len(HEADLINE))
         achieved = alg / (kernel_ms * 1e-3) / 1e9
         ms_per_step = dt / args.steps * 1e3
-        rec = profile_record('pm::k_disc_sph<1,') if sz == 4096 else {}
+        rec, traffic_stale = profile_record('pm::k_disc_sph<1,') if sz == 4096 else ({}, False)
         # step-level bytes: 5 planes + x/y map (16 B in + 16 B out per cell) + 1-plane reprojection
         step_bytes = alg + n0 * n1 * 32 + n0 * n1 * (16 + 40)
         line = {
@@ -809,6 +822,8 @@ def headline(args) -> None:
                 'unit': 'GB/s',
                 'frac': round(achieved / HBM_PEAK_GBS, 5),
                 'traffic': int(rec['hbm_bytes']) if 'hbm_bytes' in rec else None,
+                'traffic_stale': traffic_stale,  # true: profiles/traffic.json was measured on another build of the library
+                'library_sha256': library_sha256()[:16],
                 'kernel_ms': round(kernel_ms, 4),
                 'algorithmic_bytes': alg,
             },

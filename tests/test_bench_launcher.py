@@ -61,3 +61,28 @@ def test_runs_under_an_external_torchrun_too():
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=REPO)
     assert r.returncode == 0, r.stderr[-2000:]
     assert _json_lines(r.stdout)[0]['n_gpus'] == 2
+
+
+def test_pmc_figures_are_reported_only_for_the_build_they_were_measured_on(tmp_path, monkeypatch):
+    """
+    `roofline.traffic` / `fp64` of the bench line come from profiles/traffic.json (PMC counters cannot be read
+    inside the timed process). The file is stamped with the sha256 of the library it was measured on
+    (tools/pmc_summary.py); with another build loaded the figures are withheld and the line says
+    `traffic_stale: true`.
+    """
+    import json
+
+    import bench
+
+    (tmp_path / 'profiles').mkdir()
+    rec = {'pm::k_disc_sph<1, false>': {'hbm_bytes': 671213229.0, 'fp64_flop': 4.5e9}}
+    monkeypatch.setattr(bench, 'REPO', str(tmp_path))
+    (tmp_path / 'profiles' / 'traffic.json').write_text(json.dumps(dict(rec, _library_sha256=bench.library_sha256())))
+    got, stale = bench.profile_record('pm::k_disc_sph<1,')
+    assert not stale and got['hbm_bytes'] == 671213229.0
+    (tmp_path / 'profiles' / 'traffic.json').write_text(json.dumps(dict(rec, _library_sha256='0' * 64)))
+    assert bench.profile_record('pm::k_disc_sph<1,') == ({}, True)
+    (tmp_path / 'profiles' / 'traffic.json').write_text(json.dumps(rec))  # a file from before the stamp existed
+    assert bench.profile_record('pm::k_disc_sph<1,') == ({}, True)
+    (tmp_path / 'profiles' / 'traffic.json').unlink()
+    assert bench.profile_record('pm::k_disc_sph<1,') == ({}, False)

@@ -31,5 +31,11 @@ for k, cs in sorted(acc.items()):
         name = k.replace('void ', '')
         traffic.setdefault(name, {})['fp64_flop'] = 64.0 * (2 * m[f64[0]] + m[f64[1]] + m[f64[2]] + m[f64[3]])
         traffic[name]['fp64_wave_insts'] = sum(m.values())
+# which build these counters belong to: bench.py reports them only while the library it has loaded is this one
+import hashlib
+
+lib = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'planetmapper_amd', 'libplanetmapper_hip.so')
+if os.path.exists(lib):
+    traffic['_library_sha256'] = hashlib.sha256(open(lib, 'rb').read()).hexdigest()
 with open(os.path.join(root, 'traffic.json'), 'w') as f:
     json.dump(traffic, f, indent=1)

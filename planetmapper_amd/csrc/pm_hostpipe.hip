@@ -34,25 +34,10 @@
 //
 // No compute happens on the CPU here: the threads move bytes (and write the constant NaN where the
 // kernels' own pre-mask says nothing else can be).
-#include <emmintrin.h>
-
-#include <atomic>
 #include <chrono>
-#include <condition_variable>
-#include <deque>
-#include <memory>
-#include <mutex>
-#include <thread>
 
 #include "pm_host.hip.h"
-
-// how far ahead of the copy the pool's block gather requests cache lines, and into which level
-#ifndef PM_GATHER_AHEAD_BYTES
-#define PM_GATHER_AHEAD_BYTES 4096
-#endif
-#ifndef PM_GATHER_HINT
-#define PM_GATHER_HINT _MM_HINT_T0
-#endif
+#include "pm_hostpool.h"
 
 namespace pmh {
 
@@ -77,7 +62,32 @@ int usable_cores()
 
 }  // namespace
 
-struct HostPipe {
+// the device side of the pool's staging ring: DMA engines and events of the HIP runtime
+struct HipBackend : CopyBackend {
+    int device = 0;
+    hipEvent_t ev_stage[HostPool::kSlots] = {};
+    void thread_init() override { (void)hipSetDevice(device); }
+    int copy_d2h(void *dst, const void *src, size_t bytes, void *stream) override
+    {
+        return (int)hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    }
+    int copy_d2h_2d(void *dst, size_t dpitch, const void *src, size_t spitch, size_t width, size_t height, void *stream) override
+    {
+        return (int)hipMemcpy2DAsync(dst, dpitch, src, spitch, width, height, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    }
+    int record(int slot, void *stream) override { return (int)hipEventRecord(ev_stage[slot], (hipStream_t)stream); }
+    int wait(int slot) override { return (int)hipEventSynchronize(ev_stage[slot]); }
+    void *alloc_pinned(size_t bytes) override
+    {
+        void *p = nullptr;
+        return hipHostMalloc(&p, bytes, hipHostMallocNonCoherent) == hipSuccess ? p : nullptr;
+    }
+    void free_pinned(void *p) override { (void)hipHostFree(p); }
+};
+
+// the pool + ring of pm_hostpool.h (HIP-free, sanitizer-tested on the CPU) and the HIP state of the cube pipeline
+struct HostPipe : HostPool {
+    HipBackend hip;
     // ---- streams / events of the cube pipeline
     hipStream_t s_in = nullptr, s_out = nullptr;
     static constexpr int kRing = 3;
@@ -117,315 +127,6 @@ struct HostPipe {
     RouteStats rstats;
     double *d_maps = nullptr;  // the x/y maps of a PM_MEM_HOST call
     size_t d_maps_cap = 0;
-    // ---- pinned staging ring of the D2H leg
-    static constexpr int kSlots = 4;
-    char *stage[kSlots] = {};
-    size_t stage_bytes = 0;
-    hipEvent_t ev_stage[kSlots] = {};
-    // rows of a frame plane of which only the columns [xa, xb) hold anything but NaN (d2h_issue_disc)
-    struct Rows {
-        size_t nx = 0, n = 0;  // row length (pixels), rows
-        size_t xa = 0, xb = 0;
-    };
-    struct Piece {
-        int slot;
-        char *dst;
-        size_t bytes;
-        Rows rows;  // rows.n != 0: the staged piece is the rectangle rows.n x (xb - xa), dst the first row
-    };
-    // pieces whose DMA has been enqueued, oldest first; the retire thread waits for each DMA and has
-    // the pool copy the piece out, so the calling thread stays free to feed the next chunk
-    std::deque<Piece> inflight;
-    int next_slot = 0;
-    std::thread retirer;
-    std::mutex rmu;
-    std::condition_variable cv_piece, cv_slot;
-    int pieces_out = 0;  // issued and not yet copied out (<= kSlots)
-    bool slot_busy[kSlots] = {};  // DMA in flight or being copied out (copy-outs may finish out of order)
-    bool rstop = false;
-    int device = 0;
-    hipError_t rerror = hipSuccess;
-
-    // (slot < 0: an asynchronous job that holds no staging slot, counted in pieces_out all the same)
-    void release_slot(int slot, hipError_t e)
-    {
-        {
-            std::lock_guard<std::mutex> lk(rmu);
-            if (e != hipSuccess && rerror == hipSuccess) rerror = e;
-            if (slot >= 0) slot_busy[slot] = false;
-            pieces_out--;
-        }
-        cv_slot.notify_all();
-    }
-    // Waits for each DMA in turn and hands the piece to the pool WITHOUT waiting for the copy-out: while
-    // the pool copies piece k the thread is already waiting for the DMA of piece k + 1 (the wake-up
-    // latencies of an event wait and of a pool job, ~0.1 ms each, used to sit between any two pieces).
-    void retire_main()
-    {
-        (void)hipSetDevice(device);
-        for (;;) {
-            Piece pc;
-            {
-                std::unique_lock<std::mutex> lk(rmu);
-                cv_piece.wait(lk, [&] { return rstop || !inflight.empty(); });
-                if (inflight.empty()) return;  // rstop
-                pc = inflight.front();
-                inflight.pop_front();
-            }
-            const hipError_t e = hipEventSynchronize(ev_stage[pc.slot]);
-            if (e != hipSuccess)
-                release_slot(pc.slot, e);
-            else if (pc.rows.n)
-                rows_async(pc.dst, stage[pc.slot], pc.rows, pc.slot);
-            else
-                copy_async(pc.dst, stage[pc.slot], pc.bytes, pc.slot);
-        }
-    }
-    void start_retirer(int dev)
-    {
-        if (retirer.joinable()) return;
-        device = dev;
-        rstop = false;
-        retirer = std::thread([this] { retire_main(); });
-    }
-    void stop_retirer()
-    {
-        if (!retirer.joinable()) return;
-        {
-            std::lock_guard<std::mutex> lk(rmu);
-            rstop = true;
-        }
-        cv_piece.notify_all();
-        retirer.join();
-    }
-    // ---- copy pool: a queue of jobs, each cut into parts that any pool thread takes; threads move on
-    // to the next job as soon as the parts of the front one are handed out
-    struct Job {
-        char *dst = nullptr;
-        const char *src = nullptr;
-        size_t total = 0, part = 0;  // units: bytes (copy) or blocks (gather)
-        // gather: block i of dst is block list[i % nlist] of source plane i / nlist
-        const int *list = nullptr;
-        size_t nlist = 0, plane_bytes = 0;
-        int shift = 0;  // log2 of the block size (>= 4)
-        size_t nparts = 0;
-        std::atomic<size_t> next{0}, finished{0};
-        int slot = -1;      // copy-out of a staged piece: the staging slot it frees
-        bool counted = false;  // an asynchronous job without a slot: completion decrements pieces_out
-        bool done = false;  // (under mu)
-        // rows job (units: rows): row r of dst (rows.nx doubles) <- NaN | row r of the staged rectangle | NaN;
-        // src == nullptr: the columns [xa, xb) are left alone (a DMA writes them) or do not exist
-        Rows rows;
-    };
-    std::vector<std::thread> workers;
-    std::mutex mu;
-    std::condition_variable cv_work, cv_done;
-    std::deque<std::shared_ptr<Job>> queue;  // jobs that may still have parts to hand out
-    bool stop = false;
-
-    void run_part(const Job &j, size_t i)
-    {
-        const size_t a = i * j.part;
-        const size_t n = std::min(j.part, j.total - a);
-        if (j.rows.n) {
-            const Rows &rw = j.rows;
-            const uint64_t nan_bits = 0x7ff8000000000000ull;  // the quiet NaN the kernels store
-            const size_t w = rw.xb - rw.xa;
-            for (size_t r = a; r < a + n; r++) {
-                uint64_t *row = (uint64_t *)(j.dst + r * rw.nx * sizeof(double));
-                for (size_t x = 0; x < rw.xa; x++) row[x] = nan_bits;
-                if (j.src && w) std::memcpy(row + rw.xa, j.src + r * w * sizeof(double), w * sizeof(double));
-                for (size_t x = rw.xb; x < rw.nx; x++) row[x] = nan_bits;
-            }
-            return;
-        }
-        if (!j.list) {
-            std::memcpy(j.dst + a, j.src + a, n);
-            return;
-        }
-        // Scattered small reads: the hardware prefetchers see no stream, so the cache line of the
-        // block `ahead` rows on is requested by hand (once per line); the table itself is written
-        // around the caches - it is read next by the DMA engine, not by this core.
-        const int sh = j.shift;
-        const size_t kB = (size_t)1 << sh;
-        const size_t ahead = PM_GATHER_AHEAD_BYTES >> sh;
-        size_t plane = a / j.nlist, row = a % j.nlist;
-        const char *src = j.src + plane * j.plane_bytes;
-        char *dst = j.dst + a * kB;
-        size_t last_line = ~(size_t)0;
-        for (size_t q = 0; q < n; q++, dst += kB) {
-            if (row + ahead < j.nlist) {
-                const size_t o = (size_t)j.list[row + ahead] << sh;
-                for (size_t l = o; l < o + kB; l += 64)
-                    if ((l >> 6) != last_line) {
-                        _mm_prefetch(src + l, PM_GATHER_HINT);
-                        last_line = l >> 6;
-                    }
-            }
-            const char *from = src + ((size_t)j.list[row] << sh);
-            for (size_t l = 0; l < kB; l += 16)
-                _mm_stream_si128((__m128i *)(dst + l), _mm_loadu_si128((const __m128i *)(from + l)));
-            if (++row == j.nlist) {
-                row = 0;
-                src += j.plane_bytes;
-            }
-        }
-        _mm_sfence();
-    }
-    void finish_part(const std::shared_ptr<Job> &j)
-    {
-        if (j->finished.fetch_add(1, std::memory_order_acq_rel) + 1 != j->nparts) return;
-        if (j->slot >= 0 || j->counted) release_slot(j->slot, hipSuccess);
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            j->done = true;
-        }
-        cv_done.notify_all();
-    }
-    // parts of `j` until none is left to hand out
-    void take_parts(const std::shared_ptr<Job> &j)
-    {
-        for (;;) {
-            const size_t i = j->next.fetch_add(1, std::memory_order_relaxed);
-            if (i >= j->nparts) return;
-            run_part(*j, i);
-            finish_part(j);
-        }
-    }
-    void worker_main()
-    {
-        for (;;) {
-            std::shared_ptr<Job> j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                for (;;) {
-                    while (!queue.empty() && queue.front()->next.load(std::memory_order_relaxed) >= queue.front()->nparts)
-                        queue.pop_front();
-                    if (!queue.empty()) {
-                        j = queue.front();
-                        break;
-                    }
-                    // (only with nothing left to hand out: a queued copy-out owns a staging slot that
-                    //  nobody else would ever release)
-                    if (stop) return;
-                    cv_work.wait(lk);
-                }
-            }
-            take_parts(j);
-        }
-    }
-    void start_workers(int threads)
-    {
-        const int want = std::max(0, threads - 1);  // the calling thread works too
-        if ((int)workers.size() == want) return;
-        stop_workers();
-        stop = false;
-        for (int i = 0; i < want; i++) workers.emplace_back([this] { worker_main(); });
-    }
-    void stop_workers()
-    {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            stop = true;
-        }
-        cv_work.notify_all();
-        for (auto &t : workers) t.join();
-        workers.clear();
-    }
-    void post(const std::shared_ptr<Job> &j)
-    {
-        if (workers.empty()) return;  // (a pool of one: the poster does all the parts itself, see run())
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            queue.push_back(j);
-        }
-        cv_work.notify_all();
-    }
-    // post, work on it, return when it is complete
-    void run(const std::shared_ptr<Job> &j)
-    {
-        post(j);
-        take_parts(j);
-        std::unique_lock<std::mutex> lk(mu);
-        cv_done.wait(lk, [&] { return j->done; });
-    }
-    std::shared_ptr<Job> copy_job(char *dst, const char *src, size_t bytes)
-    {
-        auto j = std::make_shared<Job>();
-        j->dst = dst;
-        j->src = src;
-        j->total = bytes;
-        const size_t t = workers.size() + 1;
-        size_t part = (bytes + 2 * t - 1) / (2 * t);
-        part = std::max<size_t>(part, (size_t)1 << 20);
-        j->part = (part + 4095) & ~(size_t)4095;
-        j->nparts = (bytes + j->part - 1) / j->part;
-        return j;
-    }
-    // dst <- src with every pool thread (and the caller) taking 1 MiB+ parts
-    void copy(char *dst, const char *src, size_t bytes)
-    {
-        if (bytes < ((size_t)1 << 20) || workers.empty()) {
-            std::memcpy(dst, src, bytes);
-            return;
-        }
-        run(copy_job(dst, src, bytes));
-    }
-    // the same for a staged piece, without waiting: completion frees staging slot `slot`
-    void copy_async(char *dst, const char *src, size_t bytes, int slot)
-    {
-        if (bytes < ((size_t)1 << 20) || workers.empty()) {
-            std::memcpy(dst, src, bytes);
-            release_slot(slot, hipSuccess);
-            return;
-        }
-        auto j = copy_job(dst, src, bytes);
-        j->slot = slot;
-        post(j);
-    }
-    // rows of a frame plane, asynchronously: NaN outside [xa, xb), the staged rectangle (or nothing) inside.
-    // slot >= 0: the staging slot to free on completion; otherwise the job is counted in pieces_out here.
-    void rows_async(char *dst, const char *src, const Rows &rw, int slot)
-    {
-        auto j = std::make_shared<Job>();
-        j->dst = dst;
-        j->src = src;
-        j->rows = rw;
-        j->total = rw.n;
-        const size_t t = workers.size() + 1;
-        const size_t row_bytes = std::max<size_t>(rw.nx * sizeof(double), 1);
-        j->part = std::max<size_t>(std::max<size_t>((rw.n + 2 * t - 1) / (2 * t), ((size_t)512 << 10) / row_bytes), 1);
-        j->nparts = (rw.n + j->part - 1) / j->part;
-        j->slot = slot;
-        if (slot < 0) {
-            j->counted = true;
-            std::lock_guard<std::mutex> lk(rmu);
-            pieces_out++;
-        }
-        if (workers.empty()) {
-            take_parts(j);
-            return;
-        }
-        post(j);
-    }
-    // dst[plane][row] <- the (1 << shift)-byte block list[row] of source plane `plane`, for n_planes planes
-    // plane_bytes apart: the rows of a block table (pm::BlockTable), collected by the pool
-    void gather(char *dst, const char *src, size_t plane_bytes, size_t n_planes, const int *list, size_t n_list, int shift)
-    {
-        auto j = std::make_shared<Job>();
-        j->dst = dst;
-        j->src = src;
-        j->total = n_planes * n_list;
-        j->list = list;
-        j->nlist = n_list;
-        j->plane_bytes = plane_bytes;
-        j->shift = shift;
-        const size_t t = workers.size() + 1;
-        j->part = std::max<size_t>((j->total + 4 * t - 1) / (4 * t), ((size_t)256 << 10) >> shift);
-        j->nparts = (j->total + j->part - 1) / j->part;
-        if (j->nparts == 0) return;
-        run(j);
-    }
 };
 
 static int pipe_get(pm_ctx *ctx, HostPipe **out)
@@ -444,7 +145,9 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
         PM_HIP(ctx, hipEventCreate(&hp->ev_t0));
         PM_HIP(ctx, hipEventCreate(&hp->ev_t1));
         for (int i = 0; i < HostPipe::kSlots; i++)
-            PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_stage[i], hipEventDisableTiming));
+            PM_HIP(ctx, hipEventCreateWithFlags(&hp->hip.ev_stage[i], hipEventDisableTiming));
+        hp->hip.device = ctx->device;
+        hp->be = &hp->hip;
     }
     HostPipe *hp = ctx->pipe;
     int threads = ctx->host_copy_threads;
@@ -459,7 +162,7 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
         threads = std::min(16, cores);
     }
     hp->start_workers(threads);
-    hp->start_retirer(ctx->device);
+    hp->start_retirer();
     *out = hp;
     return PM_OK;
 }
@@ -470,10 +173,10 @@ void pipe_destroy(pm_ctx *ctx)
     if (!hp) return;
     hp->stop_retirer();
     hp->stop_workers();
-    for (int i = 0; i < HostPipe::kSlots; i++) {
-        if (hp->stage[i]) (void)hipHostFree(hp->stage[i]);
-        if (hp->ev_stage[i]) (void)hipEventDestroy(hp->ev_stage[i]);
-    }
+    hp->free_stage();
+    hp->be = nullptr;  // (the pool's own destructor runs after the backend member is gone)
+    for (int i = 0; i < HostPipe::kSlots; i++)
+        if (hp->hip.ev_stage[i]) (void)hipEventDestroy(hp->hip.ev_stage[i]);
     for (auto &t : hp->tab) {
         if (t.d_flags) (void)hipFree(t.d_flags);
         if (t.d_tiles) (void)hipFree(t.d_tiles);
@@ -527,20 +230,7 @@ bool host_is_pinned(const void *p, size_t bytes)
 static int ensure_stage(pm_ctx *ctx, HostPipe *hp)
 {
     const size_t want = std::min<size_t>(std::max<size_t>(ctx->host_chunk_bytes / 2, (size_t)4 << 20), (size_t)64 << 20);
-    if (hp->stage[0] && hp->stage_bytes == want) return PM_OK;
-    {
-        std::unique_lock<std::mutex> lk(hp->rmu);  // (resized between calls only; nothing is out then)
-        hp->cv_slot.wait(lk, [&] { return hp->pieces_out == 0; });
-    }
-    for (int i = 0; i < HostPipe::kSlots; i++) {
-        if (hp->stage[i]) PM_HIP(ctx, hipHostFree(hp->stage[i]));
-        hp->stage[i] = nullptr;
-    }
-    for (int i = 0; i < HostPipe::kSlots; i++) {
-        hipError_t e = hipHostMalloc((void **)&hp->stage[i], want, hipHostMallocNonCoherent);
-        if (e != hipSuccess) return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc of a %zu-byte staging buffer failed", want);
-    }
-    hp->stage_bytes = want;
+    if (!hp->ensure_stage(want)) return fail(ctx, PM_ERR_ALLOC, "hipHostMalloc of a %zu-byte staging buffer failed", want);
     return PM_OK;
 }
 
@@ -578,8 +268,7 @@ static int ensure_in_stage(pm_ctx *ctx, HostPipe *hp, size_t bytes)
 }
 
 // Enqueue dst_host <- src_dev on `stream`. Pinned destinations: one DMA. Pageable destinations:
-// pieces through the staging ring; at most kSlots pieces are out at a time (DMA in flight or being
-// copied out by the retire thread and the pool). d2h_finish() completes everything.
+// pieces through the pool's staging ring (pm_hostpool.h). d2h_finish() completes everything.
 int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_dev, size_t bytes)
 {
     if (bytes == 0) return PM_OK;
@@ -593,37 +282,13 @@ int d2h_issue(pm_ctx *ctx, hipStream_t stream, void *dst_host, const void *src_d
     }
     rc = ensure_stage(ctx, hp);
     if (rc != PM_OK) return rc;
-    for (size_t off = 0; off < bytes; off += hp->stage_bytes) {
-        const size_t n = std::min(hp->stage_bytes, bytes - off);
-        const int slot = hp->next_slot;
-        hp->next_slot = (slot + 1) % HostPipe::kSlots;
-        {
-            // the slot about to be reused is the oldest one out: wait until it has been copied out
-            std::unique_lock<std::mutex> lk(hp->rmu);
-            hp->cv_slot.wait(lk, [&] { return !hp->slot_busy[slot]; });
-            if (hp->rerror != hipSuccess) return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(hp->rerror));
-            hp->slot_busy[slot] = true;
-            hp->pieces_out++;
-        }
-        hipError_t e = hipMemcpyAsync(hp->stage[slot], (const char *)src_dev + off, n, hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipEventRecord(hp->ev_stage[slot], stream);
-        if (e != hipSuccess) {
-            hp->release_slot(slot, hipSuccess);  // nothing will ever retire it
-            return fail(ctx, PM_ERR_HIP, "staged D2H copy failed: %s", hipGetErrorString(e));
-        }
-        {
-            std::lock_guard<std::mutex> lk(hp->rmu);
-            hp->inflight.push_back({slot, (char *)dst_host + off, n, HostPipe::Rows{}});
-        }
-        hp->cv_piece.notify_one();
-    }
+    const int e = hp->issue(dst_host, src_dev, bytes, (void *)stream);
+    if (e != 0) return fail(ctx, PM_ERR_HIP, "staged D2H copy failed: %s", hipGetErrorString((hipError_t)e));
     return PM_OK;
 }
 
 // A frame plane that is NaN outside the circle (x - x0)^2 + (y - y0)^2 <= r2 (the image kernels' radius
-// pre-mask, y counted from `y_first` for the plane's first row): only bands of rows around that circle
-// cross the link, as rectangles; the copy threads write the NaN of everything else. The spans are
-// taken a pixel wider than the circle, so no rounding of this arithmetic decides a pixel.
+// pre-mask): only bands of rows around that circle cross the link (HostPool::issue_disc).
 int d2h_issue_disc(pm_ctx *ctx, hipStream_t stream, double *dst_host, const double *src_dev, size_t nx, size_t n_rows, double y_first,
                    double x0, double y0, double r2)
 {
@@ -635,57 +300,8 @@ int d2h_issue_disc(pm_ctx *ctx, hipStream_t stream, double *dst_host, const doub
         rc = ensure_stage(ctx, hp);
         if (rc != PM_OK) return rc;
     }
-    const size_t band = std::max<size_t>(1, std::min<size_t>(256, hp->stage_bytes ? hp->stage_bytes / (nx * sizeof(double)) : 256));
-    const double rr = std::sqrt(std::fmax(r2, 0.0));
-    for (size_t r0 = 0; r0 < n_rows; r0 += band) {
-        const size_t nr = std::min(band, n_rows - r0);
-        // widest span of the circle over the rows of the band (dy closest to 0), one pixel of margin
-        const double ya = y_first + (double)r0 - y0, yb = y_first + (double)(r0 + nr - 1) - y0;
-        const double dy = (ya <= 0.0 && yb >= 0.0) ? 0.0 : std::fmin(std::fabs(ya), std::fabs(yb));
-        HostPipe::Rows rw;
-        rw.nx = nx;
-        rw.n = nr;
-        char *dst = (char *)(dst_host + r0 * nx);
-        const double reach = dy - 0.5 <= rr ? std::sqrt(std::fmax(rr * rr - std::fmax(dy - 0.5, 0.0) * std::fmax(dy - 0.5, 0.0), 0.0)) : -1.0;
-        double fa = std::floor(x0 - reach) - 1.0, fb = std::ceil(x0 + reach) + 2.0;
-        if (reach < 0.0 || fb <= 0.0 || fa >= (double)nx) {
-            rw.xa = rw.xb = 0;  // nothing of the circle in these rows: all NaN
-            hp->rows_async(dst, nullptr, rw, -1);
-            continue;
-        }
-        rw.xa = (size_t)std::fmax(fa, 0.0);
-        rw.xb = (size_t)std::fmin(fb, (double)nx);
-        const size_t w = rw.xb - rw.xa;
-        const double *src = src_dev + r0 * nx + rw.xa;
-        if (pinned) {
-            // the DMA writes the rectangle in place, the pool the NaN around it
-            PM_HIP(ctx, hipMemcpy2DAsync(dst_host + r0 * nx + rw.xa, nx * sizeof(double), src, nx * sizeof(double), w * sizeof(double), nr,
-                                         hipMemcpyDeviceToHost, stream));
-            hp->rows_async(dst, nullptr, rw, -1);
-            continue;
-        }
-        const int slot = hp->next_slot;
-        hp->next_slot = (slot + 1) % HostPipe::kSlots;
-        {
-            std::unique_lock<std::mutex> lk(hp->rmu);
-            hp->cv_slot.wait(lk, [&] { return !hp->slot_busy[slot]; });
-            if (hp->rerror != hipSuccess) return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(hp->rerror));
-            hp->slot_busy[slot] = true;
-            hp->pieces_out++;
-        }
-        hipError_t e = hipMemcpy2DAsync(hp->stage[slot], w * sizeof(double), src, nx * sizeof(double), w * sizeof(double), nr,
-                                        hipMemcpyDeviceToHost, stream);
-        if (e == hipSuccess) e = hipEventRecord(hp->ev_stage[slot], stream);
-        if (e != hipSuccess) {
-            hp->release_slot(slot, hipSuccess);
-            return fail(ctx, PM_ERR_HIP, "staged D2H copy failed: %s", hipGetErrorString(e));
-        }
-        {
-            std::lock_guard<std::mutex> lk(hp->rmu);
-            hp->inflight.push_back({slot, dst, w * nr * sizeof(double), rw});
-        }
-        hp->cv_piece.notify_one();
-    }
+    const int e = hp->issue_disc(dst_host, src_dev, nx, n_rows, y_first, x0, y0, r2, (void *)stream, pinned);
+    if (e != 0) return fail(ctx, PM_ERR_HIP, "staged D2H copy failed: %s", hipGetErrorString((hipError_t)e));
     return PM_OK;
 }
 
@@ -696,11 +312,7 @@ void pipe_abort(pm_ctx *ctx)
 {
     HostPipe *hp = ctx->pipe;
     if (hp) {
-        {
-            std::unique_lock<std::mutex> lk(hp->rmu);
-            hp->cv_slot.wait(lk, [&] { return hp->pieces_out == 0; });
-            hp->rerror = hipSuccess;
-        }
+        hp->drain();
         if (hp->s_in) (void)hipStreamSynchronize(hp->s_in);
         if (hp->s_out) (void)hipStreamSynchronize(hp->s_out);
     }
@@ -712,13 +324,8 @@ int d2h_finish(pm_ctx *ctx, hipStream_t stream)
 {
     HostPipe *hp = ctx->pipe;
     if (hp) {
-        std::unique_lock<std::mutex> lk(hp->rmu);
-        hp->cv_slot.wait(lk, [&] { return hp->pieces_out == 0; });
-        if (hp->rerror != hipSuccess) {
-            const hipError_t e = hp->rerror;
-            hp->rerror = hipSuccess;
-            return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString(e));
-        }
+        const int e = hp->finish();
+        if (e != 0) return fail(ctx, PM_ERR_HIP, "D2H staging failed: %s", hipGetErrorString((hipError_t)e));
     }
     PM_HIP(ctx, hipStreamSynchronize(stream));
     return PM_OK;

@@ -853,7 +853,12 @@ def headline(args) -> None:
     if not args.no_extras:
         if d.world == 1 and d.rank == 0:
             line['host_path'] = host_path_section(eng, g, sz)
-        sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50)
+        # (its own failure must not cost the headline line: the section's code path at N > 1 - pipelined NCCL
+        #  all-gathers from inside the engine's chunk callback - has only ever run under gloo and at N = 1)
+        try:
+            sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50)
+        except Exception as e:  # noqa: BLE001
+            sec = {'error': f'{type(e).__name__}: {e}'[:500]}
         if d.rank == 0:
             line['cube_host'] = sec
     if d.rank == 0:

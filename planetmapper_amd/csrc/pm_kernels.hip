@@ -476,10 +476,17 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // lanes must see exactly the reference's epochs. For the lanes that take the step the epoch
             // error it leaves moves the target by ~E'^3 of the ray's margin to the limb: < 1e-5.
             const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
-            const double ep = fma(-dot(P, vbs), inv_root, dot(vbs, X)) * ixx * kp->inv_c;
+            const double pv = dot(P, vbs);
+            const double ep = fma(-pv, inv_root, dot(vbs, X)) * ixx * kp->inv_c;
             const double d0 = (kp->g.et - lt) - kp->t0;
             const double stepped = fma(ep * d0, 1.0 - ep, lt);
-            lt = fabs(ep) < 0.02 ? stepped : lt;
+            // ... and the step must not jump over a pass of the reference's sequence at which the ray MISSES:
+            // its second pass sits at t0 + d0, the farthest of all from the fixed point (the later ones lie
+            // between the two), and the squared half chord there is root^2 + 2 (P.VBs) d0 / X.X to first order
+            // (the target moves 3 km across the ray in the 0.24 s of a Jupiter radius). A near observer brought
+            // it up (fuzz seed 900030: 19 radii away, emission 89.992 deg at the fixed point, a miss at pass 2).
+            const double r2_pass2 = fma((pv + pv) * d0, ixx, root * root);
+            lt = (fabs(ep) < 0.02 && r2_pass2 > 1e-9 * ixx) ? stepped : lt;
         }
         // (a wave of the pre-mask annulus - candidates, but every ray misses - is done after that one
         //  evaluation: nothing is left to converge)

@@ -91,7 +91,9 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
             * np.abs(np.sin(np.deg2rad(ref['EMISSION'])))
             * np.abs(np.sin(np.deg2rad(ref['INCIDENCE'])))
         )
-        tol['AZIMUTH'] = np.minimum(1e-6, 5.0 * BASE_DEG * kappa / np.clip(s, 1e-9, None))
+        # (capped at 1e-5: next to its singularities - sin az of 1e-5, a point a pixel from the sub-solar or the
+        #  sub-observer point - the quotient loses what the cap would ask for in any evaluation; soak seeds 5017, 5023)
+        tol['AZIMUTH'] = np.minimum(1e-5, 5.0 * BASE_DEG * kappa / np.clip(s, 1e-9, None))
     else:
         tol['AZIMUTH'] = 1e-6
     tol['LOCAL-SOLAR-TIME'] = 0.0
@@ -103,7 +105,12 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
     # nearest limb point: ill-defined for rays through the body centre; conditioning is
     # r_eq / (distance of the ray from the centre)
     if 'LIMB-DISTANCE' in ref:
-        rho = np.clip(ref['LIMB-DISTANCE'] + r_polar, 1.0, None)
+        # distance of the ray from the body centre: the km planes say it exactly; LIMB-DISTANCE + r_polar is a lower
+        # bound that is useless within r_eq - r_polar of the centre (soak seed 5016: the pixel AT the centre)
+        if 'KM-X' in ref and 'KM-Y' in ref:
+            rho = np.clip(np.hypot(ref['KM-X'], ref['KM-Y']), 1e-3, None)
+        else:
+            rho = np.clip(ref['LIMB-DISTANCE'] + r_polar, 1.0, None)
         k = np.maximum(1.0, r_eq / rho)
         llat = ref.get('LIMB-LAT-GRAPHIC', np.zeros_like(rho))
         cl = np.clip(np.cos(np.deg2rad(llat)), 1e-7, None)
@@ -121,25 +128,46 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
     dist = float(np.linalg.norm(t0))
     sin_b = max(abs(float(np.dot(np.array(g.ring_n[:]), t0))) / dist, 1e-6)
     ring_pos = max(2e-5, 10 * 1.11e-16 * dist / sin_b)
+    # towards the ring plane's horizon the intercept distance s = k / (n.u) is conditioned by 1 / (n.u) = s / k: two
+    # ulps of n.u move it by 4e-16 s^2 / k - 3 km at 2.5e10 km for a plane 6e4 km from the observer (soak seeds
+    # 5009, 5012) - and over that light time PM's transform (body.py:972-1006) spins the body by wdot dt
+    k_plane = max(abs(g.ring_k), 1e-3)
+    far = 0.0
+    if 'RING-DISTANCE' in ref:
+        far = 6e-16 * np.nan_to_num(ref['RING-DISTANCE'], nan=0.0) ** 2 / k_plane
     if 'RING-RADIUS' in ref:
         rad = np.abs(ref['RING-RADIUS'])
-        # (relative part: a ray nearly parallel to the plane meets it 1e9 km away with n.u ~ 1e-5: 1e-16 / 1e-5)
-        tol['RING-RADIUS'] = ring_pos + 3e-11 * rad
-        # a ray near the ring plane's horizon meets it 1e10 km away: the 3e-11 of that distance is seconds of
-        # light time, over which PM's transform (body.py:972-1006) spins the body by wdot dt (seed 3276483807 of
-        # the fuzz test: at 1.8e10 km the binary64 ORACLE is 0.37 km and 1.3e-8 deg from the binary128 truth)
+        tol['RING-RADIUS'] = ring_pos + 3e-11 * rad + far
         tol['RING-LON-GRAPHIC'] = (BASE_DEG + np.rad2deg(ring_pos / np.clip(rad, 1.0, None))
-                                   + np.rad2deg(abs(g.wdot) * 3e-11 * rad / g.clight))
+                                   + np.rad2deg(abs(g.wdot) * (3e-11 * rad + far) / g.clight))
     else:
         tol['RING-RADIUS'] = 1e-3
         tol['RING-LON-GRAPHIC'] = 1e-7
     if 'RING-DISTANCE' in ref:
         rd = ref['RING-DISTANCE']
         rd_min = np.nanmin(rd) if np.isfinite(rd).any() else 0.0
-        tol['RING-DISTANCE'] = 10 * ring_pos + 3e-11 * np.abs(rd - rd_min)
+        tol['RING-DISTANCE'] = 10 * ring_pos + 3e-11 * np.abs(rd - rd_min) + far
     else:
         tol['RING-DISTANCE'] = 1e-3
     return tol
+
+
+def masks_agree(name: str, a, b) -> bool:
+    """
+    NaN masks of a plane: identical - except AZIMUTH at the singularities of the reference's own formula
+    (body.py:2319-2332: pi - arccos(q) with |q| = 1 where the point, the Sun and the observer lie in one plane with
+    the normal): there q = +-(1 + a few 1e-16) decides between 0 / 180 deg and NaN by rounding, in the reference too.
+    A mismatch is accepted only on pixels whose finite value is within 1e-3 deg of 0 or 180, at most a handful.
+    """
+    na, nb = np.isnan(a), np.isnan(b)
+    if np.array_equal(na, nb):
+        return True
+    if name != 'AZIMUTH':
+        return False
+    diff = na != nb
+    val = np.where(na, b, a)[diff]
+    near = np.minimum(np.abs(val), np.abs(180.0 - val)) < 1e-3
+    return bool(near.all()) and int(diff.sum()) <= max(2, int(1e-5 * a.size))
 
 
 def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate_scale_arcsec=None) -> dict:
@@ -153,8 +181,8 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
     for n in names:
         a, b = out[n], ref[n]
         assert a.shape == b.shape, n
-        assert np.array_equal(np.isnan(a), np.isnan(b)), f'{n}: NaN mask differs'
-        fin = np.isfinite(b)
+        assert masks_agree(n, a, b), f'{n}: NaN mask differs'
+        fin = np.isfinite(b) & np.isfinite(a)
         if not fin.any():
             stats[n] = (0.0, 1.0)
             continue

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""
+The fresh-seed legs of the three GPU fuzz tests (tests/test_gpu_parity.py) over many seeds in ONE process:
+`python tests/soak_fuzz.py --seeds 60 [--first 1]`. Not collected by pytest. Prints one JSON line per failure
+(test, seed, message) and a summary; a failing seed is replayed with `PM_FUZZ_SEED=<seed> pytest -m gpu -k fuzz`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import traceback
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [os.path.dirname(HERE), HERE]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--seeds', type=int, default=40)
+    ap.add_argument('--first', type=int, default=int(time.time()) % 100000 * 1000)
+    args = ap.parse_args()
+    import test_gpu_parity as T
+    from oracle import oracle
+    from planetmapper_amd import _lib
+    from planetmapper_amd.engine import Engine
+    from planetmapper_amd.scenarios import load_scenario
+
+    jupiter, saturn = load_scenario('jupiter_hst_2005'), load_scenario('saturn_earth_2005')
+    eng = Engine(0)
+    failures = []
+    t0 = time.time()
+    for k in range(args.seeds):
+        seed = args.first + k
+        os.environ['PM_FUZZ_SEED'] = str(seed)
+        cases = [('discs_fast', lambda: T.test_random_discs_and_frames_fuzz.__wrapped__(eng, oracle, jupiter, saturn, 'fresh_seed')
+                  if hasattr(T.test_random_discs_and_frames_fuzz, '__wrapped__') else T.test_random_discs_and_frames_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed')),
+                 ('reprojection', lambda: T.test_random_reprojection_fuzz(eng, oracle, jupiter, 'fresh_seed')),
+                 ('geometries', lambda: T.test_random_geometries_fuzz(eng, oracle, 'fresh_seed'))]  # fmt: skip
+        for general in (0, 1):
+            eng.set_option(_lib.PM_OPT_GENERAL_KERNEL, general)
+            for name, fn in (cases if general == 0 else cases[:1]):
+                try:
+                    fn()
+                except Exception as e:  # noqa: BLE001
+                    failures.append({'test': name, 'general': general, 'seed': seed, 'error': str(e)[:400],
+                                     'where': traceback.format_exc().strip().splitlines()[-3][:200]})
+                    print(json.dumps(failures[-1]), flush=True)
+        if k % 10 == 9:
+            print(json.dumps({'done': k + 1, 'failures': len(failures), 'seconds': round(time.time() - t0, 1)}), flush=True)
+    eng.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
+    eng.close()
+    print(json.dumps({'seeds': args.seeds, 'first': args.first, 'failures': len(failures), 'seconds': round(time.time() - t0, 1)}), flush=True)
+    return 1 if failures else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -463,13 +463,17 @@ int pm_mapped_data(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const
  * world * per_rank * n0 * n1 doubles, block r at out_all + r * per_rank * n0 * n1 (planes beyond P
  * are NaN padding). With gather != 0 the block is cut into exchanges of
  * pm_exchange_planes(per_rank, n0, n1) planes (a function of shapes only: every rank issues the same
- * sequence): each exchange is mapped, finished (flag check / nanmedian replay) and then sent to / received
- * from every peer on the communicator's own stream (ncclSend / ncclRecv in one group: an all-gather
- * whose pieces land rank-major), so exchange k crosses xGMI while exchange k + 1 is collected, copied
- * and mapped. A rank whose mapping fails still takes part in every exchange, and a closing 4-byte
- * all-reduce of the ranks' status codes makes every rank return an error if any rank had one (its own
- * code, PM_ERR_PEER for a failure elsewhere): no rank is left waiting in a collective and the gathered
- * cube is valid everywhere or nowhere. The call returns when out_all is complete on this rank.
+ * sequence). ONE pm_map_cube maps the block - its own pipeline stays whole - and each time the kernels of
+ * further planes are on the context stream (pm_set_chunk_callback) the exchanges they complete are started
+ * on the communicator's own stream (ncclSend / ncclRecv with every peer in one group: an all-gather whose
+ * pieces land rank-major), so exchange k crosses xGMI while later planes are still being collected and
+ * copied in. After the mapping has finished (flag check / nanmedian replay) whatever was not started - a
+ * rank without planes, a rank whose mapping failed - is started all the same, and one 8-byte all-reduce
+ * closes the call: (ranks that failed, ranks that redid planes after sending them). Any failure: every
+ * rank returns an error (its own code, PM_ERR_PEER for a failure elsewhere) - no rank is left waiting in a
+ * collective, the gathered cube is valid everywhere or nowhere. Any redo (rare: +-inf pixels): every rank
+ * sends its block once more. A failing RCCL call aborts the communicator. The call returns when out_all is
+ * complete on this rank.
  * With gather == 0, or comm == NULL (single process), only this rank's block is written - no
  * collective (each rank keeps / writes its slice). mem = PM_MEM_HOST (gather == 0 only):
  * everything is host memory and out_all is the caller's whole (P, n0, n1) array, e.g. ONE array in

@@ -1906,3 +1906,73 @@ def test_all_planes_from_one_launch_equal_the_launch_per_group(engine, oracle, j
     finally:
         engine.set_option(_lib.PM_OPT_FUSE_PLANES, 0)
         engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, was_general)
+
+
+def test_cache_invalidation_matrix_through_the_real_engine(engine, jupiter):
+    """
+    The reference's cache contract (tests/test_body_xy.py:2495-2590) on the HIP engine: for five kinds of
+    change (disc parameters, image size, an altitude, and both with an altitude) x all 26 backplanes x
+    image / map space, a body that had its cache filled, was changed and changed back must give what a
+    clean body with the same parameters gives - and, back at the start, exactly what it gave before.
+    """
+    from planetmapper_amd import BodyXY
+
+    def make_body():
+        body = BodyXY('Jupiter', geometry=jupiter, nx=6, ny=5, engine=engine)
+        body.set_disc_params(2.5, 2, 2, 45)
+        return body
+
+    changes = {
+        'set_disc_params': (lambda b: b.set_disc_params(3, 1.5, 2.5, 42), lambda b: b.set_disc_params(5, 3, 2, 123), 0.0),
+        'set_img_size': (lambda b: b.set_img_size(6, 2), lambda b: b.set_img_size(3, 4), 0.0),
+        'alt': (lambda b: None, lambda b: None, 123.456),
+        'set_disc_params+alt': (lambda b: b.set_disc_params(3, 1.5, 2.5, 42), lambda b: b.set_disc_params(5, 3, 2, 123), 123.456),
+        'set_img_size+alt': (lambda b: b.set_img_size(6, 2), lambda b: b.set_img_size(3, 4), 123.456),
+    }  # fmt: skip
+    names = list(make_body().backplanes.keys())
+    assert len(names) == 26
+    n_checked = 0
+    for change_name, (reset, change, alt) in changes.items():
+        for space in ('img', 'map'):
+            def get(b, name, a):
+                return b.get_backplane_img(name, alt=a) if space == 'img' else b.get_backplane_map(name, alt=a, degree_interval=45)
+
+            # one body per (change, space) walks all planes: its cache holds every plane family at each step
+            body = make_body()
+            reset(body)
+            before = {n: get(body, n, 0.0) for n in names}
+            clean = make_body()
+            change(body)
+            change(clean)
+            for n in names:
+                assert np.allclose(get(body, n, alt), get(clean, n, alt), rtol=1e-5, atol=1e-8, equal_nan=True), (change_name, space, n)
+            clean = make_body()
+            reset(body)
+            reset(clean)
+            for n in names:
+                back = get(body, n, 0.0)
+                assert np.allclose(back, get(clean, n, 0.0), rtol=1e-5, atol=1e-8, equal_nan=True), (change_name, space, n)
+                assert np.array_equal(back, before[n], equal_nan=True), (change_name, space, n)
+                n_checked += 1
+    assert n_checked == 5 * 2 * 26
+
+
+def test_mapping_visible_areas_through_the_real_engine(engine, oracle):
+    """
+    tests/test_body_xy.py:2592-2607 restated: a map cell is mapped exactly where it is visible - RA and the
+    mapped image finite where the emission angle is <= 90 deg, NaN beyond. Near observer (4 radii) so that
+    the horizon cuts across the map well away from the 90 deg meridians.
+    """
+    from planetmapper_amd import BodyXY
+    from test_motion_model import load
+
+    _, g = load('jupiter_near_field')
+    body = BodyXY('Jupiter', geometry=g, sz=10, engine=engine)
+    body.set_disc_params(5, 5, 3, 0)
+    emission = body.get_backplane_map('EMISSION', degree_interval=15)
+    ra = body.get_backplane_map('RA', degree_interval=15)
+    img = body.map_img(np.ones((10, 10)), degree_interval=15)
+    assert (emission <= 90).sum() > 20 and (emission > 90).sum() > 100
+    assert np.isfinite(ra[emission <= 90]).all() and not np.isfinite(ra[emission > 90]).any()
+    # (map_img needs the cell's pixel inside the frame as well: the disc, r0 = 3 in a 10 x 10 frame, is)
+    assert np.isfinite(img[emission <= 90]).all() and not np.isfinite(img[emission > 90]).any()

@@ -126,12 +126,12 @@ def tolerances(ref: dict, g, plate_scale_arcsec: float | None = None) -> dict:
         tol['LIMB-LAT-GRAPHIC'] = tol['LIMB-LON-GRAPHIC'] = 1e-6
     # ring plane: intercept distance s = k / (n.u); 1 ulp of n.u moves the intercept by
     # ~2e-6 km for Jupiter's 3 deg opening, more towards the plane horizon
-    # (in general: 10 half-ulps of the unit ray x distance / sin(ring opening angle), never below
+    # (in general: 15 half-ulps of the unit ray x distance / sin(ring opening angle), never below
     #  the 2e-5 km calibrated on the Jupiter / HST geometry)
     t0 = np.array(g.T0[:])
     dist = float(np.linalg.norm(t0))
     sin_b = max(abs(float(np.dot(np.array(g.ring_n[:]), t0))) / dist, 1e-6)
-    ring_pos = max(2e-5, 10 * 1.11e-16 * dist / sin_b)
+    ring_pos = max(2e-5, 15 * 1.11e-16 * dist / sin_b)  # (10 until fuzz seed 2500067: 1.16 x at 17 au, opening 1 deg)
     # towards the ring plane's horizon the intercept distance s = k / (n.u) is conditioned by 1 / (n.u) = s / k: two
     # ulps of n.u move it by 4e-16 s^2 / k - 3 km at 2.5e10 km for a plane 6e4 km from the observer (soak seeds
     # 5009, 5012) - and over that light time PM's transform (body.py:972-1006) spins the body by wdot dt

@@ -310,6 +310,57 @@ class ExactBody:
         return out
 
 
+    # -- the map direction (body_xy.py:3227-3300, 3419-3491, 3667-3675)
+    def pgrrec(self, lon_deg: float, lat_deg: float) -> np.ndarray:
+        """pgrrec_c on the surface (body.py:903-910)"""
+        lon, lat = math.radians(lon_deg), math.radians(lat_deg)
+        lam = -lon if self.west else lon
+        e2 = self.f * (2.0 - self.f)
+        n = self.a / math.sqrt(1.0 - e2 * math.sin(lat) ** 2)
+        return np.array([n * math.cos(lat) * math.cos(lam), n * math.cos(lat) * math.sin(lam), n * (1.0 - self.f) ** 2 * math.sin(lat)])
+
+    def map_cells(self, lon_deg, lat_deg, x0: float, y0: float, r0: float, rotation_rad: float, nx: int, ny: int) -> dict[str, np.ndarray]:
+        """
+        For each (lon, lat): the map-space planes EMISSION / INCIDENCE / PHASE (defined everywhere), RA / DEC and
+        the pixel coordinates PIXEL-X / PIXEL-Y (NaN where not visible / outside the frame): pgrrec -> illumf
+        (kernel data re-evaluated per epoch) -> PM's _targvec2obsvec (pxfrm2 evaluated directly) -> recrad ->
+        degrees -> radrec -> _obsvec2angular -> inverse affine -> in-frame test.
+        """
+        lon_deg, lat_deg = np.asarray(lon_deg, dtype=float), np.asarray(lat_deg, dtype=float)
+        shape = lon_deg.shape
+        names = ['PHASE', 'INCIDENCE', 'EMISSION', 'RA', 'DEC', 'PIXEL-X', 'PIXEL-Y']
+        out = {n: np.full(lon_deg.size, np.nan) for n in names}
+        s = self.g.diameter_arcsec / (2.0 * r0)
+        th = -rotation_rad
+        c, sn = math.cos(th), math.sin(th)
+        a2 = np.array([[s * c, s * sn], [-s * sn, s * c]])
+        a2i = np.linalg.inv(a2)
+        off = a2 @ np.array([x0, y0])
+        for i, (lo, la) in enumerate(zip(lon_deg.ravel(), lat_deg.ravel())):
+            if not (math.isfinite(lo) and math.isfinite(la)):
+                continue
+            tv = self.pgrrec(lo % 360.0, la)
+            ph, inc, emi, _ = self.illum(tv)
+            out['PHASE'][i], out['INCIDENCE'][i], out['EMISSION'][i] = ph, inc, emi
+            if not emi < 90.0:
+                continue
+            ov = self.targvec2obsvec(tv)
+            _, ra, dec = recrad(ov)
+            ra_d, dec_d = math.degrees(ra), math.degrees(dec)
+            out['RA'][i], out['DEC'][i] = ra_d, dec_d
+            ra, dec = math.radians(ra_d), math.radians(dec_d)
+            u = np.array([math.cos(dec) * math.cos(ra), math.cos(dec) * math.sin(ra), math.sin(dec)])
+            _, wr, wd = recrad(self.M @ u)
+            ax = (-math.degrees(wr)) % 360.0
+            if ax > 180.0:
+                ax -= 360.0
+            ax, ay = ax * 3600.0, math.degrees(wd) * 3600.0
+            x, y = a2i @ (np.array([ax, ay]) + off)
+            if -0.5 < x < nx - 0.5 and -0.5 < y < ny - 0.5:
+                out['PIXEL-X'][i], out['PIXEL-Y'][i] = x, y
+        return {n: v.reshape(shape) for n, v in out.items()}
+
+
 def from_scenario(d: dict, g: PMGeometry) -> ExactBody:
     """`d`: a scenario / motion fixture (planetmapper_amd/data/*.json, tests/golden/motion_*.json)"""
     return ExactBody(Ephemeris.from_json(d['ephemeris']), RotationModel.from_json(d['pck']), d['target_id'], g,

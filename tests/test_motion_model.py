@@ -234,3 +234,67 @@ def test_hip_against_the_exact_ephemeris_mode(name):
         rep = _compare_with_exact(planes, exact, px, g, f'{name} general={general}', slack=2.0)
         assert rep['PHASE']['max'] < 1e-11 or name == 'jupiter_near_field', rep['PHASE']
         assert rep['LAT-GRAPHIC']['inside_flat_bar'] > 0.97 and rep['EMISSION']['inside_flat_bar'] > 0.95, rep
+
+
+def _compare_map_with_exact(planes: dict, exact: dict, g, r0: float, label: str, slack: float = 1.0) -> None:
+    """map-space planes against the exact-ephemeris values: a map cell is a FIXED surface point (no ray meets the
+    surface at a grazing angle), so the bars are flat"""
+    from parity import base_deg
+
+    bar = base_deg(g)
+    ps = g.diameter_arcsec / (2.0 * r0)
+    near = g.radii[0] / (g.lt_c * g.clight)  # a near observer sees the direction to itself change across the body
+    # the exact mode evaluates W (1.6e6 ... 4.9e6 deg) afresh at every cell's epoch: each carries its own rounding,
+    # one ulp of W = 2.3e-10 ... 9.3e-10 deg of body orientation (the block model rounds W once, at t0)
+    w_ulp = float(np.spacing(abs(g.wdot) * abs(g.et) * 57.29577951308232 + 1e5))
+    px = max(4e-9, 32 * 2.05e-10 / ps) * (1.0 + 50.0 * near)
+    tol = {'PHASE': 1e-11 + bar * near, 'INCIDENCE': bar + 2 * w_ulp, 'EMISSION': bar * (1.0 + 10.0 * near) + 2 * w_ulp,
+           'RA': bar * (1.0 + 50.0 * near), 'DEC': bar * (1.0 + 50.0 * near), 'PIXEL-X': px, 'PIXEL-Y': px}  # fmt: skip
+    for n, e in exact.items():
+        v = planes[n]
+        assert np.array_equal(np.isnan(v), np.isnan(e)), (label, n, int((np.isnan(v) != np.isnan(e)).sum()))
+        if np.isfinite(e).any():
+            d = np.abs(v - e)
+            if n == 'RA':
+                d = np.minimum(d, 360.0 - d)
+            assert np.nanmax(d) <= slack * tol[n], (label, n, float(np.nanmax(d)), tol[n])
+
+
+@pytest.mark.parametrize('name', SCENARIOS)
+def test_c_oracle_map_chain_against_the_exact_ephemeris_mode(name):
+    """the map direction (pgrrec -> illumf -> PM's targvec2obsvec -> RA / Dec -> pixel) of the block-model oracle vs
+    per-epoch kernel evaluation on a 6 deg grid: visibility and in-frame masks identical, values inside flat bars"""
+    from oracle import exact_ephemeris as xe
+    from oracle import oracle
+
+    d, g = load(name)
+    sz, x0, r0, rot_deg, _ = _frame(name, g)
+    lon, lat = oracle.rectangular_grid(g, 6.0)
+    exact = xe.from_scenario(d, g).map_cells(lon, lat, x0, x0, r0, float(np.deg2rad(rot_deg)), sz, sz)
+    assert np.isfinite(exact['PIXEL-X']).sum() > 300 and np.isnan(exact['RA']).sum() > 300
+    planes = oracle.backplanes_map(g, oracle.make_disc(x0, x0, r0, rot_deg, sz, sz), list(exact), lon, lat)
+    _compare_map_with_exact(planes, exact, g, r0, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['saturn_earth_2005', 'mars_earth_2012', 'jupiter_earth_1998', 'jupiter_near_field'])
+def test_hip_map_chain_against_the_exact_ephemeris_mode(name):
+    """`k_map` (all planes) and `k_map_xy` (the x/y map of a reprojection) against per-epoch kernel evaluation"""
+    from oracle import exact_ephemeris as xe
+    from oracle import oracle
+    from planetmapper_amd.engine import Engine
+
+    d, g = load(name)
+    sz, x0, r0, rot_deg, _ = _frame(name, g)
+    lon, lat = oracle.rectangular_grid(g, 6.0)
+    exact = xe.from_scenario(d, g).map_cells(lon, lat, x0, x0, r0, float(np.deg2rad(rot_deg)), sz, sz)
+    eng = Engine(0)
+    try:
+        eng.set_geometry(g)
+        eng.set_disc(x0, x0, r0, float(np.deg2rad(rot_deg)), sz, sz, True)
+        planes = eng.backplanes_map(list(exact), lon, lat)
+        xm, ym = eng.xy_map(lon, lat)
+    finally:
+        eng.close()
+    _compare_map_with_exact(planes, exact, g, r0, name, slack=2.0)
+    _compare_map_with_exact({'PIXEL-X': xm, 'PIXEL-Y': ym}, {k: exact[k] for k in ('PIXEL-X', 'PIXEL-Y')}, g, r0, name + ' k_map_xy', slack=2.0)

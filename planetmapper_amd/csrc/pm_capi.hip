@@ -239,6 +239,32 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         const double vt = std::sqrt(g.VT[0] * g.VT[0] + g.VT[1] * g.VT[1] + g.VT[2] * g.VT[2]);
         const double rmin_ = std::fmin(p.radii[0], std::fmin(p.radii[1], p.radii[2]));
         p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_) ? 1 : 0;
+        if (ctx->lt_mode == 1 || (ctx->lt_mode == 2 && !p.plain_lt)) p.plain_lt = ctx->lt_mode;
+    }
+    {
+        // closed-form light time (Params::Y00 ...): in long double, rounded once
+        p.lt_c_eff = g.et - p.t0;
+        long double v2 = 0.0L;
+        for (int i = 0; i < 3; i++) {
+            const long double v = (long double)p.VB[i] / (long double)p.radii[i];
+            // (O0 = -R0 T0 carries the rounding of its own dot products, 1e-16 relative: taken again here)
+            const long double o0 = -((long double)g.R0[3 * i] * g.T0[0] + (long double)g.R0[3 * i + 1] * g.T0[1] +
+                                     (long double)g.R0[3 * i + 2] * g.T0[2]);
+            const long double vb = (long double)g.R0[3 * i] * g.VT[0] + (long double)g.R0[3 * i + 1] * g.VT[1] +
+                                   (long double)g.R0[3 * i + 2] * g.VT[2];
+            const long double y = o0 / (long double)p.radii[i] - vb / (long double)p.radii[i] * (long double)p.lt_c_eff;
+            p.Y00[i] = (double)y;
+            p.Y00lo[i] = (double)(y - (long double)p.Y00[i]);
+            p.Wc[i] = (double)(v / (long double)g.clight);
+            v2 += v * v;
+        }
+        // |d| <= R / c between the first pass and the fixed point (observer outside the body); P.P moves by
+        // 2 |P| |VBs| |d| + (|VBs| d)^2 over that, |P| <= 1 in the band that matters
+        const double rmax_ = std::fmax(p.radii[0], std::fmax(p.radii[1], p.radii[2]));
+        const double dv = std::sqrt((double)v2) * 1.05 * rmax_ / g.clight;
+        const double band = 1.5 * (2.0 * dv + dv * dv) + 1e-10;
+        p.p2_lo = 1.0 - band;
+        p.p2_hi = 1.0 + band;
     }
     for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
     {
@@ -344,6 +370,7 @@ pm_ctx *pm_create(int device, int *status)
     const char *fg = std::getenv("PM_FORCE_GENERAL");
     ctx->force_general = fg && fg[0] == '1';
     if (const char *fp = std::getenv("PM_FUSE_PLANES")) ctx->fuse_planes = fp[0] != '0';  // (A/B runs of tools / bench)
+    if (const char *m = std::getenv("PM_LT_MODE")) ctx->lt_mode = (m[0] == '1') ? 1 : (m[0] == '2') ? 2 : 0;
     set(PM_OK);
     return ctx;
 }

@@ -130,7 +130,15 @@ struct Params {
     // Where that jump is visible on the body (Mars seen from Earth in 2012: 2.4e-8 deg per quantum) only the
     // reference's own iterates reproduce its choice of quantum; where it is not (Jupiter 2005: 3e-10 deg),
     // the shorter sequence is taken. Host: pm_capi.hip fill_params.
+    // (2, tools/ only: the Newton step on the seed without the closed form in front of it)
     int32_t plain_lt;
+    // Closed-form light time of the spheroid fast path (k_disc_sph): the observer in the scaled frame when the
+    // target is taken at the epoch the light left it, Y = Y00 + s Wc for an intercept s km down the ray.
+    double Y00[3];    // O0s - VBs (et - t0)
+    double Y00lo[3];  // ... and what its rounding to binary64 dropped
+    double Wc[3];     // VBs / c
+    double lt_c_eff;  // et - t0 (exact: t0 = fl(et - lt_c) is within a factor 2 of et)
+    double p2_lo, p2_hi;  // 1 -+ the change of the squared impact parameter P.P over the light-time span of a disc (with margin)
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

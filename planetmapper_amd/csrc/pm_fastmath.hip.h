@@ -64,6 +64,17 @@ __device__ __forceinline__ double sqrt_pos(double x)
     h = fma(h, r, h);
     return fma(fma(-g, g, x), h, g);
 }
+// sqrt_pos that also hands out h = 1 / (2 sqrt(x)) to 2^-45 relative (it is computed anyway)
+__device__ __forceinline__ double sqrt_pos_h(double x, double &h)
+{
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    return fma(fma(-g, g, x), h, g);
+}
 // sqrt(x), x >= 1e-300, to 2^-45 relative (sqrt_pos without its closing residual step)
 __device__ __forceinline__ double sqrt_seed_pos(double x)
 {

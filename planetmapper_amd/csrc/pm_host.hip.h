@@ -105,6 +105,8 @@ struct pm_ctx {
     int sparse_frame = -1;       // PM_OPT_SPARSE_FRAME
     int table_cache = 1;         // PM_OPT_BLOCK_TABLE_CACHE
     int fuse_planes = 0;         // PM_OPT_FUSE_PLANES
+    int lt_mode = 0;             // env PM_LT_MODE at pm_create (A/B runs of tools/): 0 closed-form light time of the
+                                 // spheroid kernel, 1 the reference's sequence of epochs, 2 Newton step on its seed
     int route_explore = 1;       // PM_OPT_ROUTE_EXPLORE
     int last_cube_route = -1;    // PM_OPT_LAST_CUBE_ROUTE
     int last_redo_planes = 0;    // PM_OPT_LAST_REDO_PLANES: planes of the latest finished pm_map_cube redone with their nanmedian

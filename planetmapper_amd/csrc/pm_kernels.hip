@@ -396,18 +396,77 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             (const __attribute__((address_space(4))) Params *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
 
-        // surfpt_c in scaled coordinates; for a spheroid X and 1/(X.X) are fixed for the pixel
-        V3 X = {u.x * kp->ir[0], u.y * kp->ir[1], u.z * kp->ir[2]};
-        double ixx = rcp_fast(dot(X, X));
-        double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
-
-        // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
-        // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
-        double lt = kp->g.lt_c, d = 0.0, k = 0.0, root = 0.0, inv_root = 0.0;
-        V3 P = {0.0, 0.0, 0.0};
+        V3 Xf = {0.0, 0.0, 0.0};  // the intercept in scaled coordinates (unit sphere)
+        double lt = kp->g.lt_c, d = 0.0;
         // lanes still holding an intercept, as a wave-uniform mask in scalar registers (a
         // per-lane bool carried around the loop costs four VALU operations per evaluation)
         unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(cand);
+        bool solved = false;  // wave-uniform: the closed form below has settled every lane of this wave
+        if (!TRI && kp->plain_lt == 0) {  // (kernel-argument flag: a scalar branch)
+            // sincpt_c 'CN' for a target in linear motion, in closed form. The converged light time is the fixed
+            // point lt = E((et - lt) - t0) of the iteration further down: the target is taken at the epoch offset
+            // d = (et - t0) - s / c when the ray meets it s km from the observer, so in the scaled frame of
+            // surfpt_c the observer sits at Y(d) = O0s - VBs d = Y00 + s W (Y00 = O0s - VBs (et - t0), W = VBs / c)
+            // and the point of the ray at s is Y00 + s (X + W): ONE intercept, with the ray direction bent by the
+            // target's velocity, instead of a sequence of them. The rejection form (k, P, root) is kept - the
+            // quadratic's discriminant would cancel eight digits at D / R ~ 1e4.
+            const V3 Xp = {fma(u.x, kp->ir[0], kp->Wc[0]), fma(u.y, kp->ir[1], kp->Wc[1]), fma(u.z, kp->ir[2], kp->Wc[2])};
+            const double ixp = rcp_fast(dot(Xp, Xp));
+            const V3 y00 = {kp->Y00[0], kp->Y00[1], kp->Y00[2]};
+            const double yx = dot(y00, Xp);
+            const double kq = yx * ixp;
+            // (Y00 ~ D / R ~ 1e4 radii is rounded at 1e-12: its low part goes in where the magnitude has dropped to 1)
+            const V3 Pq = {fma(-kq, Xp.x, y00.x) + kp->Y00lo[0], fma(-kq, Xp.y, y00.y) + kp->Y00lo[1],
+                           fma(-kq, Xp.z, y00.z) + kp->Y00lo[2]};
+            const double p2 = dot(Pq, Pq);
+            // The reference decides hit or miss at EVERY pass of its own sequence of epochs (CSPICE sincpt: no
+            // intercept in any pass -> not found); between the first pass (target at t0) and the fixed point the
+            // target moves |VBs| |d| <= |VBs| R / c across the ray, which changes P.P by less than 1 - p2_lo = p2_hi - 1 (host).
+            // A lane clear of 1 by that band hits in every pass, or misses in the first; a wave with a lane
+            // inside the band (the limb runs through it) walks the reference's sequence instead.
+            const unsigned long long hits =
+                hit_mask & __builtin_amdgcn_ballot_w64(p2 < kp->p2_lo) & __builtin_amdgcn_ballot_w64(yx < 0.0);
+            const unsigned long long misses = ~hit_mask | __builtin_amdgcn_ballot_w64(p2 > kp->p2_hi);
+            if ((hits | misses) == ~0ull) {
+                solved = true;
+                hit_mask = hits;
+                // (a wave of the pre-mask annulus - candidates, but every ray misses - is done here)
+                if (hits != 0) {
+                    // (clamped away from 0 for the reciprocal square root: lanes that miss carry garbage)
+                    const double r2 = fmax((1.0 - p2) * ixp, 1e-300);
+                    double half_inv_root;
+                    const double root = sqrt_pos_h(r2, half_inv_root);
+                    const double s = -kq - root;
+                    const double lts = s * kp->inv_c;
+                    // The reference evaluates its final state at the epoch et - lt ROUNDED to a double (one
+                    // quantum: 3e-8 s at et = 1.6e8 s, in which Jupiter moves 4e-7 km = 3e-10 deg of
+                    // longitude), the closed form at the unrounded one. The target's linear motion over the
+                    // difference `dq` (< 1 quantum) moves the intercept by dq (s' X - VBs), s' = F.VBs / F.X
+                    // keeping it on the surface and F.X = -root X.X: first order is exact here (dq^2 ~ 1e-16).
+                    // (X' stands in for X and X'.X' for X.X in that term: v / c ~ 1e-4 of 4e-12.)
+                    d = (kp->g.et - lts) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+                    const double dq = d - (kp->lt_c_eff - lts);
+                    const V3 F = {fma(-root, Xp.x, Pq.x), fma(-root, Xp.y, Pq.y), fma(-root, Xp.z, Pq.z)};
+                    const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
+                    const double sp = dot(F, vbs) * (half_inv_root * ixp) * -2.0;
+                    Xf = {fma(dq, fma(sp, Xp.x, -vbs.x), F.x), fma(dq, fma(sp, Xp.y, -vbs.y), F.y),
+                          fma(dq, fma(sp, Xp.z, -vbs.z), F.z)};
+                    lt = fma(dq, sp, s) * kp->inv_c;
+                }
+            }
+        }
+
+        // surfpt_c in scaled coordinates; for a spheroid X and 1/(X.X) are fixed for the pixel
+        V3 X = {u.x * kp->ir[0], u.y * kp->ir[1], u.z * kp->ir[2]};
+        double ixx = 0.0;
+        double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
+        if (!solved) {
+        ixx = rcp_fast(dot(X, X));
+
+        // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
+        // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
+        double k = 0.0, root = 0.0, inv_root = 0.0;
+        V3 P = {0.0, 0.0, 0.0};
         // An FMA takes one scalar operand: with VBs there, O0s has to sit in vector registers.
         // Pinned outside the loop (left alone, hipcc re-copies the three pairs every evaluation).
         double o0x = kp->O0s[0], o0y = kp->O0s[1], o0z = kp->O0s[2];
@@ -459,7 +518,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
         // converged light time changes nothing. No test, no select after it.
         lt = evaluate(0.0, true);
-        if (!TRI && !kp->plain_lt) {  // (kernel-argument flag: a scalar branch)
+        if (!TRI && kp->plain_lt != 1) {  // (kernel-argument flag: a scalar branch)
             // One Newton-like step on that seed. The light time is a smooth function E(d) of the epoch
             // offset d, and the fixed point lt = E((et - lt) - t0) is what the iteration below converges
             // to. With the slope E'(0) = [VBs.X - (P.VBs) / root] / (X.X c) (the target's velocity along
@@ -499,6 +558,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // wave-uniform exit once no lane with an intercept is still moving
             if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
         }
+        Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
+        }  // !solved
 
         // From here on EVERY lane of a wave that holds at least one intercept computes: no
         // exec masking and no NaN-initialised result registers (16 v_mov per candidate wave).
@@ -511,7 +572,6 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double miss = hit ? 0.0 : nan;
             // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
             if (FLAGS & (DF_RING | DF_STATE)) dist_lt = fma(lt, kp->g.clight, miss);
-            const V3 Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
             // body-fixed at te for TRI, B0 otherwise (body-fixed = Rz_frame(delta) * B0)
             const V3 sp = {Xf.x * kp->radii[0], Xf.y * kp->radii[1], Xf.z * kp->radii[2]};
             // (for a spheroid x and y share their radius: longitude and latitude follow from the

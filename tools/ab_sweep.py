@@ -17,7 +17,9 @@ dev = torch.device('cuda', 0)
 g = load_scenario(os.environ.get('SCENARIO', 'jupiter_hst_2005'))
 planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
 engines = []
-for path in sys.argv[1:3]:
+for path, envs in zip(sys.argv[1:3], (os.environ.get('AB_ENV_A', ''), os.environ.get('AB_ENV_B', ''))):
+    for kv in filter(None, envs.split(',')):  # e.g. AB_ENV_B=PM_LT_MODE=2 (read by the library at pm_create)
+        os.environ[kv.split('=')[0]] = kv.split('=', 1)[1]
     _lib._lib = None
     _lib.LIB_PATH = os.path.abspath(path)
     e = eng_mod.Engine(0)

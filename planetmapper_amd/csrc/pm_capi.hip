@@ -183,6 +183,32 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
             p.C[3 * i + j] = acc;
         }
     rot(g.T0, p.O0, -1.0);
+    p.optimize_speed = d.optimize_speed;
+    {
+        // A pixel whose line of sight passes the body centre by more than the limb's angular radius misses the body
+        // whatever the reference's pre-mask (a circle of 1.05 r0 + 1 pixels, body_xy.py:3201-3203) lets through: where
+        // that bound is the tighter one it replaces the pre-mask radius - the 5 % annulus (a tenth of a full-disc
+        // frame's candidates) never builds a ray. Conservative by construction: rmax, the target's motion over the
+        // light-time span of the passes, the offset of the angular origin from the centre direction (1e-16 rad for
+        // Body's own matrix, but the block is the caller's), the spherical excess of sqrt(ax^2 + ay^2) over the true
+        // separation (cos sep = cos ax cos ay: < sep^2 / 24 relative) and half a pixel on top.
+        const double D = std::sqrt(g.T0[0] * g.T0[0] + g.T0[1] * g.T0[1] + g.T0[2] * g.T0[2]);
+        const double vt = std::sqrt(g.VT[0] * g.VT[0] + g.VT[1] * g.VT[1] + g.VT[2] * g.VT[2]);
+        const double reach = rmax * (1.0 + 1e-9) + 4.0 * vt * rmax / g.clight + 1e-6;
+        // |M row 0 x T0| / D = sine of the angle between the angular frame's origin and the centre direction
+        const double cx = g.M[1] * g.T0[2] - g.M[2] * g.T0[1], cy = g.M[2] * g.T0[0] - g.M[0] * g.T0[2],
+                     cz = g.M[0] * g.T0[1] - g.M[1] * g.T0[0];
+        const double off = std::sqrt(cx * cx + cy * cy + cz * cz) / D;
+        const double s_rad = std::hypot(p.A[0], p.A[1]) * (3.14159265358979323846 / 648000.0);  // plate scale, rad / pixel
+        if (D > 0.0 && reach / D < 0.09 && off < 0.009 && s_rad > 0.0) {
+            const double theta = std::asin(reach / D) + 1.001 * off;  // (asin(off) < 1.001 off below 0.009)
+            const double rt = theta / s_rad * 1.002 + 0.5;
+            if (!d.optimize_speed || rt * rt < p.r2) {
+                p.r2 = rt * rt;
+                p.optimize_speed = 1;
+            }
+        }
+    }
     rot(g.VT, p.VB, 1.0);
     rot(g.AT, p.AB, 1.0);
     rot(g.S0, p.SB0, 1.0);
@@ -277,7 +303,6 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
     p.ny = d.ny;
     p.y_off = 0;
     set_row_order(p, d.ny);
-    p.optimize_speed = d.optimize_speed;
     p.n0 = p.n1 = 0;
     p.mask = 0;
     for (int i = 0; i < PM_NUM_PLANES; i++) p.out[i] = nullptr;
@@ -707,7 +732,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         // Planes of the disc (not the ring planes, which every pixel has) are NaN outside the radius
         // pre-mask: when that circle leaves a good part of the frame empty only bands around it are
         // copied and the copy threads write the NaN (PM_OPT_SPARSE_FRAME).
-        const uint64_t nan_outside = d.optimize_speed ? (kDiscBits & ~kRingBits) : 0;
+        const uint64_t nan_outside = p.optimize_speed ? (kDiscBits & ~kRingBits) : 0;  // (the pre-mask, or the limb bound of fill_params)
         const double circle = 3.14159265358979323846 * p.r2 / ((double)d.nx * (double)n_rows);
         const bool sparse = ctx->sparse_frame != 0 && (size_t)d.nx * sizeof(double) <= ((size_t)1 << 20) &&
                             (ctx->sparse_frame > 0 || (npx * sizeof(double) >= ((size_t)64 << 20) && circle < 0.85));

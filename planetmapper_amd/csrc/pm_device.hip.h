@@ -433,10 +433,10 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
     }
     if (!__any(mid)) {
         const double r = asin_half(s);
-        return d > 0.0 ? 2.0 * r : kPi - 2.0 * r;
+        return d > 0.0 ? r + r : fma_m2_c(r, kPi);
     }
     const double r = asin_half(mid ? d : s);
-    return mid ? kHalfPi - r : (d > 0.0 ? 2.0 * r : kPi - 2.0 * r);
+    return mid ? kHalfPi - r : (d > 0.0 ? r + r : fma_m2_c(r, kPi));
 }
 
 

@@ -101,12 +101,57 @@ __device__ __forceinline__ double fma_c(double q, double z, double c)
     return r;
 }
 
+// -q * z + C, q * z - C, z * C and z + C with C as the scalar operand of one instruction (see fma_c)
+__device__ __forceinline__ double fnma_c(double q, double z, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, -%1, %2, %3" : "=v"(r) : "v"(q), "v"(z), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double fma_cn(double q, double z, double c)
+{
+    double r;
+    asm("v_fma_f64 %0, %1, %2, -%3" : "=v"(r) : "v"(q), "v"(z), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double mul_c(double z, double c)
+{
+    double r;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(r) : "v"(z), "s"(c));
+    return r;
+}
+__device__ __forceinline__ double add_c(double z, double c)
+{
+    double r;
+    asm("v_add_f64 %0, %1, %2" : "=v"(r) : "v"(z), "s"(c));
+    return r;
+}
+// C - z (an explicit instruction also keeps the compiler from contracting it with a product behind z into an
+// FMA that would hold two scalars)
+__device__ __forceinline__ double rsub_c(double z, double c)
+{
+    double r;
+    asm("v_add_f64 %0, %2, -%1" : "=v"(r) : "v"(z), "s"(c));
+    return r;
+}
+// C - 2 r in one instruction (-2.0 is an inline constant, C the scalar operand)
+__device__ __forceinline__ double fma_m2_c(double r, double c)
+{
+    double o;
+    asm("v_fma_f64 %0, %1, -2.0, %2" : "=v"(o) : "v"(r), "s"(c));
+    return o;
+}
+// The first Horner step c0 z + c1 of a polynomial with constant coefficients holds two scalars, and one
+// instruction reads one: as an FMA the leading coefficient is first copied into a vector register pair (two
+// v_mov_b32), as a product and a sum it is two FP64 operations and no copy. (The highest coefficient carries
+// 1e-10 of the result: the extra rounding is far below the last place.)
+__device__ __forceinline__ double horner_head(double z, double c0, double c1) { return add_c(mul_c(z, c0), c1); }
+
 // asin(x) for |x| <= 0.5
 __device__ __forceinline__ double asin_half(double x)
 {
     const double z = x * x;
-    double q = 0.028169218060881414;
-    q = fma_c(q, z, -0.010749050339697808);
+    double q = horner_head(z, 0.028169218060881414, -0.010749050339697808);
     q = fma_c(q, z, 0.01603551434914882);
     q = fma_c(q, z, 0.0078029494773533175);
     q = fma_c(q, z, 0.011875494382636922);
@@ -124,8 +169,7 @@ __device__ __forceinline__ double asin_half(double x)
 __device__ __forceinline__ double atan_small(double t)
 {
     const double z = t * t;
-    double q = 0.02275052699336167;
-    q = fma_c(q, z, -0.04483334622272886);
+    double q = horner_head(z, 0.02275052699336167, -0.04483334622272886);
     q = fma_c(q, z, 0.05736332165907643);
     q = fma_c(q, z, -0.06649613695291669);
     q = fma_c(q, z, 0.0769105515839315);
@@ -144,7 +188,9 @@ __device__ __forceinline__ double atan_small(double t)
 // directly (through fmax(fabs()) hipcc first canonicalises each operand with an extra
 // v_max_f64), and the reduction is blended in with a 0/1 factor: two FMAs instead of two
 // differences and four selects.
-template <bool XPOS = false>
+// ZERO_OK: (0, 0) gives 0 (recpgr_c's longitude of a point on the axis) instead of NaN: the denominator is kept
+// off zero, 0 / 1e-300 = 0 goes through the polynomial and the selects as any other first-octant angle.
+template <bool XPOS = false, bool ZERO_OK = false>
 __device__ __forceinline__ double atan2_fast(double y, double x)
 {
     double mx, mn;
@@ -153,7 +199,8 @@ __device__ __forceinline__ double atan2_fast(double y, double x)
     const bool big = mn > kTanPi8 * mx;
     const double bf = big ? 1.0 : 0.0;
     const double num = fma(-bf, mx, mn);
-    const double den = fma(bf, mn, mx);
+    double den = fma(bf, mn, mx);
+    if (ZERO_OK) den = fmax(den, 1e-300);
     double a = atan_small(div_fast(num, den));
     a = big ? a + 0.25 * kPiF : a;
     a = (fabs(y) > fabs(x)) ? 0.5 * kPiF - a : a;

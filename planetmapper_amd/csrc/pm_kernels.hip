@@ -30,9 +30,14 @@ enum DiscFlags : int {
 
 // Store through a wave-uniform row pointer (SGPR pair) + 32-bit lane offset: the
 // global_store saddr form, one address dword per lane instead of a 64-bit VGPR pointer.
+// PM_EXPERIMENT (instrumented builds of tools/, never the shipped library): 1 = waves without an intercept do
+// not store their NaN fill, 2 = no plane is stored at all (behind a condition the compiler cannot see through)
+#ifndef PM_EXPERIMENT
+#define PM_EXPERIMENT 0
+#endif
 #define PM_PUT_ROW(pl, val)                                               \
     do {                                                                  \
-        if (PM_WANT(pl))                                                  \
+        if (PM_WANT(pl) && (PM_EXPERIMENT != 2 || p.nx < 0))              \
             *reinterpret_cast<double *>(reinterpret_cast<char *>(p.out[pl] + row_base) + lane_off) = (val); \
     } while (0)
 
@@ -185,12 +190,11 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
         const double sd = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
         s = close ? sd : s;
     }
-    if (!__any(mid)) {
-        const double r = asin_half(s);
-        return d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi);
-    }
+    // (pi/2 - 2 r >= pi/6 towards the north pole and its negative towards the south: one FMA and the sign of d,
+    //  the same bits as the two mirrored FMAs)
+    if (!__any(mid)) return copysign(fma_m2_c(asin_half(s), kHalfPi), d);
     const double r = asin_half(mid ? d : s);
-    return mid ? r : (d > 0.0 ? fma(-2.0, r, kHalfPi) : fma(2.0, r, -kHalfPi));
+    return mid ? r : copysign(fma_m2_c(r, kHalfPi), d);
 }
 
 // pixel -> unit vector in the angular frame (BodyXY._xy2obsvec_norm body_xy.py:375: radrec of the view
@@ -198,9 +202,12 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
 // arcsec -> rad into its six constants moves an angle of 1e-4 rad by 1 ulp.
 __device__ __forceinline__ V3 pixel_va(const Params &p, const int x, const int y)
 {
-    const double fx = (double)x, fy = (double)y;
-    const double ra = fma(p.Ar[0], fx, fma(p.Ar[1], fy, p.Ar[2]));
-    const double de = fma(p.Ar[3], fx, fma(p.Ar[4], fy, p.Ar[5]));
+    // (about the disc centre, where the affine map has no constant term: Ar[2] = -(Ar[0] x0 + Ar[1] y0). One
+    //  scalar operand per instruction - the constant term would first be copied into vector registers - and
+    //  the image kernels hold x - x0, y - y0 for their pre-mask anyway.)
+    const double dx = (double)x - p.x0, dy = (double)y - p.y0;
+    const double ra = fma(p.Ar[0], dx, p.Ar[1] * dy);
+    const double de = fma(p.Ar[3], dx, p.Ar[4] * dy);
     double sr, cr, sd, cd;
     if (p.view_tiny) {  // kernel-argument flag: a scalar branch, no wave vote
         sincos_tiny(ra, sr, cr);
@@ -396,8 +403,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             (const __attribute__((address_space(4))) Params *)__builtin_amdgcn_kernarg_segment_ptr();
         asm volatile("" : "+s"(kp));
 
-        V3 Xf = {0.0, 0.0, 0.0};  // the intercept in scaled coordinates (unit sphere)
-        double lt = kp->g.lt_c, d = 0.0;
+        // the intercept in scaled coordinates (unit sphere) and its epoch offset: read only by waves that hold an
+        // intercept, which have set them (no defaults: four 64-bit moves per candidate wave)
+        V3 Xf;
+        double lt = kp->g.lt_c, d;
         // lanes still holding an intercept, as a wave-uniform mask in scalar registers (a
         // per-lane bool carried around the loop costs four VALU operations per evaluation)
         unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(cand);
@@ -416,8 +425,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double yx = dot(y00, Xp);
             const double kq = yx * ixp;
             // (Y00 ~ D / R ~ 1e4 radii is rounded at 1e-12: its low part goes in where the magnitude has dropped to 1)
-            const V3 Pq = {fma(-kq, Xp.x, y00.x) + kp->Y00lo[0], fma(-kq, Xp.y, y00.y) + kp->Y00lo[1],
-                           fma(-kq, Xp.z, y00.z) + kp->Y00lo[2]};
+            const V3 Pq = {fnma_c(kq, Xp.x, y00.x) + kp->Y00lo[0], fnma_c(kq, Xp.y, y00.y) + kp->Y00lo[1],
+                           fnma_c(kq, Xp.z, y00.z) + kp->Y00lo[2]};
             const double p2 = dot(Pq, Pq);
             // The reference decides hit or miss at EVERY pass of its own sequence of epochs (CSPICE sincpt: no
             // intercept in any pass -> not found); between the first pass (target at t0) and the fixed point the
@@ -437,20 +446,20 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     double half_inv_root;
                     const double root = sqrt_pos_h(r2, half_inv_root);
                     const double s = -kq - root;
-                    const double lts = s * kp->inv_c;
+                    const double lts = mul_c(s, kp->inv_c);  // (rounded on its own, as the reference's light time is)
                     // The reference evaluates its final state at the epoch et - lt ROUNDED to a double (one
                     // quantum: 3e-8 s at et = 1.6e8 s, in which Jupiter moves 4e-7 km = 3e-10 deg of
                     // longitude), the closed form at the unrounded one. The target's linear motion over the
                     // difference `dq` (< 1 quantum) moves the intercept by dq (s' X - VBs), s' = F.VBs / F.X
                     // keeping it on the surface and F.X = -root X.X: first order is exact here (dq^2 ~ 1e-16).
                     // (X' stands in for X and X'.X' for X.X in that term: v / c ~ 1e-4 of 4e-12.)
-                    d = (kp->g.et - lts) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
-                    const double dq = d - (kp->lt_c_eff - lts);
+                    d = rsub_c(lts, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+                    const double dq = d - rsub_c(lts, kp->lt_c_eff);
                     const V3 F = {fma(-root, Xp.x, Pq.x), fma(-root, Xp.y, Pq.y), fma(-root, Xp.z, Pq.z)};
                     const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
                     const double sp = dot(F, vbs) * (half_inv_root * ixp) * -2.0;
-                    Xf = {fma(dq, fma(sp, Xp.x, -vbs.x), F.x), fma(dq, fma(sp, Xp.y, -vbs.y), F.y),
-                          fma(dq, fma(sp, Xp.z, -vbs.z), F.z)};
+                    Xf = {fma(dq, fma_cn(sp, Xp.x, vbs.x), F.x), fma(dq, fma_cn(sp, Xp.y, vbs.y), F.y),
+                          fma(dq, fma_cn(sp, Xp.z, vbs.z), F.z)};
                     lt = fma(dq, sp, s) * kp->inv_c;
                 }
             }
@@ -461,6 +470,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         double ixx = 0.0;
         double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
         if (!solved) {
+        d = 0.0;
         ixx = rcp_fast(dot(X, X));
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
@@ -567,7 +577,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // hits) is the addend of each plane's closing radians -> degrees FMA.
         if (hit_mask != 0) {
             static_assert(kSphBlock == 64, "lane id = threadIdx.x: one wave per workgroup");
-            const bool hit = (hit_mask >> threadIdx.x) & 1;  // one wave per workgroup
+            const bool hit = __builtin_amdgcn_inverse_ballot_w64(hit_mask);  // (the mask IS the select operand)
             stored = true;
             const double miss = hit ? 0.0 : nan;
             // intercept in B0; body-fixed = Rz_frame(delta) * B0 with delta = wdot d
@@ -577,12 +587,12 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // (for a spheroid x and y share their radius: longitude and latitude follow from the
             //  scaled intercept Xf directly, sp / rho are only needed by the triaxial variant)
             const V3 ll = TRI ? sp : Xf;
-            const bool polar = (ll.x == 0.0 && ll.y == 0.0);
             // recpgr_c body.py:1030: east longitude in the frame at te = B0 longitude - wdot d,
             // sign by the body's convention (lon_k = {+-1, +-wdot}), then into [0, 2 pi]
-            const double theta = polar ? 0.0 : atan2_fast(ll.y, ll.x);
+            // (a point on the axis, x = y = 0, has longitude 0: ZERO_OK)
+            const double theta = atan2_fast<false, true>(ll.y, ll.x);
             double l = TRI ? kp->lon_k[0] * theta : fma(-kp->lon_k[1], d, kp->lon_k[0] * theta);
-            if (l < 0.0) l += kTwoPi;
+            l = fma((l < 0.0) ? 1.0 : 0.0, kTwoPi, l);  // (l + 2 pi, rounded once either way: a select of one word)
             const double lon_deg = fma(l, kDeg, miss);
             // surfnm_c: sp / radii^2 = Xf / radii; for a spheroid its z component IS sin(latitude)
             // (a triaxial body's latitude refers to the reference spheroid instead, recpgr_c)
@@ -627,9 +637,11 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 // q^2 / (2 |SB0|) ~ 3 km, i.e. 1e-5 s of a Sun that moves 0.013 km/s = 1e-7 km at
                 // 8e8 km (2e-16 rad): the square root of the exact form buys nothing, the linear
                 // form is one dot product.
-                const double ds = d + fma(dot(v3(kp->SB0[0], kp->SB0[1], kp->SB0[2]), q), kp->sun_k, kp->sun_ds0);
-                V3 sv = v3(fma(kp->VSB[0], ds, kp->SB0[0]) - q.x, fma(kp->VSB[1], ds, kp->SB0[1]) - q.y,
-                        fma(kp->VSB[2], ds, kp->SB0[2]) - q.z);
+                // (operations ordered so that each holds ONE scalar constant: two of them in an FMA cost a copy
+                //  of one into a vector register pair first)
+                const double ds = fma(dot(v3(kp->SB0[0], kp->SB0[1], kp->SB0[2]), q), kp->sun_k, d) + kp->sun_ds0;
+                V3 sv = v3(fma(kp->VSB[0], ds, rsub_c(q.x, kp->SB0[0])), fma(kp->VSB[1], ds, rsub_c(q.y, kp->SB0[1])),
+                           fma(kp->VSB[2], ds, rsub_c(q.z, kp->SB0[2])));
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
                 if (TRI) {
@@ -641,7 +653,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 double phr;
                 if (kp->phase_series) {  // kernel-argument flag: a scalar branch
                     const double t = dot(sunb, ob) - kp->ph[0];
-                    phr = fma(t, fma(t, fma(t, fma(t, kp->ph[5], kp->ph[4]), kp->ph[3]), kp->ph[2]), kp->ph[1]);
+                    phr = fma_c(t, fma_c(t, fma_c(t, horner_head(t, kp->ph[5], kp->ph[4]), kp->ph[3]), kp->ph[2]), kp->ph[1]);
                 } else {
                     phr = vsep_fast(sunb, ob);
                 }
@@ -672,7 +684,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         }
     }
 
-    if (!stored && inside) {
+    if (!stored && inside && PM_EXPERIMENT != 1) {
         // no intercept anywhere in this wave: every disc plane is NaN
         PM_PUT_ROW(PM_LON_GRAPHIC, nan);
         PM_PUT_ROW(PM_LAT_GRAPHIC, nan);

@@ -415,7 +415,8 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
     // the 60..120 deg band, and then the half-chord, its square root and every select below are dead
     // weight. Same operations on the same operands as the general form: the same bits whatever the
     // wave's other lanes hold (the wave votes below only skip work, they never change a lane's result).
-    if (__all(mid)) return kHalfPi - asin_half(d);
+    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(true), mid_m = __builtin_amdgcn_ballot_w64(mid);
+    if (mid_m == lanes) return kHalfPi - asin_half(d);
     // sin^2 of half the angle to the nearer of v and -v: |u -+ v|^2 / 4 = (1 - |u . v|) / 2 for unit
     // vectors. The short form loses relative accuracy as the angle closes (the 1e-16 of the dot
     // product against 1 - |d|): a lane takes it while its own 1 - |d| > 1e-4 (angles beyond 0.8 deg
@@ -423,15 +424,15 @@ __device__ __forceinline__ double vsep_fast(V3 u, V3 v)
     // otherwise. The choice is PER LANE - a point's bits do not depend on which points share its
     // wave; the difference form is only evaluated in waves where some lane needs it.
     const double h = fma(-0.5, fabs(d), 0.5);
-    const bool close = !mid && !(h > 5e-5);
+    const unsigned long long close_m = ~mid_m & __builtin_amdgcn_ballot_w64(!(h > 5e-5));  // (votes on the masks: wave_any)
     double s = sqrt_fast(h);
-    if (__any(close)) {
+    if (close_m != 0) {
         const double sg = (d > 0.0) ? -1.0 : 1.0;
         const V3 w = {fma(sg, v.x, u.x), fma(sg, v.y, u.y), fma(sg, v.z, u.z)};
         const double sd = 0.5 * sqrt_fast(dot(w, w));
-        s = close ? sd : s;
+        s = __builtin_amdgcn_inverse_ballot_w64(close_m) ? sd : s;
     }
-    if (!__any(mid)) {
+    if (mid_m == 0) {
         const double r = asin_half(s);
         return d > 0.0 ? r + r : fma_m2_c(r, kPi);
     }
@@ -449,7 +450,7 @@ __device__ __forceinline__ void rot_at(const Params &p, double t, M3 &R)
 {
     double ang = p.g.wdot * (t - p.t0);
     double s, c;
-    if (SMALL ? fabs(ang) < 1e-3 : __all(fabs(ang) < 1e-3)) {
+    if (SMALL ? fabs(ang) < 1e-3 : wave_all(fabs(ang) < 1e-3)) {
         double a2 = ang * ang;
         s = ang * fma(a2, fma(a2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
         c = fma(a2, fma(a2, fma(a2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
@@ -664,7 +665,7 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     // corrections: raw 2^-24 seeds do. This replaces the Newton iteration and its finish - ten
     // reciprocal / square-root seeds and ~90 FP64 operations per pixel of a ring frame.
     // (care: lanes whose result is used; the others must not veto the wave-uniform choice)
-    if (__all(!care || (rho > a && fabs(v.z) <= 1e-3 * (rho - a)))) {
+    if (wave_all(!care || (rho > a && fabs(v.z) <= 1e-3 * (rho - a)))) {
         const double dxa = rho - a;
         const double rc = __builtin_amdgcn_rcp(fma(a, dxa, c2));  // 1 / (c^2 + lam0)
         const double e = (c * v.z) * rc;
@@ -696,7 +697,7 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
         const double nl = lam - step;
         const bool stop = (nl == lam) || fabs(step) <= 1e-15 * fabs(nl);
         lam = nl;
-        if (__all(stop)) break;
+        if (wave_all(stop)) break;
     }
     double bx = a2 * rho * rcp_fast(a2 + lam), bz = c2 * v.z * rcp_fast(c2 + lam);
     const double s = rsqrt_fast(bx * bx * (p.ira * p.ira) + bz * bz * (p.irc * p.irc));
@@ -1049,7 +1050,7 @@ __device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double l
         const double h = 0.5 * d * d;
         const double ang = wdot * d;
         double sa, ca;
-        if (__all(fabs(ang) <= 1e-3)) {
+        if (wave_all(fabs(ang) <= 1e-3)) {
             sincos_tiny(ang, sa, ca);
         } else {
             sincos_auto(ang, sa, ca);
@@ -1070,7 +1071,7 @@ __device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double l
     const double t = kp->g.sub_et - dist * kp->inv_c;
     const double ang2 = wdot * (t - kp->t0);
     double s2, c2;
-    if (__all(fabs(ang2) <= 1e-3)) {
+    if (wave_all(fabs(ang2) <= 1e-3)) {
         sincos_tiny(ang2, s2, c2);
     } else {
         sincos_auto(ang2, s2, c2);

@@ -18,6 +18,12 @@
 
 namespace pm {
 
+// Wave votes on the lane mask itself. HIP's __any / __all take an int: the condition is first written to a
+// vector register as 0 / 1 and compared again (two VALU instructions per vote); a ballot leaves the mask in
+// a scalar register pair, and the test is one scalar compare.
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+__device__ __forceinline__ bool wave_all(bool c) { return __builtin_amdgcn_ballot_w64(!c) == 0; }
+
 constexpr double kPiF = 3.14159265358979323846;
 constexpr double kTanPi8 = 0.41421356237309503;
 
@@ -269,9 +275,9 @@ __device__ __forceinline__ void sincos_medium(double x, double &s, double &c)
 // inside their range (always true for planetary fields of view), libm otherwise.
 __device__ __forceinline__ void sincos_auto(double x, double &s, double &c)
 {
-    if (__all(fabs(x) <= 0.25)) {
+    if (wave_all(fabs(x) <= 0.25)) {
         sincos_small(x, s, c);
-    } else if (__all(fabs(x) <= 1e5)) {
+    } else if (wave_all(fabs(x) <= 1e5)) {
         sincos_medium(x, s, c);
     } else {
         sincos(x, &s, &c);

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
     double lt = 0.0;
     bool on_disc = false;
     // wave-uniform skip of the intercept when no lane of the wave can be on the disc
-    if (__any(cand)) {
+    if (wave_any(cand)) {
         if (cand) on_disc = sincpt(p, ray, sp, lt);
     }
 
@@ -180,19 +180,21 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
 {
     const double d = n.z;
     const bool mid = fabs(d) < 0.5;
-    if (__all(mid)) return asin_half(d);  // a wave wholly within 30 deg of the equator (see vsep_fast)
+    // (votes on the lane masks themselves: see wave_any)
+    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(true), mid_m = __builtin_amdgcn_ballot_w64(mid);
+    if (mid_m == lanes) return asin_half(d);  // a wave wholly within 30 deg of the equator (see vsep_fast)
     // (half-chord to the nearer pole: (1 - |n.z|) / 2 while that keeps its accuracy, chosen per lane: see vsep_fast)
     const double h = fma(-0.5, fabs(d), 0.5);
-    const bool close = !mid && !(h > 5e-5);
+    const unsigned long long close_m = ~mid_m & __builtin_amdgcn_ballot_w64(!(h > 5e-5));
     double s = sqrt_fast(h);
-    if (__any(close)) {
+    if (close_m != 0) {
         const double wz = d + ((d > 0.0) ? -1.0 : 1.0);
         const double sd = 0.5 * sqrt_fast(fma(n.x, n.x, fma(n.y, n.y, wz * wz)));
-        s = close ? sd : s;
+        s = __builtin_amdgcn_inverse_ballot_w64(close_m) ? sd : s;
     }
     // (pi/2 - 2 r >= pi/6 towards the north pole and its negative towards the south: one FMA and the sign of d,
     //  the same bits as the two mirrored FMAs)
-    if (!__any(mid)) return copysign(fma_m2_c(asin_half(s), kHalfPi), d);
+    if (mid_m == 0) return copysign(fma_m2_c(asin_half(s), kHalfPi), d);
     const double r = asin_half(mid ? d : s);
     return mid ? r : copysign(fma_m2_c(r, kHalfPi), d);
 }
@@ -276,7 +278,7 @@ __device__ __forceinline__ void sky_block(const V3 va, const int x, const int y,
         const double t = p.g.sub_et - dd * p.inv_c;
         const double ang = p.g.wdot * (t - p.t0);
         double sa, ca;
-        if (__all(fabs(ang) <= 1e-3)) {
+        if (wave_all(fabs(ang) <= 1e-3)) {
             sincos_tiny(ang, sa, ca);
         } else {
             sincos_auto(ang, sa, ca);
@@ -334,20 +336,23 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
     const double nan = __builtin_nan("");
 
     const double dx = (double)x - p.x0, dy = (double)y - p.y0;
-    const bool cand = inside && !(p.optimize_speed && (dx * dx + dy * dy) > p.r2);
+    const bool beyond = (dx * dx + dy * dy) > p.r2;
 
     double rr = nan, rl = nan, rd = nan;
     double dist_lt = nan;  // observer -> surface distance (lt * c) of on-disc pixels
     bool stored = false;   // wave-uniform: the disc planes of this wave have been written
 
-    const bool any_cand = __any(cand);
-    V3 va = {0.0, 0.0, 0.0};  // unit vector of the pixel in the angular frame
+    // candidates of the pre-mask as a lane mask (the only form they are used in; combined on the scalar unit)
+    const unsigned long long cand_mask =
+        __builtin_amdgcn_ballot_w64(inside) & ~(p.optimize_speed ? __builtin_amdgcn_ballot_w64(beyond) : 0ull);
+    const bool any_cand = cand_mask != 0;
+    V3 va;  // unit vector of the pixel in the angular frame (no default: a store-only wave would set it for nothing)
     if (any_cand || (FLAGS & DF_RING) || SKY != 0) va = pixel_va(p, x, y);
     // the planes every pixel has first: the wave issues their stores and computes its intercept while they drain
     if (SKY != 0 && inside) sky_block<SKY == 2>(va, x, y, row_base, lane_off);
 
     // the ray in B0 (both the ring and the disc block work there)
-    V3 u = {0.0, 0.0, 0.0};
+    V3 u;
     if (any_cand || (FLAGS & DF_RING)) u = mxv(p.C, va);
 
     if (FLAGS & DF_RING) {
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         const double pd = dot(u, ld3(p.ring_nb));
         const double kk = p.g.ring_k;
         const bool ok = (kk == 0.0) ? (pd != 0.0) : (pd > 0.0 && kk < pd * (1.7976931348623157e308 / 3.0));
-        if (__any(ok)) {
+        if (wave_any(ok)) {
             // lanes without an intersection carry a harmless finite point through the math
             const double s = !ok ? 1.0 : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
             const V3 ob = {fma(s, u.x, -p.sub_obs_b[0]), fma(s, u.y, -p.sub_obs_b[1]), fma(s, u.z, -p.sub_obs_b[2])};
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double t = p.g.sub_et - dd * p.inv_c;
             double sa, ca;
             const double ang = p.g.wdot * (t - p.t0);  // spin over the light-time offset: ~1e-4 rad
-            if (__all(!ok || fabs(ang) <= 1e-3)) {
+            if (wave_all(!ok || fabs(ang) <= 1e-3)) {
                 sincos_tiny(ang, sa, ca);
             } else {
                 sincos_auto(ang, sa, ca);
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         double lt = kp->g.lt_c, d;
         // lanes still holding an intercept, as a wave-uniform mask in scalar registers (a
         // per-lane bool carried around the loop costs four VALU operations per evaluation)
-        unsigned long long hit_mask = __builtin_amdgcn_ballot_w64(cand);
+        unsigned long long hit_mask = cand_mask;
         bool solved = false;  // wave-uniform: the closed form below has settled every lane of this wave
         if (!TRI && kp->plain_lt == 0) {  // (kernel-argument flag: a scalar branch)
             // sincpt_c 'CN' for a target in linear motion, in closed form. The converged light time is the fixed

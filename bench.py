@@ -815,7 +815,7 @@ def headline(args) -> None:
                 'preheat_steps': args.preheat_steps,
             },
             'roofline': {
-                'kernel': 'pm::k_disc_sph<1, false> (DF_ILLUM, spheroid)',
+                'kernel': 'pm::k_disc_sph<1, false, 0, 28675ull> (DF_ILLUM, spheroid, the headline plane set)',
                 'bound': 'hbm',
                 'achieved': round(achieved, 2),
                 'peak': HBM_PEAK_GBS,

@@ -1976,3 +1976,95 @@ def test_mapping_visible_areas_through_the_real_engine(engine, oracle):
     assert np.isfinite(ra[emission <= 90]).all() and not np.isfinite(ra[emission > 90]).any()
     # (map_img needs the cell's pixel inside the frame as well: the disc, r0 = 3 in a 10 x 10 frame, is)
     assert np.isfinite(img[emission <= 90]).all() and not np.isfinite(img[emission > 90]).any()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('which', ['jupiter', 'saturn', 'near_field'])
+def test_closed_form_light_time_against_the_reference_sequence(oracle, jupiter, saturn, which):
+    """
+    k_disc_sph settles the waves clear of the limb with the light time in closed form; the
+    library can be told at context creation to walk the reference's own sequence of epochs everywhere instead
+    (PM_LT_MODE=1) or to take the round-2 path (2: Newton step on the seed). Same frame through all three:
+    NaN masks identical - the closed form may not decide a single limb pixel differently -, values inside the
+    bars against the oracle in every mode, and the closed form no further from the reference's sequence than
+    one epoch quantum allows (the two can round `et - lt` to neighbouring doubles: 3e-8 s, 3e-10 deg of
+    longitude on Jupiter, amplified towards the limb as every error is).
+    """
+    from planetmapper_amd.engine import Engine
+
+    g = {'jupiter': jupiter, 'saturn': saturn}.get(which) or _near_field_geometry(1.2e6)
+    sz = 1536
+    x0, y0, r0, rot = sz / 2 - 3.25, sz / 2 + 11.5, 0.43 * sz, 17.0
+    names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION', 'DISTANCE', 'RADIAL-VELOCITY']
+    outs = {}
+    old = os.environ.get('PM_LT_MODE')
+    try:
+        for mode in ('0', '1', '2'):
+            os.environ['PM_LT_MODE'] = mode
+            eng = Engine(0)
+            try:
+                eng.set_geometry(g)
+                eng.set_disc(x0, y0, r0, float(np.deg2rad(rot)), sz, sz, True)
+                outs[mode] = eng.backplanes_img(names)
+            finally:
+                eng.close()
+    finally:
+        if old is None:
+            os.environ.pop('PM_LT_MODE', None)
+        else:
+            os.environ['PM_LT_MODE'] = old
+    d = oracle.make_disc(x0, y0, r0, rot, sz, sz)
+    d.rotation_rad = float(np.deg2rad(rot))
+    ref = oracle.backplanes_img(g, d, names)
+    for mode in ('0', '1', '2'):
+        for n in names:
+            assert np.array_equal(np.isnan(outs[mode][n]), np.isnan(ref[n])), (which, mode, n)
+        _compare(outs[mode], ref, names, g, r0=r0)
+    on = np.isfinite(ref['EMISSION'])
+    assert 0.3 < on.mean() < 0.7
+    # one epoch quantum as an angle on the body: the spin plus the target's motion across the line of sight
+    quantum = np.spacing(g.et)
+    vt = float(np.linalg.norm(np.asarray(g.VT)))
+    per_quantum = np.rad2deg(quantum * (abs(g.wdot) + vt / min(g.radii)))
+    kappa = 1.0 / np.maximum(np.cos(np.deg2rad(ref['EMISSION'][on])), 1e-3)
+    for n in ('LON-GRAPHIC', 'LAT-GRAPHIC', 'INCIDENCE', 'EMISSION'):
+        diff = np.abs(outs['0'][n][on] - outs['1'][n][on])
+        diff = np.minimum(diff, 360.0 - diff) if n == 'LON-GRAPHIC' else diff
+        lat_k = 1.0 / np.maximum(np.cos(np.deg2rad(ref['LAT-GRAPHIC'][on])), 1e-3) if n == 'LON-GRAPHIC' else 1.0
+        assert (diff <= (1.5 * per_quantum + 2e-10) * kappa * lat_k).all(), (which, n, float(diff.max()), per_quantum)
+        # ... and most pixels chose the same quantum: the two differ by rounding noise only
+        assert np.median(diff) <= 1.5e-10, (which, n, float(np.median(diff)))
+
+
+@pytest.mark.gpu
+def test_limb_bound_is_never_tighter_than_the_limb(engine, oracle, jupiter):
+    """
+    fill_params replaces the reference's pre-mask radius (1.05 r0 + 1 pixels) by the limb's own reach where that is
+    tighter, and gives frames without a pre-mask one. Discs of many sizes, off-centre, rotated, with altitude
+    offsets and with `optimize_speed=False`: the NaN mask is the oracle's (which tests every pixel the reference
+    does) and the values sit inside the bars both ways. (Not bit-identical to each other: with the pre-mask off a
+    wave at the limb can hold a candidate it did not hold before, and a wave with a lane in the limb band walks the
+    reference's sequence of epochs instead of the closed form - DESIGN §4, round 3 - for all of its lanes.)
+    """
+    rng = np.random.default_rng(20261004)
+    engine.set_geometry(jupiter)
+    names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'EMISSION']  # (the longitude's bar needs the latitude: 1 / cos(lat))
+    for k in range(24):
+        nx, ny = int(rng.integers(90, 700)), int(rng.integers(90, 700))
+        r0 = float(rng.uniform(8.0, 0.8 * max(nx, ny)))
+        x0, y0 = float(rng.uniform(-0.2, 1.2) * nx), float(rng.uniform(-0.2, 1.2) * ny)
+        rot = float(rng.uniform(0, 360))
+        alt = float(rng.choice([0.0, 0.0, 500.0, 4000.0, -300.0]))
+        d = oracle.make_disc(x0, y0, r0, rot, nx, ny)
+        d.rotation_rad = float(np.deg2rad(rot))
+        got = {}
+        for speed in (True, False):
+            engine.set_disc(x0, y0, r0, float(np.deg2rad(rot)), nx, ny, speed)
+            got[speed] = engine.backplanes_img(names, alt=alt)
+            d.optimize_speed = int(speed)
+            ref = oracle.backplanes_img(jupiter, d, names, alt=alt)
+            for n in names:
+                assert np.array_equal(np.isnan(got[speed][n]), np.isnan(ref[n])), (k, speed, n, nx, ny, r0, x0, y0, alt)
+            _compare(got[speed], ref, names, jupiter, r0=r0, flat=False)
+        fin = np.isfinite(got[True]['EMISSION'])
+        assert np.allclose(got[True]['EMISSION'][fin], got[False]['EMISSION'][fin], rtol=0, atol=1e-7), k

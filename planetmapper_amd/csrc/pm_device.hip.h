@@ -450,14 +450,22 @@ __device__ __forceinline__ void rot_at(const Params &p, double t, M3 &R)
 {
     double ang = p.g.wdot * (t - p.t0);
     double s, c;
-    if (SMALL ? fabs(ang) < 1e-3 : wave_all(fabs(ang) < 1e-3)) {
+    // (the form is the lane's own - a point's bits do not depend on its wave's other lanes -, the wave only
+    //  decides which forms are evaluated)
+    const bool tiny = fabs(ang) < 1e-3;
+    const unsigned long long tiny_m = __builtin_amdgcn_ballot_w64(tiny);
+    if (SMALL ? tiny : tiny_m != 0) {
         double a2 = ang * ang;
         s = ang * fma(a2, fma(a2, 1.0 / 120.0, -1.0 / 6.0), 1.0);
         c = fma(a2, fma(a2, fma(a2, -1.0 / 720.0, 1.0 / 24.0), -0.5), 1.0);
     } else if (SMALL) {
         sincos(ang, &s, &c);
-    } else {
-        sincos_auto(ang, s, c);  // (wave-uniform choice of the range-aware polynomials, libm beyond 1e5)
+    }
+    if (!SMALL && tiny_m != __builtin_amdgcn_ballot_w64(true)) {
+        double s2, c2;
+        sincos_auto(ang, s2, c2);  // (range-aware polynomials by lane, libm beyond 1e5)
+        s = tiny ? s : s2;
+        c = tiny ? c : c2;
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -665,21 +673,27 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     // corrections: raw 2^-24 seeds do. This replaces the Newton iteration and its finish - ten
     // reciprocal / square-root seeds and ~90 FP64 operations per pixel of a ring frame.
     // (care: lanes whose result is used; the others must not veto the wave-uniform choice)
-    if (wave_all(!care || (rho > a && fabs(v.z) <= 1e-3 * (rho - a)))) {
+    // The form is each LANE's own (a point gets the closed form iff IT lies in the plane's vicinity, whatever
+    // the other lanes of its wave hold); the wave only decides what is evaluated: the closed form alone when every
+    // lane that matters takes it (ring frames), both with a select per lane otherwise.
+    const bool near_plane = rho > a && fabs(v.z) <= 1e-3 * (rho - a);
+    const unsigned long long plane_m = __builtin_amdgcn_ballot_w64(near_plane);
+    const unsigned long long other_m = __builtin_amdgcn_ballot_w64(care) & ~plane_m;
+    double alt_plane = 0.0;
+    if (plane_m != 0) {
         const double dxa = rho - a;
         const double rc = __builtin_amdgcn_rcp(fma(a, dxa, c2));  // 1 / (c^2 + lam0)
         const double e = (c * v.z) * rc;
         const double dx = fma(0.5 * a * e, e, dxa);  // rho - a (1 - e^2 / 2)
         const double dz = fma(-c, e, v.z);
         const double t = dz * __builtin_amdgcn_rcp(dx);
-        alt = dx * fma(0.5 * t, t, 1.0);
+        alt_plane = dx * fma(0.5 * t, t, 1.0);
+    }
+    if (other_m == 0) {
+        alt = alt_plane;
         return;
     }
     const double q = rho2 * (p.ira * p.ira) + (v.z * v.z) * (p.irc * p.irc);
-    if (q == 0.0) {
-        alt = -fmin(a, c);
-        return;
-    }
     const double l1 = (rho != 0.0) ? fma(a, rho, -a2) : -1e300;
     const double l2 = (v.z != 0.0) ? fma(c, fabs(v.z), -c2) : -1e300;
     double lam = fmax(fmax(l1, l2), (q >= 1.0) ? 0.0 : -1e300);
@@ -687,6 +701,9 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     // Newton from a lower bound is monotone and quadratic; once the step falls to the rounding
     // floor (a few ulps of lam) it only dithers, so stop there: 1e-15 |lam| moves the near
     // point by < 1e-9 km.
+    // (a lane that has stopped keeps its value while the wave goes on for the others: further steps would dither
+    //  it by an ulp, and how many there are depends on the company)
+    bool done = !(q > 0.0);  // (the centre itself, or NaN: nothing to iterate)
 #pragma unroll 1
     for (int it = 0; it < 12; it++) {
         const double ra = rcp_fast(a2 + lam), rc = rcp_fast(c2 + lam);
@@ -696,8 +713,9 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
         const double step = div_fast(f, df);
         const double nl = lam - step;
         const bool stop = (nl == lam) || fabs(step) <= 1e-15 * fabs(nl);
-        lam = nl;
-        if (wave_all(stop)) break;
+        lam = done ? lam : nl;
+        done = done || stop;
+        if (wave_all(done)) break;
     }
     double bx = a2 * rho * rcp_fast(a2 + lam), bz = c2 * v.z * rcp_fast(c2 + lam);
     const double s = rsqrt_fast(bx * bx * (p.ira * p.ira) + bz * bz * (p.irc * p.irc));
@@ -706,6 +724,8 @@ __device__ __forceinline__ void recpgr_alt_lon(const Params &p, V3 v, double &lo
     const double dx = rho - bx, dz = v.z - bz;
     alt = sqrt_fast(fma(dx, dx, dz * dz));
     if (q < 1.0) alt = -alt;
+    if (q == 0.0) alt = -fmin(a, c);
+    alt = near_plane ? alt_plane : alt;
 }
 
 // pgrrec_c (body.py:903-910): surface point of the spheroid `radii` + alt along its normal
@@ -1050,11 +1070,7 @@ __device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double l
         const double h = 0.5 * d * d;
         const double ang = wdot * d;
         double sa, ca;
-        if (wave_all(fabs(ang) <= 1e-3)) {
-            sincos_tiny(ang, sa, ca);
-        } else {
-            sincos_auto(ang, sa, ca);
-        }
+        sincos_tiered<true>(ang, sa, ca);
         q = {fma(ca, tv.x, -sa * tv.y), fma(sa, tv.x, ca * tv.y), tv.z};
         w = {fma(kp->AB[0], h, fma(kp->VB[0], d, q.x - kp->O0[0])), fma(kp->AB[1], h, fma(kp->VB[1], d, q.y - kp->O0[1])),
              fma(kp->AB[2], h, fma(kp->VB[2], d, q.z - kp->O0[2]))};
@@ -1071,11 +1087,7 @@ __device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double l
     const double t = kp->g.sub_et - dist * kp->inv_c;
     const double ang2 = wdot * (t - kp->t0);
     double s2, c2;
-    if (wave_all(fabs(ang2) <= 1e-3)) {
-        sincos_tiny(ang2, s2, c2);
-    } else {
-        sincos_auto(ang2, s2, c2);
-    }
+    sincos_tiered<true>(ang2, s2, c2);
     // R0 ov = R0 sub_obsvec + Rz(ang2)^T off
     const V3 b = {kp->sub_obs_b[0] + fma(c2, off.x, -s2 * off.y), kp->sub_obs_b[1] + fma(s2, off.x, c2 * off.y),
                   kp->sub_obs_b[2] + off.z};

@@ -271,17 +271,57 @@ __device__ __forceinline__ void sincos_medium(double x, double &s, double &c)
     c = ((q + 1) & 2) ? -cc : cc;
 }
 
-// sincos with a wave-uniform choice: the short polynomials when every lane of the wave is
-// inside their range (always true for planetary fields of view), libm otherwise.
-__device__ __forceinline__ void sincos_auto(double x, double &s, double &c)
+// sincos by tiers: the short polynomials where they hold, libm beyond. The tier is each LANE's own (|x| <= 1e-3 with
+// TINY, <= 0.25, <= 1e5, the rest), so what a lane gets does not depend on the lanes that share its wave; the wave
+// only decides which tiers are EVALUATED - one of them when every lane sits in it (always the case for planetary
+// fields of view), the others as well in a wave that straddles a boundary, with a select per lane.
+template <bool TINY = false>
+__device__ __forceinline__ void sincos_tiered(double x, double &s, double &c)
 {
-    if (wave_all(fabs(x) <= 0.25)) {
-        sincos_small(x, s, c);
-    } else if (wave_all(fabs(x) <= 1e5)) {
-        sincos_medium(x, s, c);
-    } else {
-        sincos(x, &s, &c);
+    const double ax = fabs(x);
+    const unsigned long long lanes = __builtin_amdgcn_ballot_w64(true);
+    const unsigned long long tiny_m = TINY ? __builtin_amdgcn_ballot_w64(ax <= 1e-3) : 0ull;
+    if (TINY && tiny_m == lanes) {
+        sincos_tiny(x, s, c);
+        return;
     }
+    const unsigned long long small_m = __builtin_amdgcn_ballot_w64(ax <= 0.25) & ~tiny_m;
+    if (small_m == lanes) {
+        sincos_small(x, s, c);
+        return;
+    }
+    const unsigned long long med_m = __builtin_amdgcn_ballot_w64(ax <= 1e5) & ~(small_m | tiny_m);
+    if (med_m == lanes) {
+        sincos_medium(x, s, c);
+        return;
+    }
+    // a wave across tiers (lanes outside a tier's range carry its garbage, which the selects drop)
+    double sr = 0.0, cr = 0.0;
+    if ((lanes & ~(tiny_m | small_m | med_m)) != 0) sincos(x, &sr, &cr);  // (NaN and infinities end here too)
+    if (med_m != 0) {
+        double t, u;
+        sincos_medium(x, t, u);
+        const bool m = __builtin_amdgcn_inverse_ballot_w64(med_m);
+        sr = m ? t : sr;
+        cr = m ? u : cr;
+    }
+    if (small_m != 0) {
+        double t, u;
+        sincos_small(x, t, u);
+        const bool m = __builtin_amdgcn_inverse_ballot_w64(small_m);
+        sr = m ? t : sr;
+        cr = m ? u : cr;
+    }
+    if (TINY && tiny_m != 0) {
+        double t, u;
+        sincos_tiny(x, t, u);
+        const bool m = __builtin_amdgcn_inverse_ballot_w64(tiny_m);
+        sr = m ? t : sr;
+        cr = m ? u : cr;
+    }
+    s = sr;
+    c = cr;
 }
+__device__ __forceinline__ void sincos_auto(double x, double &s, double &c) { sincos_tiered<false>(x, s, c); }
 
 }  // namespace pm

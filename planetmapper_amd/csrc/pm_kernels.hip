@@ -213,6 +213,18 @@ __device__ __forceinline__ double lat_of_normal(V3 n)
 // pixel -> unit vector in the angular frame (BodyXY._xy2obsvec_norm body_xy.py:375: radrec of the view
 // angles; the ray is M^T of it in J2000, C of it in B0). The affine map is taken in radians: folding
 // arcsec -> rad into its six constants moves an angle of 1e-4 rad by 1 ulp.
+// (the view angles of a frame that is not a planetary field of view: out of line, 2 KB of tiers that the
+//  frame kernel's instruction stream would otherwise carry around its hot path - measured +1.4 % inlined)
+struct SinCos2 {
+    double sr, cr, sd, cd;
+};
+__device__ __attribute__((noinline)) SinCos2 sincos_wide(double ra, double de)  // (by value: in registers, no scratch)
+{
+    SinCos2 o;
+    sincos_auto(ra, o.sr, o.cr);
+    sincos_auto(de, o.sd, o.cd);
+    return o;
+}
 __device__ __forceinline__ V3 pixel_va(const Params &p, const int x, const int y)
 {
     // (about the disc centre, where the affine map has no constant term: Ar[2] = -(Ar[0] x0 + Ar[1] y0). One
@@ -226,8 +238,8 @@ __device__ __forceinline__ V3 pixel_va(const Params &p, const int x, const int y
         sincos_tiny(ra, sr, cr);
         sincos_tiny(de, sd, cd);
     } else {
-        sincos_auto(ra, sr, cr);
-        sincos_auto(de, sd, cd);
+        const SinCos2 w = sincos_wide(ra, de);
+        sr = w.sr, cr = w.cr, sd = w.sd, cd = w.cd;
     }
     return v3(cr * cd, sr * cd, sd);
 }
@@ -289,11 +301,7 @@ __device__ __forceinline__ void sky_block(const V3 va, const int x, const int y,
         const double t = p.g.sub_et - dd * p.inv_c;
         const double ang = p.g.wdot * (t - p.t0);
         double sa, ca;
-        if (wave_all(fabs(ang) <= 1e-3)) {
-            sincos_tiny(ang, sa, ca);
-        } else {
-            sincos_auto(ang, sa, ca);
-        }
+        sincos_tiered<true>(ang, sa, ca);
         const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1], ob.z + p.g.sub_sp[2]};
         const V3 X = {tv.x * p.ir[0], tv.y * p.ir[1], tv.z * p.ir[2]};
         const double sc = rsqrt_fast(dot(X, X));
@@ -388,19 +396,16 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         const double kk = p.g.ring_k;
         const bool ok = (kk == 0.0) ? (pd != 0.0) : (pd > 0.0 && kk < pd * (1.7976931348623157e308 / 3.0));
         if (wave_any(ok)) {
-            // lanes without an intersection carry a harmless finite point through the math
-            const double s = !ok ? 1.0 : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
+            // lanes without an intersection carry a harmless finite point through the math (at the sub-observer
+            // point's distance: its light-time offset, and with it the spin angle below, stays tiny)
+            const double s = !ok ? p.g.sub_dist : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
             const V3 ob = {fma(s, u.x, -p.sub_obs_b[0]), fma(s, u.y, -p.sub_obs_b[1]), fma(s, u.z, -p.sub_obs_b[2])};
             const V3 w = ob - ld3(p.sub_ray_b);
             const double dd = sqrt_fast(dot(w, w)) - p.g.sub_dist;
             const double t = p.g.sub_et - dd * p.inv_c;
             double sa, ca;
             const double ang = p.g.wdot * (t - p.t0);  // spin over the light-time offset: ~1e-4 rad
-            if (wave_all(!ok || fabs(ang) <= 1e-3)) {
-                sincos_tiny(ang, sa, ca);
-            } else {
-                sincos_auto(ang, sa, ca);
-            }
+            sincos_tiered<true>(ang, sa, ca);
             // R(t) off = Rz_frame(ang) (R0 off)
             const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1],
                            ob.z + p.g.sub_sp[2]};
@@ -434,6 +439,12 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // per-lane bool carried around the loop costs four VALU operations per evaluation)
         unsigned long long hit_mask = cand_mask;
         bool solved = false;  // wave-uniform: the closed form below has settled every lane of this wave
+        // ... or, in a wave the limb runs through, the lanes clear of it (`cf_mask`): their closed-form state is kept
+        // while the wave walks the reference's sequence for the others, and put back afterwards - what a pixel
+        // gets does not depend on which pixels share its wave
+        unsigned long long cf_mask = 0;
+        V3 Xf_cf = {0.0, 0.0, 0.0};
+        double d_cf = 0.0, lt_cf = 0.0;  // (set where cf_mask is; the defaults only quiet the TRI instantiations)
         if (!TRI && kp->plain_lt == 0) {  // (kernel-argument flag: a scalar branch)
             // sincpt_c 'CN' for a target in linear motion, in closed form. The converged light time is the fixed
             // point lt = E((et - lt) - t0) of the iteration further down: the target is taken at the epoch offset
@@ -455,14 +466,15 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // intercept in any pass -> not found); between the first pass (target at t0) and the fixed point the
             // target moves |VBs| |d| <= |VBs| R / c across the ray, which changes P.P by less than 1 - p2_lo = p2_hi - 1 (host).
             // A lane clear of 1 by that band hits in every pass, or misses in the first; a wave with a lane
-            // inside the band (the limb runs through it) walks the reference's sequence instead.
+            // inside the band (the limb runs through it) walks the reference's sequence as well, for those lanes.
             const unsigned long long hits =
                 hit_mask & __builtin_amdgcn_ballot_w64(p2 < kp->p2_lo) & __builtin_amdgcn_ballot_w64(yx < 0.0);
             const unsigned long long misses = ~hit_mask | __builtin_amdgcn_ballot_w64(p2 > kp->p2_hi);
-            if ((hits | misses) == ~0ull) {
-                solved = true;
-                hit_mask = hits;
-                // (a wave of the pre-mask annulus - candidates, but every ray misses - is done here)
+            solved = (hits | misses) == ~0ull;
+            if (solved) hit_mask = hits;
+            else cf_mask = hits;
+            // (a wave of the pre-mask annulus - candidates, but every ray misses - is done here)
+            {
                 if (hits != 0) {
                     // (clamped away from 0 for the reciprocal square root: lanes that miss carry garbage)
                     const double r2 = fmax((1.0 - p2) * ixp, 1e-300);
@@ -476,14 +488,19 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     // difference `dq` (< 1 quantum) moves the intercept by dq (s' X - VBs), s' = F.VBs / F.X
                     // keeping it on the surface and F.X = -root X.X: first order is exact here (dq^2 ~ 1e-16).
                     // (X' stands in for X and X'.X' for X.X in that term: v / c ~ 1e-4 of 4e-12.)
-                    d = rsub_c(lts, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
-                    const double dq = d - rsub_c(lts, kp->lt_c_eff);
+                    d_cf = rsub_c(lts, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+                    const double dq = d_cf - rsub_c(lts, kp->lt_c_eff);
                     const V3 F = {fma(-root, Xp.x, Pq.x), fma(-root, Xp.y, Pq.y), fma(-root, Xp.z, Pq.z)};
                     const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
                     const double sp = dot(F, vbs) * (half_inv_root * ixp) * -2.0;
-                    Xf = {fma(dq, fma_cn(sp, Xp.x, vbs.x), F.x), fma(dq, fma_cn(sp, Xp.y, vbs.y), F.y),
-                          fma(dq, fma_cn(sp, Xp.z, vbs.z), F.z)};
-                    lt = fma(dq, sp, s) * kp->inv_c;
+                    Xf_cf = {fma(dq, fma_cn(sp, Xp.x, vbs.x), F.x), fma(dq, fma_cn(sp, Xp.y, vbs.y), F.y),
+                             fma(dq, fma_cn(sp, Xp.z, vbs.z), F.z)};
+                    lt_cf = fma(dq, sp, s) * kp->inv_c;
+                    if (solved) {
+                        Xf = Xf_cf;
+                        d = d_cf;
+                        lt = lt_cf;
+                    }
                 }
             }
         }
@@ -592,6 +609,12 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
         }
         Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
+        if (!TRI && cf_mask != 0) {  // (those lanes hit in every pass: they are in hit_mask)
+            const bool cf = __builtin_amdgcn_inverse_ballot_w64(cf_mask);
+            Xf = {cf ? Xf_cf.x : Xf.x, cf ? Xf_cf.y : Xf.y, cf ? Xf_cf.z : Xf.z};
+            d = cf ? d_cf : d;
+            lt = cf ? lt_cf : lt;
+        }
         }  // !solved
 
         // From here on EVERY lane of a wave that holds at least one intercept computes: no

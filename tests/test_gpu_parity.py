@@ -2068,3 +2068,34 @@ def test_limb_bound_is_never_tighter_than_the_limb(engine, oracle, jupiter):
             _compare(got[speed], ref, names, jupiter, r0=r0, flat=False)
         fin = np.isfinite(got[True]['EMISSION'])
         assert np.allclose(got[True]['EMISSION'][fin], got[False]['EMISSION'][fin], rtol=0, atol=1e-7), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('which', ['jupiter', 'saturn'])
+def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupiter, saturn, which):
+    """
+    The frame kernel takes wave-uniform shortcuts (the closed-form light time for waves clear of the limb, the
+    angle forms of vsep_fast / lat_of_normal): each is either the same operations on the same operands or chosen
+    per lane, so what a pixel gets must not depend on which 63 pixels share its wave. The same frame shifted by
+    17 and by 40 columns (every wave then holds other pixels, the limb crosses other waves): bit-identical planes
+    on the common pixels.
+    """
+    g = {'jupiter': jupiter, 'saturn': saturn}[which]
+    names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC', 'LAT-CENTRIC', 'PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH',
+             'DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'] + (['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE'] if which == 'saturn' else [])  # fmt: skip
+    from planetmapper_amd import _lib
+
+    nx, ny = 1100, 900
+    x0, y0, r0, rot = 531.25, 466.5, 402.75, float(np.deg2rad(23.0))
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)  # (the spheroid kernel, whatever an earlier test left)
+    engine.set_geometry(g)
+    engine.set_disc(x0, y0, r0, rot, nx, ny, True)
+    base = engine.backplanes_img(names)
+    assert 0.3 < np.isfinite(base['EMISSION']).mean() < 0.8
+    for shift in (17, 40):
+        engine.set_disc(x0 + shift, y0, r0, rot, nx + shift, ny, True)
+        moved = engine.backplanes_img(names)
+        for n in names:
+            a, b = base[n], moved[n][:, shift:]
+            same = (a == b) | (np.isnan(a) & np.isnan(b))
+            assert same.all(), (which, shift, n, int((~same).sum()), float(np.nanmax(np.abs(a - b))))

@@ -2072,13 +2072,15 @@ def test_limb_bound_is_never_tighter_than_the_limb(engine, oracle, jupiter):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('which', ['jupiter', 'saturn'])
-def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupiter, saturn, which):
+def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupiter, saturn, which, general=0):
     """
     The frame kernel takes wave-uniform shortcuts (the closed-form light time for waves clear of the limb, the
     angle forms of vsep_fast / lat_of_normal): each is either the same operations on the same operands or chosen
     per lane, so what a pixel gets must not depend on which 63 pixels share its wave. The same frame shifted by
     17 and by 40 columns (every wave then holds other pixels, the limb crosses other waves): bit-identical planes
-    on the common pixels.
+    on the common pixels. (The spheroid kernel: it takes the view angles from x - x0, which the shift leaves
+    unchanged to the bit. The general kernel follows the reference's affine map with its constant term, whose
+    rounding moves with x0 - a different INPUT, 1e-18 rad, that flips the epoch quantum of a few pixels.)
     """
     g = {'jupiter': jupiter, 'saturn': saturn}[which]
     names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC', 'LAT-CENTRIC', 'PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH',
@@ -2087,7 +2089,7 @@ def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupit
 
     nx, ny = 1100, 900
     x0, y0, r0, rot = 531.25, 466.5, 402.75, float(np.deg2rad(23.0))
-    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)  # (the spheroid kernel, whatever an earlier test left)
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, general)  # (whatever an earlier test left)
     engine.set_geometry(g)
     engine.set_disc(x0, y0, r0, rot, nx, ny, True)
     base = engine.backplanes_img(names)
@@ -2099,3 +2101,4 @@ def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupit
             a, b = base[n], moved[n][:, shift:]
             same = (a == b) | (np.isnan(a) & np.isnan(b))
             assert same.all(), (which, shift, n, int((~same).sum()), float(np.nanmax(np.abs(a - b))))
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)

@@ -154,7 +154,10 @@ typedef struct pm_disc {
     double x0, y0, r0;      /* pixels */
     double rotation_rad;    /* BodyXY._rotation_radians, already reduced mod 2 pi */
     int32_t nx, ny;
-    int32_t optimize_speed; /* enables the radius pre-mask of body_xy.py:3201-3218 */
+    int32_t optimize_speed; /* enables the radius pre-mask of body_xy.py:3201-3218. (Either way the library also skips
+                             * pixels whose line of sight passes the body further out than its limb can reach - a
+                             * conservative bound from the geometry block; they are NaN in the reference with or without
+                             * the pre-mask, so the planes do not change.) */
     int32_t reserved;
 } pm_disc;
 

@@ -199,7 +199,13 @@ int pm_abi_version(void);
 /* Number of usable gfx950 devices (0 if none); never fails. */
 int pm_device_count(void);
 /* Create a context on GPU `device`. Fails (NULL + *status) if there is no GPU:
- * this library has no CPU fallback. */
+ * this library has no CPU fallback.
+ * Environment read here (defaults of the context; for the A/B tools under tools/ and for debugging, none changes
+ * a result beyond the parity bars): PM_FORCE_GENERAL=1 (PM_OPT_GENERAL_KERNEL), PM_FUSE_PLANES=0/1
+ * (PM_OPT_FUSE_PLANES), PM_LT_MODE=0/1/2 (light time of the spheroid image kernel: 0 closed form where the
+ * limb is clear - the default -, 1 the reference's own sequence of epochs for every pixel, 2 that sequence
+ * shortened by a Newton step on its seed). Elsewhere: PM_RCCL_LIBRARY (pm_comm_*),
+ * PM_HOSTPIPE_TRACE (stage times of the host path on stderr), PM_SM_WORKERS / PM_SM_DEBUG (smoothing splines). */
 pm_ctx *pm_create(int device, int *status);
 void pm_destroy(pm_ctx *ctx);
 const char *pm_last_error(const pm_ctx *ctx);

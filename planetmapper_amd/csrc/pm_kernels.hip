@@ -599,12 +599,16 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         }
         // (a wave of the pre-mask annulus - candidates, but every ray misses - is done after that one
         //  evaluation: nothing is left to converge)
+        // Each lane stops where the reference stops for its pixel: once an evaluation has confirmed its light
+        // time, the lane keeps that epoch while the wave goes on for the others (evaluating it again gives the
+        // same state) - advancing it would move it to another epoch quantum depending on its company.
+        double lt_e = lt;  // the light time the next epoch is formed from
 #pragma unroll 1
         for (int it = 1; it < 10 && hit_mask != 0; it++) {
-            d = (kp->g.et - lt) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
-            const double nlt = evaluate(d, false);
-            const bool moving = !(fabs(nlt - lt) <= kp->lt_tol);
-            lt = nlt;  // (lanes without an intercept carry a value nobody reads)
+            d = (kp->g.et - lt_e) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+            lt = evaluate(d, false);  // (lanes without an intercept carry a value nobody reads)
+            const bool moving = !(fabs(lt - lt_e) <= kp->lt_tol);
+            lt_e = moving ? lt : lt_e;
             // wave-uniform exit once no lane with an intercept is still moving
             if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
         }

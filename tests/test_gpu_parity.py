@@ -2071,7 +2071,7 @@ def test_limb_bound_is_never_tighter_than_the_limb(engine, oracle, jupiter):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('which', ['jupiter', 'saturn'])
+@pytest.mark.parametrize('which', ['jupiter', 'saturn', 'triaxial'])
 def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupiter, saturn, which, general=0):
     """
     The frame kernel takes wave-uniform shortcuts (the closed-form light time for waves clear of the limb, the
@@ -2082,7 +2082,12 @@ def test_a_pixel_does_not_depend_on_the_pixels_that_share_its_wave(engine, jupit
     unchanged to the bit. The general kernel follows the reference's affine map with its constant term, whose
     rounding moves with x0 - a different INPUT, 1e-18 rad, that flips the epoch quantum of a few pixels.)
     """
-    g = {'jupiter': jupiter, 'saturn': saturn}[which]
+    import copy
+
+    g = {'jupiter': jupiter, 'saturn': saturn, 'triaxial': jupiter}[which]
+    if which == 'triaxial':  # the TRI variant of the frame kernel: every pixel walks the reference's sequence
+        g = copy.deepcopy(g)
+        g.radii[1] = g.radii[0] * 0.97
     names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC', 'LAT-CENTRIC', 'PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH',
              'DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'] + (['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE'] if which == 'saturn' else [])  # fmt: skip
     from planetmapper_amd import _lib

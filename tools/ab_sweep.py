@@ -15,6 +15,9 @@ names = sys.argv[3].split(',') if len(sys.argv) > 3 else ['LON-GRAPHIC', 'LAT-GR
 sz = 4096
 dev = torch.device('cuda', 0)
 g = load_scenario(os.environ.get('SCENARIO', 'jupiter_hst_2005'))
+if os.environ.get('TRIAXIAL'):  # a triaxial body: the TRI variant of the frame kernel (TRIAXIAL = b / a, WDOT_SCALE: slower spin)
+    g.radii[1] = g.radii[0] * float(os.environ['TRIAXIAL'])
+    g.wdot *= float(os.environ.get('WDOT_SCALE', '1'))
 planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
 engines = []
 for path, envs in zip(sys.argv[1:3], (os.environ.get('AB_ENV_A', ''), os.environ.get('AB_ENV_B', ''))):

@@ -925,6 +925,9 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     if (n_planes < 0 || n0 < 0 || n1 < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "negative shape");
     size_t nmap = (size_t)n0 * n1;
     size_t npx = (size_t)d.nx * d.ny;
+    // (PM_OPT_LAST_REDO_PLANES describes THIS call once it has finished: the spline / smoothing / 'smooth'
+    //  paths never redo planes and must not leave an earlier call's count behind)
+    ctx->last_redo_planes = 0;
     if (n_planes == 0 || nmap == 0) return PM_OK;
     // propagate_nan == 0 almost always needs the statistics pass: complete such calls (and
     // whatever is pending before them) synchronously

@@ -108,7 +108,10 @@ int exchange_planes(int per_rank, size_t nmap)
 int nccl_fail(pm_ctx *ctx, pm_comm *comm, const char *what, int nrc)
 {
     Rccl *r = rccl();
-    // peers blocked in the same collective are released by tearing the communicator down
+    // ncclCommAbort frees THIS rank (kernels of the failed collective, the proxy threads); peers blocked in
+    // the same collective see it only through RCCL's own error propagation / their watchdog - the protocol
+    // of pm_map_cube_sharded therefore keeps every rank moving to the agreement for every failure that is
+    // not RCCL's own, and aborts only when the transport itself has failed
     if (comm && comm->comm && r->CommAbort && !comm->broken) {
         (void)r->CommAbort(comm->comm);
         comm->comm = nullptr;
@@ -215,15 +218,16 @@ struct Exchanger {
     int nrc = ncclSuccess;
     hipError_t herr = hipSuccess;
 
-    bool failed() const { return nrc != ncclSuccess || herr != hipSuccess; }
-    // one group of sends / receives: planes [e0, e1) of every rank's block, behind the context stream
+    // one group of sends / receives: planes [e0, e1) of every rank's block, behind the context stream.
+    // A HIP failure while ordering the exchange behind the mapping is remembered (this rank then reports
+    // itself failed in the agreement) but the group is issued all the same: the peers wait for it.
     void issue(int e0, int e1)
     {
-        if (failed()) return;
+        if (nrc != ncclSuccess) return;  // (the communicator is gone: nccl_fail() aborts it)
         Rccl *r = rccl();
-        herr = hipEventRecord(comm->ev_ready, ctx->stream);
-        if (herr == hipSuccess) herr = hipStreamWaitEvent(comm->stream, comm->ev_ready, 0);
-        if (herr != hipSuccess) return;
+        hipError_t e = hipEventRecord(comm->ev_ready, ctx->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(comm->stream, comm->ev_ready, 0);
+        if (e != hipSuccess && herr == hipSuccess) herr = e;
         const size_t count = (size_t)(e1 - e0) * nmap;
         nrc = r->GroupStart();
         for (int peer = 0; peer < comm->world && nrc == ncclSuccess; peer++) {
@@ -298,17 +302,20 @@ int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int 
     double *mine = out_all + (size_t)rank * per_rank * nmap;
     Rccl *r = rccl();
     // planes of a short last block: NaN padding, so that the gathered buffer is defined everywhere
+    int status = PM_OK;
     if (mine_n < per_rank) {
         const size_t pad = (size_t)(per_rank - mine_n) * nmap;
         std::vector<double> nanrow(std::min<size_t>(pad, nmap), std::nan(""));
-        for (size_t off = 0; off < pad; off += nanrow.size())
-            PM_HIP(ctx, hipMemcpyAsync(mine + (size_t)mine_n * nmap + off, nanrow.data(), std::min(nanrow.size(), pad - off) * sizeof(double),
-                                       hipMemcpyHostToDevice, ctx->stream));
-        PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        hipError_t he = hipSuccess;
+        for (size_t off = 0; off < pad && he == hipSuccess; off += nanrow.size())
+            he = hipMemcpyAsync(mine + (size_t)mine_n * nmap + off, nanrow.data(), std::min(nanrow.size(), pad - off) * sizeof(double),
+                                hipMemcpyHostToDevice, ctx->stream);
+        if (he == hipSuccess) he = hipStreamSynchronize(ctx->stream);
+        // (reported through the agreement, like every failure that can differ between ranks)
+        if (he != hipSuccess) status = pmh::fail(ctx, PM_ERR_HIP, "writing the padding of a short block failed: %s", hipGetErrorString(he));
     }
     Exchanger ex{ctx, comm, out_all, mine, nmap, per_rank, mine_n, exchange ? exchange_planes(per_rank, nmap) : std::max(per_rank, 1)};
-    int status = PM_OK;
-    if (mine_n > 0) {
+    if (mine_n > 0 && status == PM_OK) {
         if (!local_cube) {
             status = pmh::fail(ctx, PM_ERR_INVALID_ARGUMENT, "local_cube is NULL but this rank owns planes");
         } else {
@@ -325,35 +332,49 @@ int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int 
             if (status == PM_OK) status = pm_synchronize(ctx);
         }
     }
-    const std::string first_error = status != PM_OK ? ctx->error : std::string();
+    std::string first_error = status != PM_OK ? ctx->error : std::string();
     if (!exchange) return status;
+    // From here to the agreement nothing returns early except on a failure of RCCL itself (which aborts the
+    // communicator): a rank that left with a local error would strand its peers in their receives.
     ex.progress(per_rank);  // whatever has not been sent yet (no planes here, or a failed mapping)
-    if (ex.herr != hipSuccess) return pmh::fail(ctx, PM_ERR_HIP, "ordering the exchange failed: %s", hipGetErrorString(ex.herr));
     if (ex.nrc != ncclSuccess) return nccl_fail(ctx, comm, "exchange of mapped planes (ncclSend / ncclRecv)", ex.nrc);
+    if (ex.herr != hipSuccess && status == PM_OK) {
+        status = pmh::fail(ctx, PM_ERR_HIP, "ordering the exchange behind the mapping failed: %s", hipGetErrorString(ex.herr));
+        first_error = ctx->error;
+    }
     // the agreement: (failed ranks, ranks that redid planes after sending them)
     comm->h_status[0] = status != PM_OK ? 1 : 0;
     comm->h_status[1] = (status == PM_OK && mine_n > 0 && ctx->last_redo_planes > 0) ? 1 : 0;
-    PM_HIP(ctx, hipMemcpyAsync(comm->d_status, comm->h_status, 2 * sizeof(int), hipMemcpyHostToDevice, comm->stream));
+    comm->h_status[2] = comm->h_status[3] = 0;
+    hipError_t he = hipMemcpyAsync(comm->d_status, comm->h_status, 2 * sizeof(int), hipMemcpyHostToDevice, comm->stream);
+    if (he != hipSuccess) {
+        // this rank cannot even say that it failed: tear the communicator down rather than leave the peers in the all-reduce
+        (void)nccl_fail(ctx, comm, "the status all-reduce (could not stage this rank's status)", ncclSuccess);
+        return pmh::fail(ctx, PM_ERR_HIP, "staging the status of this rank failed: %s", hipGetErrorString(he));
+    }
     int nrc = r->AllReduce(comm->d_status, comm->d_status + 2, 2, ncclInt32, ncclSum, comm->comm, comm->stream);
     if (nrc != ncclSuccess) return nccl_fail(ctx, comm, "ncclAllReduce of the ranks' status", nrc);
-    PM_HIP(ctx, hipMemcpyAsync(comm->h_status + 2, comm->d_status + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, comm->stream));
-    PM_HIP(ctx, hipStreamSynchronize(comm->stream));
-    const int n_failed = comm->h_status[2], n_redo = comm->h_status[3];
+    he = hipMemcpyAsync(comm->h_status + 2, comm->d_status + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, comm->stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(comm->stream);
+    // (a rank that cannot read the verdict treats the call as failed; it has taken part in every collective)
+    int n_failed = he == hipSuccess ? comm->h_status[2] : -1;
+    const int n_redo = he == hipSuccess ? comm->h_status[3] : 0;
     if (n_failed == 0 && n_redo > 0) {
         // somebody's planes changed after they had been sent: everybody sends the whole block again
-        ex.nrc = ncclSuccess;
         ex.issue(0, per_rank);
-        if (ex.herr != hipSuccess) return pmh::fail(ctx, PM_ERR_HIP, "ordering the exchange failed: %s", hipGetErrorString(ex.herr));
         if (ex.nrc != ncclSuccess) return nccl_fail(ctx, comm, "second exchange of mapped planes", ex.nrc);
     }
     // pm_synchronize() / later work on the context stream waits for the exchange; so does this call
-    PM_HIP(ctx, hipEventRecord(comm->ev_done, comm->stream));
-    PM_HIP(ctx, hipStreamWaitEvent(ctx->stream, comm->ev_done, 0));
-    PM_HIP(ctx, hipStreamSynchronize(comm->stream));
+    hipError_t hw = hipEventRecord(comm->ev_done, comm->stream);
+    if (hw == hipSuccess) hw = hipStreamWaitEvent(ctx->stream, comm->ev_done, 0);
+    if (hw == hipSuccess) hw = hipStreamSynchronize(comm->stream);
     if (status != PM_OK) {
         ctx->error = first_error;
         return status;
     }
+    if (he != hipSuccess || hw != hipSuccess || ex.herr != hipSuccess)
+        return pmh::fail(ctx, PM_ERR_HIP, "the exchange of mapped planes failed on this rank: %s",
+                         hipGetErrorString(he != hipSuccess ? he : (hw != hipSuccess ? hw : ex.herr)));
     if (n_failed > 0)
         return pmh::fail(ctx, PM_ERR_PEER, "%d other rank(s) failed to map their planes: the gathered cube is not valid", n_failed);
     return PM_OK;

@@ -47,8 +47,10 @@ def exchange_planes(per_rank: int, n0: int, n1: int) -> int:
     return min(per_rank, max(by_count, by_bytes, 1))
 
 
-class PeerFailedError(RuntimeError):
-    """A sharded call failed on ANOTHER rank: the gathered result is not valid on this rank either."""
+# ONE class for "a sharded call failed on ANOTHER rank: the gathered result is not valid on this rank
+# either", whichever layer reports it: `Engine._check` for `PM_ERR_PEER` of the C ABI, `agree_on_success` /
+# `map_cube_sharded_pipelined` for the torch.distributed form
+from ._lib import PeerFailedError  # noqa: E402
 
 
 def agree_on_success(error: BaseException | None, group=None) -> None:
@@ -325,10 +327,19 @@ def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x
         # collectives are ordered behind torch's CURRENT stream: make that the engine's stream while they are queued
         ext = torch.cuda.ExternalStream(engine.stream, device=slot.device)
 
+    own_echo = []  # where the collective puts ITS copy of this rank's planes (kept alive until the works are done)
+
     def issue(e0: int, e1: int) -> None:
         if not exchange:
             return
-        outs = [gathered[r, e0:e1] for r in range(world)]
+        # The collective must not write into this rank's slot: a list all-gather lands in a flat buffer and is
+        # copied out entry by entry on the backend's own stream - this rank's entry included - unordered
+        # against the engine stream, on which a nanmedian replay may rewrite the slot with its final planes
+        # after the exchange was started. The echo of this rank's planes goes to scratch; peers' pieces go
+        # where they belong (as in the C form: sends and receives with peers only).
+        echo = torch.empty_like(slot[e0:e1])
+        own_echo.append(echo)
+        outs = [echo if r == rank else gathered[r, e0:e1] for r in range(world)]
         if ext is not None:
             with torch.cuda.stream(ext):
                 works.append(dist.all_gather(outs, slot[e0:e1], group=group, async_op=True))
@@ -387,7 +398,8 @@ def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x
     n_failed, n_redo = (int(v) for v in verdict.tolist())
     if n_failed == 0 and n_redo > 0:
         # somebody's planes changed after they had been sent: everybody gathers the whole block again
-        dist.all_gather([gathered[r] for r in range(world)], slot, group=group)
+        dist.all_gather([torch.empty_like(slot) if r == rank else gathered[r] for r in range(world)], slot, group=group)
+    own_echo.clear()
     if error is not None:
         raise error
     if n_failed > 0:

@@ -1,0 +1,120 @@
+"""
+The multi-rank code on ONE MI355X (`-m gpu`): the boxes of this pool have one GPU and RCCL refuses two ranks
+on one card ("Duplicate GPU detected", profiles/r04_multiproc_probe.jsonl), so
+
+  * the C ABI's sharded cube (`pm_comm_*`, `pm_map_cube_sharded`, planetmapper_amd/csrc/pm_comm.hip) runs at
+    world sizes 2, 3 and 8 over the loopback transport of tests/loopback, bound through the library's own
+    PM_RCCL_LIBRARY override: its Send / Recv groups issued from the chunk callback, the closing all-reduce, a
+    rank whose mapping fails, the redo round after a nanmedian replay, a failing transport;
+  * the torch.distributed form (`distributed.map_cube_sharded_pipelined`) runs with 2 and 4 REAL engines on
+    device 0 - one process each, pinned host blocks, `host_cube=True` - over a gloo group.
+
+Each rank compares the gathered cube, bit for bit, with the whole cube mapped by itself alone
+(tests/multirank_worker.py). The children are fresh processes that initialise the GPU themselves; this
+process only starts them and reads their reports (at most 4 at a time: the pool allows 6 processes on a card).
+Reference: the plane loop of Observation._get_mapped_data, observation.py:876-905.
+"""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+WORKER = os.path.join(HERE, 'multirank_worker.py')
+LOOPBACK = os.path.join(HERE, 'loopback', 'libpm_loopback_nccl.so')
+
+
+def _env(**extra):
+    env = dict(os.environ, PM_RCCL_LIBRARY=LOOPBACK, PM_LOOPBACK_TIMEOUT_S='60', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.pop('PM_LOOPBACK_HOST_ONLY', None)
+    env.update(extra)
+    return env
+
+
+def _reports(procs, timeout=600):
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+            o += '\n[test] killed after timeout'
+        outs.append(o)
+    reps = []
+    for p, o in zip(procs, outs):
+        lines = [ln for ln in o.splitlines() if ln.startswith('{')]
+        assert p.returncode == 0 and lines, o[-3000:]
+        reps.append(json.loads(lines[-1]))
+    return reps
+
+
+def _build_loopback():
+    if not os.path.exists(LOOPBACK):
+        subprocess.run(['make', '-C', os.path.join(HERE, 'loopback')], check=True)
+
+
+@pytest.mark.parametrize('world', [2, 3, 8])
+def test_c_abi_sharded_cube_over_the_loopback_transport_threads(world):
+    """ranks = threads of one child process, each with its own pm_ctx and pm_comm"""
+    _build_loopback()
+    p = subprocess.Popen([sys.executable, WORKER, 'capi', '--threads', '--world', str(world)], env=_env(),
+                         stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    (rep,) = _reports([p])
+    assert rep['ok'] and not rep['hung'], rep
+    assert set(rep['checks']) == {str(r) for r in range(world)}
+    for checks in rep['checks'].values():
+        assert set(checks) == {'device', 'host', 'pageable', 'uneven', 'redo', 'fail', 'fail_then_ok'}, checks
+    groups, sends, recvs, nbytes, allreduces, aborts = rep['loopback_stats[groups,sends,recvs,bytes,allreduces,aborts]']
+    # every call closes with one status all-reduce per rank; the exchanges are groups of (world - 1) sends and receives
+    assert allreduces >= 7 * world and sends == recvs and sends >= groups * (world - 1) > 0 and aborts == 0
+    assert nbytes > 0
+
+
+def test_c_abi_sharded_cube_survives_a_failing_transport():
+    """the third send of rank 1 fails inside the exchange: every rank returns an error, nobody waits for ever"""
+    _build_loopback()
+    world = 4
+    p = subprocess.Popen([sys.executable, WORKER, 'capi', '--threads', '--world', str(world), '--cases', 'send_fault', '--deadline', '240'],
+                         env=_env(PM_LOOPBACK_FAIL='1:3', PM_LOOPBACK_TIMEOUT_S='30'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    (rep,) = _reports([p])
+    assert rep['ok'] and not rep['hung'], rep
+    assert rep['loopback_stats[groups,sends,recvs,bytes,allreduces,aborts]'][5] >= 1
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_c_abi_sharded_cube_over_the_loopback_transport_processes(world, tmp_path):
+    """ranks = processes sharing device 0 (the shape of a real launch: one process per rank)"""
+    _build_loopback()
+    uid = str(tmp_path / 'uid')
+    procs = [subprocess.Popen([sys.executable, WORKER, 'capi', '--world', str(world), '--rank', str(r), '--uid-file', uid,
+                               '--cases', 'device,host,uneven,redo,fail'], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    reps = _reports(procs)
+    assert all(r['ok'] for r in reps), reps
+    assert sorted(r['rank'] for r in reps) == list(range(world))
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_torch_distributed_protocol_with_real_engines_sharing_one_gpu(world):
+    """map_cube_sharded_pipelined(host_cube=True): real engines, pinned blocks, gloo group, device 0 for every rank"""
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, WORKER, 'pyproto', '--cases', 'host,uneven,redo,fail'],
+                              env=_env(RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    reps = _reports(procs)
+    assert all(r['ok'] for r in reps), reps
+    for r in reps:
+        assert set(r['checks']) == {'host', 'uneven', 'redo', 'fail', 'fail_then_ok'}, r

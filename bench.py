@@ -75,6 +75,11 @@ def parse_args(argv=None):
     )  # fmt: skip
     ap.add_argument('--planes', type=int, default=512, help='cube workloads: total planes')
     ap.add_argument('--rehearse', action='store_true', help='CPU / gloo rehearsal of the N > 1 plumbing (no GPU work)')
+    ap.add_argument('--shared-gpu', action='store_true',
+                    help='N > 1 ranks that all use GPU 0, process group over gloo (RCCL refuses two ranks on one card): the '
+                    'N-rank code of the cube-host workload on a one-GPU box - one PCIe link and one CPU quota shared by '
+                    'the ranks, so the times measure host-side contention, not scaling')
+    ap.add_argument('--no-shared-gpu', action='store_true', help='default run at N = 1: skip the cube_host.shared_gpu section')
     ap.add_argument('--gather-mapped', action='store_true',
                     help='headline at N > 1: also all-gather the N mapped planes every step (the frames are '
                          'independent, so by default nothing is exchanged; the sharded-cube case with its RCCL '
@@ -220,6 +225,9 @@ class Dist:
         import torch
 
         self.torch = torch
+        self.shared_gpu = bool(getattr(args, 'shared_gpu', False))
+        if self.shared_gpu:
+            self.local_rank = 0  # every rank on the one card
         if self.rehearse:
             self.dev = torch.device('cpu')
         else:
@@ -231,7 +239,7 @@ class Dist:
             import torch.distributed as dist
 
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            if self.rehearse:
+            if self.rehearse or self.shared_gpu:
                 dist.init_process_group('gloo', rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group('nccl', rank=self.rank, world_size=self.world, device_id=self.dev)
@@ -347,25 +355,37 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     torch.from_numpy(cube_h).copy_(cube_d)
     gathered = torch.full((d.world, per_rank, n0, n1), float('nan'), dtype=torch.float64, device=d.dev)
 
-    from planetmapper_amd.distributed import exchange_planes, map_cube_sharded_pipelined
+    from planetmapper_amd.distributed import agree_on_success, exchange_planes, map_cube_sharded_pipelined
 
-    def step(fed: bool):
-        # the x/y map of the grid, then this rank's planes exchange by exchange: each one mapped,
-        # finished (flag check) and its all-gather started while the next is collected / copied / mapped;
-        # a closing 4-byte agreement on success (distributed.map_cube_sharded_pipelined)
+    slot = gathered[d.rank]
+
+    def step(fed: bool, pipelined: bool = True):
+        # the x/y map of the grid, then this rank's planes
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-        map_cube_sharded_pipelined(eng, cube_h if fed else cube_d, np.float64, planes, xm, ym, n0, n1, gathered, d.rank, d.world,
-                                   host_cube=fed)
+        if pipelined:
+            # exchange by exchange: each one mapped and its all-gather started while the next is collected /
+            # copied / mapped; a closing agreement on success (distributed.map_cube_sharded_pipelined)
+            map_cube_sharded_pipelined(eng, cube_h if fed else cube_d, np.float64, planes, xm, ym, n0, n1, gathered, d.rank, d.world,
+                                       host_cube=fed)
+            return
+        # the plain form: map the block, finish it, ONE all-gather of the slots (no callback, no overlap)
+        if mine_n > 0:
+            if fed:
+                eng.map_cube_host_to_device(cube_h[:mine_n], xm, ym, n0, n1, slot[:mine_n])
+            else:
+                eng.map_cube_device(cube_d, np.float64, mine_n, xm, ym, n0, n1, slot[:mine_n])
+        eng.synchronize()
+        d.all_gather(gathered, slot)
 
-    def run(fed: bool, steps: int):
+    def run(fed: bool, steps: int, pipelined: bool = True):
         for _ in range(2):
-            step(fed)
+            step(fed, pipelined)
         d.barrier()
         own = []
         t0 = time.perf_counter()
         for _ in range(steps):
             t = time.perf_counter()
-            step(fed)
+            step(fed, pipelined)
             d.sync()
             own.append(time.perf_counter() - t)
         d.barrier()
@@ -378,34 +398,92 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     from planetmapper_amd import _lib
 
     real = hasattr(eng, 'set_option')  # (the CPU rehearsal's engine double has no options)
-    t_res, own_res = run(False, steps_resident)
-    ref = gathered.clone()
-    t_fed, own_fed = run(True, steps_fed)
-    same = bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+    pix = planes * sz * sz
+    block_bytes = mine_n * sz * sz * 8
+    sec = {
+        'workload': f'host-resident IFU cube {planes}x{sz}x{sz} f64 -> 1 deg map ({n0}x{n1}), bilinear, '
+        f'{per_rank} planes per rank from pinned host memory, pipelined all-gather of the mapped planes '
+        f'({exchange_planes(per_rank, n0, n1)} planes per exchange) + agreement on success'
+        + ('' if d.world > 1 else ' (no collective at N=1)'),
+        'collective_backend': None if d.world == 1 else ('gloo (host-staged; every rank on GPU 0)' if d.shared_gpu else 'nccl (RCCL)'),
+        'rccl_ranks': 0 if d.shared_gpu else d.world,
+        'ranks': d.world,
+        'planes': planes,
+        'planes_per_rank': per_rank,
+        'all_gather_bytes_per_rank': per_rank * n0 * n1 * 8,
+        'pinned_alloc_ms': round(t_pin * 1e3, 1),
+        'scaling': 'strong',
+    }
+    equal = lambda: bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))  # noqa: E731
+    if d.world > 1:
+        # The plain form first: its pieces (one engine call, one all-gather) are what every other N > 1 code of
+        # this repo already does - whatever the pipelined form below does on this node, these numbers stand.
+        t_res_plain, own = run(False, steps_resident, pipelined=False)
+        ref = gathered.clone()
+        t_fed_plain, own_fed_plain = run(True, steps_fed, pipelined=False)
+        sec.update({
+            'ms_per_step_host_fed_plain_allgather': round(t_fed_plain * 1e3, 3),
+            'ms_per_step_resident_plain_allgather': round(t_res_plain * 1e3, 4),
+            'rank0_step_ms_host_fed_plain_allgather': spread(own_fed_plain),
+            'Mpix_s_host_fed_plain_allgather': round(pix / t_fed_plain / 1e6, 1),
+            'fed_equals_resident_plain_allgather': equal(),
+        })
+    # the pipelined protocol. A failure on any rank is agreed on (every rank raises or none does), so the ranks
+    # stay in step for whatever follows; the caller records it and keeps the headline.
+    error = None
+    try:
+        t_res, own_res = run(False, steps_resident)
+        if d.world == 1:
+            ref = gathered.clone()
+        same = equal()
+        t_fed, own_fed = run(True, steps_fed)
+        same = same and equal()
+    except Exception as e:  # noqa: BLE001
+        error = e
+    if d.world > 1:
+        try:
+            agree_on_success(error)
+        except Exception as e:  # noqa: BLE001
+            sec['pipelined_error'] = f'{type(e).__name__}: {e}'[:500]
+            if 'ms_per_step_host_fed_plain_allgather' in sec:
+                sec['ms_per_step_host_fed'] = sec['ms_per_step_host_fed_plain_allgather']
+                sec['Mpix_s_host_fed'] = sec['Mpix_s_host_fed_plain_allgather']
+            return sec
+    elif error is not None:
+        raise error
+    if d.world > 1:
+        # every rank feeding and mapping its block at the same time, nothing exchanged: the per-rank host leg alone
+        def nocoll():
+            eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
+            map_cube_sharded_pipelined(eng, cube_h, np.float64, planes, xm, ym, n0, n1, gathered, d.rank, d.world, host_cube=True,
+                                       gather=False)
+            d.sync()
+
+        nocoll()
+        d.barrier()
+        ts = []
+        for _ in range(steps_fed):
+            t = time.perf_counter()
+            nocoll()
+            ts.append(time.perf_counter() - t)
+        d.barrier()
+        sec['ms_per_step_host_fed_no_collective'] = round(d.max_over_ranks(float(np.median(ts))) * 1e3, 3)
+        sec['rank0_step_ms_host_fed_no_collective'] = spread(ts)
     route = eng.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) if real else None
-    route_ns = {str(r): eng.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(4)} if real else None
+    route_ns = {str(r): eng.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(_lib.NUM_CUBE_ROUTES)} if real else None
     table_hits = eng.get_option(_lib.PM_OPT_BLOCK_TABLE_HITS) if real else None
     # the same step with the GPU fetching its blocks itself over its own PCIe link (route 2: no copy
     # threads; slower on one GPU, but the leg that is private to each rank when N grows - the copy
     # threads of the default route share the host's memory system)
     t_fetch = own_fetch = None
-    if real:
+    if real and not d.shared_gpu:
         eng.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, 2)
         try:
             t_fetch, own_fetch = run(True, max(3, steps_fed // 2))
-            same = same and bool(torch.equal(torch.nan_to_num(ref, nan=-1.0), torch.nan_to_num(gathered, nan=-1.0)))
+            same = same and equal()
         finally:
             eng.set_option(_lib.PM_OPT_HOST_CUBE_ROUTE, -1)
-    pix = planes * sz * sz
-    block_bytes = mine_n * sz * sz * 8
-    sec = {
-        'workload': f'host-resident IFU cube {planes}x{sz}x{sz} f64 -> 1 deg map ({n0}x{n1}), bilinear, '
-        f'{per_rank} planes per rank from pinned host memory, pipelined RCCL all-gather of the mapped planes '
-        f'({exchange_planes(per_rank, n0, n1)} planes per exchange) + agreement on success'
-        + ('' if d.world > 1 else ' (no collective at N=1)'),
-        'rccl_ranks': d.world,
-        'planes': planes,
-        'planes_per_rank': per_rank,
+    sec.update({
         'ms_per_step_host_fed': round(t_fed * 1e3, 3),
         'ms_per_step_resident': round(t_res * 1e3, 4),
         'ms_per_step_host_fed_gpu_fetch': None if t_fetch is None else round(t_fetch * 1e3, 3),
@@ -415,18 +493,17 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         'Mpix_s_host_fed': round(pix / t_fed / 1e6, 1),
         'Mpix_s_resident': round(pix / t_res / 1e6, 1),
         'host_feed_GBps_per_rank': round(block_bytes / t_fed / 1e9, 2),
-        'host_feed': 'the route the library measured fastest on this rank (PM_OPT_HOST_CUBE_ROUTE -1: three short chunks '
+        'host_feed': 'the route the library measured fastest on this rank (PM_OPT_HOST_CUBE_ROUTE -1: one chunk '
         'through each candidate on the first call, then the fastest): 3 = the 16-byte blocks of each plane that the map '
         'samples, collected by the copy threads into pinned staging and sent by DMA; 0 = whole planes by DMA; 2 = 256-byte '
-        'blocks fetched by the GPU itself; block table cached across calls by map fingerprint',
+        'blocks fetched by the GPU itself; 4 = hybrid, chunks alternately collected by the threads and fetched by the GPU; '
+        'block table cached across calls by map fingerprint',
         'route_chosen': route,
         'route_ns_per_plane': route_ns,
+        'copy_threads': eng.get_option(_lib.PM_OPT_HOST_COPY_THREADS_IN_USE) if real else None,
         'block_table_cache_hits': table_hits,
         'fed_equals_resident': same,
-        'all_gather_bytes_per_rank': per_rank * n0 * n1 * 8,
-        'pinned_alloc_ms': round(t_pin * 1e3, 1),
-        'scaling': 'strong',
-    }
+    })
     if real and d.world == 1 and mine_n >= 16:
         sec['shard_proxy'] = shard_proxy(eng, step_fed_n=lambda n_local, n_total: _proxy_step(
             eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local, n_total, gathered), planes=planes, n0=n0, n1=n1, t_n1=t_fed,
@@ -469,7 +546,9 @@ def shard_proxy(eng, step_fed_n, planes: int, n0: int, n1: int, t_n1: float, t_n
             for label, threads in (('cores/N', max(2, cores // n)), ('cores', min(16, cores))):
                 eng.set_option(_lib.PM_OPT_HOST_COPY_THREADS, threads)
                 eng.set_option(_lib.PM_OPT_ROUTE_EXPLORE, 1)  # forget what another thread count measured
-                for _ in range(2):
+                # (untimed: the call that probes the routes, then - where the probes make a hybrid a candidate - two
+                #  whole calls each by the best single route and by the hybrid, after which the library has committed)
+                for _ in range(6):
                     step_fed_n(per, planes)
                 ts = []
                 for _ in range(7):
@@ -483,10 +562,14 @@ def shard_proxy(eng, step_fed_n, planes: int, n0: int, n1: int, t_n1: float, t_n
                 out['cases'].append({
                     'N': n, 'planes_per_rank': per, 'copy_threads': threads, 'threads_rule': label,
                     'route_chosen': eng.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE),
+                    'route_ns_per_plane': {str(r): eng.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(_lib.NUM_CUBE_ROUTES)},
                     'rank0_ms': {'median': round(t_med * 1e3, 3), 'min': round(min(ts) * 1e3, 3), 'max': round(max(ts) * 1e3, 3)},
-                    'exposed_allgather_ms_assumed': round(exposed * 1e3, 3),
-                    'predicted_step_ms': round((t_med + exposed) * 1e3, 3),
-                    'predicted_scaling': round(t_n1_median / (t_med + exposed), 2),
+                    # NOT measured: a model on top of the measured rank-0 time (one assumed link rate, no host contention)
+                    'model': {
+                        'exposed_allgather_ms_assumed': round(exposed * 1e3, 3),
+                        'step_ms': round((t_med + exposed) * 1e3, 3),
+                        'scaling_vs_n1': round(t_n1_median / (t_med + exposed), 2),
+                    },
                 })
     finally:
         eng.set_option(_lib.PM_OPT_HOST_COPY_THREADS, 0)
@@ -551,6 +634,94 @@ def host_path_section(eng, g, sz: int) -> dict:
         'the NaN outside them; the GB/s figures count the bytes DELIVERED, so they can exceed the link rate; '
         '*_whole_planes = PM_OPT_SPARSE_FRAME 0',
     }
+
+
+def api_path_section(g, sz: int, device: int) -> dict:
+    """
+    The drop-in surface itself, timed: what a user of the reference types -
+    `BodyXY.get_{lon,lat,phase_angle,incidence_angle,emission_angle}_img()` (body_xy.py:2586-2630 and the getters
+    built on `_get_lonlat_img` / `_get_illumination_gie_img`, :3281, :3658) and
+    `Observation.get_mapped_data(degree_interval=1)` (observation.py:826-872) - through the Python shim
+    (planetmapper_amd.BodyXY / Observation -> Engine -> ctypes -> C ABI), cold cache every repetition.
+    The five getters are two families, hence two `pm_backplanes_img` calls (2 + 3 planes) into fresh numpy
+    arrays; `host_path.ms_fresh_numpy_arrays` is the same 671 MB through ONE Engine call.
+    """
+    from planetmapper_amd import Observation
+
+    rng = np.random.default_rng(7)
+    data = rng.standard_normal((1, sz, sz))
+    obs = Observation(data=data, geometry=g, device=device)
+    x0 = (sz - 1) / 2
+    getters = ('get_lon_img', 'get_lat_img', 'get_phase_angle_img', 'get_incidence_angle_img', 'get_emission_angle_img')
+
+    def once():
+        obs.set_disc_params(x0, x0, 0.9 * x0, 0.0)  # (clears every cache, like the reference: body_xy.py:696-698)
+        t0 = time.perf_counter()
+        planes = [getattr(obs, name)() for name in getters]
+        t1 = time.perf_counter()
+        mapped = obs.get_mapped_data(degree_interval=1)
+        t2 = time.perf_counter()
+        assert all(p.shape == (sz, sz) for p in planes) and mapped.shape == (1, 180, 360)
+        return t1 - t0, t2 - t1
+
+    once()
+    reps = [once() for _ in range(7)]
+    imgs, maps = [r[0] for r in reps], [r[1] for r in reps]
+    tot = [a + b for a, b in reps]
+    ms = lambda ts: {'median': round(float(np.median(ts)) * 1e3, 2), 'min': round(min(ts) * 1e3, 2), 'max': round(max(ts) * 1e3, 2),  # noqa: E731
+                     'reps': len(ts)}
+    return {
+        'calls': 'Observation(data=(1, %d, %d) f64).get_{lon,lat,phase_angle,incidence_angle,emission_angle}_img() + '
+        'get_mapped_data(degree_interval=1), cold cache, through the Python shim' % (sz, sz),
+        'ms': ms(tot),
+        'ms_five_backplane_getters': ms(imgs),
+        'ms_get_mapped_data': ms(maps),
+        'Mpix_s_median': round(sz * sz / float(np.median(tot)) / 1e6, 1),
+        'note': 'compare ms_five_backplane_getters with host_path.ms_fresh_numpy_arrays (the same planes through one '
+        'Engine call); get_mapped_data adds the host-resident data plane (134 MB, of which the sampled blocks cross PCIe)',
+    }
+
+
+def shared_gpu_section(args) -> dict:
+    """
+    The N-rank code of the sharded host-fed cube, EXECUTED on this one GPU: for N = 2 and 4 this process starts
+    `torch.distributed.run` with N fresh ranks of `bench.py --workload cube-host --shared-gpu` - every rank a real
+    engine on GPU 0 with its own pinned block of ceil(P / N) planes, the process group over gloo (RCCL refuses two
+    ranks on one card), `LOCAL_WORLD_SIZE` = N so that each rank takes cores / N copy threads by the library's own
+    rule. All ranks collect at once: the host-memory and CPU-quota contention that `shard_proxy` (one rank alone)
+    leaves out is in these times. What they are NOT: a scaling figure - the N ranks share ONE PCIe link (the bytes
+    over it do not shrink with N) and the collective is gloo's host-staged one, not RCCL over xGMI.
+    N = 8 is not run: the pool allows six processes on a card.
+    """
+    out = {'what': 'N real ranks on ONE GPU (gloo group, one PCIe link and one CPU quota shared): measured, not a scaling figure',
+           'runs': []}
+    for n in (2, 4):
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port()), os.path.abspath(__file__), '--gpus', str(n), '--workload', 'cube-host',
+               '--shared-gpu', '--planes', str(args.planes), '--steps', '7']
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        env.setdefault('OMP_NUM_THREADS', '1')
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+        except subprocess.TimeoutExpired:
+            out['runs'].append({'N': n, 'error': 'timed out after 420 s'})
+            break
+        wall = time.perf_counter() - t0
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+        if p.returncode != 0 or not lines:
+            out['runs'].append({'N': n, 'error': f'rc {p.returncode}: ' + (p.stdout + p.stderr)[-600:]})
+            break
+        sec = json.loads(lines[-1]).get('cube_host', {})
+        keep = ('ranks', 'collective_backend', 'planes_per_rank', 'copy_threads', 'route_chosen', 'route_ns_per_plane',
+                'ms_per_step_host_fed_no_collective', 'rank0_step_ms_host_fed_no_collective',
+                'ms_per_step_host_fed', 'rank0_step_ms_host_fed', 'ms_per_step_resident',
+                'ms_per_step_host_fed_plain_allgather', 'fed_equals_resident', 'fed_equals_resident_plain_allgather', 'pipelined_error')
+        run = {'N': n, 'wall_s': round(wall, 1)}
+        run.update({k: sec[k] for k in keep if k in sec})
+        out['runs'].append(run)
+    return out
 
 
 # ------------------------------------------------------------------ secondary workloads
@@ -851,14 +1022,21 @@ def headline(args) -> None:
         line['cpu_baseline_1thread'] = cpu_baseline(g, sz, 1, budget_s=8.0, max_frames=1)
         line['cpu_model'] = cpu_model()
     if not args.no_extras:
+        if d.world > 1 and d.rank == 0:
+            # The headline of an N > 1 run is out BEFORE the extra sections start: the sharded host-fed cube below
+            # issues collectives from inside the engine's chunk callback, which has run on one GPU (gloo, loopback
+            # transport) but never over RCCL between GPUs - if that hangs and the run is killed, this line stands.
+            # The complete line (same fields + cube_host) follows when the sections are through.
+            print(json.dumps(dict(line, extras='pending: the complete line, with cube_host, follows')), flush=True)
         if d.world == 1 and d.rank == 0:
             line['host_path'] = host_path_section(eng, g, sz)
-        # (its own failure must not cost the headline line: the section's code path at N > 1 - pipelined NCCL
-        #  all-gathers from inside the engine's chunk callback - has only ever run under gloo and at N = 1)
+            line['api_path'] = api_path_section(g, sz, d.local_rank)
         try:
             sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50)
         except Exception as e:  # noqa: BLE001
             sec = {'error': f'{type(e).__name__}: {e}'[:500]}
+        if d.world == 1 and d.rank == 0 and not args.no_shared_gpu and 'error' not in sec:
+            sec['shared_gpu'] = shared_gpu_section(args)
         if d.rank == 0:
             line['cube_host'] = sec
     if d.rank == 0:

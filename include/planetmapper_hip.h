@@ -237,19 +237,27 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           0 = whole planes by DMA;
  *                           1 = a PINNED cube (pm_host_alloc / pm_host_register) is gathered in
  *                               place by the reprojection kernel;
- *                           2 = the 256-byte blocks of a plane that the map samples (the same in
+ *                           2 = the 128-byte blocks (PM_OPT_FETCH_BLOCK_BYTES) of a plane that the map samples (the same in
  *                               every plane; found once per call by the sampling code itself) are
  *                               fetched by the GPU from a PINNED cube, once each, into a table in
  *                               HBM and sampled from there;
  *                           3 = the same table in 16-byte blocks, collected by the copy threads
  *                               into pinned staging and sent by DMA - any host memory; the link
  *                               carries little more than the sampled pixels;
+ *                           4 = hybrid of 2 and 3 for a PINNED cube and a rank short of CPU threads:
+ *                               short chunks of planes, alternately fetched by the GPU and collected by
+ *                               the threads, so that the threads collect chunk k + 1 while the GPU's
+ *                               reads of chunk k cross the link; the share of fetched planes is the one
+ *                               at which both legs take the same time by the measured rates (one half
+ *                               when forced before anything was measured);
  *                          -1 (default) = the library chooses, per context (i.e. per rank of a sharded
  *                               cube), the route that MEASURED fastest on the problem at hand: the first
  *                               call with enough planes feeds three short chunks through each candidate
  *                               (3, 0, and 2 for a pinned cube), times them, and maps the rest - and
  *                               every later call on the same plane size / map / memory kind / thread
- *                               count - by the fastest (results are bit-identical whatever the route).
+ *                               count - by the fastest, or by 4 where the measured rates of 2 and 3
+ *                               predict a hybrid 7 % or more faster than either (kept only while whole
+ *                               calls confirm it; results are bit-identical whatever the route).
  *                               Until then: 3 when the table is under 40 % of the size of the planes,
  *                               else 0.
  *                           (1 and 2 on pageable memory, 2 and 3 on planes that are not a whole
@@ -270,7 +278,15 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *   PM_OPT_ROUTE_EXPLORE    1 (default): measure the candidate routes as described under
  *                           PM_OPT_HOST_CUBE_ROUTE -1; 0: choose by table size only. Setting it (to either
  *                           value) forgets what has been measured.
- *   PM_OPT_LAST_CUBE_ROUTE  read-only: the route (0..3) the latest host-cube call ended on, -1 none yet.
+ *   PM_OPT_LAST_CUBE_ROUTE  read-only: the route (0..4) the latest host-cube call ended on, -1 none yet.
+ *   PM_OPT_FETCH_BLOCK_BYTES 128 (default), 64 or 256: the size of the blocks of routes 2 and 4 (the GPU's own reads
+ *                           of a pinned cube). 128 bytes is the granularity of PCIe reads: at BASELINE config 5 it
+ *                           moves 4.2 MB per plane instead of the 4.7 MB of 256-byte blocks and measured 8 % faster
+ *                           (64 planes: 5.46 against 5.95 ms; 64-byte blocks 5.60 ms, profiles/r04_route_ab.jsonl).
+ *   PM_OPT_HYBRID_FETCH_PERMILLE read-only: the share of planes (in 1/1000) a hybrid segment (route 4) has the GPU
+ *                           fetch on the current problem; 0 while no hybrid has been planned.
+ *   PM_OPT_HOST_COPY_THREADS_IN_USE read-only: the copy threads the host pipe of this context runs with (0 before
+ *                           its first host-buffer call).
  *   PM_OPT_FUSE_PLANES      1: an image-plane request that holds planes of the intercept AND planes every pixel
  *                           has (RA / Dec, pixel x / y, km, angular, limb) runs as ONE launch on the spheroid
  *                           fast path (k_disc_sph<FLAGS, TRI, SKY>); 0 (default): one launch per group. The same
@@ -301,7 +317,10 @@ typedef enum pm_option {
     PM_OPT_LAST_CUBE_ROUTE = 10,
     PM_OPT_LAST_REDO_PLANES = 11,
     PM_OPT_FUSE_PLANES = 12,
-    PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..3 */
+    PM_OPT_HOST_COPY_THREADS_IN_USE = 13,
+    PM_OPT_HYBRID_FETCH_PERMILLE = 14,
+    PM_OPT_FETCH_BLOCK_BYTES = 15,
+    PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..4 */
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);
 int pm_get_option(pm_ctx *ctx, int option, int64_t *value);

@@ -74,7 +74,11 @@ PM_OPT_ROUTE_EXPLORE = 9
 PM_OPT_LAST_CUBE_ROUTE = 10
 PM_OPT_LAST_REDO_PLANES = 11
 PM_OPT_FUSE_PLANES = 12
-PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..3
+PM_OPT_HOST_COPY_THREADS_IN_USE = 13
+PM_OPT_HYBRID_FETCH_PERMILLE = 14
+PM_OPT_FETCH_BLOCK_BYTES = 15
+PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..4
+NUM_CUBE_ROUTES = 5
 
 
 # pm_chunk_callback: void (*)(void *user, int first_plane, int n_planes)

@@ -467,7 +467,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         ctx->host_copy_threads = (int)value;
         return PM_OK;
     case PM_OPT_ZERO_COPY:
-        if (value < -1 || value > 3) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_ZERO_COPY takes -1 .. 3");
+        if (value < -1 || value > 4) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_HOST_CUBE_ROUTE takes -1 .. 4");
         ctx->zero_copy = (int)value;
         return PM_OK;
     case PM_OPT_SPARSE_FRAME:
@@ -480,6 +480,11 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_FUSE_PLANES:
         ctx->fuse_planes = value != 0;
         return PM_OK;
+    case PM_OPT_FETCH_BLOCK_BYTES:
+        if (value != 64 && value != 128 && value != 256) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_FETCH_BLOCK_BYTES takes 64, 128 or 256");
+        ctx->fetch_shift = value == 64 ? 6 : value == 128 ? 7 : 8;
+        pipe_reset_route_stats(ctx);
+        return PM_OK;
     case PM_OPT_ROUTE_EXPLORE:
         ctx->route_explore = value != 0;
         pipe_reset_route_stats(ctx);  // (what was measured is forgotten: the next large call measures again)
@@ -488,6 +493,8 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_LAST_CUBE_ROUTE:
     case PM_OPT_LAST_REDO_PLANES:
     case PM_OPT_LAST_DISC_KERNEL:
+    case PM_OPT_HOST_COPY_THREADS_IN_USE:
+    case PM_OPT_HYBRID_FETCH_PERMILLE:
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "option %d is read-only", option);
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -515,10 +522,13 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_FUSE_PLANES: *value = ctx->fuse_planes; return PM_OK;
     case PM_OPT_BLOCK_TABLE_HITS: *value = pipe_table_hits(ctx); return PM_OK;
     case PM_OPT_ROUTE_EXPLORE: *value = ctx->route_explore; return PM_OK;
+    case PM_OPT_FETCH_BLOCK_BYTES: *value = 1 << ctx->fetch_shift; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
+    case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;
+    case PM_OPT_HYBRID_FETCH_PERMILLE: *value = pipe_hybrid_fetch_permille(ctx); return PM_OK;
     }
-    if (option >= PM_OPT_ROUTE_NS_PER_PLANE && option < PM_OPT_ROUTE_NS_PER_PLANE + 4) {
+    if (option >= PM_OPT_ROUTE_NS_PER_PLANE && option < PM_OPT_ROUTE_NS_PER_PLANE + 5) {
         *value = pipe_route_ns_per_plane(ctx, option - PM_OPT_ROUTE_NS_PER_PLANE);
         return PM_OK;
     }

@@ -108,6 +108,7 @@ struct pm_ctx {
     int lt_mode = 0;             // env PM_LT_MODE at pm_create (A/B runs of tools/): 0 closed-form light time of the
                                  // spheroid kernel, 1 the reference's sequence of epochs, 2 Newton step on its seed
     int route_explore = 1;       // PM_OPT_ROUTE_EXPLORE
+    int fetch_shift = 7;         // PM_OPT_FETCH_BLOCK_BYTES: log2 of the blocks the GPU fetches from a pinned cube (routes 2, 4)
     int last_cube_route = -1;    // PM_OPT_LAST_CUBE_ROUTE
     int last_redo_planes = 0;    // PM_OPT_LAST_REDO_PLANES: planes of the latest finished pm_map_cube redone with their nanmedian
     // pm_set_chunk_callback: told, on the calling thread, each time the kernels of further planes of a
@@ -149,6 +150,8 @@ void pipe_destroy(pm_ctx *ctx);
 // counters / measurements of the host pipe for pm_get_option (0 when the pipe does not exist yet)
 long pipe_table_hits(const pm_ctx *ctx);
 long pipe_route_ns_per_plane(const pm_ctx *ctx, int route);
+int pipe_copy_threads(const pm_ctx *ctx);
+long pipe_hybrid_fetch_permille(const pm_ctx *ctx);
 void pipe_reset_route_stats(pm_ctx *ctx);
 bool host_is_pinned(const void *p, size_t bytes);
 // dst_host <- src_dev on `stream` (staged through pinned buffers + copy threads for pageable

@@ -27,10 +27,16 @@
 //     prefetchers) while the DMA of the previous chunk's table runs, and k_reproject_blocks samples
 //     the table: 0.59 GB cross the link instead of 4.3 GB (16-35 ms depending on the host, pageable
 //     or pinned cube alike);
-//   * a PINNED cube without CPU threads: the GPU fetches the 256-byte blocks the map samples, each
-//     once, into the table (PM_OPT_ZERO_COPY 2: 2.4 GB at the full PCIe rate, 47 ms), or the
-//     reprojection kernel gathers from host memory in place (1: uncached 128-byte line requests that
-//     neighbouring waves repeat, 68-71 ms; the result can be stored straight into a pinned output).
+//   * a PINNED cube without CPU threads: the GPU fetches the 128-byte blocks the map samples (the granularity
+//     of PCIe reads; PM_OPT_FETCH_BLOCK_BYTES), each once, into the table (PM_OPT_HOST_CUBE_ROUTE 2: 2.2 GB over
+//     the link, 44 ms), or the reprojection kernel gathers from host memory in place (1: uncached 128-byte
+//     line requests that neighbouring waves repeat, 68-71 ms; the result can be stored straight into a pinned
+//     output);
+//   * a pinned cube and FEW CPU threads (a rank of a sharded cube whose node shares one CPU quota): a hybrid
+//     of the last two (4) - short chunks of planes dealt out as the call runs, to the GPU's fetch while fewer
+//     than two of its chunks are queued, else to the copy threads, who collect while those fetches cross the
+//     link; the split follows the speed of the two legs by itself (64 planes, 2 threads: 3.7-4.6 ms against
+//     5.5-6.0 fetched and 6.3-9.1 collected, box to box; tools/route_ab.py).
 //
 // No compute happens on the CPU here: the threads move bytes (and write the constant NaN where the
 // kernels' own pre-mask says nothing else can be).
@@ -93,12 +99,14 @@ struct HostPipe : HostPool {
     static constexpr int kRing = 3;
     hipEvent_t ev_in[kRing] = {}, ev_k[kRing] = {};
     hipEvent_t ev_tmp = nullptr;
+    static constexpr int kFq = 4;  // GPU-fetched chunks of a hybrid segment in flight at most (+1: ring of events)
+    hipEvent_t ev_f0[kFq] = {}, ev_f1[kFq] = {};  // start / end of each (timing enabled: the fetch rate is measured as it runs)
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // (with timing: stage times of a probe chunk)
     // ---- pinned staging of the H2D leg of block tables collected by the pool (one per ring slot)
     char *in_stage[kRing] = {};
     size_t in_stage_bytes = 0;
     // ---- how a host cube crosses the link (PM_OPT_HOST_CUBE_ROUTE)
-    enum Route : int { kWhole = 0, kInPlace = 1, kFetch = 2, kCollect = 3 };
+    enum Route : int { kWhole = 0, kInPlace = 1, kFetch = 2, kCollect = 3, kHybrid = 4, kRoutes = 5 };
     // ---- a block table's bookkeeping (grow-only buffers): flags / tile sums / block -> row / row -> block
     // on the device, the pinned host mirror of the count + list - and what they currently describe: the
     // table is kept between calls and reused while the x/y map (by fingerprint), the plane geometry and
@@ -113,7 +121,7 @@ struct HostPipe : HostPool {
         size_t n_map = 0, plane_bytes = 0, esz = 0, n_list = 0;
         int shift = 0, ny = 0, nx = 0, interpolation = 0, propagate_nan = 0;
     };
-    Table tab[2];  // [0]: 16-byte blocks (collected by the pool), [1]: 256-byte blocks (fetched by the GPU)
+    Table tab[2];  // [0]: 16-byte blocks (collected by the pool), [1]: the GPU's fetch blocks (128 bytes; `t256`, `have256` below keep the names of its first size)
     unsigned long long *d_hash = nullptr, *h_hash = nullptr;
     long table_hits = 0, table_builds = 0;
     // ---- what each route has cost on the problem at hand (ns per plane, whole pipeline), measured
@@ -121,8 +129,19 @@ struct HostPipe : HostPool {
         size_t plane_bytes = 0, n_list16 = 0, esz = 0;
         bool pinned = false, device_out = false;
         int threads = 0;
-        double ns_per_plane[4] = {0.0, 0.0, 0.0, 0.0};  // 0: not measured yet
+        double ns_per_plane[kRoutes] = {0.0, 0.0, 0.0, 0.0, 0.0};  // 0: not measured yet
+        // the two legs of the collected route, apart (probe chunk): the copy threads' collection and the DMA of
+        // the table - what a hybrid's split is computed from
+        double collect_cpu_ns = 0.0, collect_dma_ns = 0.0;
+        double hybrid_fetch_share = 0.0;  // of the planes of a hybrid segment: fetched by the GPU
+        double hybrid_fetch_ns = 0.0;     // the GPU's fetch per plane as measured INSIDE hybrid segments (the link is shared there)
         int committed = -1;
+        // a hybrid is a candidate on the strength of single-chunk probes, which are noisy (cold threads, a lone chunk):
+        // it is committed only after WHOLE calls by the best single route and by the hybrid have been timed in turn
+        int single = -1;            // the best single route by the probes
+        bool trial = false;         // whole calls still alternate between `single` and the hybrid
+        double trial_ns[2] = {0.0, 0.0};  // [0] single, [1] hybrid: fastest whole call so far, ns per plane
+        int trial_n[2] = {0, 0};
     };
     RouteStats rstats;
     double *d_maps = nullptr;  // the x/y maps of a PM_MEM_HOST call
@@ -142,6 +161,10 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
             PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_k[i], hipEventDisableTiming));
         }
         PM_HIP(ctx, hipEventCreateWithFlags(&hp->ev_tmp, hipEventDisableTiming));
+        for (int i = 0; i < HostPipe::kFq; i++) {
+            PM_HIP(ctx, hipEventCreate(&hp->ev_f0[i]));
+            PM_HIP(ctx, hipEventCreate(&hp->ev_f1[i]));
+        }
         PM_HIP(ctx, hipEventCreate(&hp->ev_t0));
         PM_HIP(ctx, hipEventCreate(&hp->ev_t1));
         for (int i = 0; i < HostPipe::kSlots; i++)
@@ -193,6 +216,10 @@ void pipe_destroy(pm_ctx *ctx)
         if (hp->ev_k[i]) (void)hipEventDestroy(hp->ev_k[i]);
     }
     if (hp->ev_tmp) (void)hipEventDestroy(hp->ev_tmp);
+    for (int i = 0; i < HostPipe::kFq; i++) {
+        if (hp->ev_f0[i]) (void)hipEventDestroy(hp->ev_f0[i]);
+        if (hp->ev_f1[i]) (void)hipEventDestroy(hp->ev_f1[i]);
+    }
     if (hp->ev_t0) (void)hipEventDestroy(hp->ev_t0);
     if (hp->ev_t1) (void)hipEventDestroy(hp->ev_t1);
     if (hp->s_in) (void)hipStreamDestroy(hp->s_in);
@@ -204,9 +231,11 @@ void pipe_destroy(pm_ctx *ctx)
 long pipe_table_hits(const pm_ctx *ctx) { return ctx->pipe ? ctx->pipe->table_hits : 0; }
 long pipe_route_ns_per_plane(const pm_ctx *ctx, int route)
 {
-    if (!ctx->pipe || route < 0 || route > 3) return 0;
+    if (!ctx->pipe || route < 0 || route >= HostPipe::kRoutes) return 0;
     return (long)ctx->pipe->rstats.ns_per_plane[route];
 }
+long pipe_hybrid_fetch_permille(const pm_ctx *ctx) { return ctx->pipe ? (long)std::llround(ctx->pipe->rstats.hybrid_fetch_share * 1000.0) : 0; }
+int pipe_copy_threads(const pm_ctx *ctx) { return ctx->pipe ? (int)ctx->pipe->workers.size() + 1 : 0; }
 void pipe_reset_route_stats(pm_ctx *ctx)
 {
     if (ctx->pipe) ctx->pipe->rstats = HostPipe::RouteStats{};
@@ -467,14 +496,23 @@ struct Segment {
 
 struct SegLayout {
     size_t chunk, batch, slot_bytes, table_row_bytes, blk_off, need;
+    size_t chunk_f = 0, table_row_bytes_f = 0;  // hybrid: planes per GPU-fetched chunk, one plane's rows of the fetched table
     bool zero_copy, direct_out;
 };
 
-SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, size_t n_list, int shift, bool dst_pinned)
+// planes per chunk of a hybrid segment: collected chunks, and the (shorter) GPU-fetched ones, of which up to
+// kHybridInFlight are queued ahead of the threads
+constexpr size_t kHybridCollectChunk = 4, kHybridFetchChunk = 4;
+constexpr int kHybridInFlight = 2;
+
+// (hybrid: n_list / shift describe the 16-byte table, n_list_f the fetched one)
+SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, size_t n_list, int shift, bool dst_pinned, size_t n_list_f = 0,
+                     double fetch_share = 0.5)
 {
     SegLayout L{};
     const size_t nmap = j.nmap;
-    const bool gather = sg.route == HostPipe::kInPlace, blocks = sg.route == HostPipe::kFetch, host_blocks = sg.route == HostPipe::kCollect;
+    const bool hybrid = sg.route == HostPipe::kHybrid;
+    const bool gather = sg.route == HostPipe::kInPlace, blocks = sg.route == HostPipe::kFetch, host_blocks = sg.route == HostPipe::kCollect || hybrid;
     L.zero_copy = gather || blocks;  // no staging ring: the kernels read the caller's cube
     L.table_row_bytes = (blocks || host_blocks) ? n_list << shift : 0;  // one plane's rows of the block table
     size_t chunk = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
@@ -484,6 +522,15 @@ SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, siz
     if (host_blocks)  // chunks of the table, not of the cube (smaller chunks for short cubes: no gain, measured)
         chunk = std::min<size_t>(std::max<size_t>(1, ctx->host_chunk_bytes / L.table_row_bytes), std::min<size_t>(sg.n, 32768));
     if (sg.chunk) chunk = std::min<size_t>(sg.chunk, sg.n);
+    if (hybrid) {
+        // short chunks, dealt out as the segment runs (run_segment): to the GPU while fewer than kHybridInFlight
+        // fetched chunks are queued, else to the copy threads
+        (void)fetch_share;
+        chunk = std::min<size_t>(kHybridCollectChunk, sg.n);
+        L.table_row_bytes_f = n_list_f << ctx->fetch_shift;
+        // (the closing chunk of a segment may hand the GPU whatever is left after the threads' last share)
+        L.chunk_f = std::min<size_t>(sg.n, std::max<size_t>(kHybridFetchChunk, 3 * kHybridCollectChunk));
+    }
     L.chunk = chunk;
     L.batch = std::min<size_t>(sg.n, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
     L.slot_bytes = ((host_blocks ? chunk * L.table_row_bytes : chunk * j.plane_bytes) + 255) & ~(size_t)255;
@@ -494,6 +541,7 @@ SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, siz
     if (!L.direct_out) need += L.batch * nmap * sizeof(double);
     L.blk_off = (need + 255) & ~(size_t)255;  // the table of a GPU-fetched chunk
     if (blocks) need = L.blk_off + chunk * L.table_row_bytes;
+    if (hybrid) need = L.blk_off + L.chunk_f * L.table_row_bytes_f;
     L.need = need;
     return L;
 }
@@ -504,30 +552,73 @@ SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, siz
 // what a long run of such chunks costs per chunk once the stages overlap: the copy threads' collection
 // against the DMA of the table (3), the DMA of the planes (0), the GPU's own fetch over the link (2).
 // (The wall time of a lone chunk would add the stages up and charge the pipeline's fill to the route.)
+// A hybrid segment (route 4) deals its chunks out between the GPU's fetch (`tab_f`, the table of fetch blocks) and the
+// copy threads (`tab`, the 16-byte table) as it runs: see the loop. `stage2` (probes): [0] the CPU leg, [1] the device leg of the stage.
 int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, const SegLayout &L, const HostPipe::Table *tab,
-                const double *dxm, const double *dym, const char *cube_dev, double *out_dev, double *stage_ns)
+                const double *dxm, const double *dym, const char *cube_dev, double *out_dev, double *stage_ns, double *stage2 = nullptr,
+                const HostPipe::Table *tab_f = nullptr, double *hybrid_obs = nullptr)
 {
+    // (hybrid_obs, hybrid segments. In: [0] ns per plane the threads took to collect in earlier calls, [2] the GPU to
+    //  fetch. Out: [0] ns the threads spent collecting, [1] planes they collected, [2] ns the GPU spent fetching,
+    //  [3] planes it fetched)
+    double hy_cpu_ns = 0.0, hy_c_planes = 0.0, hy_f_ns = 0.0, hy_f_planes = 0.0;
+    // GPU-fetched chunks of a hybrid segment in flight: [f_tail, f_head) in the ring of event pairs
+    size_t f_head = 0, f_tail = 0, f_planes_out = 0;
+    size_t f_np[HostPipe::kFq] = {};
+    double t_f_est = hybrid_obs ? hybrid_obs[2] : 0.0, t_c_est = hybrid_obs ? hybrid_obs[0] : 0.0;  // ns per plane, from earlier calls
+    bool endgame_done = false;
+    auto retire_fetched = [&](bool wait) -> int {
+        while (f_tail < f_head) {
+            const int k = (int)(f_tail % HostPipe::kFq);
+            if (wait) {
+                PM_HIP(ctx, hipEventSynchronize(hp->ev_f1[k]));
+            } else {
+                const hipError_t q = hipEventQuery(hp->ev_f1[k]);
+                if (q == hipErrorNotReady) {
+                    (void)hipGetLastError();
+                    break;
+                }
+                PM_HIP(ctx, q);
+            }
+            float ms = 0.0f;
+            PM_HIP(ctx, hipEventElapsedTime(&ms, hp->ev_f0[k], hp->ev_f1[k]));
+            hy_f_ns += (double)ms * 1e6;
+            hy_f_planes += (double)f_np[k];
+            f_planes_out -= f_np[k];
+            f_tail++;
+        }
+        return PM_OK;
+    };
     double cpu_stage_ns = 0.0;
     bool timed_events = false;
     const hipStream_t sk = ctx->stream;
     const size_t nmap = j.nmap;
-    const bool blocks = sg.route == HostPipe::kFetch, host_blocks = sg.route == HostPipe::kCollect;
+    const bool hybrid = sg.route == HostPipe::kHybrid;
+    const bool seg_blocks = sg.route == HostPipe::kFetch, seg_host_blocks = sg.route == HostPipe::kCollect;
     char *base = (char *)ctx->scratch;
     char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
     double *dout_all = (double *)(ring + (L.zero_copy ? 0 : HostPipe::kRing * L.slot_bytes));
-    pm::BlockTable table{};
-    if (blocks || host_blocks) {
-        table.blkmap = tab->d_blkmap;
-        table.blklist = tab->d_blklist;
-        table.n_list = (unsigned)tab->n_list;
-        table.shift = tab->shift;
-        table.plane_bytes = j.plane_bytes;
+    auto describe = [&](const HostPipe::Table *t) {
+        pm::BlockTable bt{};
+        bt.blkmap = t->d_blkmap;
+        bt.blklist = t->d_blklist;
+        bt.n_list = (unsigned)t->n_list;
+        bt.shift = t->shift;
+        bt.plane_bytes = j.plane_bytes;
+        return bt;
+    };
+    pm::BlockTable table{}, table_f{};
+    if (seg_blocks || seg_host_blocks || hybrid) table = describe(tab);
+    if (seg_blocks) table.table = base + L.blk_off;
+    if (hybrid) {
+        table_f = describe(tab_f);
+        table_f.table = base + L.blk_off;
     }
-    if (blocks) table.table = base + L.blk_off;
-    const int *hlist = (host_blocks && tab->h_list) ? tab->h_list + 16 : nullptr;
+    const int *hlist = ((seg_host_blocks || hybrid) && tab->h_list) ? tab->h_list + 16 : nullptr;
     int rc;
     // s_out drains finished output while later chunks are still being copied in / mapped
-    size_t c = 0;  // running chunk number of the segment (ring slot = c % kRing)
+    size_t c = 0;   // running chunk number of the segment
+    size_t cs = 0;  // running number of the chunks that use a ring slot (slot = cs % kRing; hybrid: the collected ones)
     for (size_t b0 = 0; b0 < sg.n; b0 += L.batch) {
         const size_t nb = std::min(L.batch, sg.n - b0);
         size_t drained = 0;  // planes of this batch already handed to the D2H leg
@@ -536,31 +627,69 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
         //  to shorten the pipeline's fill and drain for short blocks. Same-box A/B, 64 and 512 planes, three
         //  process pairs: 2.26-2.86 vs 2.17-2.52 ms and 11.9-16.3 vs 13.0-14.6 ms - inside the run-to-run
         //  spread of the collecting threads' placement; not kept.)
-        for (size_t q0 = 0; q0 < nb; q0 += L.chunk, c++) {
-            const size_t np = std::min(L.chunk, nb - q0);
+        size_t np = 0;
+        for (size_t q0 = 0; q0 < nb; q0 += np, c++) {
+            // Hybrid: chunks are dealt out as the segment runs - to the GPU while fewer than kHybridInFlight of its
+            // fetches are queued, else to the copy threads (who collect while those fetches cross the link): the
+            // split follows the speed of the two legs by itself. Only the END needs rates: when little is left, the
+            // threads take the share x of it that lets both legs finish together - x t_c = (queued + rest - x) t_f,
+            // with t_c, t_f as measured in this segment so far (earlier calls before that) - and the GPU the rest.
+            bool fetch_chunk = false;
+            size_t want = L.chunk;
+            if (hybrid) {
+                if ((rc = retire_fetched(false)) != PM_OK) return rc;
+                const size_t rest = nb - q0;
+                const double tc = hy_c_planes > 0.0 ? hy_cpu_ns / hy_c_planes : t_c_est;
+                const double tf = hy_f_planes > 0.0 ? hy_f_ns / hy_f_planes : t_f_est;
+                if (!endgame_done && rest <= 2 * kHybridCollectChunk + kHybridFetchChunk && tc > 0.0 && tf > 0.0) {
+                    const double x = (double)(f_planes_out + rest) * tf / (tc + tf);
+                    const size_t xc = std::min<size_t>(rest, (size_t)std::llround(x));
+                    // (a collected chunk never exceeds the ring slot: a larger share is taken in two goes)
+                    endgame_done = xc <= L.chunk;
+                    fetch_chunk = xc == 0;
+                    want = fetch_chunk ? rest : std::min(xc, L.chunk);
+                } else if (endgame_done) {
+                    fetch_chunk = true;  // what the threads' last share left over
+                    want = rest;
+                } else {
+                    fetch_chunk = (int)(f_head - f_tail) < kHybridInFlight;
+                    want = fetch_chunk ? kHybridFetchChunk : kHybridCollectChunk;
+                }
+                if (fetch_chunk) want = std::min(want, L.chunk_f);
+                if (fetch_chunk && (int)(f_head - f_tail) >= HostPipe::kFq && (rc = retire_fetched(true)) != PM_OK) return rc;
+            }
+            const bool blocks = seg_blocks || fetch_chunk, host_blocks = seg_host_blocks || (hybrid && !fetch_chunk);
+            const bool chunk_zero_copy = L.zero_copy || fetch_chunk;
+            np = std::min(want, nb - q0);
             const size_t pl = sg.p0 + b0 + q0;  // first plane of the chunk within the call
-            const int slot = (int)(c % HostPipe::kRing);
+            const int slot = (int)(cs % HostPipe::kRing);
+            const size_t cslot = cs;  // (this chunk's number among the slot users)
+            if (!chunk_zero_copy) cs++;
             pm::ReprojectArgs b = j.a;
             b.x_map = dxm;
             b.y_map = dym;
             b.n_planes = (int)np;
             b.plane_flags = ctx->flags + pl;
             b.out = L.direct_out ? out_dev + pl * nmap : dout_all + q0 * nmap;
-            pm::BlockTable tb = table;
-            if (L.zero_copy) {
+            pm::BlockTable tb = fetch_chunk ? table_f : table;
+            if (chunk_zero_copy) {
                 b.cube = cube_dev + pl * j.plane_bytes;
             } else if (host_blocks) {
                 // the pool fills this slot's pinned buffer (free once the DMA of three chunks ago is
                 // done) while the DMA of the previous chunk runs
                 char *dslot = ring + (size_t)slot * L.slot_bytes;
-                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
-                const double tg = stage_ns ? now_ns() : 0.0;
+                if (cslot >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
+                const double tg = (stage_ns || hybrid) ? now_ns() : 0.0;
                 hp->gather(hp->in_stage[slot], j.cube + pl * j.plane_bytes, j.plane_bytes, np, hlist, tab->n_list, tab->shift);
                 if (stage_ns) cpu_stage_ns += now_ns() - tg;
-                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
-                if (stage_ns && c == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
+                if (hybrid) {
+                    hy_cpu_ns += now_ns() - tg;
+                    hy_c_planes += (double)np;
+                }
+                if (cslot >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                if (stage_ns && cslot == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
                 PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * L.table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
-                if (stage_ns && c == 0) {
+                if (stage_ns && cslot == 0) {
                     PM_HIP(ctx, hipEventRecord(hp->ev_t1, hp->s_in));
                     timed_events = true;
                 }
@@ -570,7 +699,7 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 tb.table = dslot;
             } else {
                 char *dslot = ring + (size_t)slot * L.slot_bytes;
-                if (c >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                if (cslot >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
                 if (stage_ns && c == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
                 const double tc = stage_ns ? now_ns() : 0.0;
                 PM_HIP(ctx, hipMemcpyAsync(dslot, j.cube + pl * j.plane_bytes, np * j.plane_bytes, hipMemcpyHostToDevice, hp->s_in));
@@ -583,7 +712,11 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 PM_HIP(ctx, hipStreamWaitEvent(sk, hp->ev_in[slot], 0));
                 b.cube = dslot;
             }
-            const bool time_kernel = stage_ns && c == 0 && L.zero_copy;  // (the GPU's reads over the link ARE the stage)
+            // (the GPU's reads over the link ARE the stage; a hybrid segment times its SECOND fetched chunk - the one
+            //  that shares the link with the threads' table, as every later one does)
+            const bool time_kernel = stage_ns && c == 0 && chunk_zero_copy;
+            const int fk = (int)(f_head % HostPipe::kFq);
+            if (fetch_chunk) PM_HIP(ctx, hipEventRecord(hp->ev_f0[fk], sk));
             if (time_kernel) PM_HIP(ctx, hipEventRecord(hp->ev_t0, sk));
             if (blocks || host_blocks)
                 pm_launch_reproject_blocks(b, tb, j.dtype, sk, /*fetch=*/blocks);
@@ -594,12 +727,19 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 timed_events = true;
             }
             PM_HIP(ctx, hipGetLastError());
-            PM_HIP(ctx, hipEventRecord(hp->ev_k[slot], sk));
+            // (a fetched chunk of a hybrid segment holds no ring slot: its kernel gets the segment's own event)
+            hipEvent_t ev_done = fetch_chunk ? hp->ev_f1[fk] : hp->ev_k[slot];
+            PM_HIP(ctx, hipEventRecord(ev_done, sk));
+            if (fetch_chunk) {
+                f_np[fk] = np;
+                f_planes_out += np;
+                f_head++;
+            }
             if (ctx->chunk_cb) ctx->chunk_cb(ctx->chunk_user, (int)pl, (int)np);
             launched = q0 + np;
             // hand finished output to the D2H leg in pieces worth a DMA
             if (!L.direct_out && (launched - drained) * nmap * sizeof(double) >= ((size_t)8 << 20)) {
-                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, hp->ev_k[slot], 0));
+                PM_HIP(ctx, hipStreamWaitEvent(hp->s_out, ev_done, 0));
                 rc = d2h_issue(ctx, hp->s_out, j.out + (sg.p0 + b0 + drained) * nmap, dout_all + drained * nmap,
                                (launched - drained) * nmap * sizeof(double));
                 if (rc != PM_OK) return rc;
@@ -626,6 +766,19 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
         float ms = 0.0f;
         if (timed_events) PM_HIP(ctx, hipEventElapsedTime(&ms, hp->ev_t0, hp->ev_t1));
         *stage_ns = std::max(cpu_stage_ns, (double)ms * 1e6);
+        if (stage2) {
+            stage2[0] = cpu_stage_ns;
+            stage2[1] = (double)ms * 1e6;
+        }
+    }
+    if (hybrid) {
+        if ((rc = retire_fetched(true)) != PM_OK) return rc;
+        if (hybrid_obs) {
+            hybrid_obs[0] = hy_cpu_ns;
+            hybrid_obs[1] = hy_c_planes;
+            hybrid_obs[2] = hy_f_ns;
+            hybrid_obs[3] = hy_f_planes;
+        }
     }
     return PM_OK;
 }
@@ -690,7 +843,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     }
     // How the cube crosses the link (PM_OPT_HOST_CUBE_ROUTE): whole planes by DMA (0); a pinned cube
     // gathered in place by the kernel (1); the blocks the map samples brought into a table in HBM,
-    // either fetched by the GPU from a pinned cube in 256-byte blocks (2) or collected by the copy
+    // either fetched by the GPU from a pinned cube in 128-byte blocks (2) or collected by the copy
     // threads in 16-byte blocks into pinned staging, chunk by chunk, and sent by DMA (3: any host
     // memory). Left to the library (-1) the route is the one that MEASURED fastest for this problem on
     // this context (below); until enough planes have come by to measure, (3) when the table is well
@@ -700,12 +853,12 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     am.x_map = dxm;
     am.y_map = dym;
     auto splits = [&](int shift) { return j.plane_bytes % ((size_t)1 << shift) == 0 && (j.plane_bytes >> shift) < ((size_t)1 << 31); };
-    const bool can_collect = splits(pm::kBlkShiftHost), can_fetch = src_pinned && splits(pm::kBlkShiftFetch);
+    const bool can_collect = splits(pm::kBlkShiftHost), can_fetch = src_pinned && splits(ctx->fetch_shift);
     unsigned long long hash[2] = {0, 0};
     bool have_hash = false;
-    const bool want16 = (mode < 0 || mode == HostPipe::kCollect) && can_collect;
-    const bool want256 = mode == HostPipe::kFetch && can_fetch;
-    bool have256 = false;  // the 256-byte table describes THIS call's map
+    const bool want16 = (mode < 0 || mode == HostPipe::kCollect || mode == HostPipe::kHybrid) && can_collect;
+    const bool want256 = (mode == HostPipe::kFetch || (mode == HostPipe::kHybrid && can_collect)) && can_fetch;
+    bool have256 = false;  // the table of fetch blocks describes THIS call's map
     if ((want16 || want256) && ctx->table_cache) {
         if ((rc = maps_fingerprint(ctx, hp, dxm, dym, nmap, hash)) != PM_OK) return rc;
         have_hash = true;
@@ -714,7 +867,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     if (want16 && (rc = table_get(ctx, hp, t16, pm::kBlkShiftHost, am, dtype, j.plane_bytes, j.esz, have_hash, hash, /*want_list=*/true)) != PM_OK)
         return rc;
     if (want256) {
-        if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
+        if ((rc = table_get(ctx, hp, t256, ctx->fetch_shift, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
         have256 = t256.n_list > 0;
     }
 
@@ -726,7 +879,11 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     bool exploring = false;
     if (mode == HostPipe::kInPlace && src_pinned) {
         plan.push_back({HostPipe::kInPlace, 0, P, 0, false});
-    } else if (mode == HostPipe::kFetch && have256) {
+    } else if (mode == HostPipe::kHybrid && have256 && want16 && t16.n_list > 0) {
+        // (asked for: the split from what has been measured on this problem, else half and half)
+        if (rs.hybrid_fetch_share <= 0.0) rs.hybrid_fetch_share = 0.5;
+        plan.push_back({HostPipe::kHybrid, 0, P, 0, false});
+    } else if ((mode == HostPipe::kFetch || mode == HostPipe::kHybrid) && have256) {
         plan.push_back({HostPipe::kFetch, 0, P, 0, false});
     } else if (mode == HostPipe::kCollect && want16 && t16.n_list > 0) {
         plan.push_back({HostPipe::kCollect, 0, P, 0, false});
@@ -754,11 +911,18 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         const size_t c0 = std::max<size_t>(1, ctx->host_chunk_bytes / j.plane_bytes);
         const size_t c2 = std::max<size_t>(1, std::min<size_t>(c3, ((size_t)64 << 20) / j.plane_bytes));
         const size_t need_planes = c3 + c0 + (can_fetch ? c2 : 0);
-        if (rs.committed == HostPipe::kFetch && can_fetch) {
-            if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
+        if ((rs.committed == HostPipe::kFetch || rs.committed == HostPipe::kHybrid || rs.trial) && can_fetch) {
+            if ((rc = table_get(ctx, hp, t256, ctx->fetch_shift, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
             have256 = t256.n_list > 0;
         }
-        if (rs.committed >= 0 && (rs.committed != HostPipe::kFetch || have256)) {
+        // calls long enough to be pipelines take part in the trial (below); shorter ones go by the single route
+        const bool long_call = P >= 6 * kHybridCollectChunk;
+        if (rs.trial && rs.single >= 0 && (rs.single != HostPipe::kFetch || have256)) {
+            if (have256 && long_call && rs.trial_n[1] < rs.trial_n[0])
+                plan.push_back({HostPipe::kHybrid, 0, P, 0, false});
+            else
+                plan.push_back({rs.single, 0, P, 0, false});
+        } else if (rs.committed >= 0 && ((rs.committed != HostPipe::kFetch && rs.committed != HostPipe::kHybrid) || have256)) {
             plan.push_back({rs.committed, 0, P, 0, false});
         } else if (ctx->route_explore && P > need_planes) {
             exploring = true;
@@ -768,7 +932,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
             plan.push_back({HostPipe::kWhole, at, c0, c0, true});
             at += c0;
             if (can_fetch) {
-                if ((rc = table_get(ctx, hp, t256, pm::kBlkShiftFetch, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
+                if ((rc = table_get(ctx, hp, t256, ctx->fetch_shift, am, dtype, j.plane_bytes, j.esz, have_hash, hash, false)) != PM_OK) return rc;
                 have256 = t256.n_list > 0;
                 if (have256) {
                     plan.push_back({HostPipe::kFetch, at, c2, c2, true});
@@ -791,15 +955,16 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     size_t in_stage_need = 0;
     for (size_t i = 0; i < plan.size(); i++) {
         // (the remainder of an exploring call may take any route: size it for the most demanding)
-        const int routes[3] = {HostPipe::kCollect, HostPipe::kWhole, HostPipe::kFetch};
-        for (int r = 0; r < (plan[i].route < 0 ? 3 : 1); r++) {
+        const int routes[4] = {HostPipe::kCollect, HostPipe::kWhole, HostPipe::kFetch, HostPipe::kHybrid};
+        for (int r = 0; r < (plan[i].route < 0 ? 4 : 1); r++) {
             Segment sg = plan[i];
             if (sg.route < 0) sg.route = routes[r];
-            if (sg.route == HostPipe::kFetch && !have256) continue;
+            if ((sg.route == HostPipe::kFetch || sg.route == HostPipe::kHybrid) && !have256) continue;
             const HostPipe::Table &tt = sg.route == HostPipe::kFetch ? t256 : t16;
-            const SegLayout L = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned);
+            // (the split of a hybrid remainder is not known yet: size it for the widest fetched chunk)
+            const SegLayout L = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned, t256.n_list, plan[i].route < 0 ? 0.95 : rs.hybrid_fetch_share);
             need = std::max(need, L.need);
-            if (sg.route == HostPipe::kCollect) in_stage_need = std::max(in_stage_need, L.slot_bytes);
+            if (sg.route == HostPipe::kCollect || sg.route == HostPipe::kHybrid) in_stage_need = std::max(in_stage_need, L.slot_bytes);
             if (plan[i].route >= 0) lay[i] = L;
         }
     }
@@ -812,7 +977,8 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     const char *cube_dev = nullptr;  // zero copy: the device's view of the caller's pinned cube
     double *out_dev = nullptr;
     bool dev_view = false;  // some segment has the GPU read the caller's cube in place
-    for (const Segment &sg : plan) dev_view = dev_view || sg.route == HostPipe::kInPlace || sg.route == HostPipe::kFetch || (sg.route < 0 && have256);
+    for (const Segment &sg : plan)
+        dev_view = dev_view || sg.route == HostPipe::kInPlace || sg.route == HostPipe::kFetch || sg.route == HostPipe::kHybrid || (sg.route < 0 && have256);
     if (dev_view) PM_HIP(ctx, hipHostGetDevicePointer((void **)&cube_dev, (void *)cube, 0));
     if (device_out)
         out_dev = out;
@@ -829,24 +995,67 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
             for (int r = 0; r < 4; r++)
                 if (rs.ns_per_plane[r] > 0.0 && (best < 0 || rs.ns_per_plane[r] < rs.ns_per_plane[best])) best = r;
             rs.committed = best < 0 ? HostPipe::kCollect : best;
+            rs.single = rs.committed;
+            // ... or, later, by a hybrid of the collected and the fetched route, when the copy threads are the slower
+            // leg of the collected one: with a share f of the planes fetched by the GPU (t_f per plane, all of it
+            // link time) the threads collect the rest (t_c per plane) while the link also carries their table (t_d
+            // per plane): both finish together at f = (t_c - t_d) / (t_c - t_d + t_f), in (1 - f) t_c per plane.
+            // Where the probes predict a gain, the next whole calls alternate between the two and the faster stays.
+            const double t_c = rs.collect_cpu_ns, t_d = rs.collect_dma_ns, t_f = rs.ns_per_plane[HostPipe::kFetch];
+            if (have256 && t_c > 0.0 && t_f > 0.0 && t_c > 1.2 * t_d) {
+                const double f = (t_c - t_d) / (t_c - t_d + t_f);
+                const double t_h = (1.0 - f) * t_c;
+                if (f >= 0.1 && best >= 0 && t_h < 0.95 * rs.ns_per_plane[best]) {
+                    rs.hybrid_fetch_share = f;
+                    rs.hybrid_fetch_ns = t_f;
+                    rs.trial = true;
+                }
+            }
             sg.route = rs.committed;
             const HostPipe::Table &tt = sg.route == HostPipe::kFetch ? t256 : t16;
-            lay[i] = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned);
+            lay[i] = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned, t256.n_list, rs.hybrid_fetch_share);
         }
         const HostPipe::Table *tt = sg.route == HostPipe::kFetch ? &t256 : &t16;
         const double t_begin = now_ns();
-        double stage = 0.0;
-        rc = run_segment(ctx, hp, j, sg, lay[i], tt, dxm, dym, cube_dev, out_dev, sg.probe ? &stage : nullptr);
+        double stage = 0.0, stage2[2] = {0.0, 0.0};
+        double hy[4] = {rs.collect_cpu_ns, 0.0, rs.hybrid_fetch_ns > 0.0 ? rs.hybrid_fetch_ns : rs.ns_per_plane[HostPipe::kFetch], 0.0};
+        rc = run_segment(ctx, hp, j, sg, lay[i], tt, dxm, dym, cube_dev, out_dev, sg.probe ? &stage : nullptr, stage2, &t256,
+                         sg.route == HostPipe::kHybrid ? hy : nullptr);
         if (rc != PM_OK) return rc;
         const double wall = now_ns() - t_begin;
+        if (sg.route == HostPipe::kHybrid && hy[1] > 0.0 && hy[3] > 0.0) {
+            // the rates the two legs showed while they ran side by side (the next call's closing split starts from them)
+            rs.collect_cpu_ns = hy[0] / hy[1];
+            rs.hybrid_fetch_ns = hy[2] / hy[3];
+            rs.hybrid_fetch_share = hy[3] / (hy[1] + hy[3]);
+            if (trace)
+                std::fprintf(stderr, "[pm hostpipe] hybrid: threads collected %.0f planes in %.3f ms (%.1f us each), GPU fetched %.0f in %.3f ms (%.1f us each)\n",
+                             hy[1], hy[0] * 1e-6, hy[0] / hy[1] * 1e-3, hy[3], hy[2] * 1e-6, hy[2] / hy[3] * 1e-3);
+        }
+        if (mode < 0 && rs.trial && !exploring && plan.size() == 1 && P >= 6 * kHybridCollectChunk &&
+            (sg.route == HostPipe::kHybrid || sg.route == rs.single)) {
+            const int k = sg.route == HostPipe::kHybrid ? 1 : 0;
+            const double v = wall / (double)sg.n;
+            rs.trial_ns[k] = rs.trial_n[k] == 0 ? v : std::min(rs.trial_ns[k], v);
+            rs.trial_n[k]++;
+            if (rs.trial_n[0] >= 2 && rs.trial_n[1] >= 2) {
+                rs.trial = false;
+                // (the hybrid must earn its keep: it also loads the link and the GPU's fetch path)
+                rs.committed = rs.trial_ns[1] < 0.93 * rs.trial_ns[0] ? (int)HostPipe::kHybrid : rs.single;
+            }
+        }
         ctx->last_cube_route = sg.route;
+        if (sg.probe && sg.route == HostPipe::kCollect) {
+            rs.collect_cpu_ns = stage2[0] / (double)sg.n;
+            rs.collect_dma_ns = stage2[1] / (double)sg.n;
+        }
         if (trace) std::fprintf(stderr, "[pm hostpipe] segment route %d planes %zu+%zu: %.3f ms%s (stage %.3f ms)\n", sg.route, sg.p0, sg.n,
                                 wall * 1e-6, sg.probe ? " probe" : "", stage * 1e-6);
-        if (mode < 0 && sg.route >= 0 && sg.route < 4) {
+        if (mode < 0 && sg.route >= 0 && sg.route < HostPipe::kRoutes) {
             double &v = rs.ns_per_plane[sg.route];
             if (sg.probe)
                 v = stage / (double)sg.n;
-            else if (!exploring && sg.n >= 3 * lay[i].chunk)  // (a running mean once committed, from calls long enough to be pipelines)
+            else if (!exploring && sg.n >= 3 * (lay[i].chunk + lay[i].chunk_f))  // (a running mean once committed, from calls long enough to be pipelines)
                 v = v > 0.0 ? 0.75 * v + 0.25 * wall / (double)sg.n : wall / (double)sg.n;
         }
     }

@@ -318,16 +318,17 @@ __global__ __launch_bounds__(kBlock) void k_hash_maps(const double *__restrict__
     }
 }
 
-// blockIdx.y = plane of the chunk; 16 lanes x 16 bytes per 256-byte block, 4 blocks per wave
+// blockIdx.y = plane of the chunk; 16 bytes per lane: 16 lanes per 256-byte block (4 blocks per wave), 8 per 128-byte block
 __global__ __launch_bounds__(kBlock) void k_fetch_blocks(const char *__restrict__ cube, const BlockTable t)
 {
     const unsigned q = blockIdx.x * kBlock + threadIdx.x;
-    const unsigned row = q >> 4, piece = q & 15u;
+    const int lane_shift = t.shift - 4;
+    const unsigned row = q >> lane_shift, piece = q & ((1u << lane_shift) - 1u);
     if (row >= t.n_list) return;
     const size_t pl = blockIdx.y;
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 *src = (const u32x4 *)(cube + pl * t.plane_bytes + ((size_t)t.blklist[row] << kBlkShiftFetch)) + piece;
-    u32x4 *dst = (u32x4 *)(t.table + ((pl * t.n_list + row) << kBlkShiftFetch)) + piece;
+    const u32x4 *src = (const u32x4 *)(cube + pl * t.plane_bytes + ((size_t)t.blklist[row] << t.shift)) + piece;
+    u32x4 *dst = (u32x4 *)(t.table + ((pl * t.n_list + row) << t.shift)) + piece;
     *dst = *src;
 }
 
@@ -1056,7 +1057,7 @@ void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable
 {
     // (fetch == false: the host has filled the table, a.cube may be null)
     if (fetch)
-        hipLaunchKernelGGL(pm::k_fetch_blocks, dim3((t.n_list * 16 + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
+        hipLaunchKernelGGL(pm::k_fetch_blocks, dim3((((size_t)t.n_list << (t.shift - 4)) + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
                            0, s, (const char *)a.cube, t);
     switch (dtype) {
     case PM_F64: launch_reproject_blocks_t<double>(a, t, s); break;

@@ -64,7 +64,7 @@ def main():
             info = np.iinfo(dtype)
             cube = rng.integers(info.min, info.max, (planes, ny, nx), dtype=dtype)
         interp = 'linear' if rng.random() < 0.7 else 'nearest'
-        mode = int(rng.integers(-1, 4))
+        mode = int(rng.integers(-1, 5))  # -1 the library chooses, 0 whole, 1 in place, 2 fetched, 3 collected, 4 hybrid
         chunk = int(rng.choice([1, 2, 8, 32, 64])) << 20
         threads = int(rng.choice([1, 2, 5, 8, 16]))
         pin_cube, pin_out = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))

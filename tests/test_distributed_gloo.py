@@ -227,6 +227,8 @@ def _cube_host_worker(rank: int, world: int, port: int, planes: int, tmpdir: str
         a, b, per_rank = shard_bounds(planes, world, rank)
         assert sec['rccl_ranks'] == world and sec['planes_per_rank'] == per_rank
         assert sec['fed_equals_resident'] is True  # the gathered cube of the host-fed step == the resident one
+        assert sec['fed_equals_resident_plain_allgather'] is True  # ... and so is the plain form's (one all-gather per step)
+        assert sec['ms_per_step_host_fed_no_collective'] > 0 and 'pipelined_error' not in sec
         fed = [c for c in eng.calls if c[0] == 'host_cube']
         assert all(c[1][0] == b - a for c in fed) and (len(fed) > 0) == (b > a)
         # every step finishes this rank's planes before the collective

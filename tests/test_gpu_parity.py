@@ -483,7 +483,8 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
             assert np.array_equal(a, b, equal_nan=True), interp
             # gathered in place (1), through the table of sampled blocks fetched by the GPU (2) /
             # collected by the copy threads (3), the library's choice (-1)
-            for zc in (1, 2, 3, -1):
+            # and the hybrid of the last two (4)
+            for zc in (1, 2, 3, 4, -1):
                 engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
                 c = engine.map_cube(pc, xm, ym, interp, True)
                 assert np.array_equal(a, c, equal_nan=True), (interp, zc)
@@ -501,7 +502,7 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         ci = (rng.standard_normal((planes, sz, sz)) * 1000).astype(np.int16)
         pci = engine.pinned_copy(ci)
         ri = engine.map_cube(ci, xm, ym)
-        for zc in (-1, 0, 1, 2, 3):
+        for zc in (-1, 0, 1, 2, 3, 4):
             engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
             assert np.array_equal(ri, engine.map_cube(pci, xm, ym), equal_nan=True), zc
             assert np.array_equal(ri, engine.map_cube(ci, xm, ym), equal_nan=True), zc
@@ -516,14 +517,14 @@ def test_host_path_pageable_pinned_and_zero_copy_agree(engine, oracle, jupiter):
         xmf, ymf = oracle.xy_map(jupiter, d, lonf, latf)
         p8, p6 = engine.pinned_copy(c8), engine.pinned_copy(cube[:6])
         fine = engine.map_cube(cube[:6], xmf, ymf)
-        for zc in (-1, 1, 2, 3):
+        for zc in (-1, 1, 2, 3, 4):
             engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
             assert np.array_equal(fine, engine.map_cube(p6, xmf, ymf), equal_nan=True), zc
             assert np.array_equal(fine, engine.map_cube(cube[:6], xmf, ymf), equal_nan=True), zc
         engine.set_disc(124.5, 124.5, 110.0, 0.0, 250, 250, True)
         small = engine.map_cube(c8, xm8, ym8)
         assert np.max(np.abs(np.nan_to_num(small - oracle.map_cube(c8, xm8, ym8)))) <= 1e-11
-        for zc in (-1, 1, 2, 3):
+        for zc in (-1, 1, 2, 3, 4):
             engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
             assert np.array_equal(small, engine.map_cube(p8, xm8, ym8), equal_nan=True), zc
             assert np.array_equal(small, engine.map_cube(c8, xm8, ym8), equal_nan=True), zc
@@ -642,6 +643,14 @@ def test_host_cube_block_table_at_config5_plane_size(engine, oracle, jupiter, dt
             for zc in (-1, 3):
                 engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
                 assert np.array_equal(whole, engine.map_cube(cube, xm, ym, interp, True), equal_nan=True), (interp, zc)
+            # a pinned cube: fetched by the GPU (2) and the hybrid of fetched and collected chunks (4: 24 planes are
+            # a fetched chunk of 8, a collected one of 8 and another fetched one)
+            pinned = engine.pinned_copy(cube)
+            for zc in (2, 4):
+                engine.set_option(_lib.PM_OPT_ZERO_COPY, zc)
+                assert np.array_equal(whole, engine.map_cube(pinned, xm, ym, interp, True), equal_nan=True), (interp, zc)
+                assert engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) == zc
+            del pinned
             n0, n1 = xm.shape
             out = torch.empty((planes, n0, n1), dtype=torch.float64, device='cuda')
             raw = cube.view(np.int16) if dtype == np.uint16 else cube  # (bytes only: torch need not know uint16)

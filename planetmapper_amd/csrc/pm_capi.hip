@@ -291,6 +291,16 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         const double band = 1.5 * (2.0 * dv + dv * dv) + 1e-10;
         p.p2_lo = 1.0 - band;
         p.p2_hi = 1.0 + band;
+        // ... and for a body that is not a spheroid the shape itself turns under the ray by wdot |d|, which moves its
+        // limb by that angle times (a^2 - b^2) / b^2 of a radius; the target's acceleration adds A d^2 / 2 (general kernel)
+        const double ab = p.radii[0] / p.radii[1], ba = p.radii[1] / p.radii[0];
+        p.tri_k = g.wdot * (ba - ab);
+        const double dmax = 1.05 * rmax_ / g.clight;
+        const double rmin_ = std::fmin(p.radii[0], std::fmin(p.radii[1], p.radii[2]));
+        double a2 = 0.0;
+        for (int i = 0; i < 3; i++) a2 += g.AT[i] * g.AT[i];
+        const double turn = std::fabs(g.wdot) * dmax * std::fabs(ab * ab - 1.0) + 0.5 * std::sqrt(a2) * dmax * dmax / rmin_;
+        p.p2_lo_rot = 1.0 - (band + 4.0 * turn);
     }
     for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
     {

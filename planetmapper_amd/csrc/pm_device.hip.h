@@ -139,6 +139,9 @@ struct Params {
     double Wc[3];     // VBs / c
     double lt_c_eff;  // et - t0 (exact: t0 = fl(et - lt_c) is within a factor 2 of et)
     double p2_lo, p2_hi;  // 1 -+ the change of the squared impact parameter P.P over the light-time span of a disc (with margin)
+    // triaxial / general variants of k_disc_sph (Newton step on the light-time seed)
+    double tri_k;      // wdot (b / a - a / b): the turn of the shape under the ray, per unit Xf_x Xf_y
+    double p2_lo_rot;  // p2_lo widened by that turn (and the target's acceleration) over a light-time span
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

@@ -342,9 +342,17 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p_)
 // incidence / emission), config 4 (+ the ring planes) and the whole intercept group of save_observation.
 #undef PM_MASK
 #define PM_MASK (MASK != 0 ? MASK : p.mask)
-template <int FLAGS, bool TRI, int SKY = 0, unsigned long long MASK = 0>
+// BODY: 0 = spheroid (the closed-form / rotation-free path above), 1 = TRI as described, 2 = GEN: the same B0
+// formulation for ANY body and observer - what the general kernel of rounds 1-3 (k_disc: J2000 vectors, a 3 x 3
+// rotation matrix per light-time evaluation) did for 0.41 ms per headline frame: the spin angle of an evaluation by
+// range-tiered sincos instead of a series (fast rotators, the 1000 s light-time spans of near-field geometry), the
+// target's and the Sun's acceleration carried, an observer inside or on the surface (surfpt_c's far
+// intersection), the Sun's light time iterated as illumf_c does. Serves near-field observers, fast spinners,
+// large accelerations and PM_OPT_GENERAL_KERNEL.
+template <int FLAGS, int BODY, int SKY = 0, unsigned long long MASK = 0>
 __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 {
+    constexpr bool TRI = BODY != 0, GEN = BODY == 2;
     // Workgroups are dealt round-robin to the 8 XCDs (linear id % 8); with a row-major grid
     // each XCD would always get the same image columns, and the columns through the disc
     // centre cost far more than the ones at the frame edge. Rotating the column block by the
@@ -515,7 +523,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 
         // sincpt_c 'CN': converged light time, CSPICE stopping rule, <= 10 evaluations
         // CSPICE's rule is |dlt| <= 1e-17 |et - lt|; lt varies by 1e-9 relative over a disc
-        double k = 0.0, root = 0.0, inv_root = 0.0;
+        // (sroot: the signed root - the intercept is P + sroot X, -root for an observer outside the body)
+        double k = 0.0, root = 0.0, sroot = 0.0, inv_root = 0.0, p2_first = 0.0;
+        bool outside = true;  // (GEN) the observer of the lane's latest evaluation is outside the body
         V3 P = {0.0, 0.0, 0.0};
         // An FMA takes one scalar operand: with VBs there, O0s has to sit in vector registers.
         // Pinned outside the loop (left alone, hipcc re-copies the three pairs every evaluation).
@@ -531,10 +541,17 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 // t0 = et - lt_c on the host, the same subtraction as on the device: d == 0 exactly
                 Y = TRI ? v3(kp->O0[0] * kp->ir[0], kp->O0[1] * kp->ir[1], kp->O0[2] * kp->ir[2]) : v3(o0x, o0y, o0z);
             } else if (TRI) {
-                const V3 obs = {fma(-kp->VB[0], dd, kp->O0[0]), fma(-kp->VB[1], dd, kp->O0[1]), fma(-kp->VB[2], dd, kp->O0[2])};
-                const double dl = kp->g.wdot * dd, d2 = dl * dl;  // |dl| < 1e-3 (host check)
-                cz = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
-                sz = dl * fma(d2, -1.0 / 6.0, 1.0);
+                V3 obs = {fma(-kp->VB[0], dd, kp->O0[0]), fma(-kp->VB[1], dd, kp->O0[1]), fma(-kp->VB[2], dd, kp->O0[2])};
+                const double dl = kp->g.wdot * dd;
+                if (GEN) {
+                    const double h = -0.5 * dd * dd;  // the target's acceleration: obs = -(T0 + VT d + AT d^2 / 2) in B0
+                    obs = {fma(kp->AB[0], h, obs.x), fma(kp->AB[1], h, obs.y), fma(kp->AB[2], h, obs.z)};
+                    sincos_tiered<true>(dl, sz, cz);  // (the tier is the lane's own)
+                } else {
+                    const double d2 = dl * dl;  // |dl| < 1e-3 (host check)
+                    cz = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+                    sz = dl * fma(d2, -1.0 / 6.0, 1.0);
+                }
                 const V3 ub = {fma(cz, u.x, sz * u.y), fma(cz, u.y, -sz * u.x), u.z};
                 X = {ub.x * kp->ir[0], ub.y * kp->ir[1], ub.z * kp->ir[2]};
                 ixx = rcp_fast(dot(X, X));
@@ -546,9 +563,19 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             k = yx * ixx;
             P = {fma(-k, X.x, Y.x), fma(-k, X.y, Y.y), fma(-k, X.z, Y.z)};
             const double p2 = dot(P, P);
-            // (an observer inside the body, Y.Y <= 1, never reaches this kernel: the
-            //  launcher requires |O0| scaled > 1 and the target moves km, not radii)
-            hit_mask &= ~(__builtin_amdgcn_ballot_w64(p2 > 1.0) | __builtin_amdgcn_ballot_w64(yx > 0.0));
+            if (first) p2_first = p2;
+            double y2 = 2.0;
+            if (GEN) {
+                // surfpt_c: a ray from outside misses when it passes the centre by more than the (unit) radius or
+                // points away; from inside or on the surface it always meets the surface
+                y2 = dot(Y, Y);
+                outside = y2 > 1.0;
+                hit_mask &= ~(__builtin_amdgcn_ballot_w64(outside) & (__builtin_amdgcn_ballot_w64(p2 > 1.0) | __builtin_amdgcn_ballot_w64(yx > 0.0)));
+            } else {
+                // (an observer inside the body, Y.Y <= 1, never reaches the fast paths: the
+                //  launcher requires |O0| scaled > 2 and the target moves km, not radii)
+                hit_mask &= ~(__builtin_amdgcn_ballot_w64(p2 > 1.0) | __builtin_amdgcn_ballot_w64(yx > 0.0));
+            }
             // (clamped away from 0 once, for the reciprocal square root: a grazing ray gets
             //  root = 1e-150 instead of 0)
             const double r2 = fmax((1.0 - p2) * ixx, 1e-300);
@@ -562,7 +589,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             } else {
                 root = sqrt_pos(r2);
             }
-            return (-k - root) * kp->inv_c;
+            // (outside: the near intersection; inside: the one ahead; ON the surface surfpt_c returns the observer's own point)
+            sroot = !GEN ? -root : (outside ? -root : (y2 == 1.0 ? k : root));
+            return (sroot - k) * kp->inv_c;
         };
         // The first evaluation, at t0 itself, is never the last: |lt - lt_c| would have to be
         // below 1e-17 |t0| ~ 1e-8 s for every pixel of the wave, and one more evaluation of a
@@ -597,6 +626,22 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const double r2_pass2 = fma((pv + pv) * d0, ixx, root * root);
             lt = (fabs(ep) < 0.02 && r2_pass2 > 1e-9 * ixx) ? stepped : lt;
         }
+        if (TRI && kp->plain_lt != 1) {
+            // The same step for a body whose shape turns under the ray. With the intercept x = obs + t u in the
+            // body-fixed frame and the surface G(x) = |x / radii|^2 = 1, dt / dd = -grad G . (obs' + t u') / (grad G . u):
+            // grad G . u = 2 Xf . X = 2 sroot X.X; the translation gives -Xf . VBs, and the two rotation terms - the
+            // observer and the ray turn TOGETHER, each by wdot D ~ 1e4 km/s - add up to the motion of the surface
+            // itself, wdot Xf_x Xf_y (b / a - a / b): zero for a spheroid, 1e-9 for Io. No cancellation is left.
+            // Lanes the limb could touch in a later pass of the reference's sequence (the band of the closed form,
+            // widened by the turn of the shape over a light-time span - host: p2_lo_rot) keep the plain seed, and so
+            // do lanes of an observer inside the body.
+            const V3 xf1 = {fma(sroot, X.x, P.x), fma(sroot, X.y, P.y), fma(sroot, X.z, P.z)};
+            const double a = fma(kp->tri_k * xf1.x, xf1.y, -dot(xf1, v3(kp->VBs[0], kp->VBs[1], kp->VBs[2])));
+            const double ep = a * ixx * inv_root * kp->inv_c;
+            const double d0 = (kp->g.et - lt) - kp->t0;
+            const double stepped = fma(ep * d0, 1.0 - ep, lt);
+            lt = (fabs(ep) < 0.02 && p2_first < kp->p2_lo_rot && outside) ? stepped : lt;
+        }
         // (a wave of the pre-mask annulus - candidates, but every ray misses - is done after that one
         //  evaluation: nothing is left to converge)
         // Each lane stops where the reference stops for its pixel: once an evaluation has confirmed its light
@@ -612,7 +657,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // wave-uniform exit once no lane with an intercept is still moving
             if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
         }
-        Xf = {fma(-root, X.x, P.x), fma(-root, X.y, P.y), fma(-root, X.z, P.z)};
+        Xf = {fma(sroot, X.x, P.x), fma(sroot, X.y, P.y), fma(sroot, X.z, P.z)};
         if (!TRI && cf_mask != 0) {  // (those lanes hit in every pass: they are in hit_mask)
             const bool cf = __builtin_amdgcn_inverse_ballot_w64(cf_mask);
             Xf = {cf ? Xf_cf.x : Xf.x, cf ? Xf_cf.y : Xf.y, cf ? Xf_cf.z : Xf.z};
@@ -679,9 +724,13 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             const V3 sp0 = TRI ? v3(fma(cz, sp.x, -sz * sp.y), fma(sz, sp.x, cz * sp.y), sp.z) : sp;
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
-                const V3 q = TRI ? v3(fma(kp->VB[0], d, sp0.x), fma(kp->VB[1], d, sp0.y), fma(kp->VB[2], d, sp0.z))
-                                 : v3(fma(kp->VBs[0], d, Xf.x) * kp->radii[0], fma(kp->VBs[1], d, Xf.y) * kp->radii[1],
-                                      fma(kp->VBs[2], d, Xf.z) * kp->radii[2]);
+                V3 q = TRI ? v3(fma(kp->VB[0], d, sp0.x), fma(kp->VB[1], d, sp0.y), fma(kp->VB[2], d, sp0.z))
+                           : v3(fma(kp->VBs[0], d, Xf.x) * kp->radii[0], fma(kp->VBs[1], d, Xf.y) * kp->radii[1],
+                                fma(kp->VBs[2], d, Xf.z) * kp->radii[2]);
+                if (GEN) {
+                    const double h = 0.5 * d * d;
+                    q = {fma(kp->AB[0], h, q.x), fma(kp->AB[1], h, q.y), fma(kp->AB[2], h, q.z)};
+                }
                 // Sun light time (spkcpo_c 'CN'): the Sun is taken at te - |S - q| / c. Its epoch
                 // offset from ts0 is d + (lts0 - |SB0 - q| / c), and |SB0 - q| = |SB0| - s0.q up to
                 // q^2 / (2 |SB0|) ~ 3 km, i.e. 1e-5 s of a Sun that moves 0.013 km/s = 1e-7 km at
@@ -689,9 +738,23 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 // form is one dot product.
                 // (operations ordered so that each holds ONE scalar constant: two of them in an FMA cost a copy
                 //  of one into a vector register pair first)
+                V3 sv;
+                if (GEN) {
+                    // illumf_c's own iteration (spkcpo_c 'CN'): two passes from the centre value, the Sun's acceleration carried
+                    const double dts = (kp->t0 - kp->g.ts0) + d;  // te - ts0
+                    double ds = 0.0;
+#pragma unroll
+                    for (int it = 0; it < 3; it++) {
+                        const double h = 0.5 * ds * ds;
+                        sv = {fma(kp->ASB[0], h, fma(kp->VSB[0], ds, kp->SB0[0])) - q.x, fma(kp->ASB[1], h, fma(kp->VSB[1], ds, kp->SB0[1])) - q.y,
+                              fma(kp->ASB[2], h, fma(kp->VSB[2], ds, kp->SB0[2])) - q.z};
+                        if (it < 2) ds = dts - norm_f(sv) * kp->inv_c;
+                    }
+                } else {
                 const double ds = fma(dot(v3(kp->SB0[0], kp->SB0[1], kp->SB0[2]), q), kp->sun_k, d) + kp->sun_ds0;
-                V3 sv = v3(fma(kp->VSB[0], ds, rsub_c(q.x, kp->SB0[0])), fma(kp->VSB[1], ds, rsub_c(q.y, kp->SB0[1])),
-                           fma(kp->VSB[2], ds, rsub_c(q.z, kp->SB0[2])));
+                sv = v3(fma(kp->VSB[0], ds, rsub_c(q.x, kp->SB0[0])), fma(kp->VSB[1], ds, rsub_c(q.y, kp->SB0[1])),
+                        fma(kp->VSB[2], ds, rsub_c(q.z, kp->SB0[2])));
+                }
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
                 if (TRI) {
@@ -1096,19 +1159,37 @@ __global__ __launch_bounds__(kBlock) void k_radec_query(const Params p_, const d
 // ------------------------------------------------------------------ launchers (called from pm_capi.hip)
 extern "C++" {
 
+// the general image kernel: k_disc_sph<FLAGS, 2> (PM_GENERAL_LEGACY in the environment of a tools/ A/B run: the
+// J2000 kernel k_disc of rounds 1-3, kept as the second implementation the parity suite can be pointed at)
 void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
 {
-    dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.rows);
-    dim3 block(pm::kBlock);
+    static const bool legacy = std::getenv("PM_GENERAL_LEGACY") != nullptr;
+    if (legacy) {
+        dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.rows);
+        dim3 block(pm::kBlock);
+        switch (flags & 7) {
+        case 0: hipLaunchKernelGGL(pm::k_disc<0>, grid, block, 0, s, p); break;
+        case 1: hipLaunchKernelGGL(pm::k_disc<1>, grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL(pm::k_disc<2>, grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL(pm::k_disc<3>, grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL(pm::k_disc<4>, grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL(pm::k_disc<5>, grid, block, 0, s, p); break;
+        case 6: hipLaunchKernelGGL(pm::k_disc<6>, grid, block, 0, s, p); break;
+        case 7: hipLaunchKernelGGL(pm::k_disc<7>, grid, block, 0, s, p); break;
+        }
+        return;
+    }
+    dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
+    dim3 block(pm::kSphBlock);
     switch (flags & 7) {
-    case 0: hipLaunchKernelGGL(pm::k_disc<0>, grid, block, 0, s, p); break;
-    case 1: hipLaunchKernelGGL(pm::k_disc<1>, grid, block, 0, s, p); break;
-    case 2: hipLaunchKernelGGL(pm::k_disc<2>, grid, block, 0, s, p); break;
-    case 3: hipLaunchKernelGGL(pm::k_disc<3>, grid, block, 0, s, p); break;
-    case 4: hipLaunchKernelGGL(pm::k_disc<4>, grid, block, 0, s, p); break;
-    case 5: hipLaunchKernelGGL(pm::k_disc<5>, grid, block, 0, s, p); break;
-    case 6: hipLaunchKernelGGL(pm::k_disc<6>, grid, block, 0, s, p); break;
-    case 7: hipLaunchKernelGGL(pm::k_disc<7>, grid, block, 0, s, p); break;
+    case 0: hipLaunchKernelGGL((pm::k_disc_sph<0, 2>), grid, block, 0, s, p); break;
+    case 1: hipLaunchKernelGGL((pm::k_disc_sph<1, 2>), grid, block, 0, s, p); break;
+    case 2: hipLaunchKernelGGL((pm::k_disc_sph<2, 2>), grid, block, 0, s, p); break;
+    case 3: hipLaunchKernelGGL((pm::k_disc_sph<3, 2>), grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((pm::k_disc_sph<4, 2>), grid, block, 0, s, p); break;
+    case 5: hipLaunchKernelGGL((pm::k_disc_sph<5, 2>), grid, block, 0, s, p); break;
+    case 6: hipLaunchKernelGGL((pm::k_disc_sph<6, 2>), grid, block, 0, s, p); break;
+    case 7: hipLaunchKernelGGL((pm::k_disc_sph<7, 2>), grid, block, 0, s, p); break;
     }
 }
 
@@ -1121,18 +1202,18 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
     const int sky = (flags >> 3) & 3;
 #define PM_SPH_CASE(F)                                                                                          \
     case F:                                                                                                     \
-        if (tri && sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, true, 0>), grid, block, 0, s, p);            \
-        else if (tri && sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, true, 1>), grid, block, 0, s, p);       \
-        else if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, true, 2>), grid, block, 0, s, p);                   \
+        if (tri && sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 0>), grid, block, 0, s, p);            \
+        else if (tri && sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 1>), grid, block, 0, s, p);       \
+        else if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 2>), grid, block, 0, s, p);                   \
         else if (sky == 0 && F == 1 && p.mask == pm::kMaskHeadline)                                              \
-            hipLaunchKernelGGL((pm::k_disc_sph<1, false, 0, pm::kMaskHeadline>), grid, block, 0, s, p);         \
+            hipLaunchKernelGGL((pm::k_disc_sph<1, 0, 0, pm::kMaskHeadline>), grid, block, 0, s, p);         \
         else if (sky == 0 && F == 5 && p.mask == pm::kMaskRings)                                                 \
-            hipLaunchKernelGGL((pm::k_disc_sph<5, false, 0, pm::kMaskRings>), grid, block, 0, s, p);            \
+            hipLaunchKernelGGL((pm::k_disc_sph<5, 0, 0, pm::kMaskRings>), grid, block, 0, s, p);            \
         else if (sky == 0 && F == 7 && p.mask == pm::kMaskDisc)                                                  \
-            hipLaunchKernelGGL((pm::k_disc_sph<7, false, 0, pm::kMaskDisc>), grid, block, 0, s, p);             \
-        else if (sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, false, 0>), grid, block, 0, s, p);             \
-        else if (sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, false, 1>), grid, block, 0, s, p);             \
-        else hipLaunchKernelGGL((pm::k_disc_sph<F, false, 2>), grid, block, 0, s, p);                           \
+            hipLaunchKernelGGL((pm::k_disc_sph<7, 0, 0, pm::kMaskDisc>), grid, block, 0, s, p);             \
+        else if (sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 0>), grid, block, 0, s, p);             \
+        else if (sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 1>), grid, block, 0, s, p);             \
+        else hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 2>), grid, block, 0, s, p);                           \
         break;
     switch (flags & 7) {
         PM_SPH_CASE(0)

@@ -39,7 +39,8 @@ def main():
                  ('geometries', lambda: T.test_random_geometries_fuzz(eng, oracle, 'fresh_seed'))]  # fmt: skip
         for general in (0, 1):
             eng.set_option(_lib.PM_OPT_GENERAL_KERNEL, general)
-            for name, fn in (cases if general == 0 else cases[:1]):
+            # (general kernel forced: the frames sweep and the geometries sweep - near field, triaxial, fast approach)
+            for name, fn in (cases if general == 0 else [cases[0], cases[2]]):
                 try:
                     fn()
                 except Exception as e:  # noqa: BLE001

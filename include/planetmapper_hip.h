@@ -200,12 +200,11 @@ int pm_abi_version(void);
 int pm_device_count(void);
 /* Create a context on GPU `device`. Fails (NULL + *status) if there is no GPU:
  * this library has no CPU fallback.
- * Environment read here (defaults of the context; for the A/B tools under tools/ and for debugging, none changes
- * a result beyond the parity bars): PM_FORCE_GENERAL=1 (PM_OPT_GENERAL_KERNEL), PM_FUSE_PLANES=0/1
- * (PM_OPT_FUSE_PLANES), PM_LT_MODE=0/1/2 (light time of the spheroid image kernel: 0 closed form where the
- * limb is clear - the default -, 1 the reference's own sequence of epochs for every pixel, 2 that sequence
- * shortened by a Newton step on its seed). Elsewhere: PM_RCCL_LIBRARY (pm_comm_*),
- * PM_HOSTPIPE_TRACE (stage times of the host path on stderr), PM_SM_WORKERS / PM_SM_DEBUG (smoothing splines). */
+ * Environment: the library reads PM_RCCL_LIBRARY (pm_comm_*: the collective library to bind) and the launcher's
+ * LOCAL_WORLD_SIZE (copy threads per rank). The debug / A-B knobs of tools/ - PM_FORCE_GENERAL, PM_FUSE_PLANES,
+ * PM_LT_MODE, PM_HOSTPIPE_TRACE, PM_SM_DEBUG, PM_SM_WORKERS - set the DEFAULTS of the matching pm_set_option()
+ * options at pm_create, and ONLY when PM_DEBUG_ENV=1 is set beside them: without it they are ignored, so a stray
+ * variable in a user's shell cannot select another algorithm. */
 pm_ctx *pm_create(int device, int *status);
 void pm_destroy(pm_ctx *ctx);
 const char *pm_last_error(const pm_ctx *ctx);
@@ -283,6 +282,13 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           of a pinned cube). 128 bytes is the granularity of PCIe reads: at BASELINE config 5 it
  *                           moves 4.2 MB per plane instead of the 4.7 MB of 256-byte blocks and measured 8 % faster
  *                           (64 planes: 5.46 against 5.95 ms; 64-byte blocks 5.60 ms, profiles/r04_route_ab.jsonl).
+ *   PM_OPT_LT_MODE          light time of the spheroid image kernel (A/B and the light-time test; none changes a result
+ *                           beyond the parity bars): 0 (default) closed form where the limb is clear, 1 the
+ *                           reference's own sequence of epochs for every pixel, 2 that sequence shortened by a Newton
+ *                           step on its seed.
+ *   PM_OPT_TRACE            mask, on stderr: 1 stage times of every host-path call, 2 the knot / smoothing-parameter
+ *                           search of the smoothing splines. Default 0.
+ *   PM_OPT_SM_WORKERS       threads the smoothing-spline fits of a cube's planes are dealt to (1 .. 8, default 4).
  *   PM_OPT_HYBRID_FETCH_PERMILLE read-only: the share of planes (in 1/1000) a hybrid segment (route 4) has the GPU
  *                           fetch on the current problem; 0 while no hybrid has been planned.
  *   PM_OPT_HOST_COPY_THREADS_IN_USE read-only: the copy threads the host pipe of this context runs with (0 before
@@ -320,6 +326,9 @@ typedef enum pm_option {
     PM_OPT_HOST_COPY_THREADS_IN_USE = 13,
     PM_OPT_HYBRID_FETCH_PERMILLE = 14,
     PM_OPT_FETCH_BLOCK_BYTES = 15,
+    PM_OPT_LT_MODE = 24,
+    PM_OPT_TRACE = 25,
+    PM_OPT_SM_WORKERS = 26,
     PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..4 */
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);

@@ -77,6 +77,9 @@ PM_OPT_FUSE_PLANES = 12
 PM_OPT_HOST_COPY_THREADS_IN_USE = 13
 PM_OPT_HYBRID_FETCH_PERMILLE = 14
 PM_OPT_FETCH_BLOCK_BYTES = 15
+PM_OPT_LT_MODE = 24
+PM_OPT_TRACE = 25
+PM_OPT_SM_WORKERS = 26
 PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..4
 NUM_CUBE_ROUTES = 5
 

@@ -402,10 +402,14 @@ pm_ctx *pm_create(int device, int *status)
         return nullptr;
     }
     ctx->own_stream = true;
-    const char *fg = std::getenv("PM_FORCE_GENERAL");
+    // defaults from the environment for the A/B tools - only behind PM_DEBUG_ENV=1 (pm_debug_env)
+    const char *fg = pm_debug_env("PM_FORCE_GENERAL");
     ctx->force_general = fg && fg[0] == '1';
-    if (const char *fp = std::getenv("PM_FUSE_PLANES")) ctx->fuse_planes = fp[0] != '0';  // (A/B runs of tools / bench)
-    if (const char *m = std::getenv("PM_LT_MODE")) ctx->lt_mode = (m[0] == '1') ? 1 : (m[0] == '2') ? 2 : 0;
+    if (const char *fp = pm_debug_env("PM_FUSE_PLANES")) ctx->fuse_planes = fp[0] != '0';
+    if (const char *m = pm_debug_env("PM_LT_MODE")) ctx->lt_mode = (m[0] == '1') ? 1 : (m[0] == '2') ? 2 : 0;
+    if (pm_debug_env("PM_HOSTPIPE_TRACE")) ctx->trace |= 1;
+    if (pm_debug_env("PM_SM_DEBUG")) ctx->trace |= 2;
+    if (const char *w = pm_debug_env("PM_SM_WORKERS")) ctx->sm_worker_count = std::max(1, std::min(std::atoi(w), (int)pm_ctx::kSmWorkers));
     set(PM_OK);
     return ctx;
 }
@@ -490,6 +494,18 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_FUSE_PLANES:
         ctx->fuse_planes = value != 0;
         return PM_OK;
+    case PM_OPT_LT_MODE:
+        if (value < 0 || value > 2) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_LT_MODE takes 0, 1 or 2");
+        ctx->lt_mode = (int)value;
+        return PM_OK;
+    case PM_OPT_TRACE:
+        if (value < 0 || value > 3) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_TRACE takes a mask of 1 (host path) and 2 (smoothing splines)");
+        ctx->trace = (int)value;
+        return PM_OK;
+    case PM_OPT_SM_WORKERS:
+        if (value < 1 || value > (int64_t)pm_ctx::kSmWorkers) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SM_WORKERS takes 1 .. %d", (int)pm_ctx::kSmWorkers);
+        ctx->sm_worker_count = (int)value;
+        return PM_OK;
     case PM_OPT_FETCH_BLOCK_BYTES:
         if (value != 64 && value != 128 && value != 256) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_FETCH_BLOCK_BYTES takes 64, 128 or 256");
         ctx->fetch_shift = value == 64 ? 6 : value == 128 ? 7 : 8;
@@ -533,6 +549,9 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_BLOCK_TABLE_HITS: *value = pipe_table_hits(ctx); return PM_OK;
     case PM_OPT_ROUTE_EXPLORE: *value = ctx->route_explore; return PM_OK;
     case PM_OPT_FETCH_BLOCK_BYTES: *value = 1 << ctx->fetch_shift; return PM_OK;
+    case PM_OPT_LT_MODE: *value = ctx->lt_mode; return PM_OK;
+    case PM_OPT_TRACE: *value = ctx->trace; return PM_OK;
+    case PM_OPT_SM_WORKERS: *value = ctx->sm_worker_count; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;

@@ -47,6 +47,16 @@ void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, 
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
 
+// Debug / A-B knobs of the environment are honoured ONLY with PM_DEBUG_ENV=1 beside them: a stray PM_LT_MODE in a
+// user's shell must not select another algorithm. Every one of them has a pm_set_option() form; the tools under
+// tools/ set PM_DEBUG_ENV themselves. (PM_RCCL_LIBRARY and the launcher's LOCAL_WORLD_SIZE are deployment
+// settings, not debug knobs, and are read as they are.)
+inline const char *pm_debug_env(const char *name)
+{
+    const char *gate = std::getenv("PM_DEBUG_ENV");
+    return (gate && gate[0] == '1') ? std::getenv(name) : nullptr;
+}
+
 namespace pmh { struct HostPipe; }
 
 struct pm_ctx {
@@ -92,7 +102,7 @@ struct pm_ctx {
         void *tables_host = nullptr;  // pinned mirror of its table block
         size_t arena_bytes = 0;
     };
-    static constexpr int kSmWorkers = 8;  // upper bound; PM_SM_WORKERS=n selects fewer (default 4)
+    static constexpr int kSmWorkers = 8;  // upper bound; PM_OPT_SM_WORKERS selects fewer (default 4)
     SmWorker sm_workers[kSmWorkers];
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
@@ -104,8 +114,10 @@ struct pm_ctx {
     int zero_copy = -1;          // PM_OPT_ZERO_COPY
     int sparse_frame = -1;       // PM_OPT_SPARSE_FRAME
     int table_cache = 1;         // PM_OPT_BLOCK_TABLE_CACHE
+    int trace = 0;               // PM_OPT_TRACE: 1 stage times of the host path, 2 the smoothing-spline search, on stderr
+    int sm_worker_count = 4;     // PM_OPT_SM_WORKERS: threads that run the smoothing-spline fits of a cube's planes
     int fuse_planes = 0;         // PM_OPT_FUSE_PLANES
-    int lt_mode = 0;             // env PM_LT_MODE at pm_create (A/B runs of tools/): 0 closed-form light time of the
+    int lt_mode = 0;             // PM_OPT_LT_MODE (A/B runs of tools/, the light-time test): 0 closed-form light time of the
                                  // spheroid kernel, 1 the reference's sequence of epochs, 2 Newton step on its seed
     int route_explore = 1;       // PM_OPT_ROUTE_EXPLORE
     int fetch_shift = 7;         // PM_OPT_FETCH_BLOCK_BYTES: log2 of the blocks the GPU fetches from a pinned cube (routes 2, 4)

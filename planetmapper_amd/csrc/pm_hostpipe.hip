@@ -802,7 +802,7 @@ int map_cube_host_pipelined(pm_ctx *ctx, const void *cube, int dtype, int n_plan
 static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const double *x_map,
                                         const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
 {
-    static const bool trace = std::getenv("PM_HOSTPIPE_TRACE") != nullptr;  // stage times of every call on stderr
+    const bool trace = (ctx->trace & 1) != 0;  // PM_OPT_TRACE: stage times of every call on stderr
     const double t_call = trace ? now_ns() : 0.0;
     HostPipe *hp;
     int rc = pipe_get(ctx, &hp);

@@ -1,7 +1,7 @@
 // pm_kernels.hip -- gfx950 kernels of the planetmapper hot path.
 //
-//   k_disc<FLAGS>   image-space planes that need the ray/ellipsoid intercept
-//                   (lon/lat, centric, illumination, azimuth, LST, state, ring)
+//   k_disc_sph<FLAGS, BODY, SKY, MASK>  image-space planes that need the ray/ellipsoid intercept
+//                   (lon/lat, centric, illumination, azimuth, LST, state, ring); BODY: spheroid / triaxial / general
 //   k_sky<LIMB>     image-space planes defined for every pixel
 //                   (RA/Dec, pixel x/y, km, angular, limb)
 //   k_map           map-space planes + x_map/y_map for a lon/lat grid
@@ -52,124 +52,13 @@ constexpr unsigned long long kMaskDisc =
             *reinterpret_cast<double *>(reinterpret_cast<char *>(p.out[pl] + row_base) + lane_off) = (val); \
     } while (0)
 
-// Reference loops fused here: BodyXY._get_targvec_img body_xy.py:3195, _get_lonlat_img
-// :3281, _get_lonlat_centric_img :3346, _get_illumination_gie_img :3658,
-// get_azimuth_angle_img :3742, get_local_solar_time_img :3787, _get_state_imgs :3830,
-// get_radial_velocity_img :3895, get_doppler_img :3938,
+// Reference loops fused in the image kernel k_disc_sph below: BodyXY._get_targvec_img body_xy.py:3195, _get_lonlat_img
+// :3281, _get_lonlat_centric_img :3346, _get_illumination_gie_img :3658, get_azimuth_angle_img :3742,
+// get_local_solar_time_img :3787, _get_state_imgs :3830, get_radial_velocity_img :3895, get_doppler_img :3938,
 // _get_ring_plane_coordinate_imgs :4059.
-template <int FLAGS>
-__global__ __launch_bounds__(kBlock) void k_disc(const Params p_)
-{
-    // constants through the laundered kernel-argument pointer, loaded where they are used (k_map)
-    const Params &p = *(const Params *)kernarg_params();
-    const int x = blockIdx.x * kBlock + threadIdx.x;
-    const int y = p.y_off + (int)blockIdx.y;
-    const bool inside = x < p.nx;
-    const size_t row_base = (size_t)blockIdx.y * p.nx;  // wave-uniform: stores use the saddr form
-    const unsigned lane_off = (unsigned)x * 8u;
-    const double nan = __builtin_nan("");
-
-    // radius pre-mask of _get_targvec_img (only with optimize_speed)
-    const double dx = (double)x - p.x0, dy = (double)y - p.y0;
-    bool cand = inside && !(p.optimize_speed && (dx * dx + dy * dy) > p.r2);
-
-    V3 ray = xy2ray(p, (double)x, (double)y);
-
-    // rays rebuilt from the RA/Dec degree images for the ring planes
-    // (_get_obsvec_norm_img body_xy.py:3262-3271)
-    V3 ray2 = ray;
-    if (FLAGS & DF_RING) {
-        double ra, dec;
-        recrad_f(ray, ra, dec);
-        ray2 = radrec_f((ra * kDeg) * kRad, (dec * kDeg) * kRad);
-    }
-
-    V3 sp = {nan, nan, nan};
-    double lt = 0.0;
-    bool on_disc = false;
-    // wave-uniform skip of the intercept when no lane of the wave can be on the disc
-    if (wave_any(cand)) {
-        if (cand) on_disc = sincpt(p, ray, sp, lt);
-    }
-
-    double lon_deg = nan, lat_deg = nan;
-    if (on_disc) {
-        double lon, lat;
-        recpgr_surface(p, sp, lon, lat);
-        lon_deg = lon * kDeg;
-        lat_deg = lat * kDeg;
-    }
-    if (inside) {
-        PM_PUT_ROW(PM_LON_GRAPHIC, lon_deg);
-        PM_PUT_ROW(PM_LAT_GRAPHIC, lat_deg);
-    }
-    if (PM_WANT(PM_LON_CENTRIC) || PM_WANT(PM_LAT_CENTRIC)) {
-        double lc = nan, bc = nan;
-        if (on_disc) {
-            // reclat_c: Body._targvec2lonlat_centric body.py:2905
-            bc = atan2_fast<true>(sp.z, sqrt_fast(fma(sp.x, sp.x, sp.y * sp.y))) * kDeg;
-            lc = ((sp.x == 0.0 && sp.y == 0.0) ? 0.0 : atan2_fast(sp.y, sp.x)) * kDeg;
-        }
-        if (inside) {
-            PM_PUT_ROW(PM_LON_CENTRIC, lc);
-            PM_PUT_ROW(PM_LAT_CENTRIC, bc);
-        }
-    }
-    if (PM_WANT(PM_LOCAL_SOLAR_TIME)) {
-        double v = local_solar_time(p, lon_deg);
-        if (inside) PM_PUT_ROW(PM_LOCAL_SOLAR_TIME, v);
-    }
-
-    double surf_dist = nan;
-    if (FLAGS & (DF_ILLUM | DF_STATE | DF_RING)) {
-        double ph = nan, in = nan, em = nan, az = nan, rv = nan, dop = nan;
-        if (on_disc) {
-            // the intercept's light time is already the fixed point of the point's own
-            // light-time equation to ~4e-10 s: one more pass converges it
-            V3 pos;
-            M3 R;
-            point_lt<1>(p, sp, lt, pos, R);
-            if (FLAGS & DF_ILLUM) {
-                illum_angles(p, sp, lt, pos, R, ph, in, em);
-                ph *= kDeg;
-                in *= kDeg;
-                em *= kDeg;
-                if (PM_WANT(PM_AZIMUTH)) az = azimuth_deg(ph, in, em);
-            }
-            if (FLAGS & (DF_STATE | DF_RING)) surf_dist = lt * p.g.clight;
-            if (FLAGS & DF_STATE) {
-                rv = radial_velocity(p, sp, lt, pos, R);
-                double beta = rv / p.g.clight;  // SpiceBase.calculate_doppler_factor base.py:550
-                dop = sqrt((1.0 + beta) / (1.0 - beta));
-            }
-        }
-        if (inside) {
-            if (FLAGS & DF_ILLUM) {
-                PM_PUT_ROW(PM_PHASE, ph);
-                PM_PUT_ROW(PM_INCIDENCE, in);
-                PM_PUT_ROW(PM_EMISSION, em);
-                PM_PUT_ROW(PM_AZIMUTH, az);
-            }
-            if (FLAGS & DF_STATE) {
-                PM_PUT_ROW(PM_DISTANCE, surf_dist);
-                PM_PUT_ROW(PM_RADIAL_VELOCITY, rv);
-                PM_PUT_ROW(PM_DOPPLER, dop);
-            }
-        }
-    }
-
-    if (FLAGS & DF_RING) {
-        double rr, rl, rd;
-        ring_coords(p, ray2, rr, rl, rd);
-        // hidden behind the disc (NaN compares false): body_xy.py:4077-4080
-        if (rd > surf_dist) rr = rl = rd = nan;
-        if (inside) {
-            PM_PUT_ROW(PM_RING_RADIUS, rr);
-            PM_PUT_ROW(PM_RING_LON_GRAPHIC, rl);
-            PM_PUT_ROW(PM_RING_DISTANCE, rd);
-        }
-    }
-}
+// (Rounds 1-3 kept a second, general image kernel here - k_disc<FLAGS>: J2000 vectors, a 3 x 3 rotation matrix per
+//  light-time evaluation, 0.41 ms per headline frame. Round 4 replaced it with the GEN mode of k_disc_sph, the same B0
+//  formulation made exact for any body and observer: 0.21 ms, profiles/r04_disc_kernel_times.jsonl.)
 
 // ------------------------------------------------------------------ spheroid fast path
 // Same planes as k_disc (without the ring planes) for bodies with radii[0] == radii[1].
@@ -1159,26 +1048,10 @@ __global__ __launch_bounds__(kBlock) void k_radec_query(const Params p_, const d
 // ------------------------------------------------------------------ launchers (called from pm_capi.hip)
 extern "C++" {
 
-// the general image kernel: k_disc_sph<FLAGS, 2> (PM_GENERAL_LEGACY in the environment of a tools/ A/B run: the
-// J2000 kernel k_disc of rounds 1-3, kept as the second implementation the parity suite can be pointed at)
+// the general image kernel: k_disc_sph<FLAGS, 2> (near-field observers, fast spinners, large accelerations,
+// PM_OPT_GENERAL_KERNEL)
 void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s)
 {
-    static const bool legacy = std::getenv("PM_GENERAL_LEGACY") != nullptr;
-    if (legacy) {
-        dim3 grid((p.nx + pm::kBlock - 1) / pm::kBlock, p.rows);
-        dim3 block(pm::kBlock);
-        switch (flags & 7) {
-        case 0: hipLaunchKernelGGL(pm::k_disc<0>, grid, block, 0, s, p); break;
-        case 1: hipLaunchKernelGGL(pm::k_disc<1>, grid, block, 0, s, p); break;
-        case 2: hipLaunchKernelGGL(pm::k_disc<2>, grid, block, 0, s, p); break;
-        case 3: hipLaunchKernelGGL(pm::k_disc<3>, grid, block, 0, s, p); break;
-        case 4: hipLaunchKernelGGL(pm::k_disc<4>, grid, block, 0, s, p); break;
-        case 5: hipLaunchKernelGGL(pm::k_disc<5>, grid, block, 0, s, p); break;
-        case 6: hipLaunchKernelGGL(pm::k_disc<6>, grid, block, 0, s, p); break;
-        case 7: hipLaunchKernelGGL(pm::k_disc<7>, grid, block, 0, s, p); break;
-        }
-        return;
-    }
     dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
     dim3 block(pm::kSphBlock);
     switch (flags & 7) {

@@ -411,7 +411,7 @@ int sm_fit(pm_ctx *ctx, hipStream_t s, const double *z, SmAxis &ay, SmAxis &ax, 
     PM_HIP(ctx, hipStreamSynchronize(s));
     fp = 0.0;
     for (int i = 0; i < ny; i++) fp += sums[i];
-    if (std::getenv("PM_SM_DEBUG"))  // trace of the knot / smoothing-parameter search
+    if (ctx->trace & 2)  // PM_OPT_TRACE: the knot / smoothing-parameter search
         std::fprintf(stderr, "sm_fit ny=%d nx=%d knots=(%d,%d) p=%g fp=%.17g\n", ny, nx, ay.n, ax.n, p, fp);
     ay.account(sums);
     ax.account(sums + ny);
@@ -517,9 +517,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
     // The fit of a plane is a host-driven search (a few dozen fits, each a chain of small launches
     // and a read-back the next decision waits for): planes are dealt to worker threads, each with
     // its own stream and workspace, so that several such chains are in flight.
-    int want = 4;
-    if (const char *e = std::getenv("PM_SM_WORKERS")) want = std::atoi(e);
-    want = std::max(1, std::min(want, (int)pm_ctx::kSmWorkers));
+    const int want = std::max(1, std::min(ctx->sm_worker_count, (int)pm_ctx::kSmWorkers));  // PM_OPT_SM_WORKERS
     const int n_workers = (int)std::min<size_t>((size_t)want, std::min<size_t>(chunk, (size_t)a.n_planes));
     std::vector<SmDevice> devs(n_workers);
     for (int w = 0; w < n_workers; w++) {

@@ -35,6 +35,15 @@ COND = 1.0
 # disc at high latitude, where the longitude's 1 / cos(lat) works): LON 98.2 %, LAT 99.58 %, INC / EMI 99.44 %; a
 # fresh-seed fuzz cases (f = 0.2 spheroid at 10 - 16 au, seeds 987530021, 1530440826): LAT 99.36 %, EMI 99.10 %.
 MIN_FLAT = {'LON-GRAPHIC': 0.98, 'LAT-GRAPHIC': 0.99, 'PHASE': 0.9999, 'INCIDENCE': 0.99, 'EMISSION': 0.99}
+# Round 4: per geometry class (geometry_class below). Lowest shares over every frame of the GPU suite, both image
+# kernels (profiles/r04_parity_margins.json): equatorial LON 98.74 %, LAT 99.98 %, INC 99.46 %, EMI 99.22 %; tilted
+# (Saturn at -22.5 deg, f = 0.098; against ITS flat bar of 1.53e-9 deg, see base_deg) LON 98.22 %, LAT 98.89 %,
+# INC 99.33 %, EMI 98.79 % - those minima include windows on the limb and random aspects to which the floor does not
+# apply. Floor = that measurement - 0.3 %, never below the round-3 floor.
+MIN_FLAT_BY_CLASS = {
+    'equatorial': {'LON-GRAPHIC': 0.984, 'LAT-GRAPHIC': 0.9968, 'PHASE': 0.9999, 'INCIDENCE': 0.9916, 'EMISSION': 0.99},
+    'tilted': {'LON-GRAPHIC': 0.98, 'LAT-GRAPHIC': 0.99, 'PHASE': 0.9999, 'INCIDENCE': 0.9903, 'EMISSION': 0.99},
+}
 _REPORT = os.environ.get('PM_PARITY_REPORT')
 
 
@@ -46,6 +55,28 @@ def base_deg(g) -> float:
     """
     d_over_r = g.lt_c * g.clight / g.radii[0]
     return max(BASE_DEG, float(np.rad2deg(12 * 1.11e-16 * d_over_r)))
+
+
+def sub_observer_latitude_deg(g) -> float:
+    """planetocentric latitude of the observer seen from the body (from the block's R0 and T0)"""
+    r0 = np.array(g.R0[:]).reshape(3, 3)
+    o = -r0 @ np.array(g.T0[:])
+    return float(np.rad2deg(np.arcsin(o[2] / np.linalg.norm(o))))
+
+
+def geometry_class(g) -> str:
+    """
+    What the share of pixels inside the FLAT bar depends on: how much of the disc sits at high latitude, where the
+    longitude's 1 / cos(lat) works (the tilt of the pole towards the observer), and the flattening.
+    'equatorial': seen within 10 deg of the equator, f < 0.08 (Jupiter / HST, every golden); 'tilted': anything else
+    (Saturn 2005 at -23 deg, f = 0.098; the f = 0.2 spheroids and random aspects of the fuzz sweeps).
+    """
+    f = 1.0 - g.radii[2] / g.radii[0]
+    return 'equatorial' if abs(sub_observer_latitude_deg(g)) < 10.0 and f < 0.08 and g.radii[0] == g.radii[1] else 'tilted'
+
+
+def min_flat(g) -> dict:
+    return MIN_FLAT_BY_CLASS[geometry_class(g)]
 
 
 def _wrap(d):
@@ -161,7 +192,8 @@ def masks_agree(name: str, a, b) -> bool:
     NaN masks of a plane: identical - except AZIMUTH at the singularities of the reference's own formula
     (body.py:2319-2332: pi - arccos(q) with |q| = 1 where the point, the Sun and the observer lie in one plane with
     the normal): there q = +-(1 + a few 1e-16) decides between 0 / 180 deg and NaN by rounding, in the reference too.
-    A mismatch is accepted only on pixels whose finite value is within 1e-3 deg of 0 or 180, at most a handful.
+    A mismatch is accepted only on pixels whose finite value is within 1e-3 deg of 0 or 180, at most four of them in a
+    frame of any size.
     """
     na, nb = np.isnan(a), np.isnan(b)
     if np.array_equal(na, nb):
@@ -171,13 +203,15 @@ def masks_agree(name: str, a, b) -> bool:
     diff = na != nb
     val = np.where(na, b, a)[diff]
     near = np.minimum(np.abs(val), np.abs(180.0 - val)) < 1e-3
-    return bool(near.all()) and int(diff.sum()) <= max(2, int(1e-5 * a.size))
+    # (an absolute handful, whatever the size of the frame: the soaks see a few such pixels per THOUSAND frames)
+    return bool(near.all()) and int(diff.sum()) <= 4
 
 
 def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate_scale_arcsec=None) -> dict:
     """
     Assert parity of `out` (HIP) with `ref` (oracle). Returns statistics
-    {name: (max_abs_diff, fraction within the flat bar `base_deg(g)`)}.
+    {name: (max_abs_diff, fraction within the flat bar `base_deg(g)`, fraction within the north star's own flat
+    1e-9 deg - the same number wherever base_deg(g) is 1e-9)}.
     """
     tol = tolerances(ref, g, plate_scale_arcsec)
     flat_bar = base_deg(g)
@@ -186,9 +220,12 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
         a, b = out[n], ref[n]
         assert a.shape == b.shape, n
         assert masks_agree(n, a, b), f'{n}: NaN mask differs'
-        fin = np.isfinite(b) & np.isfinite(a)
+        # (an infinity where the oracle holds a finite value is a failure, not a pixel to leave out: only the NaN
+        #  positions masks_agree() has just accepted - AZIMUTH at its singularities - are excluded)
+        assert not np.any(np.isinf(a) & np.isfinite(b)), f'{n}: infinite where the oracle is finite'
+        fin = np.isfinite(b) & ~np.isnan(a)
         if not fin.any():
-            stats[n] = (0.0, 1.0)
+            stats[n] = (0.0, 1.0, 1.0)
             continue
         d = np.abs(a - b)
         if 'LON' in n or n == 'RA':
@@ -199,7 +236,7 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
             nbad = int(np.nansum(d > 0))
             assert np.nanmax(d) <= 1.0 / 3600 + 1e-12, n
             assert nbad <= max(1, 1e-5 * a.size), (n, nbad)
-            stats[n] = (float(np.nanmax(d)), 1.0 - nbad / max(1, fin.sum()))
+            stats[n] = (float(np.nanmax(d)), 1.0 - nbad / max(1, fin.sum()), 1.0 - nbad / max(1, fin.sum()))
             continue
         t = tol[n]
         bad = d > t
@@ -207,7 +244,10 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
             worst = float(np.nanmax(np.where(fin, d / np.maximum(t, 1e-300), 0.0)))
             with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'gpurun_out', 'parity_ratios.jsonl'), 'a') as f:
                 f.write(json.dumps({'test': os.environ.get('PYTEST_CURRENT_TEST', ''), 'plane': n, 'worst_over_bar': worst,
-                                    'pixels': int(fin.sum()), 'flat': float(np.mean(d[fin] <= flat_bar))}) + '\n')
+                                    'pixels': int(fin.sum()), 'flat': float(np.mean(d[fin] <= flat_bar)),
+                                    'flat_1e-9': float(np.mean(d[fin] <= BASE_DEG)), 'class': geometry_class(g),
+                                    'sub_observer_lat_deg': round(sub_observer_latitude_deg(g), 2),
+                                    'flattening': round(1.0 - g.radii[2] / g.radii[0], 4)}) + '\n')
         if np.any(bad & fin):
             i = np.unravel_index(np.nanargmax(np.where(fin, d / np.maximum(t, 1e-300), 0)), d.shape)
             raise AssertionError(
@@ -215,7 +255,7 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
                 f'(hip={a[i]!r}, oracle={b[i]!r})'
             )
         flat = float(np.mean(d[fin] <= flat_bar))
-        stats[n] = (float(np.nanmax(d)), flat)
+        stats[n] = (float(np.nanmax(d)), flat, float(np.mean(d[fin] <= BASE_DEG)))
         # (the shares were measured on whole discs: a frame that holds a sliver of limb has any share at all - seed
         #  1530440826 of the disc fuzz, a 53 x 161 window on the edge of Saturn: LON 97.6 %. With the plate scale
         #  known, the floor applies to frames that hold at least 60 % of the disc.)
@@ -224,5 +264,6 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
             r0_px = g.diameter_arcsec / (2.0 * plate_scale_arcsec)
             whole = fin.sum() >= 0.6 * np.pi * r0_px * r0_px * (g.radii[2] / g.radii[0])
         if n in MIN_FLAT and fin.sum() > 5000 and whole:
-            assert flat >= (MIN_FLAT[n] if min_flat_fraction is None else min_flat_fraction), (n, flat)
+            floor = min_flat(g)[n] if min_flat_fraction is None else min_flat_fraction
+            assert flat >= floor, (n, flat, floor, geometry_class(g))
     return stats

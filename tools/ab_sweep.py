@@ -21,6 +21,7 @@ if os.environ.get('TRIAXIAL'):  # a triaxial body: the TRI variant of the frame 
 planes = {n: torch.empty((sz, sz), dtype=torch.float64, device=dev) for n in names}
 engines = []
 for path, envs in zip(sys.argv[1:3], (os.environ.get('AB_ENV_A', ''), os.environ.get('AB_ENV_B', ''))):
+    os.environ['PM_DEBUG_ENV'] = '1'  # (the library reads its A/B knobs only behind this gate)
     for kv in filter(None, envs.split(',')):  # e.g. AB_ENV_B=PM_LT_MODE=2 (read by the library at pm_create)
         os.environ[kv.split('=')[0]] = kv.split('=', 1)[1]
     _lib._lib = None

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """
-Where the time of a host-fed cube call goes (config 5 geometry): `PM_HOSTPIPE_TRACE=1 python
+Where the time of a host-fed cube call goes (config 5 geometry): `PM_DEBUG_ENV=1 PM_HOSTPIPE_TRACE=1 python
 tools/cube_host_probe.py [--planes 512,64] [--threads 16,2] [--chunk-mib 32]` prints the library's own
 stage trace (stderr) and the wall time of each step (x/y map + pm_map_cube(PM_MEM_HOST_CUBE) + finish).
 """

@@ -36,6 +36,7 @@ def main():
     out = {}
     KEYS = os.environ.get('LT_PLANES', ' '.join(HEADLINE)).split()
     for mode in os.environ.get('LT_MODES', '0 1 2').split():
+        os.environ['PM_DEBUG_ENV'] = '1'  # (the library reads its A/B knobs only behind this gate)
         os.environ['PM_LT_MODE'] = mode
         eng = Engine(0)
         try:

@@ -133,25 +133,34 @@ def library_sha256() -> str:
         return hashlib.sha256(f.read()).hexdigest()
 
 
-def profile_record(kernel_prefix: str) -> tuple[dict, bool]:
+def profile_record(kernel_prefix, workload: str = 'frame') -> tuple[dict, bool]:
     """
-    Per-launch PMC figures of a kernel from the separate rocprofv3 --pmc passes of
-    tools/pmc_profile.sh (profiles/traffic.json: WRITE_SIZE + FETCH_SIZE bytes, FP64 operations).
+    Per-launch PMC figures of a kernel (or, for a tuple of prefixes, the sum over the kernels of a step) from
+    the separate rocprofv3 --pmc passes of tools/pmc_profile.sh: profiles/traffic.json for the headline frame,
+    profiles/traffic_<workload>.json for the others (WRITE_SIZE + FETCH_SIZE bytes, FP64 operations).
     PMC counters cannot be collected inside this process, so the last profiled values are reported -
     but only while they belong to THIS build: the file carries the sha256 of the library it was measured
     on. Returns (record, stale): stale = the file exists but was measured on another build (record empty).
     """
+    name = 'traffic.json' if workload == 'frame' else f'traffic_{workload}.json'
     try:
-        with open(os.path.join(REPO, 'profiles', 'traffic.json')) as f:
+        with open(os.path.join(REPO, 'profiles', name)) as f:
             t = json.load(f)
     except (OSError, ValueError):
         return {}, False
     if t.get('_library_sha256') != library_sha256():
         return {}, True
-    for k, v in t.items():
-        if k.startswith(kernel_prefix) and isinstance(v, dict):
-            return v, False
-    return {}, False
+    prefixes = (kernel_prefix,) if isinstance(kernel_prefix, str) else tuple(kernel_prefix)
+    total: dict = {}
+    for pre in prefixes:
+        for k, v in t.items():
+            if k.startswith(pre) and isinstance(v, dict):
+                for field, val in v.items():
+                    total[field] = total.get(field, 0.0) + val
+                break
+        else:
+            return {}, False  # a kernel of the step is missing from the file
+    return total, False
 
 
 def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
@@ -210,6 +219,45 @@ def cpu_baseline(g, sz: int, threads: int, budget_s: float, max_frames: int) -> 
         'kind': 'port',
         'sample': f'{frames} full {sz}x{sz} frame(s), 5 planes + 1 deg reprojection, OpenMP over rows',
     }
+
+
+def cpu_baseline_other(workload: str, g, sz: int, names, threads: int, planes: int, budget_s: float = 10.0) -> dict:
+    """
+    The CPU oracle on a bounded sample of a secondary workload (same unit as its `value`): saturn / all26 - whole
+    frames with the workload's plane set until the budget is used (at least one); cube - the x/y map of the 1 deg
+    grid + as many planes of a 1024^2 f64 cube as fit the budget (planes are independent units).
+    """
+    from oracle import oracle
+
+    oracle.set_num_threads(threads)
+    x0 = (sz - 1) / 2
+    t0 = time.perf_counter()
+    if workload == 'cube':
+        disc = oracle.make_disc(x0, x0, 0.9 * x0, 0.0, sz, sz)
+        lon, lat = rectangular_grid(bool(g.west_positive))
+        rng = np.random.default_rng(5)
+        block = rng.standard_normal((16, sz, sz))
+        xm, ym = oracle.xy_map(g, disc, lon, lat)
+        done = 0
+        while True:
+            oracle.map_cube(block, xm, ym, 'linear', True)
+            done += block.shape[0]
+            dt = time.perf_counter() - t0
+            if dt > budget_s or done >= planes:
+                break
+        return {'value': round(done * sz * sz / dt / 1e6, 1), 'unit': 'Mpix/s', 'cores': threads, 'kind': 'port',
+                'sample': f'x/y map of the 1 deg grid + {done} of the {planes} planes ({sz}x{sz} f64), bilinear, OpenMP over map rows'}
+    r0, rot = (800.0 * sz / 4096, 20.0) if workload == 'saturn' else (0.9 * x0, 0.0)
+    disc = oracle.make_disc(x0, x0, r0, rot, sz, sz)
+    frames = 0
+    while True:
+        oracle.backplanes_img(g, disc, list(names))
+        frames += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or frames >= 4:
+            break
+    return {'value': round(frames * sz * sz / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{frames} full {sz}x{sz} frame(s), {len(list(names))} planes, OpenMP over rows'}
 
 
 class Dist:
@@ -836,16 +884,27 @@ def other_workloads(args) -> None:
     step_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
     if d.rank == 0:
         n_units = units * (d.world if scaling == 'weak' else 1)
-        print(json.dumps({
+        # the step IS its kernels here (events around the step on the stream they run on); HBM traffic per step from
+        # the stamped --pmc passes of tools/pmc_profile.sh for this workload
+        kernels = {'saturn': ('pm::k_disc_sph<5,',), 'all26': ('pm::k_disc_sph<7,', 'pm::k_sky<true>'),
+                   'cube': ('pm::k_reproject<double>',)}[args.workload]
+        rec, stale = profile_record(kernels, args.workload) if (args.size == 4096 or args.workload == 'cube') else ({}, False)
+        line = {
             'metric': metric, 'value': round(n_units * args.steps / dt / 1e6, 2), 'unit': 'Mpix/s',
             'n_gpus': d.world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': workload},
-            'roofline': {'bound': 'hbm', 'achieved': round(alg / (step_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS,
+            'roofline': {'kernel': ' + '.join(k.rstrip(',') + ('...>' if k.endswith(',') else '') for k in kernels),
+                         'bound': 'hbm', 'achieved': round(alg / (step_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                         'traffic': None, 'kernel_ms': round(step_ms, 4), 'algorithmic_bytes': alg},
-        }), flush=True)  # fmt: skip
+                         'traffic': int(rec['hbm_bytes']) if 'hbm_bytes' in rec else None, 'traffic_stale': stale,
+                         'library_sha256': library_sha256()[:16], 'kernel_ms': round(step_ms, 4), 'algorithmic_bytes': alg},
+        }
+        if d.world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline_other(args.workload, g, sz, names if args.workload != 'cube' else (), host_cores(), args.planes)
+            line['cpu_model'] = cpu_model()
+        print(json.dumps(line), flush=True)
     d.close()
     eng.close()
 
@@ -986,7 +1045,7 @@ def headline(args) -> None:
                 'preheat_steps': args.preheat_steps,
             },
             'roofline': {
-                'kernel': 'pm::k_disc_sph<1, false, 0, 28675ull> (DF_ILLUM, spheroid, the headline plane set)',
+                'kernel': 'pm::k_disc_sph<1, 0, 0, 28675ull> (DF_ILLUM, spheroid, the headline plane set)',
                 'bound': 'hbm',
                 'achieved': round(achieved, 2),
                 'peak': HBM_PEAK_GBS,

@@ -1,5 +1,5 @@
 """
-The closed-form light time of the spheroid frame kernel (k_disc_sph), restated with mpmath
+The closed-form light time of the spheroid frame kernel (k_disc_sph, profiles/EXPERIMENTS.md, round 3), restated with mpmath
 from the geometry block and checked without a GPU:
   (1) it IS the fixed point of the reference's iteration lt = E((et - lt) - t0) for linear target motion;
   (2) the first-order step from the fixed point onto an epoch one quantum away lands on the intercept evaluated

@@ -2001,7 +2001,7 @@ def test_mapping_visible_areas_through_the_real_engine(engine, oracle):
 @pytest.mark.parametrize('which', ['jupiter', 'saturn', 'near_field'])
 def test_closed_form_light_time_against_the_reference_sequence(oracle, jupiter, saturn, which):
     """
-    k_disc_sph settles the waves clear of the limb with the light time in closed form; the
+    k_disc_sph settles the waves clear of the limb with the light time in closed form (profiles/EXPERIMENTS.md, round 3); the
     library can be told to walk the reference's own sequence of epochs everywhere instead (PM_OPT_LT_MODE 1) or to
     take the round-2 path (2: Newton step on the seed). Same frame through all three:
     NaN masks identical - the closed form may not decide a single limb pixel differently -, values inside the
@@ -2058,7 +2058,7 @@ def test_limb_bound_is_never_tighter_than_the_limb(engine, oracle, jupiter):
     offsets and with `optimize_speed=False`: the NaN mask is the oracle's (which tests every pixel the reference
     does) and the values sit inside the bars both ways. (Not bit-identical to each other: with the pre-mask off a
     wave at the limb can hold a candidate it did not hold before, and a wave with a lane in the limb band walks the
-    reference's sequence of epochs instead of the closed form - DESIGN §4, round 3 - for all of its lanes.)
+    reference's sequence of epochs instead of the closed form - profiles/EXPERIMENTS.md, round 3 - for all of its lanes.)
     """
     rng = np.random.default_rng(20261004)
     engine.set_geometry(jupiter)

@@ -1,5 +1,5 @@
 """
-The limb bound of the frame kernels (pm_capi.hip fill_params), restated in numpy and held
+The limb bound of the frame kernels (pm_capi.hip fill_params, profiles/EXPERIMENTS.md, round 3), restated in numpy and held
 against the CPU oracle: no pixel that the oracle finds ON the body - with the pre-mask off, i.e. every pixel
 ray-tested as the reference does with optimize_speed=False - may lie outside the bound's circle. Runs without
 a GPU: it pins the FORMULA (reach of the limb, offset of the angular origin, spherical excess, half a pixel);

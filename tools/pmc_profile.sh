@@ -20,4 +20,6 @@ run rd FETCH_SIZE
 cd $GRAFT_REPO_ROOT
 python3 tools/pmc_summary.py $OUT > $OUT/summary.txt; cat $OUT/summary.txt
 cat $OUT/stats/*/*kernel_stats.csv | head -8
+# (copy $OUT/traffic.json to profiles/traffic.json for the headline frame, profiles/traffic_<workload>.json otherwise:
+#  bench.py reports it as roofline.traffic while the library's sha256 matches)
 grep '^{' $OUT/bench_stats.log | tail -1 | cut -c1-200

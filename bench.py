@@ -559,13 +559,22 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
     return sec
 
 
+_PROXY_SLOTS: dict = {}
+
+
 def _proxy_step(eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local: int, n_total: int, gathered) -> None:
     """rank 0's step of an N-rank run on this one GPU: its block, exchange by exchange, no collective"""
     from planetmapper_amd.distributed import map_cube_sharded_pipelined
 
     world = -(-n_total // n_local)
     eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
-    slots = gathered.reshape(-1, n0, n1)[: world * n_local].reshape(world, n_local, n0, n1)
+    # (world * n_local >= n_total planes - more than the N = 1 buffer holds when N does not divide the cube: the
+    #  proxy's slots are its own, kept between steps)
+    key = (world, n_local, n0, n1)
+    if _PROXY_SLOTS.get('key') != key:
+        _PROXY_SLOTS['key'] = key
+        _PROXY_SLOTS['slots'] = gathered.new_empty((world, n_local, n0, n1))
+    slots = _PROXY_SLOTS['slots']
     map_cube_sharded_pipelined(eng, cube_h[:n_local], np.float64, n_total, xm, ym, n0, n1, slots, 0, world, host_cube=True,
                                pipeline_chunks=True)
 

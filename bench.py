@@ -510,13 +510,17 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         nocoll()
         d.barrier()
         ts = []
+        c0, w0 = time.process_time(), time.perf_counter()
         for _ in range(steps_fed):
             t = time.perf_counter()
             nocoll()
             ts.append(time.perf_counter() - t)
+        busy = (time.process_time() - c0) / max(time.perf_counter() - w0, 1e-9)  # CPUs this process kept busy (all its threads)
         d.barrier()
         sec['ms_per_step_host_fed_no_collective'] = round(d.max_over_ranks(float(np.median(ts))) * 1e3, 3)
         sec['rank0_step_ms_host_fed_no_collective'] = spread(ts)
+        sec['cpus_busy_per_rank_no_collective'] = round(d.max_over_ranks(busy), 2)
+        sec['cpus_available'] = host_cores()
     route = eng.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) if real else None
     route_ns = {str(r): eng.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(_lib.NUM_CUBE_ROUTES)} if real else None
     table_hits = eng.get_option(_lib.PM_OPT_BLOCK_TABLE_HITS) if real else None
@@ -771,7 +775,8 @@ def shared_gpu_section(args) -> dict:
             out['runs'].append({'N': n, 'error': f'rc {p.returncode}: ' + (p.stdout + p.stderr)[-600:]})
             break
         sec = json.loads(lines[-1]).get('cube_host', {})
-        keep = ('ranks', 'collective_backend', 'planes_per_rank', 'copy_threads', 'route_chosen', 'route_ns_per_plane',
+        keep = ('ranks', 'collective_backend', 'planes_per_rank', 'copy_threads', 'cpus_busy_per_rank_no_collective', 'cpus_available',
+                'route_chosen', 'route_ns_per_plane',
                 'ms_per_step_host_fed_no_collective', 'rank0_step_ms_host_fed_no_collective',
                 'ms_per_step_host_fed', 'rank0_step_ms_host_fed', 'ms_per_step_resident',
                 'ms_per_step_host_fed_plain_allgather', 'fed_equals_resident', 'fed_equals_resident_plain_allgather', 'pipelined_error')

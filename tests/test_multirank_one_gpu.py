@@ -118,3 +118,26 @@ def test_torch_distributed_protocol_with_real_engines_sharing_one_gpu(world):
     assert all(r['ok'] for r in reps), reps
     for r in reps:
         assert set(r['checks']) == {'host', 'uneven', 'redo', 'fail', 'fail_then_ok'}, r
+
+
+def test_bench_headline_and_sharded_cube_at_two_ranks_on_one_gpu():
+    """
+    `bench.py --gpus 2 --shared-gpu`: the code the driver's N > 1 runs execute - launcher, process group, barriers,
+    the headline line printed BEFORE the extra sections, the sharded host-fed cube (plain all-gather form, then the
+    pipelined protocol with its exchanges issued from the engine's chunk callback, then every rank feeding at once
+    without a collective) and the complete line - with two real engines on device 0 and a gloo group in place of
+    RCCL (which refuses two ranks on one card). Sizes cut down; the numbers mean nothing here, the flow does.
+    """
+    repo = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--shared-gpu', '--size', '1024', '--steps', '10',
+                        '--warmup', '2', '--preheat-steps', '5', '--planes', '48'], env=_env(), capture_output=True, text=True, timeout=900)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert p.returncode == 0 and len(lines) == 2, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    first, last = lines
+    assert first['n_gpus'] == 2 and 'pending' in first['extras'] and 'cube_host' not in first
+    assert last['value'] == first['value'] and last['ms_per_step'] == first['ms_per_step'] and 'extras' not in last
+    sec = last['cube_host']
+    assert 'error' not in sec and 'pipelined_error' not in sec, sec
+    assert sec['ranks'] == 2 and sec['planes_per_rank'] == 24 and sec['rccl_ranks'] == 0 and 'gloo' in sec['collective_backend']
+    assert sec['fed_equals_resident'] is True and sec['fed_equals_resident_plain_allgather'] is True
+    assert sec['ms_per_step_host_fed'] > 0 and sec['ms_per_step_host_fed_no_collective'] > 0

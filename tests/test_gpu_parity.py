@@ -1136,6 +1136,36 @@ def test_near_field_observer(engine_fg, oracle, distance_km):
     assert 0.02 < vis.mean() < 0.5
 
 
+def test_observer_inside_the_body(engine, oracle):
+    """
+    surfpt_c's other branch: an observer INSIDE the ellipsoid (0.42 equatorial radii from the centre) sees the far
+    intersection of every ray - no limb, emission angles beyond 90 deg. The reference cannot build such a Body (its
+    angular diameter is arcsin of a number above 1), but the C ABI takes any block and the general kernel
+    (k_disc_sph<FLAGS, 2>: the signed root) must do what CSPICE does: every pixel on the body, planes inside the bars
+    against the oracle. The library's own dispatch sends it there (y2 <= 4).
+    """
+    from planetmapper_amd import _lib
+
+    g = _near_field_geometry(30_000.0)
+    g.diameter_arcsec = 3600.0 * 120  # (NaN from the provider: any positive number fixes the pixel scale)
+    g.km_per_arcsec = 1.0
+    nx, ny = 131, 97
+    x0, y0, r0, rot = 60.0, 50.5, 45.0, 33.0
+    names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC', 'LAT-CENTRIC', 'PHASE', 'INCIDENCE', 'EMISSION', 'DISTANCE',
+             'RADIAL-VELOCITY', 'DOPPLER']
+    for opt in (False, True):
+        engine.set_geometry(g)
+        engine.set_disc(x0, y0, r0, float(np.deg2rad(rot)), nx, ny, opt)
+        d = oracle.make_disc(x0, y0, r0, rot, nx, ny, optimize_speed=opt)
+        d.rotation_rad = float(np.deg2rad(rot))
+        out = engine.backplanes_img(names)
+        assert engine.get_option(_lib.PM_OPT_LAST_DISC_KERNEL) == 3
+        ref = oracle.backplanes_img(g, d, names)
+        _compare(out, ref, names, g, flat=False)
+        if not opt:
+            assert np.isfinite(out['LON-GRAPHIC']).all() and np.nanmin(out['EMISSION']) > 90.0
+
+
 @pytest.mark.parametrize('force_names', [None, ['LON-GRAPHIC', 'EMISSION', 'RING-RADIUS', 'RA', 'LIMB-DISTANCE', 'PIXEL-Y']])
 def test_row_blocks_equal_the_full_frame(engine_fg, oracle, jupiter, saturn, force_names):
     """

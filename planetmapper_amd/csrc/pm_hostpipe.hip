@@ -503,7 +503,7 @@ struct SegLayout {
 // planes per chunk of a hybrid segment: collected chunks, and the (shorter) GPU-fetched ones, of which up to
 // kHybridInFlight are queued ahead of the threads
 constexpr size_t kHybridCollectChunk = 4, kHybridFetchChunk = 4;
-constexpr int kHybridInFlight = 2;
+constexpr int kHybridInFlight = 3;
 
 // (hybrid: n_list / shift describe the 16-byte table, n_list_f the fetched one)
 SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, size_t n_list, int shift, bool dst_pinned, size_t n_list_f = 0,
@@ -562,11 +562,13 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
     //  fetch. Out: [0] ns the threads spent collecting, [1] planes they collected, [2] ns the GPU spent fetching,
     //  [3] planes it fetched)
     double hy_cpu_ns = 0.0, hy_c_planes = 0.0, hy_f_ns = 0.0, hy_f_planes = 0.0;
+    const double t_seg0 = now_ns();
     // GPU-fetched chunks of a hybrid segment in flight: [f_tail, f_head) in the ring of event pairs
     size_t f_head = 0, f_tail = 0, f_planes_out = 0;
     size_t f_np[HostPipe::kFq] = {};
     double t_f_est = hybrid_obs ? hybrid_obs[2] : 0.0, t_c_est = hybrid_obs ? hybrid_obs[0] : 0.0;  // ns per plane, from earlier calls
-    bool endgame_done = false;
+    bool endgame = false;
+    size_t end_f = 0, end_c = 0;  // the closing split: planes still to hand to the GPU / to the threads
     auto retire_fetched = [&](bool wait) -> int {
         while (f_tail < f_head) {
             const int k = (int)(f_tail % HostPipe::kFq);
@@ -623,6 +625,7 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
         const size_t nb = std::min(L.batch, sg.n - b0);
         size_t drained = 0;  // planes of this batch already handed to the D2H leg
         size_t launched = 0;
+        endgame = false;  // (the closing split belongs to a batch)
         // (Tried: ramping the chunks of a collected table up and down - c/8, c/4 ... c ... halves of the rest -
         //  to shorten the pipeline's fill and drain for short blocks. Same-box A/B, 64 and 512 planes, three
         //  process pairs: 2.26-2.86 vs 2.17-2.52 ms and 11.9-16.3 vs 13.0-14.6 ms - inside the run-to-run
@@ -641,16 +644,20 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 const size_t rest = nb - q0;
                 const double tc = hy_c_planes > 0.0 ? hy_cpu_ns / hy_c_planes : t_c_est;
                 const double tf = hy_f_planes > 0.0 ? hy_f_ns / hy_f_planes : t_f_est;
-                if (!endgame_done && rest <= 2 * kHybridCollectChunk + kHybridFetchChunk && tc > 0.0 && tf > 0.0) {
+                if (!endgame && rest <= 2 * kHybridCollectChunk + kHybridFetchChunk && tc > 0.0 && tf > 0.0) {
+                    // the closing split: x planes for the threads, the others for the GPU - whose share is issued FIRST
+                    // (it runs behind what is queued while the threads collect theirs)
                     const double x = (double)(f_planes_out + rest) * tf / (tc + tf);
-                    const size_t xc = std::min<size_t>(rest, (size_t)std::llround(x));
-                    // (a collected chunk never exceeds the ring slot: a larger share is taken in two goes)
-                    endgame_done = xc <= L.chunk;
-                    fetch_chunk = xc == 0;
-                    want = fetch_chunk ? rest : std::min(xc, L.chunk);
-                } else if (endgame_done) {
-                    fetch_chunk = true;  // what the threads' last share left over
-                    want = rest;
+                    end_c = std::min<size_t>(rest, (size_t)std::llround(x));
+                    end_f = rest - end_c;
+                    endgame = true;
+                }
+                if (endgame) {
+                    fetch_chunk = end_f > 0;
+                    want = fetch_chunk ? end_f : std::min(end_c, L.chunk);  // (a collected chunk never exceeds its ring slot)
+                    want = std::max<size_t>(want, 1);
+                    if (fetch_chunk) end_f -= std::min(std::min(want, L.chunk_f), rest);
+                    else end_c -= std::min(want, rest);
                 } else {
                     fetch_chunk = (int)(f_head - f_tail) < kHybridInFlight;
                     want = fetch_chunk ? kHybridFetchChunk : kHybridCollectChunk;
@@ -661,6 +668,9 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
             const bool blocks = seg_blocks || fetch_chunk, host_blocks = seg_host_blocks || (hybrid && !fetch_chunk);
             const bool chunk_zero_copy = L.zero_copy || fetch_chunk;
             np = std::min(want, nb - q0);
+            if (hybrid && (ctx->trace & 1))
+                std::fprintf(stderr, "[pm hostpipe]   hybrid chunk %zu at %.3f ms: %s %zu planes (fetches in flight %zu, %zu planes)\n", c,
+                             (now_ns() - t_seg0) * 1e-6, fetch_chunk ? "F" : "C", np, f_head - f_tail, f_planes_out);
             const size_t pl = sg.p0 + b0 + q0;  // first plane of the chunk within the call
             const int slot = (int)(cs % HostPipe::kRing);
             const size_t cslot = cs;  // (this chunk's number among the slot users)
@@ -760,6 +770,7 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
         }
     }
     // the ring and the events are free for the next segment / the flag check
+    if (hybrid && (ctx->trace & 1)) std::fprintf(stderr, "[pm hostpipe]   hybrid: all chunks issued at %.3f ms\n", (now_ns() - t_seg0) * 1e-6);
     PM_HIP(ctx, hipStreamSynchronize(sk));
     PM_HIP(ctx, hipStreamSynchronize(hp->s_in));
     if (stage_ns) {

@@ -22,7 +22,7 @@ def main():
     ap.add_argument('--threads', default='2,4,16')
     ap.add_argument('--reps', type=int, default=9)
     ap.add_argument('--routes', default='2,3,4,-1')
-    ap.add_argument('--fetch-bytes', type=int, default=256, help='PM_OPT_FETCH_BLOCK_BYTES: 128 or 256')
+    ap.add_argument('--fetch-bytes', type=int, default=128, help='PM_OPT_FETCH_BLOCK_BYTES: 128 or 256')
     args = ap.parse_args()
     import torch
 

@@ -133,27 +133,10 @@ size_t dtype_size(int dt)
     }
 }
 
-// every queued operation of the calling thread, to completion: copy out, rings, copy in
-int run_ops(std::vector<Op> &ops)
+// every operation's host buffer through its ring (send: op.host -> ring of (rank, peer); receive: ring of (peer, rank) ->
+// op.host), all of them in turn so that two ranks sending to each other cannot block on a full ring
+int move_through_rings(std::vector<Op> &ops)
 {
-    if (ops.empty()) return ncclSuccess;
-    // what the caller's streams have produced so far is what gets sent
-    std::vector<hipStream_t> streams;
-    for (Op &op : ops) {
-        bool seen = false;
-        for (hipStream_t s : streams) seen = seen || s == op.stream;
-        if (!seen) streams.push_back(op.stream);
-    }
-    for (hipStream_t s : streams)
-        if (!dev_sync(s)) return ncclUnhandledCudaError;
-    for (Op &op : ops) {
-        op.host.resize(op.bytes);
-        if (op.kind == Op::kSend && op.bytes) {
-            if (!dev_copy(op.host.data(), op.dev, op.bytes, op.stream)) return ncclUnhandledCudaError;
-        }
-    }
-    for (hipStream_t s : streams)
-        if (!dev_sync(s)) return ncclUnhandledCudaError;
     double last_progress = now_s();
     size_t open = ops.size();
     for (Op &op : ops)
@@ -200,6 +183,32 @@ int run_ops(std::vector<Op> &ops)
             std::this_thread::yield();
         }
     }
+    return ncclSuccess;
+}
+
+// every queued operation of the calling thread, to completion: copy out, rings, copy in
+int run_ops(std::vector<Op> &ops)
+{
+    if (ops.empty()) return ncclSuccess;
+    // what the caller's streams have produced so far is what gets sent
+    std::vector<hipStream_t> streams;
+    for (Op &op : ops) {
+        bool seen = false;
+        for (hipStream_t s : streams) seen = seen || s == op.stream;
+        if (!seen) streams.push_back(op.stream);
+    }
+    for (hipStream_t s : streams)
+        if (!dev_sync(s)) return ncclUnhandledCudaError;
+    for (Op &op : ops) {
+        op.host.resize(op.bytes);
+        if (op.kind == Op::kSend && op.bytes) {
+            if (!dev_copy(op.host.data(), op.dev, op.bytes, op.stream)) return ncclUnhandledCudaError;
+        }
+    }
+    for (hipStream_t s : streams)
+        if (!dev_sync(s)) return ncclUnhandledCudaError;
+    const int mrc = move_through_rings(ops);
+    if (mrc != ncclSuccess) return mrc;
     for (Op &op : ops)
         if (op.kind == Op::kRecv && op.bytes) {
             if (!dev_copy(op.dev, op.host.data(), op.bytes, op.stream)) return ncclUnhandledCudaError;
@@ -242,46 +251,8 @@ int exchange_all(Comm *c, const void *send_dev, size_t bytes, std::vector<std::v
         ops.push_back(std::move(r));
     }
     // (host-to-host: the ring loop of run_ops without its device copies)
-    double last_progress = now_s();
-    size_t open = bytes ? ops.size() : 0;
-    while (open > 0) {
-        bool progressed = false;
-        for (Op &op : ops) {
-            if (op.moved == op.bytes) continue;
-            if (c->seg->aborted.load(std::memory_order_acquire)) return ncclRemoteError;
-            Ring &r = op.kind == Op::kSend ? c->seg->rings[(size_t)c->rank * c->world + op.peer] : c->seg->rings[(size_t)op.peer * c->world + c->rank];
-            if (op.kind == Op::kSend) {
-                const uint64_t head = r.head.load(std::memory_order_relaxed), tail = r.tail.load(std::memory_order_acquire);
-                size_t n = std::min(kRingBytes - (size_t)(head - tail), op.bytes - op.moved);
-                if (n == 0) continue;
-                const size_t at = (size_t)(head % kRingBytes), first = std::min(n, kRingBytes - at);
-                std::memcpy(r.data + at, op.host.data() + op.moved, first);
-                std::memcpy(r.data, op.host.data() + op.moved + first, n - first);
-                r.head.store(head + n, std::memory_order_release);
-                op.moved += n;
-            } else {
-                const uint64_t tail = r.tail.load(std::memory_order_relaxed), head = r.head.load(std::memory_order_acquire);
-                size_t n = std::min((size_t)(head - tail), op.bytes - op.moved);
-                if (n == 0) continue;
-                const size_t at = (size_t)(tail % kRingBytes), first = std::min(n, kRingBytes - at);
-                std::memcpy(op.host.data() + op.moved, r.data + at, first);
-                std::memcpy(op.host.data() + op.moved + first, r.data, n - first);
-                r.tail.store(tail + n, std::memory_order_release);
-                op.moved += n;
-            }
-            progressed = true;
-            if (op.moved == op.bytes) open--;
-        }
-        if (progressed) {
-            last_progress = now_s();
-        } else {
-            if (now_s() - last_progress > timeout_s()) {
-                std::fprintf(stderr, "[pm loopback] collective: no progress for %.0f s\n", timeout_s());
-                return ncclSystemError;
-            }
-            std::this_thread::yield();
-        }
-    }
+    const int mrc = move_through_rings(ops);
+    if (mrc != ncclSuccess) return mrc;
     recv.assign((size_t)c->world, {});
     for (Op &op : ops)
         if (op.kind == Op::kRecv) recv[(size_t)op.peer] = std::move(op.host);

@@ -964,35 +964,6 @@ __device__ __forceinline__ void limb_coords(const Params &p, V3 ray, double &lon
     dist = nd - norm(s);
 }
 
-// limb_coords for a finite ray, every pixel of a frame. The surface point under `tv` is
-// surfpt from the body centre, which reduces to tv / |tv / radii| (Y = 0 in surfpt above), so
-// the quadratic and its branches disappear; the spin angle over the light-time span of a frame
-// is < 1e-3 rad (series sincos, libm otherwise).
-__device__ __forceinline__ void limb_coords_f(const Params &p, V3 ray, double &lon_deg, double &lat_deg, double &dist)
-{
-    V3 T0 = ld3(p.g.T0);
-    double k = div_fast(dot(T0, ray), dot(ray, ray));
-    V3 near = k * ray;
-    double nd = norm_f(near - T0);
-    V3 off = near - ld3(p.g.sub_obsvec);
-    double dd = norm_f(off - ld3(p.g.sub_ray)) - p.g.sub_dist;
-    double t = p.g.sub_et - dd * p.inv_c;
-    M3 R;
-    rot_at<true>(p, t, R);
-    V3 tv = ld3(p.g.sub_sp) + mxv(R, off);
-    V3 X = {tv.x * p.ir[0], tv.y * p.ir[1], tv.z * p.ir[2]};
-    double xx = dot(X, X);
-    double sc = rsqrt_fast(xx);
-    V3 s = sc * tv;
-    double nx = s.x * p.limb_n[0], ny = s.y * p.limb_n[0], nz = s.z * p.limb_n[1];
-    double lat = atan2_fast(nz, sqrt_fast(fma(nx, nx, ny * ny)));
-    double l = atan2_fast(s.y, s.x);
-    if (p.g.west_positive) l = -l;
-    if (l < 0.0) l += kTwoPi;
-    lon_deg = l * kDeg;
-    lat_deg = lat * kDeg;
-    dist = nd - norm_f(s);
-}
 
 // Body.local_solar_time_from_lon body.py:2376-2398 (et2lst_c, truncated to whole seconds)
 // fmod(x, 86400) for |x| < 3 * 86400 is at most two exact subtractions (Sterbenz), the divisions are
@@ -1021,14 +992,6 @@ __device__ __forceinline__ double local_solar_time(const Params &p, double lon_d
     return hr + div_fast(mn, 60.0) + div_fast(sc, 3600.0);
 }
 
-// pixel -> unit ray: BodyXY._xy2obsvec_norm body_xy.py:375 -> Body._angular2obsvec_norm body.py:1363
-__device__ __forceinline__ V3 xy2ray(const Params &p, double x, double y)
-{
-    double ax = fma(p.A[0], x, fma(p.A[1], y, p.A[2]));
-    double ay = fma(p.A[3], x, fma(p.A[4], y, p.A[5]));
-    V3 v = radrec_f(-(div_fast(ax, 3600.0) * kRad), div_fast(ay, 3600.0) * kRad);
-    return mtxv(p.g.M, v);
-}
 
 
 // ------------------------------------------------------------------ one map cell -> pixel coordinates

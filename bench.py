@@ -1101,6 +1101,23 @@ def headline(args) -> None:
             # transport) but never over RCCL between GPUs - if that hangs and the run is killed, this line stands.
             # The complete line (same fields + cube_host) follows when the sections are through.
             print(json.dumps(dict(line, extras='pending: the complete line, with cube_host, follows')), flush=True)
+        watchdog = None
+        if d.world > 1:
+            # ... and if the section HANGS (a collective some rank never joins), every rank gives up after a deadline of
+            # its own: rank 0 prints the complete line with the section marked as timed out, and all of them leave with
+            # status 0 - the headline of this N is measured and must not be lost to an optional section.
+            import threading
+
+            deadline = float(os.environ.get('PM_BENCH_EXTRAS_TIMEOUT_S', '300'))
+
+            def bail() -> None:
+                if d.rank == 0:
+                    print(json.dumps(dict(line, cube_host={'error': f'timed out after {deadline:.0f} s: section abandoned'})), flush=True)
+                os._exit(0)
+
+            watchdog = threading.Timer(deadline, bail)
+            watchdog.daemon = True
+            watchdog.start()
         if d.world == 1 and d.rank == 0:
             line['host_path'] = host_path_section(eng, g, sz)
             line['api_path'] = api_path_section(g, sz, d.local_rank)
@@ -1110,6 +1127,8 @@ def headline(args) -> None:
             sec = {'error': f'{type(e).__name__}: {e}'[:500]}
         if d.world == 1 and d.rank == 0 and not args.no_shared_gpu and 'error' not in sec:
             sec['shared_gpu'] = shared_gpu_section(args)
+        if watchdog is not None:
+            watchdog.cancel()
         if d.rank == 0:
             line['cube_host'] = sec
     if d.rank == 0:

@@ -141,3 +141,19 @@ def test_bench_headline_and_sharded_cube_at_two_ranks_on_one_gpu():
     assert sec['ranks'] == 2 and sec['planes_per_rank'] == 24 and sec['rccl_ranks'] == 0 and 'gloo' in sec['collective_backend']
     assert sec['fed_equals_resident'] is True and sec['fed_equals_resident_plain_allgather'] is True
     assert sec['ms_per_step_host_fed'] > 0 and sec['ms_per_step_host_fed_no_collective'] > 0
+
+
+def test_bench_gives_up_on_a_hanging_extra_section_and_keeps_its_headline():
+    """
+    The optional sharded-cube section of an N > 1 run is given a deadline (PM_BENCH_EXTRAS_TIMEOUT_S): when it passes -
+    here at once - every rank leaves with status 0 and rank 0 has printed the complete headline line with the section
+    marked as timed out; the measured headline of that N is never lost to a collective that hangs.
+    """
+    repo = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--shared-gpu', '--size', '1024', '--steps', '10',
+                        '--warmup', '2', '--preheat-steps', '5', '--planes', '48'], env=_env(PM_BENCH_EXTRAS_TIMEOUT_S='0.05'),
+                       capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert p.returncode == 0 and len(lines) == 2, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert 'pending' in lines[0]['extras'] and lines[1]['value'] == lines[0]['value']
+    assert 'timed out' in lines[1]['cube_host']['error']

@@ -97,3 +97,30 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert f'rc {_lib.PM_ERR_UNSUPPORTED}' in r.stdout
+
+
+def test_hand_declared_rccl_abi_matches_the_installed_header():
+    """
+    pm_comm.hip binds RCCL at run time and declares the part of rccl.h it needs by hand (no link-time dependency):
+    the enum values and the unique-id size there must be those of the installed header, and every symbol it asks
+    dlsym for must be declared there.
+    """
+    import re
+
+    header = '/opt/rocm/include/rccl/rccl.h'
+    if not os.path.exists(header):
+        pytest.skip('no rccl.h on this machine')
+    h = open(header).read()
+    src = open(os.path.join(REPO, 'planetmapper_amd', 'csrc', 'pm_comm.hip')).read()
+    ours = dict(re.findall(r'\b(ncclSuccess|ncclInt32|ncclFloat64|ncclSum)\s*=\s*(\d+)', src))
+    assert set(ours) == {'ncclSuccess', 'ncclInt32', 'ncclFloat64', 'ncclSum'}
+    for name, value in ours.items():
+        m = re.search(r'\b%s\s*=\s*(\d+)' % name, h)
+        assert m and m.group(1) == value, (name, value, m and m.group(1))
+    assert re.search(r'#define\s+NCCL_UNIQUE_ID_BYTES\s+128\b', h) and 'char internal[128]' in src
+    for sym in re.findall(r'sym\("(nccl\w+)"\)', src):
+        assert re.search(r'\b%s\s*\(' % sym, h), sym
+    # ... and the loopback transport of the tests exports exactly those symbols
+    lb = open(os.path.join(REPO, 'tests', 'loopback', 'loopback_nccl.cpp')).read()
+    for sym in re.findall(r'sym\("(nccl\w+)"\)', src):
+        assert re.search(r'\b%s\s*\(' % sym, lb), sym

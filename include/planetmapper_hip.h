@@ -260,7 +260,7 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                               Until then: 3 when the table is under 40 % of the size of the planes,
  *                               else 0.
  *                           (1 and 2 on pageable memory, 2 and 3 on planes that are not a whole
- *                           number of blocks: as 0.)
+ *                           number of blocks: as 0; 4 on pageable memory: as 3.)
  *   PM_OPT_SPARSE_FRAME     image planes into host memory (pm_backplanes_img, PM_MEM_HOST): the planes of
  *                           the disc are NaN outside the radius pre-mask of optimize_speed; 1 = only
  *                           bands of rows around that circle cross PCIe (as rectangles) and the copy

@@ -275,7 +275,9 @@ __device__ __forceinline__ void sincos_medium(double x, double &s, double &c)
 // TINY, <= 0.25, <= 1e5, the rest), so what a lane gets does not depend on the lanes that share its wave; the wave
 // only decides which tiers are EVALUATED - one of them when every lane sits in it (always the case for planetary
 // fields of view), the others as well in a wave that straddles a boundary, with a select per lane.
-template <bool TINY = false>
+// (LIBM = false: no libm tier - angles beyond 1e5 rad, NaN and infinities give NaN; for arguments that cannot get
+//  there, the spin angle over a light-time span: the libm path costs the whole kernel its registers)
+template <bool TINY = false, bool LIBM = true>
 __device__ __forceinline__ void sincos_tiered(double x, double &s, double &c)
 {
     const double ax = fabs(x);
@@ -296,8 +298,8 @@ __device__ __forceinline__ void sincos_tiered(double x, double &s, double &c)
         return;
     }
     // a wave across tiers (lanes outside a tier's range carry its garbage, which the selects drop)
-    double sr = 0.0, cr = 0.0;
-    if ((lanes & ~(tiny_m | small_m | med_m)) != 0) sincos(x, &sr, &cr);  // (NaN and infinities end here too)
+    double sr = __builtin_nan(""), cr = __builtin_nan("");
+    if (LIBM && (lanes & ~(tiny_m | small_m | med_m)) != 0) sincos(x, &sr, &cr);  // (NaN and infinities end here too)
     if (med_m != 0) {
         double t, u;
         sincos_medium(x, t, u);

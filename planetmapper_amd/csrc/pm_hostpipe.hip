@@ -896,7 +896,8 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         plan.push_back({HostPipe::kHybrid, 0, P, 0, false});
     } else if ((mode == HostPipe::kFetch || mode == HostPipe::kHybrid) && have256) {
         plan.push_back({HostPipe::kFetch, 0, P, 0, false});
-    } else if (mode == HostPipe::kCollect && want16 && t16.n_list > 0) {
+    } else if ((mode == HostPipe::kCollect || mode == HostPipe::kHybrid) && want16 && t16.n_list > 0) {
+        // (a hybrid asked for on pageable memory, which the GPU cannot read: the collected half of it)
         plan.push_back({HostPipe::kCollect, 0, P, 0, false});
     } else if (mode < 0 && want16 && t16.n_list > 0) {
         // The library chooses, per context (= per rank), from what it has measured on this very problem:

@@ -426,7 +426,9 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         d.all_gather(gathered, slot)
 
     def run(fed: bool, steps: int, pipelined: bool = True):
-        for _ in range(2):
+        # (untimed: for a host-fed cube the call that probes the routes and, where a hybrid is a candidate, the four
+        #  whole calls of its trial - the timed steps run on the route the library has committed to)
+        for _ in range(6 if fed else 2):
             step(fed, pipelined)
         d.barrier()
         own = []

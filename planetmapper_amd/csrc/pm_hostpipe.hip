@@ -502,7 +502,16 @@ struct SegLayout {
 
 // planes per chunk of a hybrid segment: collected chunks, and the (shorter) GPU-fetched ones, of which up to
 // kHybridInFlight are queued ahead of the threads
-constexpr size_t kHybridCollectChunk = 4, kHybridFetchChunk = 4;
+// (the collected chunk grows with the copy threads, one plane each: their jobs must stay worth a wake-up - with 16
+//  threads chunks of 4 planes made the hybrid 30 % SLOWER than the collected route, chunks of 16 made it faster)
+constexpr size_t kHybridCollectChunk = 4, kHybridFetchChunk = 4, kHybridCollectChunkMax = 16;
+inline size_t hybrid_collect_chunk(const pm_ctx *ctx)
+{
+    size_t c = kHybridCollectChunk;
+    if (ctx->pipe) c = std::max<size_t>(c, ctx->pipe->workers.size() + 1);
+    if (const char *e = pm_debug_env("PM_HYBRID_CCHUNK")) c = (size_t)std::max(1, std::atoi(e));  // (A/B of tools/route_ab.py)
+    return std::min(c, kHybridCollectChunkMax);
+}
 constexpr int kHybridInFlight = 3;
 
 // (hybrid: n_list / shift describe the 16-byte table, n_list_f the fetched one)
@@ -526,10 +535,10 @@ SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, siz
         // short chunks, dealt out as the segment runs (run_segment): to the GPU while fewer than kHybridInFlight
         // fetched chunks are queued, else to the copy threads
         (void)fetch_share;
-        chunk = std::min<size_t>(kHybridCollectChunk, sg.n);
+        chunk = std::min<size_t>(hybrid_collect_chunk(ctx), sg.n);
         L.table_row_bytes_f = n_list_f << ctx->fetch_shift;
         // (the closing chunk of a segment may hand the GPU whatever is left after the threads' last share)
-        L.chunk_f = std::min<size_t>(sg.n, std::max<size_t>(kHybridFetchChunk, 3 * kHybridCollectChunk));
+        L.chunk_f = std::min<size_t>(sg.n, std::max<size_t>(kHybridFetchChunk, 3 * kHybridCollectChunk) + chunk);
     }
     L.chunk = chunk;
     L.batch = std::min<size_t>(sg.n, std::max<size_t>(chunk, ((size_t)1 << 30) / (nmap * sizeof(double))));
@@ -644,7 +653,7 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 const size_t rest = nb - q0;
                 const double tc = hy_c_planes > 0.0 ? hy_cpu_ns / hy_c_planes : t_c_est;
                 const double tf = hy_f_planes > 0.0 ? hy_f_ns / hy_f_planes : t_f_est;
-                if (!endgame && rest <= 2 * kHybridCollectChunk + kHybridFetchChunk && tc > 0.0 && tf > 0.0) {
+                if (!endgame && rest <= 2 * L.chunk + kHybridFetchChunk && tc > 0.0 && tf > 0.0) {
                     // the closing split: x planes for the threads, the others for the GPU - whose share is issued FIRST
                     // (it runs behind what is queued while the threads collect theirs)
                     const double x = (double)(f_planes_out + rest) * tf / (tc + tf);
@@ -660,7 +669,7 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                     else end_c -= std::min(want, rest);
                 } else {
                     fetch_chunk = (int)(f_head - f_tail) < kHybridInFlight;
-                    want = fetch_chunk ? kHybridFetchChunk : kHybridCollectChunk;
+                    want = fetch_chunk ? kHybridFetchChunk : L.chunk;
                 }
                 if (fetch_chunk) want = std::min(want, L.chunk_f);
                 if (fetch_chunk && (int)(f_head - f_tail) >= HostPipe::kFq && (rc = retire_fetched(true)) != PM_OK) return rc;

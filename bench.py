@@ -20,13 +20,23 @@ Beside the headline line the same JSON object carries (rank 0, after the timed r
                                     FP64 rate against the vector peak
   cpu_baseline(_1thread), cpu_model the CPU oracle on this box's host cores
   host_path                         PCIe-inclusive time of the same frame into numpy arrays
+  api_path                          the same through the drop-in surface: BodyXY.get_*_img() x 5 +
+                                    Observation.get_mapped_data(), cold cache, Python shim included
   cube_host                         BASELINE config 5, the north star's scaling case: a 512-plane
                                     1024^2 f64 cube in HOST memory, planes sharded over the ranks,
-                                    each rank feeding its block over its own PCIe link, one RCCL
-                                    all-gather of the mapped planes; step time with and without the
-                                    host feed (the driver's N = 1, 2, 4, 8 runs give the scaling curve)
+                                    each rank feeding its block over its own PCIe link, the mapped
+                                    planes all-gathered (a plain form: one all-gather per step; and the
+                                    pipelined protocol: exchanges started behind the mapping + agreement
+                                    on success); the driver's N = 1, 2, 4, 8 runs give the scaling curve.
+                                    At N = 1 also: shard_proxy (rank 0's share of an N-rank run, alone
+                                    on this GPU; its `model` keys are NOT measured) and shared_gpu (the
+                                    N-rank code executed by N = 2, 4 real ranks on this one GPU over a
+                                    gloo group: correctness + host-side contention, not scaling)
+At N > 1 rank 0 prints the headline line BEFORE these sections start (marked `extras: pending`) and the complete
+line after them; a section that hangs is abandoned after PM_BENCH_EXTRAS_TIMEOUT_S (300 s) with the complete
+line printed and exit status 0.
 
-Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frame|saturn|cube|cube-host]
+Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frame|saturn|all26|cube|cube-host]
 `--gpus N` with N > 1 launches itself: unless it already runs under torch.distributed.run
 (WORLD_SIZE set), the process - before touching the GPU - starts
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` on this

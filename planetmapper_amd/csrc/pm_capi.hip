@@ -264,7 +264,9 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         const double quantum = std::nextafter(std::fabs(p.t0), INFINITY) - std::fabs(p.t0);
         const double vt = std::sqrt(g.VT[0] * g.VT[0] + g.VT[1] * g.VT[1] + g.VT[2] * g.VT[2]);
         const double rmin_ = std::fmin(p.radii[0], std::fmin(p.radii[1], p.radii[2]));
-        p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_) ? 1 : 0;
+        // (... or as a turn of the body: a fast rotator's longitudes move by wdot x quantum - round 4, found by the
+        //  fast-spin test of the general kernel: 9e-9 deg per quantum at 30 times Jupiter's spin)
+        p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_ || std::fabs(g.wdot) * quantum > 1.7453292519943296e-11) ? 1 : 0;
         if (ctx->lt_mode == 1 || (ctx->lt_mode == 2 && !p.plain_lt)) p.plain_lt = ctx->lt_mode;
     }
     {

@@ -609,15 +609,33 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     PM_PUT_ROW(PM_LAT_CENTRIC, fma(bc, kDeg, miss));
                 }
             }
+            // illumf_c and spkcpt_c solve the surface point's OWN light time: their iteration ends on the fixed point, one
+            // contraction further than the last iterate sincpt_c stopped at (1e-10 s: the same double as a rule, the next
+            // epoch quantum in a fraction of a percent of the pixels). `lt` - the light time the last evaluation returned
+            // for sincpt's epoch - is that fixed point to 1e-14 s. Where a quantum is visible (Params::plain_lt: a fast
+            // rotator turns by wdot x quantum, a near target moves by VT x quantum) the illumination and the state are
+            // taken at ITS epoch, with the body-fixed point sincpt found, as the reference does.
+            double di = d, czi = cz, szi = sz;
+            if (TRI && kp->plain_lt == 1) {
+                di = (kp->g.et - lt) - kp->t0;
+                const double dl = kp->g.wdot * di;
+                if (GEN) {
+                    sincos_tiered<true, false>(dl, szi, czi);
+                } else {
+                    const double d2 = dl * dl;
+                    czi = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+                    szi = dl * fma(d2, -1.0 / 6.0, 1.0);
+                }
+            }
             // the point in B0 (for the Sun / observer geometry, which lives there)
-            const V3 sp0 = TRI ? v3(fma(cz, sp.x, -sz * sp.y), fma(sz, sp.x, cz * sp.y), sp.z) : sp;
+            const V3 sp0 = TRI ? v3(fma(czi, sp.x, -szi * sp.y), fma(szi, sp.x, czi * sp.y), sp.z) : sp;
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
-                V3 q = TRI ? v3(fma(kp->VB[0], d, sp0.x), fma(kp->VB[1], d, sp0.y), fma(kp->VB[2], d, sp0.z))
+                V3 q = TRI ? v3(fma(kp->VB[0], di, sp0.x), fma(kp->VB[1], di, sp0.y), fma(kp->VB[2], di, sp0.z))
                            : v3(fma(kp->VBs[0], d, Xf.x) * kp->radii[0], fma(kp->VBs[1], d, Xf.y) * kp->radii[1],
                                 fma(kp->VBs[2], d, Xf.z) * kp->radii[2]);
                 if (GEN) {
-                    const double h = 0.5 * d * d;
+                    const double h = 0.5 * di * di;
                     q = {fma(kp->AB[0], h, q.x), fma(kp->AB[1], h, q.y), fma(kp->AB[2], h, q.z)};
                 }
                 // Sun light time (spkcpo_c 'CN'): the Sun is taken at te - |S - q| / c. Its epoch
@@ -630,7 +648,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 V3 sv;
                 if (GEN) {
                     // illumf_c's own iteration (spkcpo_c 'CN'): two passes from the centre value, the Sun's acceleration carried
-                    const double dts = (kp->t0 - kp->g.ts0) + d;  // te - ts0
+                    const double dts = (kp->t0 - kp->g.ts0) + di;  // te - ts0
                     double ds = 0.0;
 #pragma unroll
                     for (int it = 0; it < 3; it++) {
@@ -640,14 +658,14 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                         if (it < 2) ds = dts - norm_f(sv) * kp->inv_c;
                     }
                 } else {
-                const double ds = fma(dot(v3(kp->SB0[0], kp->SB0[1], kp->SB0[2]), q), kp->sun_k, d) + kp->sun_ds0;
+                const double ds = fma(dot(v3(kp->SB0[0], kp->SB0[1], kp->SB0[2]), q), kp->sun_k, TRI ? di : d) + kp->sun_ds0;
                 sv = v3(fma(kp->VSB[0], ds, rsub_c(q.x, kp->SB0[0])), fma(kp->VSB[1], ds, rsub_c(q.y, kp->SB0[1])),
                         fma(kp->VSB[2], ds, rsub_c(q.z, kp->SB0[2])));
                 }
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
                 if (TRI) {
-                    n = {fma(cz, n.x, -sz * n.y), fma(sz, n.x, cz * n.y), n.z};
+                    n = {fma(czi, n.x, -szi * n.y), fma(szi, n.x, czi * n.y), n.z};
                     n = rsqrt_fast(dot(n, n)) * n;
                 }
                 // phase angle: a four-term series in cos g about the body centre's value where the host
@@ -671,8 +689,9 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             }
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
-                const V3 vp = {fma(kp->ASB_state[0], d, kp->VSB_state[0]) - kp->g.wdot * sp0.y,
-                               fma(kp->ASB_state[1], d, kp->VSB_state[1]) + kp->g.wdot * sp0.x, fma(kp->ASB_state[2], d, kp->VSB_state[2])};
+                const double dv = TRI ? di : d;
+                const V3 vp = {fma(kp->ASB_state[0], dv, kp->VSB_state[0]) - kp->g.wdot * sp0.y,
+                               fma(kp->ASB_state[1], dv, kp->VSB_state[1]) + kp->g.wdot * sp0.x, fma(kp->ASB_state[2], dv, kp->VSB_state[2])};
                 const V3 vo = v3(kp->VOB[0], kp->VOB[1], kp->VOB[2]);
                 const double dlt = (dot(u, vp - vo) * kp->inv_c) / (1.0 + dot(u, vp) * kp->inv_c);
                 const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;

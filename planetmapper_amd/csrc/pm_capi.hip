@@ -266,7 +266,8 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         const double rmin_ = std::fmin(p.radii[0], std::fmin(p.radii[1], p.radii[2]));
         // (... or as a turn of the body: a fast rotator's longitudes move by wdot x quantum - round 4, found by the
         //  fast-spin test of the general kernel: 9e-9 deg per quantum at 30 times Jupiter's spin)
-        p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_ || std::fabs(g.wdot) * quantum > 1.7453292519943296e-11) ? 1 : 0;
+        p.turn_quantum = std::fabs(g.wdot) * quantum > 1.7453292519943296e-11 ? 1 : 0;
+        p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_ || p.turn_quantum) ? 1 : 0;
         if (ctx->lt_mode == 1 || (ctx->lt_mode == 2 && !p.plain_lt)) p.plain_lt = ctx->lt_mode;
     }
     {
@@ -759,7 +760,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else
             pm_launch_disc(pd, flags, ctx->stream);
-        ctx->last_disc_kernel = spheroid ? (pd.radii[0] != pd.radii[1] ? 2 : 1) : 3;
+        ctx->last_disc_kernel = spheroid ? ((pd.radii[0] != pd.radii[1] || pd.turn_quantum) ? 2 : 1) : 3;
     }
     if ((plane_mask & kSkyBits) && !fused_sky) {
         pm::Params ps = p;

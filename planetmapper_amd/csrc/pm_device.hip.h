@@ -142,6 +142,10 @@ struct Params {
     // triaxial / general variants of k_disc_sph (Newton step on the light-time seed)
     double tri_k;      // wdot (b / a - a / b): the turn of the shape under the ray, per unit Xf_x Xf_y
     double p2_lo_rot;  // p2_lo widened by that turn (and the target's acceleration) over a light-time span
+    int32_t turn_quantum;  // 1: one quantum of the epoch et - lt TURNS the body by more than 1e-9 deg (a fast rotator): even a
+                           // spheroid then takes the BODY = 1 variant, which places illumination and state at the epoch of
+                           // illumf_c's / spkcpt_c's own light-time solution
+    int32_t pad_turn_;
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

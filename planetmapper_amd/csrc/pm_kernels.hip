@@ -1090,7 +1090,7 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 {
     dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
     dim3 block(pm::kSphBlock);
-    const bool tri = p.radii[0] != p.radii[1];
+    const bool tri = p.radii[0] != p.radii[1] || p.turn_quantum != 0;  // (Params::turn_quantum: a fast-turning spheroid)
     const int sky = (flags >> 3) & 3;
 #define PM_SPH_CASE(F)                                                                                          \
     case F:                                                                                                     \

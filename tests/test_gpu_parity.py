@@ -1218,6 +1218,36 @@ def test_fast_spin_and_large_acceleration_take_the_general_kernel(engine, oracle
     assert np.isfinite(out['LON-GRAPHIC']).sum() > 20000
 
 
+def test_frame_that_spans_most_of_the_sky(engine, oracle, jupiter):
+    """
+    A plate scale of a degree per pixel: the frame spans 200 x 150 degrees, view angles pass 1.5 rad
+    (`Params::view_direct` off: KM / ANGULAR planes through the reference's own RA / Dec round trip,
+    `Body._obsvec2angular` body.py:1345) and leave every short sincos tier; the disc is a fraction of one pixel.
+    All 26 planes against the oracle: the sky planes over the whole frame, the disc planes NaN but for the pixel
+    or two that hold the planet.
+    """
+    nx, ny = 200, 150
+    r0 = jupiter.diameter_arcsec / (2 * 3600.0)  # one degree per pixel
+    x0, y0, rot = 97.3, 71.8, 0.4
+    for opt in (True, False):
+        engine.set_geometry(jupiter)
+        engine.set_disc(x0, y0, r0, rot, nx, ny, opt)
+        d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny, optimize_speed=opt)
+        d.rotation_rad = rot
+        out = engine.backplanes_img(oracle.PLANE_NAMES)
+        ref = oracle.backplanes_img(jupiter, d, oracle.PLANE_NAMES)
+        # (the bars of the km / arcsec planes are absolute, 1e-5 km and 3e-9 arcsec, set for fields the size of a disc: a
+        #  coordinate of 1.3e9 km is not defined to 1e-5 km in binary64. Here they are relative to the coordinate -
+        #  2e-12, i.e. a direction good to 3e-12 rad = 2e-10 deg; measured 6.5e-13 at 89 deg from the centre)
+        wide = ('KM-X', 'KM-Y', 'ANGULAR-X', 'ANGULAR-Y')
+        _compare(out, ref, [n for n in oracle.PLANE_NAMES if n not in wide], jupiter, r0=r0, flat=False)
+        for n in wide:
+            assert np.isfinite(out[n]).all()
+            base = 1e-5 if n.startswith('KM') else 3e-9
+            assert (np.abs(out[n] - ref[n]) <= base + 2e-12 * np.abs(ref[n])).all(), n
+        assert np.isfinite(out['RA']).all() and np.ptp(out['ANGULAR-X']) > 150 * 3600.0
+
+
 def test_observer_inside_the_body(engine, oracle):
     """
     surfpt_c's other branch: an observer INSIDE the ellipsoid (0.42 equatorial radii from the centre) sees the far

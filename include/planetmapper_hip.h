@@ -305,6 +305,11 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           them were provisional).
  *   PM_OPT_ROUTE_NS_PER_PLANE + r  read-only: measured cost of route r on the current problem, ns per plane of
  *                           the whole pipeline (0: not measured).
+ *   PM_OPT_LAST_LT_PATH     read-only: how the latest image-plane call solved the light time of the intercept, a mask:
+ *                           1 closed form (waves clear of the limb), 2 ... stepping through the reference's iterates to
+ *                           its final epoch (one epoch quantum is visible on the body), 4 the reference's own sequence
+ *                           without the Newton step wherever the closed form does not apply, 8 one quantum TURNS the body
+ *                           visibly (illumination and state at the epoch of illumf_c's own light-time solution).
  *   PM_OPT_LAST_DISC_KERNEL read-only (pm_get_option): which kernel the latest image-plane call
  *                           dispatched for the planes that need the intercept: 0 none yet,
  *                           1 spheroid fast path, 2 its triaxial variant, 3 general kernel.
@@ -329,6 +334,7 @@ typedef enum pm_option {
     PM_OPT_LT_MODE = 24,
     PM_OPT_TRACE = 25,
     PM_OPT_SM_WORKERS = 26,
+    PM_OPT_LAST_LT_PATH = 27,
     PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..4 */
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);

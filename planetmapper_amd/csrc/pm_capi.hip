@@ -268,6 +268,7 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         //  fast-spin test of the general kernel: 9e-9 deg per quantum at 30 times Jupiter's spin)
         p.turn_quantum = std::fabs(g.wdot) * quantum > 1.7453292519943296e-11 ? 1 : 0;
         p.plain_lt = (vt * quantum > 1.7453292519943296e-11 * rmin_ || p.turn_quantum) ? 1 : 0;
+        p.cf_iter = (p.plain_lt && ctx->lt_mode == 0) ? 1 : 0;
         if (ctx->lt_mode == 1 || (ctx->lt_mode == 2 && !p.plain_lt)) p.plain_lt = ctx->lt_mode;
     }
     {
@@ -304,6 +305,13 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         for (int i = 0; i < 3; i++) a2 += g.AT[i] * g.AT[i];
         const double turn = std::fabs(g.wdot) * dmax * std::fabs(ab * ab - 1.0) + 0.5 * std::sqrt(a2) * dmax * dmax / rmin_;
         p.p2_lo_rot = 1.0 - (band + 4.0 * turn);
+        // the closed form for a triaxial body: its shape frozen over the light-time span, the turn put back to first order -
+        // while the second-order term (wdot d)^2 r |a^2 / b^2 - 1| stays below 1e-10 km (Io: 1e-12; a Jupiter-sized test
+        // body with b = 0.97 a: 4e-6, which keeps the sequence + Newton step)
+        {
+            const double ang = std::fabs(g.wdot) * dmax;
+            p.tri_cf = (p.radii[0] != p.radii[1] && ang * ang * rmax_ * std::fabs(ab * ab - 1.0) < 1e-10 && ctx->lt_mode == 0) ? 1 : 0;
+        }
     }
     for (int i = 0; i < 3; i++) p.ir[i] = 1.0 / p.radii[i];
     {
@@ -522,6 +530,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_LAST_CUBE_ROUTE:
     case PM_OPT_LAST_REDO_PLANES:
     case PM_OPT_LAST_DISC_KERNEL:
+    case PM_OPT_LAST_LT_PATH:
     case PM_OPT_HOST_COPY_THREADS_IN_USE:
     case PM_OPT_HYBRID_FETCH_PERMILLE:
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "option %d is read-only", option);
@@ -547,6 +556,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_ZERO_COPY: *value = ctx->zero_copy; return PM_OK;
     case PM_OPT_SPARSE_FRAME: *value = ctx->sparse_frame; return PM_OK;
     case PM_OPT_LAST_DISC_KERNEL: *value = ctx->last_disc_kernel; return PM_OK;
+    case PM_OPT_LAST_LT_PATH: *value = ctx->last_lt_path; return PM_OK;
     case PM_OPT_BLOCK_TABLE_CACHE: *value = ctx->table_cache; return PM_OK;
     case PM_OPT_FUSE_PLANES: *value = ctx->fuse_planes; return PM_OK;
     case PM_OPT_BLOCK_TABLE_HITS: *value = pipe_table_hits(ctx); return PM_OK;
@@ -760,7 +770,12 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
             pm_launch_disc_spheroid(pd, flags, ctx->stream);
         else
             pm_launch_disc(pd, flags, ctx->stream);
-        ctx->last_disc_kernel = spheroid ? ((pd.radii[0] != pd.radii[1] || pd.turn_quantum) ? 2 : 1) : 3;
+        ctx->last_disc_kernel = spheroid ? (pd.radii[0] != pd.radii[1] ? 2 : 1) : 3;
+        {
+            const bool tri_body = pd.radii[0] != pd.radii[1];
+            const bool closed_form = spheroid && (pd.plain_lt == 0 || pd.cf_iter) && (!tri_body || pd.tri_cf);
+            ctx->last_lt_path = (closed_form ? 1 : 0) | (closed_form && pd.cf_iter ? 2 : 0) | (pd.plain_lt ? 4 : 0) | (pd.turn_quantum ? 8 : 0);
+        }
     }
     if ((plane_mask & kSkyBits) && !fused_sky) {
         pm::Params ps = p;

@@ -142,10 +142,13 @@ struct Params {
     // triaxial / general variants of k_disc_sph (Newton step on the light-time seed)
     double tri_k;      // wdot (b / a - a / b): the turn of the shape under the ray, per unit Xf_x Xf_y
     double p2_lo_rot;  // p2_lo widened by that turn (and the target's acceleration) over a light-time span
-    int32_t turn_quantum;  // 1: one quantum of the epoch et - lt TURNS the body by more than 1e-9 deg (a fast rotator): even a
-                           // spheroid then takes the BODY = 1 variant, which places illumination and state at the epoch of
-                           // illumf_c's / spkcpt_c's own light-time solution
-    int32_t pad_turn_;
+    int32_t turn_quantum;  // 1: one quantum of the epoch et - lt TURNS the body by more than 1e-9 deg (a fast rotator, or any
+                           // planet late enough in the century): illumination and state are placed at the epoch of illumf_c's /
+                           // spkcpt_c's own light-time solution (BODY 1 / 2: in full; a spheroid: its normal and point turned)
+    int32_t cf_iter;  // 1: one epoch quantum is visible on the body and the library is left to choose (PM_OPT_LT_MODE 0): the
+                      // closed form steps through the reference's sequence of iterates to land on ITS final epoch
+    int32_t pad_cf_;
+    int32_t tri_cf;  // 1: a triaxial body takes the closed-form light time with a first-order turn of its shape (k_disc_sph, BODY 1)
 };
 
 // n mod d for wave-uniform operands without the VALU float-reciprocal sequence hipcc expands

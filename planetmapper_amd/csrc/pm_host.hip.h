@@ -122,6 +122,7 @@ struct pm_ctx {
     int route_explore = 1;       // PM_OPT_ROUTE_EXPLORE
     int fetch_shift = 7;         // PM_OPT_FETCH_BLOCK_BYTES: log2 of the blocks the GPU fetches from a pinned cube (routes 2, 4)
     int last_cube_route = -1;    // PM_OPT_LAST_CUBE_ROUTE
+    int last_lt_path = 0;        // PM_OPT_LAST_LT_PATH
     int last_redo_planes = 0;    // PM_OPT_LAST_REDO_PLANES: planes of the latest finished pm_map_cube redone with their nanmedian
     // pm_set_chunk_callback: told, on the calling thread, each time the kernels of further planes of a
     // nearest / linear pm_map_cube have been ENQUEUED on the context stream (planes arrive in order)

@@ -341,8 +341,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // gets does not depend on which pixels share its wave
         unsigned long long cf_mask = 0;
         V3 Xf_cf = {0.0, 0.0, 0.0};
-        double d_cf = 0.0, lt_cf = 0.0;  // (set where cf_mask is; the defaults only quiet the TRI instantiations)
-        if (!TRI && kp->plain_lt == 0) {  // (kernel-argument flag: a scalar branch)
+        double d_cf = 0.0, lt_cf = 0.0;  // (set where cf_mask is; the defaults only quiet the other instantiations)
+        double cz_cf = 1.0, sz_cf = 0.0;  // (TRI: the spin at the closed form's epoch)
+        double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
+        if (!GEN && (kp->plain_lt == 0 || kp->cf_iter) && (!TRI || kp->tri_cf)) {  // (kernel-argument flags: a scalar branch)
             // sincpt_c 'CN' for a target in linear motion, in closed form. The converged light time is the fixed
             // point lt = E((et - lt) - t0) of the iteration further down: the target is taken at the epoch offset
             // d = (et - t0) - s / c when the ray meets it s km from the observer, so in the scaled frame of
@@ -364,40 +366,108 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // target moves |VBs| |d| <= |VBs| R / c across the ray, which changes P.P by less than 1 - p2_lo = p2_hi - 1 (host).
             // A lane clear of 1 by that band hits in every pass, or misses in the first; a wave with a lane
             // inside the band (the limb runs through it) walks the reference's sequence as well, for those lanes.
-            const unsigned long long hits =
-                hit_mask & __builtin_amdgcn_ballot_w64(p2 < kp->p2_lo) & __builtin_amdgcn_ballot_w64(yx < 0.0);
-            const unsigned long long misses = ~hit_mask | __builtin_amdgcn_ballot_w64(p2 > kp->p2_hi);
+            // (TRI: the band widened by the turn of the shape over a light-time span, host: p2_lo_rot)
+            const double band_lo = TRI ? kp->p2_lo_rot : kp->p2_lo, band_hi = TRI ? 2.0 - kp->p2_lo_rot : kp->p2_hi;
+            unsigned long long hits =
+                hit_mask & __builtin_amdgcn_ballot_w64(p2 < band_lo) & __builtin_amdgcn_ballot_w64(yx < 0.0);
+            const unsigned long long misses = ~hit_mask | __builtin_amdgcn_ballot_w64(p2 > band_hi);
+            // (a wave of the pre-mask annulus - candidates, but every ray misses - is done here)
+            if (hits != 0) {
+                // (clamped away from 0 for the reciprocal square root: lanes that miss carry garbage)
+                const double r2 = fmax((1.0 - p2) * ixp, 1e-300);
+                double half_inv_root;
+                const double root = sqrt_pos_h(r2, half_inv_root);
+                const double s = -kq - root;
+                const double lts = mul_c(s, kp->inv_c);  // (rounded on its own, as the reference's light time is)
+                const V3 F = {fma(-root, Xp.x, Pq.x), fma(-root, Xp.y, Pq.y), fma(-root, Xp.z, Pq.z)};
+                const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
+                // ds / dd of the intercept: s' = F.VBs / F.X, F.X = -root X.X (X' stands in for X: v / c ~ 1e-4 of 4e-12)
+                const double sp = dot(F, vbs) * (half_inv_root * ixp) * -2.0;
+                const double dstar = rsub_c(lts, kp->lt_c_eff);  // the epoch offset of the fixed point, unrounded
+                // The light time whose epoch the reference evaluates its final state at. Its sequence
+                // lt_0 = lt_c, lt_(k+1) = E(d_k), d_k = fl(fl(et - lt_k) - t0) stops at the first k >= 1 with
+                // |lt_(k+1) - lt_k| <= 1e-17 |et - lt| and returns the state of epoch d_k: a point gamma^k (lt_c - lt*) from
+                // the fixed point lt* (gamma = -E' ~ 1e-4: 4e-10 s after two passes over Jupiter's disc). Where one
+                // quantum of the epoch (ulp(et): 3e-8 s in 2005, 1.2e-7 s from 2015 on) is NOT visible on the body that
+                // difference is none either, and the fixed point itself is taken ...
+                double lam = lts;
+                if (kp->cf_iter) {
+                    // ... where it is (Params::cf_iter: the target moves by more than 1e-9 deg of its own radius per
+                    // quantum - every moon, Mars, and Jupiter itself in data taken after 2015) the closed form steps
+                    // through that sequence from the fixed point, to first order in E': e_k = lt_k - lt* = gamma^k e_0
+                    // decides WHERE the reference stops (K), the rounded epoch of its last-but-one iterate gives
+                    // lt_K = lt* + E' (d_(K-1) - d*) to 1e-14 s (the second-order term of lt_1, E'' e_0^2 / 2 ~ 1e-9 s,
+                    // enters lt_K through gamma^(K-1) and through the quantum d_(K-1) rounds to: 1e-6 of the pixels).
+                    // A lane whose deciding step lies within 10 % of the tolerance - the prediction of K could be off by
+                    // one there - or that needs more than five passes leaves the closed form and walks the sequence.
+                    double e1 = sp * kp->inv_c;
+                    if (TRI) e1 = fma(kp->tri_k * F.x * F.y * ixp, (half_inv_root + half_inv_root) * kp->inv_c, e1);
+                    const double gam = -e1, g1 = gam - 1.0, tol = kp->lt_tol;
+                    // (nearly every wave clear of the limb stops at K = 2 in all its lanes: one vote, no loop)
+                    const double e_1 = gam * dstar, st1 = fabs(e_1 * g1), st2 = st1 * fabs(gam);
+                    const unsigned long long k2_m = __builtin_amdgcn_ballot_w64(st1 > 1.1 * tol && st2 < 0.9 * tol && fabs(gam) <= 3e-4);
+                    bool unsure = false;
+                    if ((hits & ~k2_m) == 0) {
+                        lam = fma(e1, (rsub_c(lts + e_1, kp->g.et) - kp->t0) - dstar, lts);
+                    } else {
+                        double e_prev = dstar, e_cur = e_1, e_km1 = dstar;
+                        bool done = false, first = false;
+#pragma unroll
+                        for (int k = 1; k <= 5; k++) {
+                            const double step = fabs(e_cur * g1);
+                            const bool stop = step <= tol;
+                            unsure = unsure || (!done && fabs(step - tol) <= 0.1 * tol);
+                            e_km1 = (!done && stop) ? e_prev : e_km1;
+                            if (k == 1) first = stop;
+                            done = done || stop;
+                            e_prev = e_cur;
+                            e_cur *= gam;
+                        }
+                        // (... and so does a lane towards the limb, where E' grows like 1 / cos(emission) and the sequence is
+                        //  no longer a geometric one to the precision needed: beyond ~82 deg for a planet seen from afar)
+                        unsure = unsure || !done || fabs(gam) > 3e-4;
+                        // d_(K-1) as the reference rounds it (d_0 = 0 exactly), then lt_K
+                        const double d_km1 = first ? 0.0 : rsub_c(lts + e_km1, kp->g.et) - kp->t0;
+                        lam = fma(e1, d_km1 - dstar, lts);
+                    }
+                    hits &= ~__builtin_amdgcn_ballot_w64(unsure);
+                }
+                // The reference evaluates its final state at the epoch et - lt ROUNDED to a double (one quantum), the
+                // closed form at the unrounded fixed point. The target's linear motion over the difference `dq`
+                // moves the intercept by dq (s' X - VBs), s' keeping it on the surface: first order is exact here
+                // (dq^2 ~ 1e-14).
+                d_cf = rsub_c(lam, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+                const double dq = d_cf - dstar;
+                Xf_cf = {fma(dq, fma_cn(sp, Xp.x, vbs.x), F.x), fma(dq, fma_cn(sp, Xp.y, vbs.y), F.y),
+                         fma(dq, fma_cn(sp, Xp.z, vbs.z), F.z)};
+                lt_cf = fma(dq, sp, s) * kp->inv_c;
+                if (TRI) {
+                    // A triaxial body (Params::tri_cf: a real moon - the turn of its shape over a light-time span is
+                    // second-order small). So far the body was FROZEN in its B0 orientation; at the epoch d it has
+                    // turned by wdot d under the ray, which moves the intercept along the ray by kappa d,
+                    // kappa = wdot (b/a - a/b) Xf_x Xf_y / (root X.X) (the slope of the Newton step below; 4e-6 km
+                    // for Io - first order is exact to 1e-12 km). The point then goes into the body-fixed frame of
+                    // its epoch, where longitude, latitude and the normal are taken.
+                    const double dt = kp->tri_k * Xf_cf.x * Xf_cf.y * ixp * (half_inv_root + half_inv_root) * d_cf;
+                    const V3 p0 = {fma(dt, u.x, Xf_cf.x * kp->radii[0]), fma(dt, u.y, Xf_cf.y * kp->radii[1]),
+                                   fma(dt, u.z, Xf_cf.z * kp->radii[2])};
+                    const double dl = kp->g.wdot * d_cf, d2 = dl * dl;
+                    cz_cf = fma(d2, fma(d2, 1.0 / 24.0, -0.5), 1.0);
+                    sz_cf = dl * fma(d2, -1.0 / 6.0, 1.0);
+                    Xf_cf = {fma(cz_cf, p0.x, sz_cf * p0.y) * kp->ir[0], fma(cz_cf, p0.y, -sz_cf * p0.x) * kp->ir[1], p0.z * kp->ir[2]};
+                    lt_cf = fma(dt, kp->inv_c, lt_cf);
+                }
+            }
             solved = (hits | misses) == ~0ull;
             if (solved) hit_mask = hits;
             else cf_mask = hits;
-            // (a wave of the pre-mask annulus - candidates, but every ray misses - is done here)
-            {
-                if (hits != 0) {
-                    // (clamped away from 0 for the reciprocal square root: lanes that miss carry garbage)
-                    const double r2 = fmax((1.0 - p2) * ixp, 1e-300);
-                    double half_inv_root;
-                    const double root = sqrt_pos_h(r2, half_inv_root);
-                    const double s = -kq - root;
-                    const double lts = mul_c(s, kp->inv_c);  // (rounded on its own, as the reference's light time is)
-                    // The reference evaluates its final state at the epoch et - lt ROUNDED to a double (one
-                    // quantum: 3e-8 s at et = 1.6e8 s, in which Jupiter moves 4e-7 km = 3e-10 deg of
-                    // longitude), the closed form at the unrounded one. The target's linear motion over the
-                    // difference `dq` (< 1 quantum) moves the intercept by dq (s' X - VBs), s' = F.VBs / F.X
-                    // keeping it on the surface and F.X = -root X.X: first order is exact here (dq^2 ~ 1e-16).
-                    // (X' stands in for X and X'.X' for X.X in that term: v / c ~ 1e-4 of 4e-12.)
-                    d_cf = rsub_c(lts, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
-                    const double dq = d_cf - rsub_c(lts, kp->lt_c_eff);
-                    const V3 F = {fma(-root, Xp.x, Pq.x), fma(-root, Xp.y, Pq.y), fma(-root, Xp.z, Pq.z)};
-                    const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
-                    const double sp = dot(F, vbs) * (half_inv_root * ixp) * -2.0;
-                    Xf_cf = {fma(dq, fma_cn(sp, Xp.x, vbs.x), F.x), fma(dq, fma_cn(sp, Xp.y, vbs.y), F.y),
-                             fma(dq, fma_cn(sp, Xp.z, vbs.z), F.z)};
-                    lt_cf = fma(dq, sp, s) * kp->inv_c;
-                    if (solved) {
-                        Xf = Xf_cf;
-                        d = d_cf;
-                        lt = lt_cf;
-                    }
+            if (solved && hits != 0) {
+                Xf = Xf_cf;
+                d = d_cf;
+                lt = lt_cf;
+                if (TRI) {
+                    cz = cz_cf;
+                    sz = sz_cf;
                 }
             }
         }
@@ -405,7 +475,6 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         // surfpt_c in scaled coordinates; for a spheroid X and 1/(X.X) are fixed for the pixel
         V3 X = {u.x * kp->ir[0], u.y * kp->ir[1], u.z * kp->ir[2]};
         double ixx = 0.0;
-        double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
         if (!solved) {
         d = 0.0;
         ixx = rcp_fast(dot(X, X));
@@ -547,11 +616,15 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             if ((hit_mask & __builtin_amdgcn_ballot_w64(moving)) == 0) break;
         }
         Xf = {fma(sroot, X.x, P.x), fma(sroot, X.y, P.y), fma(sroot, X.z, P.z)};
-        if (!TRI && cf_mask != 0) {  // (those lanes hit in every pass: they are in hit_mask)
+        if (!GEN && cf_mask != 0) {  // (those lanes hit in every pass: they are in hit_mask)
             const bool cf = __builtin_amdgcn_inverse_ballot_w64(cf_mask);
             Xf = {cf ? Xf_cf.x : Xf.x, cf ? Xf_cf.y : Xf.y, cf ? Xf_cf.z : Xf.z};
             d = cf ? d_cf : d;
             lt = cf ? lt_cf : lt;
+            if (TRI) {
+                cz = cf ? cz_cf : cz;
+                sz = cf ? sz_cf : sz;
+            }
         }
         }  // !solved
 
@@ -627,8 +700,14 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     szi = dl * fma(d2, -1.0 / 6.0, 1.0);
                 }
             }
+            // (A spheroid needs none of that for its shape - but the body-fixed POINT turns with the body between the two
+            //  epochs, and its normal with it: by wdot x (di - d), one quantum's worth in the fraction of a percent of the
+            //  pixels whose two epochs round apart. Params::turn_quantum: 1.2e-9 deg for Jupiter from 2015 on.)
+            double turn = 0.0;
+            if (!TRI && kp->turn_quantum) turn = kp->g.wdot * (((kp->g.et - lt) - kp->t0) - d);
             // the point in B0 (for the Sun / observer geometry, which lives there)
-            const V3 sp0 = TRI ? v3(fma(czi, sp.x, -szi * sp.y), fma(szi, sp.x, czi * sp.y), sp.z) : sp;
+            V3 sp0 = TRI ? v3(fma(czi, sp.x, -szi * sp.y), fma(szi, sp.x, czi * sp.y), sp.z) : sp;
+            if (!TRI && kp->turn_quantum) sp0 = {fma(-turn, sp.y, sp.x), fma(turn, sp.x, sp.y), sp.z};
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
                 V3 q = TRI ? v3(fma(kp->VB[0], di, sp0.x), fma(kp->VB[1], di, sp0.y), fma(kp->VB[2], di, sp0.z))
@@ -664,6 +743,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 }
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
+                if (!TRI && kp->turn_quantum) n = {fma(-turn, n.y, n.x), fma(turn, n.x, n.y), n.z};  // (first order: 1e-10 rad)
                 if (TRI) {
                     n = {fma(czi, n.x, -szi * n.y), fma(szi, n.x, czi * n.y), n.z};
                     n = rsqrt_fast(dot(n, n)) * n;
@@ -1090,7 +1170,7 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
 {
     dim3 grid((p.nx + pm::kSphBlock - 1) / pm::kSphBlock, p.rows);
     dim3 block(pm::kSphBlock);
-    const bool tri = p.radii[0] != p.radii[1] || p.turn_quantum != 0;  // (Params::turn_quantum: a fast-turning spheroid)
+    const bool tri = p.radii[0] != p.radii[1];
     const int sky = (flags >> 3) & 3;
 #define PM_SPH_CASE(F)                                                                                          \
     case F:                                                                                                     \

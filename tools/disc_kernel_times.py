@@ -32,7 +32,11 @@ def main():
     names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION']
     planes = {n: torch.empty((sz, sz), dtype=torch.float64, device='cuda') for n in names}
     cases = {}
-    for label, geom, general in (('spheroid', g, 0), ('triaxial', gt, 0), ('general', g, 1), ('general_triaxial', gt, 1)):
+    gm = g.copy()  # a real moon: Io's shape and spin at Jupiter's distance (the triaxial variant's closed-form light time)
+    gm.radii[0], gm.radii[1], gm.radii[2] = 1829.4, 1819.4, 1815.7
+    gm.wdot = 4.11e-5
+    gm.diameter_arcsec = g.diameter_arcsec * 1829.4 / g.radii[0]
+    for label, geom, general in (('spheroid', g, 0), ('triaxial', gt, 0), ('moon', gm, 0), ('general', g, 1), ('general_triaxial', gt, 1)):
         eng = Engine(0)
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
         eng.set_geometry(geom)

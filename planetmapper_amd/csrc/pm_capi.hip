@@ -761,7 +761,8 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         const bool small_spin = std::fabs(ctx->geometry.wdot) * span < 1e-3;
         const bool spheroid = y2 > 4.0 && slow && small_spin && !ctx->force_general;
         // every plane of the frame from one launch (PM_OPT_FUSE_PLANES): the sky / limb planes ride along
-        fused_sky = spheroid && ctx->fuse_planes && (plane_mask & kSkyBits);
+        // (no fused variant where an epoch quantum is visible: those geometries take the QUANT kernels, two launches)
+        fused_sky = spheroid && ctx->fuse_planes && (plane_mask & kSkyBits) && !pd.cf_iter && !pd.turn_quantum;
         if (fused_sky) {
             pd.mask = plane_mask;
             flags |= (plane_mask & kLimbBits) ? (2 << 3) : (1 << 3);

@@ -238,7 +238,12 @@ __global__ __launch_bounds__(kBlock) void k_sky(const Params p_)
 // target's and the Sun's acceleration carried, an observer inside or on the surface (surfpt_c's far
 // intersection), the Sun's light time iterated as illumf_c does. Serves near-field observers, fast spinners,
 // large accelerations and PM_OPT_GENERAL_KERNEL.
-template <int FLAGS, int BODY, int SKY = 0, unsigned long long MASK = 0>
+// QUANT: the variant for geometries on which one quantum of the epoch et - lt is visible (Params::cf_iter /
+// turn_quantum: every moon, every planet in data after 2015): the closed form steps through the reference's iterates,
+// a spheroid turns its point and normal by the quantum. Its own instantiation, so that the geometries that need none
+// of it - the 2005 fixtures, the benchmark - carry none of its scalar branches and registers (same-process A/B: the
+// headline kernel was 1.7 % slower with them in).
+template <int FLAGS, int BODY, int SKY = 0, unsigned long long MASK = 0, bool QUANT = false>
 __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
 {
     constexpr bool TRI = BODY != 0, GEN = BODY == 2;
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
         double d_cf = 0.0, lt_cf = 0.0;  // (set where cf_mask is; the defaults only quiet the other instantiations)
         double cz_cf = 1.0, sz_cf = 0.0;  // (TRI: the spin at the closed form's epoch)
         double cz = 1.0, sz = 0.0;  // spin since t0 at the epoch of the current evaluation (TRI)
-        if (!GEN && (kp->plain_lt == 0 || kp->cf_iter) && (!TRI || kp->tri_cf)) {  // (kernel-argument flags: a scalar branch)
+        if (!GEN && (kp->plain_lt == 0 || (QUANT && kp->cf_iter)) && (!TRI || kp->tri_cf)) {  // (kernel-argument flags: a scalar branch)
             // sincpt_c 'CN' for a target in linear motion, in closed form. The converged light time is the fixed
             // point lt = E((et - lt) - t0) of the iteration further down: the target is taken at the epoch offset
             // d = (et - t0) - s / c when the ray meets it s km from the observer, so in the scaled frame of
@@ -371,6 +376,13 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             unsigned long long hits =
                 hit_mask & __builtin_amdgcn_ballot_w64(p2 < band_lo) & __builtin_amdgcn_ballot_w64(yx < 0.0);
             const unsigned long long misses = ~hit_mask | __builtin_amdgcn_ballot_w64(p2 > band_hi);
+            // (without QUANT the votes are final here, and known before the arithmetic as in rounds 1-3: the order the
+            //  compiler lays the blocks out in is worth 1-2 % of the headline frame)
+            if (!QUANT) {
+                solved = (hits | misses) == ~0ull;
+                if (solved) hit_mask = hits;
+                else cf_mask = hits;
+            }
             // (a wave of the pre-mask annulus - candidates, but every ray misses - is done here)
             if (hits != 0) {
                 // (clamped away from 0 for the reciprocal square root: lanes that miss carry garbage)
@@ -379,11 +391,17 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 const double root = sqrt_pos_h(r2, half_inv_root);
                 const double s = -kq - root;
                 const double lts = mul_c(s, kp->inv_c);  // (rounded on its own, as the reference's light time is)
+                double dq = 0.0;
+                if (!QUANT) {
+                    // (no quantum visible: the fixed point itself. Statement order as in round 3 - see QUANT above)
+                    d_cf = rsub_c(lts, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+                    dq = d_cf - rsub_c(lts, kp->lt_c_eff);
+                }
                 const V3 F = {fma(-root, Xp.x, Pq.x), fma(-root, Xp.y, Pq.y), fma(-root, Xp.z, Pq.z)};
                 const V3 vbs = {kp->VBs[0], kp->VBs[1], kp->VBs[2]};
                 // ds / dd of the intercept: s' = F.VBs / F.X, F.X = -root X.X (X' stands in for X: v / c ~ 1e-4 of 4e-12)
                 const double sp = dot(F, vbs) * (half_inv_root * ixp) * -2.0;
-                const double dstar = rsub_c(lts, kp->lt_c_eff);  // the epoch offset of the fixed point, unrounded
+                const double dstar = QUANT ? rsub_c(lts, kp->lt_c_eff) : 0.0;  // the epoch offset of the fixed point, unrounded
                 // The light time whose epoch the reference evaluates its final state at. Its sequence
                 // lt_0 = lt_c, lt_(k+1) = E(d_k), d_k = fl(fl(et - lt_k) - t0) stops at the first k >= 1 with
                 // |lt_(k+1) - lt_k| <= 1e-17 |et - lt| and returns the state of epoch d_k: a point gamma^k (lt_c - lt*) from
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 // quantum of the epoch (ulp(et): 3e-8 s in 2005, 1.2e-7 s from 2015 on) is NOT visible on the body that
                 // difference is none either, and the fixed point itself is taken ...
                 double lam = lts;
-                if (kp->cf_iter) {
+                if (QUANT && kp->cf_iter) {
                     // ... where it is (Params::cf_iter: the target moves by more than 1e-9 deg of its own radius per
                     // quantum - every moon, Mars, and Jupiter itself in data taken after 2015) the closed form steps
                     // through that sequence from the fixed point, to first order in E': e_k = lt_k - lt* = gamma^k e_0
@@ -436,8 +454,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 // closed form at the unrounded fixed point. The target's linear motion over the difference `dq`
                 // moves the intercept by dq (s' X - VBs), s' keeping it on the surface: first order is exact here
                 // (dq^2 ~ 1e-14).
-                d_cf = rsub_c(lam, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
-                const double dq = d_cf - dstar;
+                if (QUANT) {
+                    d_cf = rsub_c(lam, kp->g.et) - kp->t0;  // two roundings, as the epoch et - lt of the reference has them
+                    dq = d_cf - dstar;
+                }
                 Xf_cf = {fma(dq, fma_cn(sp, Xp.x, vbs.x), F.x), fma(dq, fma_cn(sp, Xp.y, vbs.y), F.y),
                          fma(dq, fma_cn(sp, Xp.z, vbs.z), F.z)};
                 lt_cf = fma(dq, sp, s) * kp->inv_c;
@@ -457,17 +477,29 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     Xf_cf = {fma(cz_cf, p0.x, sz_cf * p0.y) * kp->ir[0], fma(cz_cf, p0.y, -sz_cf * p0.x) * kp->ir[1], p0.z * kp->ir[2]};
                     lt_cf = fma(dt, kp->inv_c, lt_cf);
                 }
+                if (!QUANT && solved) {
+                    Xf = Xf_cf;
+                    d = d_cf;
+                    lt = lt_cf;
+                    if (TRI) {
+                        cz = cz_cf;
+                        sz = sz_cf;
+                    }
+                }
             }
-            solved = (hits | misses) == ~0ull;
-            if (solved) hit_mask = hits;
-            else cf_mask = hits;
-            if (solved && hits != 0) {
-                Xf = Xf_cf;
-                d = d_cf;
-                lt = lt_cf;
-                if (TRI) {
-                    cz = cz_cf;
-                    sz = sz_cf;
+            if (QUANT) {
+                // (lanes the stepping was unsure about have left `hits`)
+                solved = (hits | misses) == ~0ull;
+                if (solved) hit_mask = hits;
+                else cf_mask = hits;
+                if (solved && hits != 0) {
+                    Xf = Xf_cf;
+                    d = d_cf;
+                    lt = lt_cf;
+                    if (TRI) {
+                        cz = cz_cf;
+                        sz = sz_cf;
+                    }
                 }
             }
         }
@@ -703,11 +735,8 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             // (A spheroid needs none of that for its shape - but the body-fixed POINT turns with the body between the two
             //  epochs, and its normal with it: by wdot x (di - d), one quantum's worth in the fraction of a percent of the
             //  pixels whose two epochs round apart. Params::turn_quantum: 1.2e-9 deg for Jupiter from 2015 on.)
-            double turn = 0.0;
-            if (!TRI && kp->turn_quantum) turn = kp->g.wdot * (((kp->g.et - lt) - kp->t0) - d);
             // the point in B0 (for the Sun / observer geometry, which lives there)
-            V3 sp0 = TRI ? v3(fma(czi, sp.x, -szi * sp.y), fma(szi, sp.x, czi * sp.y), sp.z) : sp;
-            if (!TRI && kp->turn_quantum) sp0 = {fma(-turn, sp.y, sp.x), fma(turn, sp.x, sp.y), sp.z};
+            const V3 sp0 = TRI ? v3(fma(czi, sp.x, -szi * sp.y), fma(szi, sp.x, czi * sp.y), sp.z) : sp;
             if (FLAGS & DF_ILLUM) {
                 // illumf_c body.py:1915: point wrt P_T(t0) in B0; Sun light time: two passes
                 V3 q = TRI ? v3(fma(kp->VB[0], di, sp0.x), fma(kp->VB[1], di, sp0.y), fma(kp->VB[2], di, sp0.z))
@@ -743,7 +772,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                 }
                 const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
                 const V3 ob = neg(u);  // observer seen from the point: -ray (unit)
-                if (!TRI && kp->turn_quantum) n = {fma(-turn, n.y, n.x), fma(turn, n.x, n.y), n.z};  // (first order: 1e-10 rad)
+                if (QUANT && !TRI && kp->turn_quantum) {  // (kernel-argument flag: one scalar branch; first order: 1e-10 rad)
+                    const double turn = kp->g.wdot * (((kp->g.et - lt) - kp->t0) - d);
+                    n = {fma(-turn, n.y, n.x), fma(turn, n.x, n.y), n.z};
+                }
                 if (TRI) {
                     n = {fma(czi, n.x, -szi * n.y), fma(szi, n.x, czi * n.y), n.z};
                     n = rsqrt_fast(dot(n, n)) * n;
@@ -770,8 +802,13 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
             if (FLAGS & DF_STATE) {
                 // spkcpt_c body.py:2830: distance = lt c; velocity with the light-time rate
                 const double dv = TRI ? di : d;
-                const V3 vp = {fma(kp->ASB_state[0], dv, kp->VSB_state[0]) - kp->g.wdot * sp0.y,
-                               fma(kp->ASB_state[1], dv, kp->VSB_state[1]) + kp->g.wdot * sp0.x, fma(kp->ASB_state[2], dv, kp->VSB_state[2])};
+                V3 sv0 = sp0;  // the point the state belongs to
+                if (QUANT && !TRI && kp->turn_quantum) {
+                    const double turn = kp->g.wdot * (((kp->g.et - lt) - kp->t0) - d);
+                    sv0 = {fma(-turn, sp0.y, sp0.x), fma(turn, sp0.x, sp0.y), sp0.z};
+                }
+                const V3 vp = {fma(kp->ASB_state[0], dv, kp->VSB_state[0]) - kp->g.wdot * sv0.y,
+                               fma(kp->ASB_state[1], dv, kp->VSB_state[1]) + kp->g.wdot * sv0.x, fma(kp->ASB_state[2], dv, kp->VSB_state[2])};
                 const V3 vo = v3(kp->VOB[0], kp->VOB[1], kp->VOB[2]);
                 const double dlt = (dot(u, vp - vo) * kp->inv_c) / (1.0 + dot(u, vp) * kp->inv_c);
                 const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;
@@ -1172,20 +1209,30 @@ void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s)
     dim3 block(pm::kSphBlock);
     const bool tri = p.radii[0] != p.radii[1];
     const int sky = (flags >> 3) & 3;
+    // (the QUANT variants exist without the fused sky planes: the caller does not fuse for such geometries)
+    const bool quant = sky == 0 && (p.cf_iter != 0 || p.turn_quantum != 0);
 #define PM_SPH_CASE(F)                                                                                          \
     case F:                                                                                                     \
-        if (tri && sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 0>), grid, block, 0, s, p);            \
-        else if (tri && sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 1>), grid, block, 0, s, p);       \
-        else if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 2>), grid, block, 0, s, p);                   \
+        if (quant && tri) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 0, 0, true>), grid, block, 0, s, p);         \
+        else if (quant && F == 1 && p.mask == pm::kMaskHeadline)                                                 \
+            hipLaunchKernelGGL((pm::k_disc_sph<1, 0, 0, pm::kMaskHeadline, true>), grid, block, 0, s, p);       \
+        else if (quant && F == 5 && p.mask == pm::kMaskRings)                                                    \
+            hipLaunchKernelGGL((pm::k_disc_sph<5, 0, 0, pm::kMaskRings, true>), grid, block, 0, s, p);          \
+        else if (quant && F == 7 && p.mask == pm::kMaskDisc)                                                     \
+            hipLaunchKernelGGL((pm::k_disc_sph<7, 0, 0, pm::kMaskDisc, true>), grid, block, 0, s, p);           \
+        else if (quant) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 0, 0, true>), grid, block, 0, s, p);           \
+        else if (tri && sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 0>), grid, block, 0, s, p);          \
+        else if (tri && sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 1>), grid, block, 0, s, p);          \
+        else if (tri) hipLaunchKernelGGL((pm::k_disc_sph<F, 1, 2>), grid, block, 0, s, p);                      \
         else if (sky == 0 && F == 1 && p.mask == pm::kMaskHeadline)                                              \
-            hipLaunchKernelGGL((pm::k_disc_sph<1, 0, 0, pm::kMaskHeadline>), grid, block, 0, s, p);         \
+            hipLaunchKernelGGL((pm::k_disc_sph<1, 0, 0, pm::kMaskHeadline>), grid, block, 0, s, p);             \
         else if (sky == 0 && F == 5 && p.mask == pm::kMaskRings)                                                 \
-            hipLaunchKernelGGL((pm::k_disc_sph<5, 0, 0, pm::kMaskRings>), grid, block, 0, s, p);            \
+            hipLaunchKernelGGL((pm::k_disc_sph<5, 0, 0, pm::kMaskRings>), grid, block, 0, s, p);                \
         else if (sky == 0 && F == 7 && p.mask == pm::kMaskDisc)                                                  \
-            hipLaunchKernelGGL((pm::k_disc_sph<7, 0, 0, pm::kMaskDisc>), grid, block, 0, s, p);             \
-        else if (sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 0>), grid, block, 0, s, p);             \
-        else if (sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 1>), grid, block, 0, s, p);             \
-        else hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 2>), grid, block, 0, s, p);                           \
+            hipLaunchKernelGGL((pm::k_disc_sph<7, 0, 0, pm::kMaskDisc>), grid, block, 0, s, p);                 \
+        else if (sky == 0) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 0>), grid, block, 0, s, p);                 \
+        else if (sky == 1) hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 1>), grid, block, 0, s, p);                 \
+        else hipLaunchKernelGGL((pm::k_disc_sph<F, 0, 2>), grid, block, 0, s, p);                               \
         break;
     switch (flags & 7) {
         PM_SPH_CASE(0)

@@ -1307,6 +1307,12 @@ def test_closed_form_steps_through_the_reference_iterates_where_a_quantum_is_vis
     oracle.set_num_threads(16)
     ref = oracle.backplanes_img(g, d, names)
     _compare_allowing_epoch_quantum_flips(out, ref, names, g, r0, label=case)
+    # the map direction at that epoch (its light-time offsets go through PM's own transforms: body.py:917-1006)
+    lon, lat = oracle.rectangular_grid(g, 5.0)
+    with _library_choice(engine):
+        om = engine.backplanes_map(oracle.PLANE_NAMES, lon, lat)
+    rm = oracle.backplanes_map(g, d, oracle.PLANE_NAMES, lon, lat)
+    _compare_allowing_epoch_quantum_flips(om, rm, oracle.PLANE_NAMES, g, r0, label=case + ' map')
     # ... and the plain sequence (PM_OPT_LT_MODE 1) gives the same answer as the stepped closed form
     from planetmapper_amd.engine import Engine
 

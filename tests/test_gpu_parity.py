@@ -1307,6 +1307,19 @@ def test_closed_form_steps_through_the_reference_iterates_where_a_quantum_is_vis
     oracle.set_num_threads(16)
     ref = oracle.backplanes_img(g, d, names)
     _compare_allowing_epoch_quantum_flips(out, ref, names, g, r0, label=case)
+    # the plane sets with their own compiled kernel (BASELINE's headline five, config 4's eight, the intercept group of
+    # save_observation) have a QUANT instantiation each: the same planes, bit for bit, as the general-mask kernel gave
+    ring = ['RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']
+    disc_group = HEADLINE + ring + ['LON-CENTRIC', 'LAT-CENTRIC', 'AZIMUTH', 'LOCAL-SOLAR-TIME', 'DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER']
+    with _library_choice(engine):
+        for subset in (HEADLINE, HEADLINE + ring, disc_group):
+            sub = engine.backplanes_img(subset)
+            for n in subset:
+                if n in out:
+                    assert np.array_equal(sub[n], out[n], equal_nan=True), (len(subset), n)
+            if subset is disc_group:
+                ref_ring = oracle.backplanes_img(g, d, ring)
+                _compare_allowing_epoch_quantum_flips({n: sub[n] for n in ring}, ref_ring, ring, g, r0, label=case + ' rings')
     # the map direction at that epoch (its light-time offsets go through PM's own transforms: body.py:917-1006)
     lon, lat = oracle.rectangular_grid(g, 5.0)
     with _library_choice(engine):

@@ -1019,6 +1019,43 @@ def _variant(g, **changes):
     return v
 
 
+def _with_its_own_sub_observer_point(g):
+    """
+    The sub-observer fields of a geometry block (subpnt 'INTERCEPT/ELLIPSOID', body.py:538-555: the point, its ray, its
+    epoch and distance - the pivot of PM's obsvec <-> targvec transforms) recomputed from the block's own motion model,
+    for variants whose radii are not the fixture's: a pivot 60 000 km off the surface of a 9000-km body is not a geometry
+    the reference can produce, and it levers one epoch quantum of the limb / ring planes up by |pivot| / |point|.
+    """
+    v = g.copy()
+    R0 = np.array(v.R0[:]).reshape(3, 3)
+    T0, VT, AT = (np.array(x[:]) for x in (v.T0, v.VT, v.AT))
+    radii = np.array(v.radii[:])
+    t0 = v.et - v.lt_c
+
+    def rot_at(t):
+        c, s = np.cos(v.wdot * (t - t0)), np.sin(v.wdot * (t - t0))
+        return np.array([[c, s, 0.0], [-s, c, 0.0], [0.0, 0.0, 1.0]]) @ R0
+
+    lt = v.lt_c
+    for _ in range(12):
+        te = v.et - lt
+        d = te - t0
+        Rk = rot_at(te)
+        obs_b = -(Rk @ (T0 + VT * d + 0.5 * AT * d * d))
+        sp = obs_b / np.sqrt(np.sum((obs_b / radii) ** 2))
+        new = float(np.linalg.norm(sp - obs_b)) / v.clight
+        if new == lt:
+            break
+        lt = new
+    ray = sp - obs_b
+    ov = Rk.T @ ray
+    for i in range(3):
+        v.sub_sp[i], v.sub_ray[i], v.sub_obsvec[i] = sp[i], ray[i], ov[i]
+    v.sub_et = v.et - lt
+    v.sub_dist = float(np.linalg.norm(ray))
+    return v
+
+
 @pytest.mark.parametrize('case', ['east_positive', 'triaxial', 'triaxial_east_small', 'io_like', 'io_like_fast'])
 def test_other_body_shapes_and_longitude_conventions(engine, oracle, jupiter, case):
     """
@@ -1189,7 +1226,7 @@ def _compare_allowing_epoch_quantum_flips(out, ref, names, g, r0, label=''):
     from parity import base_deg, tolerances
 
     tol = tolerances(ref, g, plate_scale_arcsec=g.diameter_arcsec / (2 * r0))
-    quantum = float(np.spacing(g.et))
+    quantum = float(np.spacing(abs(g.et)))  # (np.spacing of a negative number is negative: epochs before 2000)
     q_deg = float(np.rad2deg(quantum * (abs(g.wdot) + np.linalg.norm(g.VT[:]) / min(g.radii[:]))))
     # (the limb and ring planes go through PM's obsvec -> targvec transform, whose epoch sub_et - dd / c is a double too)
     turning = ('LON-GRAPHIC', 'LAT-GRAPHIC', 'LON-CENTRIC', 'LAT-CENTRIC', 'INCIDENCE', 'EMISSION', 'AZIMUTH',
@@ -1208,8 +1245,11 @@ def _compare_allowing_epoch_quantum_flips(out, ref, names, g, r0, label=''):
         if n in ('RADIAL-VELOCITY', 'DOPPLER'):
             # the intercept is defined to the rounding of the ray (1e-7 km on 7e4 km: 1e-12): so is wdot x r, which
             # is 380 km/s for the fast-spin bodies - the bar of 1e-9 km/s was set for bodies that turn at 12 km/s
-            # (measured: the median difference grows in proportion to the spin, 1e-11 -> 3e-10 km/s)
-            noise = 1e-11 * abs(g.wdot) * max(g.radii[:])
+            # (measured on a Jupiter-sized body: the median difference grows in proportion to the spin, 1e-11 -> 3e-10 km/s)
+            # (in absolute terms: five half-ulps of the unit ray at the target's distance, over cos(emission) as the
+            #  intercept slides along a slanted ray, times the spin - 2e-9 km/s for a 400-km body turning in 16 minutes)
+            kappa = np.broadcast_to(tol['LAT-GRAPHIC'], diff.shape) / base_deg(g)
+            noise = 5.0 * 1.11e-16 * float(np.linalg.norm(g.T0[:])) * abs(g.wdot) * kappa
             t = t + (noise if n == 'RADIAL-VELOCITY' else noise / g.clight)
         bad = fin & (diff > t)
         if n in turning:
@@ -1348,6 +1388,54 @@ def test_closed_form_steps_through_the_reference_iterates_where_a_quantum_is_vis
     # (measured: Jupiter 0, Saturn 9e-4 - where the stepped closed form is the one closer to the oracle, 0.57 % against 0.93 %
     #  of these pixels beyond half a quantum -, the small body 2e-3)
     assert share <= 3e-3, share
+
+
+@pytest.mark.parametrize('leg', ['fixed_seed', 'fresh_seed'])
+def test_random_epochs_body_sizes_and_spins_fuzz(engine, oracle, jupiter, saturn, leg):
+    """
+    What decides HOW the image kernels solve the light time - the epoch (ulp(et)), the size of the body (how far one
+    quantum of its motion shows on it), its spin, its shape - swept at random: epochs 1995 ... 2040, equatorial radii
+    300 ... 70 000 km, spheroids and triaxial bodies, spins from a tenth to fifty times the fixture's. Every case goes
+    through the library's own choice of kernel and light-time path (closed form; stepping through the reference's iterates;
+    its plain sequence; Newton step; first-order turn of a triaxial shape; general kernel), all 26 planes against the
+    oracle: masks identical, values inside the bars but for the handful of pixels one epoch quantum away that two
+    implementations of a rounded epoch cannot avoid (`_compare_allowing_epoch_quantum_flips`).
+    """
+    from conftest import fresh_seed
+    from planetmapper_amd import _lib
+
+    seed = 271828 if leg == 'fixed_seed' else fresh_seed('test_random_epochs_body_sizes_and_spins_fuzz')
+    rng = np.random.default_rng(seed)
+    seen = set()
+    for i in range(14):
+        base = saturn if i % 4 == 3 else jupiter
+        et = float(rng.uniform(-1.6e8, 1.26e9))  # 1995 ... 2040
+        shift = et - base.et
+        a = float(10 ** rng.uniform(np.log10(300.0), np.log10(7e4)))
+        c = a * float(rng.uniform(0.85, 1.0))
+        b = a if i % 3 else a * float(rng.uniform(0.96, 0.9995))
+        spin = base.wdot * float(10 ** rng.uniform(-1.0, 1.7))
+        g = _with_its_own_sub_observer_point(_variant(base, et=et, ts0=base.ts0 + shift, radii=[a, b, c], wdot=spin,
+                                                      diameter_arcsec=base.diameter_arcsec * a / base.radii[0]))
+        nx, ny = int(rng.integers(150, 330)), int(rng.integers(150, 330))
+        r0 = float(rng.uniform(0.25, 0.48) * min(nx, ny))
+        x0, y0 = float(rng.uniform(0.4, 0.6) * nx), float(rng.uniform(0.4, 0.6) * ny)
+        rot = float(rng.uniform(0, 2 * np.pi))
+        d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny)
+        d.rotation_rad = rot
+        with _library_choice(engine):
+            engine.set_geometry(g)
+            engine.set_disc(x0, y0, r0, rot, nx, ny, True)
+            out = engine.backplanes_img(oracle.PLANE_NAMES)
+            seen.add((engine.get_option(_lib.PM_OPT_LAST_DISC_KERNEL), engine.get_option(_lib.PM_OPT_LAST_LT_PATH)))
+        ref = oracle.backplanes_img(g, d, oracle.PLANE_NAMES)
+        try:
+            _compare_allowing_epoch_quantum_flips(out, ref, oracle.PLANE_NAMES, g, r0, label=f'fuzz {i}')
+        except AssertionError as e:
+            raise AssertionError(f'seed {seed} case {i}: et {et:.4g}, radii ({a:.5g}, {b:.5g}, {c:.5g}), spin x{spin / base.wdot:.3g}, '
+                                 f'kernel / light-time path {sorted(seen)[-1]}: {e}') from e
+    print(f'\n[seed {seed}] (kernel, light-time path) combinations met: {sorted(seen)}')
+    assert len(seen) >= 3
 
 
 def test_frame_that_spans_most_of_the_sky(engine, oracle, jupiter):

@@ -1,0 +1,45 @@
+"""Replay one case of tests/test_gpu_parity.py::test_random_epochs_body_sizes_and_spins_fuzz and print the pixels beyond the bars:
+python tools/probes/fuzz_case_probe.py SEED CASE [PLANE ...]"""
+import sys, numpy as np
+sys.path[:0]=['/root/repo','/root/repo/tests']
+from oracle import oracle
+from planetmapper_amd.engine import Engine
+from planetmapper_amd.scenarios import load_scenario
+from planetmapper_amd import _lib
+from test_gpu_parity import _variant, _with_its_own_sub_observer_point
+import parity
+jupiter=load_scenario('jupiter_hst_2005'); saturn=load_scenario('saturn_earth_2005')
+seed=int(sys.argv[1]); want=int(sys.argv[2]); planes=sys.argv[3:] or list(oracle.PLANE_NAMES)
+rng=np.random.default_rng(seed)
+for i in range(14):
+    base = saturn if i % 4 == 3 else jupiter
+    et = float(rng.uniform(-1.6e8, 1.26e9)); shift = et - base.et
+    a = float(10 ** rng.uniform(np.log10(300.0), np.log10(7e4)))
+    c = a * float(rng.uniform(0.85, 1.0))
+    b = a if i % 3 else a * float(rng.uniform(0.96, 0.9995))
+    spin = base.wdot * float(10 ** rng.uniform(-1.0, 1.7))
+    g = _with_its_own_sub_observer_point(_variant(base, et=et, ts0=base.ts0 + shift, radii=[a, b, c], wdot=spin, diameter_arcsec=base.diameter_arcsec * a / base.radii[0]))
+    nx, ny = int(rng.integers(150, 330)), int(rng.integers(150, 330))
+    r0 = float(rng.uniform(0.25, 0.48) * min(nx, ny))
+    x0, y0 = float(rng.uniform(0.4, 0.6) * nx), float(rng.uniform(0.4, 0.6) * ny)
+    rot = float(rng.uniform(0, 2 * np.pi))
+    if i != want: continue
+    print('frame', nx, ny, r0, x0, y0, rot, 'radii', a, b, c, 'wdot', spin, 'et', et)
+    e=Engine(0); e.set_geometry(g); e.set_disc(x0,y0,r0,rot,nx,ny,True)
+    d=oracle.make_disc(x0,y0,r0,0.0,nx,ny); d.rotation_rad=rot
+    out=e.backplanes_img(planes); print('kernel, lt path', e.get_option(_lib.PM_OPT_LAST_DISC_KERNEL), e.get_option(_lib.PM_OPT_LAST_LT_PATH))
+    ref=oracle.backplanes_img(g,d,planes)
+    tol=parity.tolerances(ref,g,plate_scale_arcsec=g.diameter_arcsec/(2*r0))
+    q=float(np.rad2deg(np.spacing(abs(g.et))*(abs(g.wdot)+np.linalg.norm(g.VT[:])/min(g.radii[:]))))
+    print('quantum deg', q, 'base', parity.base_deg(g))
+    for n in planes:
+        if n == 'LOCAL-SOLAR-TIME': continue
+        df=np.abs(out[n]-ref[n])
+        if 'LON' in n or n=='RA': df=np.minimum(df,360-df)
+        t=np.broadcast_to(tol[n],df.shape)
+        fin=np.isfinite(ref[n]); bad=fin&~(df<=t)
+        if not bad.any(): continue
+        print(n, 'beyond the bar:', int(bad.sum()), 'of', int(fin.sum()))
+        for k in list(zip(*np.nonzero(bad)))[:8]:
+            print('   ', k, 'out', out[n][k], 'ref', ref[n][k], 'diff', df[k], 'tol', t[k], 'emission', ref.get('EMISSION',{k:np.nan})[k] if 'EMISSION' in ref else '')
+    e.close()

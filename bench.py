@@ -559,7 +559,7 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         'host_feed_GBps_per_rank': round(block_bytes / t_fed / 1e9, 2),
         'host_feed': 'the route the library measured fastest on this rank (PM_OPT_HOST_CUBE_ROUTE -1: one chunk '
         'through each candidate on the first call, then the fastest): 3 = the 16-byte blocks of each plane that the map '
-        'samples, collected by the copy threads into pinned staging and sent by DMA; 0 = whole planes by DMA; 2 = 256-byte '
+        'samples, collected by the copy threads into pinned staging and sent by DMA; 0 = whole planes by DMA; 2 = 128-byte '
         'blocks fetched by the GPU itself; 4 = hybrid, chunks alternately collected by the threads and fetched by the GPU; '
         'block table cached across calls by map fingerprint',
         'route_chosen': route,

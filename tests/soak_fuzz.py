@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
-The fresh-seed legs of the three GPU fuzz tests (tests/test_gpu_parity.py) over many seeds in ONE process:
-`python tests/soak_fuzz.py --seeds 60 [--first 1]`. Not collected by pytest. Prints one JSON line per failure
+The fresh-seed legs of the four GPU fuzz tests (tests/test_gpu_parity.py) over many seeds in ONE process:
+`python tests/soak_fuzz.py --seeds 60 [--first 1] [--only light_time_paths]`. Not collected by pytest. Prints one JSON line per failure
 (test, seed, message) and a summary; a failing seed is replayed with `PM_FUZZ_SEED=<seed> pytest -m gpu -k fuzz`.
 """
 import argparse
@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', type=int, default=40)
     ap.add_argument('--first', type=int, default=int(time.time()) % 100000 * 1000)
+    ap.add_argument('--only', default='', help='one of discs_fast, reprojection, geometries, light_time_paths')
     args = ap.parse_args()
     import test_gpu_parity as T
     from oracle import oracle
@@ -36,11 +37,15 @@ def main():
         cases = [('discs_fast', lambda: T.test_random_discs_and_frames_fuzz.__wrapped__(eng, oracle, jupiter, saturn, 'fresh_seed')
                   if hasattr(T.test_random_discs_and_frames_fuzz, '__wrapped__') else T.test_random_discs_and_frames_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed')),
                  ('reprojection', lambda: T.test_random_reprojection_fuzz(eng, oracle, jupiter, 'fresh_seed')),
-                 ('geometries', lambda: T.test_random_geometries_fuzz(eng, oracle, 'fresh_seed'))]  # fmt: skip
+                 ('geometries', lambda: T.test_random_geometries_fuzz(eng, oracle, 'fresh_seed')),
+                 ('light_time_paths', lambda: T.test_random_epochs_body_sizes_and_spins_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed'))]  # fmt: skip
+        if args.only:
+            cases = [c for c in cases if c[0] == args.only]
         for general in (0, 1):
             eng.set_option(_lib.PM_OPT_GENERAL_KERNEL, general)
             # (general kernel forced: the frames sweep and the geometries sweep - near field, triaxial, fast approach)
-            for name, fn in (cases if general == 0 else [cases[0], cases[2]]):
+            # (the epochs / sizes / spins sweep is about the library's OWN choice of kernel: not run forced)
+            for name, fn in (cases if general == 0 else [c for c in cases if c[0] in ('discs_fast', 'geometries')]):
                 try:
                     fn()
                 except Exception as e:  # noqa: BLE001

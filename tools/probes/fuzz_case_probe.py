@@ -43,3 +43,18 @@ for i in range(14):
         for k in list(zip(*np.nonzero(bad)))[:8]:
             print('   ', k, 'out', out[n][k], 'ref', ref[n][k], 'diff', df[k], 'tol', t[k], 'emission', ref.get('EMISSION',{k:np.nan})[k] if 'EMISSION' in ref else '')
     e.close()
+    # RADIAL-VELOCITY: the distribution of |diff| against the rounding model of the test
+    if 'RADIAL-VELOCITY' in planes:
+        n='RADIAL-VELOCITY'; df=np.abs(out[n]-ref[n]); fin=np.isfinite(ref[n])
+        kappa=np.broadcast_to(tol['LAT-GRAPHIC'],df.shape)/parity.base_deg(g)
+        unit=1.11e-16*float(np.linalg.norm(g.T0[:]))*abs(g.wdot)*kappa
+        r=(df/unit)[fin]
+        print('RV diff in units of (half-ulp of the ray x distance x spin x kappa): percentiles 50/90/99/99.9/max', np.percentile(r,[50,90,99,99.9,100]))
+        print('   kappa percentiles', np.percentile(kappa[fin],[50,90,99,100]), ' unit at kappa=1', 1.11e-16*float(np.linalg.norm(g.T0[:]))*abs(g.wdot))
+        qd=oracle.backplanes_img_rows_quad(g,d,[n,'EMISSION'],0,ny)
+        eo=np.abs(ref[n]-qd[n]); eh=np.abs(out[n]-qd[n])
+        print('   against binary128: oracle err percentiles 50/99/max', np.nanpercentile(eo/unit,[50,99,100]), ' HIP err', np.nanpercentile(eh/unit,[50,99,100]))
+        k=np.unravel_index(np.nanargmax(np.where(fin,df/unit,0)),df.shape)
+        qn=float(np.spacing(abs(g.et)))
+        print('   worst pixel',k,'out',out[n][k],'ref',ref[n][k],'quad',float(qd[n][k]),'diff',df[k],'kappa',kappa[k],'emission',ref['EMISSION'][k] if 'EMISSION' in ref else None)
+        print('   one quantum: wdot^2 r q', g.wdot**2*max(g.radii[:])*qn, ' |VT| wdot q', float(np.linalg.norm(g.VT[:]))*abs(g.wdot)*qn, ' wdot r q (km)', abs(g.wdot)*max(g.radii[:])*qn)

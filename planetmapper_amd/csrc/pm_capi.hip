@@ -851,7 +851,7 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg, c
     if ((plane_mask & ~(bit(PM_PIXEL_X) | bit(PM_PIXEL_Y))) == 0 && !ctx->force_general)
         pm_launch_map_xy(p, dlon, dlat, ctx->stream);
     else
-        pm_launch_map(p, dlon, dlat, ctx->stream);
+        pm_launch_map(p, dlon, dlat, ctx->force_general != 0, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
     if (mem != PM_MEM_DEVICE) {
         for (int i = 0; i < PM_NUM_PLANES; i++)

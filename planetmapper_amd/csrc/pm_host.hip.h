@@ -21,7 +21,7 @@
 void pm_launch_disc(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_disc_spheroid(const pm::Params &p, int flags, hipStream_t s);
 void pm_launch_sky(const pm::Params &p, bool limb, hipStream_t s);
-void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
+void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, bool general, hipStream_t s);
 void pm_launch_map_xy(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
 void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
 void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *dec, unsigned long long n,

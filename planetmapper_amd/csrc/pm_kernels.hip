@@ -975,6 +975,240 @@ __global__ __launch_bounds__(kBlock) void k_map(const Params p_, const double *_
     }
 }
 
+// Ring-plane and limb coordinates of an observer-frame direction given in B0 (`u`: unit vector), for the map kernel below:
+// the arithmetic of the ring block of k_disc_sph and of the limb block of sky_block (derivations there), one lane at a time.
+// Body._ring_coordinates_from_obsvec(only_visible=False) body.py:2577-2615
+__device__ __forceinline__ void ring_coords_b0(const Params &p, const V3 u, double &radius, double &lon_deg, double &dist)
+{
+    radius = lon_deg = dist = __builtin_nan("");
+    const double pd = dot(u, ld3(p.ring_nb));
+    const double kk = p.g.ring_k;
+    const bool ok = (kk == 0.0) ? (pd != 0.0) : (pd > 0.0 && kk < pd * (1.7976931348623157e308 / 3.0));
+    if (!wave_any(ok)) return;
+    // (lanes without an intersection carry a harmless finite point through the math)
+    const double s = !ok ? p.g.sub_dist : ((kk == 0.0) ? 0.0 : div_fast(kk, pd));
+    const V3 ob = {fma(s, u.x, -p.sub_obs_b[0]), fma(s, u.y, -p.sub_obs_b[1]), fma(s, u.z, -p.sub_obs_b[2])};
+    const V3 w = ob - ld3(p.sub_ray_b);
+    const double dd = sqrt_fast(dot(w, w)) - p.g.sub_dist;
+    const double t = p.g.sub_et - dd * p.inv_c;
+    double sa, ca;
+    sincos_tiered<true>(p.g.wdot * (t - p.t0), sa, ca);
+    const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1], ob.z + p.g.sub_sp[2]};
+    double le, alt;
+    recpgr_alt_lon(p, tv, le, alt, ok);
+    double l = p.g.west_positive ? -le : le;
+    if (l < 0.0) l += kTwoPi;
+    if (ok) {
+        radius = alt + p.radii[0];
+        lon_deg = l * kDeg;
+        dist = s;
+    }
+}
+// Body._limb_coordinates_from_obsvec body.py:2081-2110
+__device__ __forceinline__ void limb_coords_b0(const Params &p, const V3 u, double &lon_deg, double &lat_deg, double &dist)
+{
+    const V3 o0 = v3(p.O0[0], p.O0[1], p.O0[2]);  // -R0 T0
+    const double k = -div_fast(dot(o0, u), dot(u, u));
+    const V3 nb = {fma(k, u.x, o0.x), fma(k, u.y, o0.y), fma(k, u.z, o0.z)};  // near point - T0, in B0
+    const double nd = norm_f(nb);
+    const V3 ob = {fma(k, u.x, -p.sub_obs_b[0]), fma(k, u.y, -p.sub_obs_b[1]), fma(k, u.z, -p.sub_obs_b[2])};
+    const V3 w = ob - ld3(p.sub_ray_b);
+    const double dd = norm_f(w) - p.g.sub_dist;
+    const double t = p.g.sub_et - dd * p.inv_c;
+    double sa, ca;
+    sincos_tiered<true>(p.g.wdot * (t - p.t0), sa, ca);
+    const V3 tv = {fma(ca, ob.x, sa * ob.y) + p.g.sub_sp[0], fma(ca, ob.y, -sa * ob.x) + p.g.sub_sp[1], ob.z + p.g.sub_sp[2]};
+    const V3 X = {tv.x * p.ir[0], tv.y * p.ir[1], tv.z * p.ir[2]};
+    const V3 sfc = rsqrt_fast(dot(X, X)) * tv;
+    const double nx = sfc.x * p.limb_n[0], ny = sfc.y * p.limb_n[0], nz = sfc.z * p.limb_n[1];
+    const double lat = atan2_fast(nz, sqrt_fast(fma(nx, nx, ny * ny)));
+    double l = atan2_fast(sfc.y, sfc.x);
+    if (p.g.west_positive) l = -l;
+    if (l < 0.0) l += kTwoPi;
+    lon_deg = l * kDeg;
+    lat_deg = lat * kDeg;
+    dist = nd - norm_f(sfc);
+}
+
+// ------------------------------------------------------------------ map-space planes in B0
+// The same chain as k_map for the planes a map is usually asked for, evaluated like k_map_xy and the image kernels: in
+// B0, the body-fixed frame frozen at t0 (every rotation a turn about z by the spin angle of the epoch), with the fast
+// elementary functions, and only the groups of the chain that the requested planes need (the plane mask is a kernel
+// argument: every `if (want...)` below is a scalar branch). k_map costs ~1400 vector instructions per cell whatever is
+// asked - fine for the 64 800 cells of a 1 deg grid, which are latency, but a 0.05 deg map has 26 M cells: 0.68 ms for
+// five planes against 0.13 ms for the five planes of a 4096^2 IMAGE, which solves an intercept on top.
+//   * surface point: pgrrec_c at altitude 0 (body.py:903), as map_cell_xy;
+//   * its light time: spkcpt_c / illumf_c 'CN' (body.py:1915, 2830) - three passes from the centre value and the state at
+//     the epoch of the third, the sequence the oracle's point_lt<3> walks, epochs rounded as the reference rounds them;
+//   * illumination: point, normal, Sun (two passes + the final evaluation, acceleration carried) and observer in B0;
+//   * state: velocity with the light-time rate, as the STATE block of k_disc_sph;
+//   * RA / Dec, pixel, km and angular coordinates: PM's own transform about the sub-observer point, as map_cell_xy;
+//   * limb / ring planes: the B0 blocks of sky_block / k_disc_sph on the observer vector (ring_coords_b0, limb_coords_b0).
+// PM_OPT_GENERAL_KERNEL keeps k_map, the independent J2000 evaluation, as the image planes keep theirs.
+template <bool SUN, bool STATE>
+__global__ __launch_bounds__(kBlock) void k_map_b0(const Params p_, const double *__restrict__ lon_in,
+                                                   const double *__restrict__ lat_in)
+{
+    const Params &p = *(const Params *)kernarg_params();
+    const size_t idx = (size_t)blockIdx.x * kBlock + threadIdx.x;
+    const size_t n = (size_t)p.n0 * p.n1;
+    if (idx >= n) return;
+    const double nan = __builtin_nan("");
+    double lon_deg = lon_in[idx], lat_deg = lat_in[idx];
+    const bool have = isfinite(lon_deg) && isfinite(lat_deg);
+    if (!have) lon_deg = lat_deg = nan;
+    const double miss = have ? 0.0 : nan;  // added to a cell's values: NaN for a cell without coordinates
+    PM_PUT(PM_LON_GRAPHIC, lon_deg);
+    PM_PUT(PM_LAT_GRAPHIC, lat_deg);
+    if (PM_WANT(PM_LOCAL_SOLAR_TIME)) PM_PUT(PM_LOCAL_SOLAR_TIME, local_solar_time(p, lon_deg));
+    constexpr unsigned long long kCellBits = plane_bit(PM_LON_GRAPHIC) | plane_bit(PM_LAT_GRAPHIC) | plane_bit(PM_LOCAL_SOLAR_TIME);
+    constexpr unsigned long long kCentricBits = plane_bit(PM_LON_CENTRIC) | plane_bit(PM_LAT_CENTRIC);
+    constexpr unsigned long long kRadecBits = plane_bit(PM_RA) | plane_bit(PM_DEC);
+    constexpr unsigned long long kXyBits = plane_bit(PM_PIXEL_X) | plane_bit(PM_PIXEL_Y) | plane_bit(PM_KM_X) | plane_bit(PM_KM_Y) |
+                                           plane_bit(PM_ANGULAR_X) | plane_bit(PM_ANGULAR_Y);
+    constexpr unsigned long long kLimbBits = plane_bit(PM_LIMB_LON_GRAPHIC) | plane_bit(PM_LIMB_LAT_GRAPHIC) | plane_bit(PM_LIMB_DISTANCE);
+    constexpr unsigned long long kRingBits = plane_bit(PM_RING_RADIUS) | plane_bit(PM_RING_LON_GRAPHIC) | plane_bit(PM_RING_DISTANCE);
+    if ((p.mask & ~kCellBits) == 0) return;
+
+    // pgrrec_c, altitude 0: (a^2 cos(lat) cos(l), a^2 cos(lat) sin(l), c^2 sin(lat)) / sqrt(a^2 cos^2 + c^2 sin^2)
+    const double lon = have ? lon_deg * kRad : 0.0, lat = have ? lat_deg * kRad : 0.0;
+    const double a = p.radii[0], c = p.radii[2];
+    double sl, cl, so, co;
+    sincos_auto(lat, sl, cl);
+    sincos_auto(p.g.west_positive ? -lon : lon, so, co);
+    const double acl = a * cl, csl = c * sl;
+    const double den = rsqrt_fast(fma(acl, acl, csl * csl));
+    const double ha = a * acl * den;
+    const V3 tv = {ha * co, ha * so, c * csl * den};
+    if (p.mask & kCentricBits) {
+        // reclat_c body.py:2905 (longitude 0 on the axis)
+        const double bc = atan2_fast(tv.z, sqrt_fast(fma(tv.x, tv.x, tv.y * tv.y)));
+        const double lc = atan2_fast<false, true>(tv.y, tv.x);
+        PM_PUT(PM_LON_CENTRIC, fma(lc, kDeg, miss));
+        PM_PUT(PM_LAT_CENTRIC, fma(bc, kDeg, miss));
+    }
+    if ((p.mask & ~(kCellBits | kCentricBits)) == 0) return;
+
+    // light time of the point: pos(te) = T(te) + R(te)^T tv, in B0  w(d) = VB d + AB d^2 / 2 - O0 + Rz(wdot d)^T tv
+    const double wdot = p.g.wdot;
+    double lt = p.g.lt_c, d = 0.0, sa = 0.0, ca = 1.0;
+    V3 w = {0.0, 0.0, 0.0}, q = tv;
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        d = (p.g.et - lt) - p.t0;
+        const double h = 0.5 * d * d;
+        sincos_tiered<true>(wdot * d, sa, ca);
+        q = {fma(ca, tv.x, -sa * tv.y), fma(sa, tv.x, ca * tv.y), tv.z};
+        w = {fma(p.AB[0], h, fma(p.VB[0], d, q.x - p.O0[0])), fma(p.AB[1], h, fma(p.VB[1], d, q.y - p.O0[1])),
+             fma(p.AB[2], h, fma(p.VB[2], d, q.z - p.O0[2]))};
+        if (it < 3) lt = sqrt_fast(dot(w, w)) * p.inv_c;
+    }
+    const V3 u = rsqrt_fast(dot(w, w)) * w;  // observer -> point
+    const V3 ob = neg(u);
+    // surfnm_c in the body-fixed frame of the epoch, turned into B0 like the point
+    const V3 nb = {tv.x * (p.ir[0] * p.ir[0]), tv.y * (p.ir[1] * p.ir[1]), tv.z * (p.ir[2] * p.ir[2])};
+    V3 nrm = {fma(ca, nb.x, -sa * nb.y), fma(sa, nb.x, ca * nb.y), nb.z};
+    nrm = rsqrt_fast(dot(nrm, nrm)) * nrm;
+    const double em = vsep_fast(nrm, ob);
+    const bool vis = have && em < kHalfPi;
+    bool lit = false;
+    PM_PUT(PM_EMISSION, fma(em, kDeg, miss));
+    const double surf_dist = lt * p.g.clight + miss;
+    PM_PUT(PM_DISTANCE, surf_dist);
+    if (SUN) {
+        // illumf_c: the point wrt P_T(t0); the Sun at te - |S - q| / c, two passes from the centre value + the final one
+        const double h = 0.5 * d * d;
+        const V3 qi = {fma(p.AB[0], h, fma(p.VB[0], d, q.x)), fma(p.AB[1], h, fma(p.VB[1], d, q.y)), fma(p.AB[2], h, fma(p.VB[2], d, q.z))};
+        const double dts = (p.t0 - p.g.ts0) + d;  // te - ts0
+        double ds = 0.0;
+        V3 sv = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int it = 0; it < 3; it++) {
+            const double hs = 0.5 * ds * ds;
+            sv = {fma(p.ASB[0], hs, fma(p.VSB[0], ds, p.SB0[0])) - qi.x, fma(p.ASB[1], hs, fma(p.VSB[1], ds, p.SB0[1])) - qi.y,
+                  fma(p.ASB[2], hs, fma(p.VSB[2], ds, p.SB0[2])) - qi.z};
+            if (it < 2) ds = dts - norm_f(sv) * p.inv_c;
+        }
+        const V3 sunb = rsqrt_fast(dot(sv, sv)) * sv;
+        const double ph = vsep_fast(sunb, ob), in = vsep_fast(nrm, sunb);
+        lit = have && in < kHalfPi;
+        PM_PUT(PM_PHASE, fma(ph, kDeg, miss));
+        PM_PUT(PM_INCIDENCE, fma(in, kDeg, miss));
+        if (PM_WANT(PM_AZIMUTH)) PM_PUT(PM_AZIMUTH, azimuth_from_cosines(dot(sunb, ob), dot(nrm, sunb), dot(nrm, ob)) + miss);
+    }
+    if (STATE) {
+        // spkcpt_c's velocity with the light-time rate (body.py:2830-2850), as the STATE block of k_disc_sph
+        const V3 vp = {fma(p.ASB_state[0], d, p.VSB_state[0]) - wdot * q.y, fma(p.ASB_state[1], d, p.VSB_state[1]) + wdot * q.x,
+                       fma(p.ASB_state[2], d, p.VSB_state[2])};
+        const V3 vo = {p.VOB[0], p.VOB[1], p.VOB[2]};
+        const double dlt = div_fast(dot(u, vp - vo) * p.inv_c, fma(dot(u, vp), p.inv_c, 1.0));
+        const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;
+        const double beta = rv * p.inv_c;  // SpiceBase.calculate_doppler_factor base.py:550
+        PM_PUT(PM_RADIAL_VELOCITY, rv);
+        PM_PUT(PM_DOPPLER, sqrt_fast(div_fast(1.0 + beta, 1.0 - beta)));
+    }
+    if ((p.mask & (kRadecBits | kXyBits | kLimbBits | kRingBits)) == 0) return;
+
+    // Body._targvec2obsvec (body.py:917-948): the offset from the sub-observer point, turned at ITS light-time epoch
+    const V3 off = {tv.x - p.g.sub_sp[0], tv.y - p.g.sub_sp[1], tv.z - p.g.sub_sp[2]};
+    const V3 sr = {p.g.sub_ray[0] + off.x, p.g.sub_ray[1] + off.y, p.g.sub_ray[2] + off.z};
+    const double dist = sqrt_fast(dot(sr, sr)) - p.g.sub_dist;
+    const double t = p.g.sub_et - dist * p.inv_c;
+    double s2, c2;
+    sincos_tiered<true>(wdot * (t - p.t0), s2, c2);
+    // R0 ov = R0 sub_obsvec + Rz(ang2)^T off
+    const V3 b = {p.sub_obs_b[0] + fma(c2, off.x, -s2 * off.y), p.sub_obs_b[1] + fma(s2, off.x, c2 * off.y), p.sub_obs_b[2] + off.z};
+    const double hide = vis ? 0.0 : nan;  // RA / Dec and what follows from them: visible cells only (body_xy.py:3430)
+    if (p.mask & kRadecBits) {
+        double ra, dec;
+        recrad_f(mtxv(p.g.R0, b), ra, dec);
+        PM_PUT(PM_RA, fma(ra, kDeg, hide));
+        PM_PUT(PM_DEC, fma(dec, kDeg, hide));
+    }
+    if (p.mask & kXyBits) {
+        // Body._obsvec2angular: M ov = C^T (R0 ov); recrad_c is scale free
+        const V3 m = {fma(p.C[0], b.x, fma(p.C[3], b.y, p.C[6] * b.z)), fma(p.C[1], b.x, fma(p.C[4], b.y, p.C[7] * b.z)),
+                      fma(p.C[2], b.x, fma(p.C[5], b.y, p.C[8] * b.z))};
+        double ra, dec;
+        recrad_f(m, ra, dec);
+        double xx = -(ra * kDeg);
+        if (xx < 0.0) xx += 360.0;
+        if (xx > 180.0) xx -= 360.0;
+        const double ax = xx * 3600.0, ay = (dec * kDeg) * 3600.0;
+        const double px = fma(p.Ai[0], ax, fma(p.Ai[1], ay, p.Ai[2]));
+        const double py = fma(p.Ai[3], ax, fma(p.Ai[4], ay, p.Ai[5]));
+        // BodyXY._xy_in_image_frame body_xy.py:1868
+        const bool in_frame = vis && -0.5 < px && px < p.nx - 0.5 && -0.5 < py && py < p.ny - 0.5;
+        PM_PUT(PM_PIXEL_X, in_frame ? px : nan);
+        PM_PUT(PM_PIXEL_Y, in_frame ? py : nan);
+        const double kx = fma(p.K[0], ax, p.K[1] * ay) + hide, ky = fma(p.K[2], ax, p.K[3] * ay) + hide;
+        PM_PUT(PM_KM_X, kx);
+        PM_PUT(PM_KM_Y, ky);
+        if (PM_WANT(PM_ANGULAR_X) || PM_WANT(PM_ANGULAR_Y)) {
+            const double ik = rcp_fast(p.g.km_per_arcsec);
+            const double qx = kx * ik, qy = ky * ik;
+            PM_PUT(PM_ANGULAR_X, fma(fma(-p.g.km_per_arcsec, qx, kx), ik, qx));
+            PM_PUT(PM_ANGULAR_Y, fma(fma(-p.g.km_per_arcsec, qy, ky), ik, qy));
+        }
+    }
+    if (SUN && (p.mask & (kLimbBits | kRingBits))) {
+        // gated on illumf column 4 (lit) like the reference (body_xy.py:3981, 4097)
+        double ll = nan, lb = nan, ld = nan, rr = nan, rl = nan, rd = nan;
+        if (lit) {
+            const V3 ub = rsqrt_fast(dot(b, b)) * b;
+            if (p.mask & kLimbBits) limb_coords_b0(p, ub, ll, lb, ld);
+            if (p.mask & kRingBits) ring_coords_b0(p, ub, rr, rl, rd);
+        }
+        if (rd > surf_dist) rr = rl = rd = nan;
+        PM_PUT(PM_LIMB_LON_GRAPHIC, ll);
+        PM_PUT(PM_LIMB_LAT_GRAPHIC, lb);
+        PM_PUT(PM_LIMB_DISTANCE, ld);
+        PM_PUT(PM_RING_RADIUS, rr);
+        PM_PUT(PM_RING_LON_GRAPHIC, rl);
+        PM_PUT(PM_RING_DISTANCE, rd);
+    }
+}
+
 // ------------------------------------------------------------------ x/y map alone
 // What a reprojection needs of the map chain: pixel coordinates of the visible grid cells,
 // nothing else (BodyXY._get_xy_map body_xy.py:3478 and its inputs :3227-3300, 3419-3491, 3667).
@@ -1278,7 +1512,8 @@ void pm_launch_map_xy(const pm::Params &p, const double *lon, const double *lat,
                        lat);
 }
 
-void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hipStream_t s)
+// general: k_map, the J2000 evaluation with the general helpers (PM_OPT_GENERAL_KERNEL); otherwise k_map_b0
+void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, bool general, hipStream_t s)
 {
     size_t n = (size_t)p.n0 * p.n1;
     dim3 grid((unsigned)((n + pm::kBlock - 1) / pm::kBlock));
@@ -1288,6 +1523,13 @@ void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, hi
                               PM_PLANE_BIT(PM_RING_LON_GRAPHIC) | PM_PLANE_BIT(PM_RING_DISTANCE);
     const uint64_t state_bits = PM_PLANE_BIT(PM_RADIAL_VELOCITY) | PM_PLANE_BIT(PM_DOPPLER);
     const bool sun = (p.mask & sun_bits) != 0, state = (p.mask & state_bits) != 0;
+    if (!general) {
+        if (sun && state) hipLaunchKernelGGL((pm::k_map_b0<true, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+        else if (sun) hipLaunchKernelGGL((pm::k_map_b0<true, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+        else if (state) hipLaunchKernelGGL((pm::k_map_b0<false, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+        else hipLaunchKernelGGL((pm::k_map_b0<false, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
+        return;
+    }
     if (sun && state) hipLaunchKernelGGL((pm::k_map<true, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
     else if (sun) hipLaunchKernelGGL((pm::k_map<true, false>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);
     else if (state) hipLaunchKernelGGL((pm::k_map<false, true>), grid, dim3(pm::kBlock), 0, s, p, lon, lat);

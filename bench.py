@@ -78,9 +78,10 @@ def parse_args(argv=None):
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='headline line only: no host_path / cube_host sections')
     ap.add_argument(
-        '--workload', default='frame', choices=['frame', 'saturn', 'all26', 'cube', 'cube-host'],
+        '--workload', default='frame', choices=['frame', 'saturn', 'all26', 'maps', 'cube', 'cube-host'],
         help='frame: BASELINE headline (default); saturn: config 4 (Saturn + rings, 8 planes); all26: every default '
-        'backplane of a 4096^2 frame (what save_observation asks for); cube: config 5 with '
+        'backplane of a 4096^2 frame (what save_observation asks for); maps: all 26 map-space planes of a 0.1 deg '
+        'rectangular grid (what save_mapped_observation(degree_interval=0.1) asks of the map chain); cube: config 5 with '
         'the cube resident in HBM; cube-host: config 5 fed from host memory (planes sharded over the GPUs)',
     )  # fmt: skip
     ap.add_argument('--planes', type=int, default=512, help='cube workloads: total planes')
@@ -257,6 +258,18 @@ def cpu_baseline_other(workload: str, g, sz: int, names, threads: int, planes: i
                 break
         return {'value': round(done * sz * sz / dt / 1e6, 1), 'unit': 'Mpix/s', 'cores': threads, 'kind': 'port',
                 'sample': f'x/y map of the 1 deg grid + {done} of the {planes} planes ({sz}x{sz} f64), bilinear, OpenMP over map rows'}
+    if workload == 'maps':
+        disc = oracle.make_disc(x0, x0, 0.9 * x0, 0.0, sz, sz)
+        lon, lat = rectangular_grid(bool(g.west_positive), 0.1)
+        rows = 0
+        while True:  # (map rows are independent units: blocks of 225 rows = 810 000 cells)
+            oracle.backplanes_map(g, disc, list(names), lon[rows : rows + 225], lat[rows : rows + 225])
+            rows += 225
+            dt = time.perf_counter() - t0
+            if dt > budget_s or rows >= lon.shape[0]:
+                break
+        return {'value': round(rows * lon.shape[1] / dt / 1e6, 3), 'unit': 'Mcell/s', 'cores': threads, 'kind': 'port',
+                'sample': f'{rows} of the {lon.shape[0]} rows of the 0.1 deg grid ({lon.shape[1]} cells each), {len(list(names))} planes, OpenMP over cells'}
     r0, rot = (800.0 * sz / 4096, 20.0) if workload == 'saturn' else (0.9 * x0, 0.0)
     disc = oracle.make_disc(x0, x0, r0, rot, sz, sz)
     frames = 0
@@ -845,6 +858,31 @@ def other_workloads(args) -> None:
                     '(k_disc_sph<7, false>) + 11 every pixel has (k_sky<true>)')
         alg = sz * sz * 8 * len(names)
         scaling = 'weak'
+    elif args.workload == 'maps':
+        # the map-space chain at throughput size (body_xy.py:3227-3300, 3419-3491, 3667-3675 and the get_*_map planes): every
+        # default backplane on a 0.1 deg rectangular grid, 1800 x 3600 cells - save_mapped_observation(degree_interval=0.1)
+        from planetmapper_amd._lib import PLANE_NAMES
+
+        sz = 1024
+        names = list(PLANE_NAMES)
+        g = load_scenario('jupiter_hst_2005')
+        eng.set_geometry(g)
+        x0 = (sz - 1) / 2
+        eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+        lon_h, lat_h = rectangular_grid(bool(g.west_positive), 0.1)
+        n0, n1 = lon_h.shape
+        lon_d, lat_d = torch.from_numpy(lon_h).to(d.dev), torch.from_numpy(lat_h).to(d.dev)
+        planes = {n: torch.empty((n0, n1), dtype=torch.float64, device=d.dev) for n in names}
+
+        def work():
+            eng.backplanes_map_device(planes, lon_d, lat_d, n0, n1)
+
+        units = n0 * n1
+        metric = 'Mcell/s all 26 default backplanes in map space, 0.1 deg rectangular grid (1800 x 3600 cells)'
+        workload = (f'Jupiter/HST 2005-01-01 geometry, {n0}x{n1} lon/lat grid resident in HBM, all {len(names)} map-space planes '
+                    '(k_map_b0<true, true>)')
+        alg = n0 * n1 * (16 + 8 * len(names))
+        scaling = 'weak'
     elif args.workload == 'saturn':
         # Saturn-like spheroid, 4096^2, r0 = 800 px, rotation 20 deg
         sz = args.size
@@ -913,10 +951,10 @@ def other_workloads(args) -> None:
         # the step IS its kernels here (events around the step on the stream they run on); HBM traffic per step from
         # the stamped --pmc passes of tools/pmc_profile.sh for this workload
         kernels = {'saturn': ('pm::k_disc_sph<5,',), 'all26': ('pm::k_disc_sph<7,', 'pm::k_sky<true>'),
-                   'cube': ('pm::k_reproject<double>',)}[args.workload]
-        rec, stale = profile_record(kernels, args.workload) if (args.size == 4096 or args.workload == 'cube') else ({}, False)
+                   'maps': ('pm::k_map_b0<true, true>',), 'cube': ('pm::k_reproject<double>',)}[args.workload]
+        rec, stale = profile_record(kernels, args.workload) if (args.size == 4096 or args.workload in ('cube', 'maps')) else ({}, False)
         line = {
-            'metric': metric, 'value': round(n_units * args.steps / dt / 1e6, 2), 'unit': 'Mpix/s',
+            'metric': metric, 'value': round(n_units * args.steps / dt / 1e6, 2), 'unit': 'Mcell/s' if args.workload == 'maps' else 'Mpix/s',
             'n_gpus': d.world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': scaling,
             'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',

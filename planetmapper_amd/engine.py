@@ -304,6 +304,17 @@ class Engine:
         )
         return outs
 
+    def backplanes_map_device(self, outs: Mapping[str, object], lon, lat, n0: int, n1: int, alt: float = 0.0) -> None:
+        """Enqueue map-space backplanes of a lon / lat grid resident in HBM into device buffers (`name -> pointer / tensor`)."""
+        ptrs = (ctypes.c_void_p * NUM_PLANES)()
+        for n, a in outs.items():
+            ptrs[PLANE_INDEX[n]] = _ptr(a)
+        self._check(
+            self._lib.pm_backplanes_map(
+                self._ctx, plane_mask(outs.keys()), _ptr(lon), _ptr(lat), int(n0), int(n1), float(alt), ptrs, _lib.PM_MEM_DEVICE
+            )
+        )
+
     def xy_map(self, lon_deg, lat_deg, alt: float = 0.0):
         o = self.backplanes_map(['PIXEL-X', 'PIXEL-Y'], lon_deg, lat_deg, alt)
         return o['PIXEL-X'], o['PIXEL-Y']

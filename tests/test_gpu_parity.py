@@ -143,6 +143,59 @@ def test_golden_maps(engine, oracle, jupiter, name, interp, alt):
     assert np.nanmax(np.abs(mapped - ref_mapped), initial=0.0) <= 1e-12
 
 
+@pytest.mark.parametrize('body', ['jupiter', 'saturn', 'triaxial_east'])
+def test_map_planes_fine_grid_both_kernels_and_any_subset(engine, oracle, jupiter, saturn, body):
+    """
+    The map-space chain at throughput size (a 0.5 deg grid, 259 200 cells, with cells at the poles, on the seam and without
+    coordinates): all 26 planes from the B0 kernel the library takes (`k_map_b0`) AND from the J2000 kernel behind
+    PM_OPT_GENERAL_KERNEL (`k_map`) against the oracle; then what the B0 kernel's scalar branches must guarantee - a plane
+    does not depend on which other planes were asked for with it (each group of the chain alone against the full request),
+    and the device-resident form (`pm_backplanes_map`, PM_MEM_DEVICE: grids and planes in HBM) gives the same bits.
+    """
+    import torch
+
+    from planetmapper_amd import _lib
+
+    g = {'jupiter': jupiter, 'saturn': saturn}.get(body) or _variant(jupiter, radii=[71492.0, 70100.0, 68800.0], west_positive=0)
+    nx, ny, x0, y0, r0, rot = 400, 300, 205.3, 148.1, 120.0, 0.7
+    engine.set_geometry(g)
+    engine.set_disc(x0, y0, r0, rot, nx, ny, True)
+    d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny)
+    d.rotation_rad = rot
+    lons = np.arange(0.25, 360, 0.5)
+    lats = np.arange(-89.75, 90, 0.5)
+    lon, lat = np.meshgrid(lons[::-1] if g.west_positive else lons, lats)
+    lon, lat = np.ascontiguousarray(lon), np.ascontiguousarray(lat)
+    lat[0, :8] = [-90.0, 90.0, -90.0, 90.0, 89.999999, -89.999999, 0.0, 0.0]
+    lon[0, :8] = [0.0, 0.0, 360.0, 180.0, 359.999999, 1e-9, 0.0, 360.0]
+    lon[5, 5], lat[6, 6], lon[7, 7] = np.nan, np.inf, -np.inf
+    names = list(oracle.PLANE_NAMES)
+    ref = oracle.backplanes_map(g, d, names, lon, lat)
+    full = engine.backplanes_map(names, lon, lat)
+    _compare(full, ref, names, g, r0=r0)
+    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1)
+    try:
+        _compare(engine.backplanes_map(names, lon, lat), ref, names, g, r0=r0)
+    finally:
+        engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
+    groups = [['LON-GRAPHIC'], ['LOCAL-SOLAR-TIME', 'LAT-GRAPHIC'], ['LON-CENTRIC'], ['LAT-CENTRIC', 'EMISSION'], ['EMISSION'], ['DISTANCE'],
+              ['PHASE'], ['INCIDENCE', 'AZIMUTH'], ['RADIAL-VELOCITY'], ['DOPPLER', 'PHASE'], ['RA'], ['DEC', 'PIXEL-Y'], ['PIXEL-X'],
+              ['KM-X', 'ANGULAR-Y'], ['ANGULAR-X'], ['LIMB-LAT-GRAPHIC'], ['LIMB-DISTANCE', 'LIMB-LON-GRAPHIC'], ['RING-RADIUS'],
+              ['RING-LON-GRAPHIC', 'RING-DISTANCE', 'KM-Y']]  # fmt: skip
+    for grp in groups:
+        part = engine.backplanes_map(grp, lon, lat)
+        for n in grp:
+            assert np.array_equal(np.isnan(part[n]), np.isnan(full[n])), (grp, n)
+            # (another instantiation of the kernel template: the same operations, not necessarily the same contractions)
+            scale = float(np.nanmax(np.abs(full[n]), initial=1.0))
+            assert np.nanmax(np.abs(part[n] - full[n]), initial=0.0) <= 4e-16 * scale + 2e-13, (grp, n)
+    dev = {n: torch.empty(lon.shape, dtype=torch.float64, device='cuda') for n in names}
+    engine.backplanes_map_device(dev, torch.from_numpy(lon).cuda(), torch.from_numpy(lat).cuda(), *lon.shape)
+    engine.synchronize()
+    for n in names:
+        assert np.array_equal(dev[n].cpu().numpy(), full[n], equal_nan=True), n
+
+
 @pytest.mark.parametrize('sz,rot', [(128, 0.0), (1024, 0.0), (517, 33.3)])
 def test_jupiter_full_set_vs_oracle(engine_fg, oracle, jupiter, sz, rot):
     """BASELINE configs 1-2: centred disc (BodyXY.centre_disc body_xy.py:791), all 26 planes."""

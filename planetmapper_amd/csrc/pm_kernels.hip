@@ -4,7 +4,8 @@
 //                   (lon/lat, centric, illumination, azimuth, LST, state, ring); BODY: spheroid / triaxial / general
 //   k_sky<LIMB>     image-space planes defined for every pixel
 //                   (RA/Dec, pixel x/y, km, angular, limb)
-//   k_map           map-space planes + x_map/y_map for a lon/lat grid
+//   k_map_b0<SUN, STATE>  map-space planes of a lon/lat grid, in B0 (k_map: the J2000 evaluation, PM_OPT_GENERAL_KERNEL)
+//   k_map_xy        the x/y map of a reprojection alone
 //   k_transform     array-valued coordinate transforms
 // (reprojection kernels: pm_kernels_reproject.hip)
 //

@@ -60,7 +60,7 @@ __device__ __forceinline__ double cleaned_at(const T *img, long i, long j, int n
 // 1855-1904): the value at pixel coordinates (x, y) of plane `pl`, NaN where the reference gives NaN.
 //
 // `ld(i)` loads pixel i of the plane as a double: straight from the plane (PlaneLoader) or through
-// the table of fetched 256-byte blocks (BlockLoader, the sparse host path below). `img` is the
+// the table of fetched blocks (BlockLoader, the sparse host path below). `img` is the
 // plane itself, which the rare NaN pre-clean reads around a non-finite pixel.
 template <typename T>
 struct PlaneLoader {
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 // every plane. k_mark_blocks runs the sampling arithmetic once and flags those blocks; k_blocks_*
 // number them (block <-> row of the table); then either CPU threads collect the 16-byte blocks of each chunk
 // of planes into pinned staging and one DMA brings the dense table over, or k_fetch_blocks pulls
-// 256-byte blocks from pinned memory, each once, 16 lanes on one block; k_reproject_blocks samples
+// 128-byte blocks (PM_OPT_FETCH_BLOCK_BYTES) from pinned memory, each once, 8 lanes on one block; k_reproject_blocks samples
 // the table.
 
 // the "load" of the marking pass: flags the block of pixel i, returns a finite value (so that the

@@ -7,7 +7,7 @@ from planetmapper_amd.engine import Engine
 from planetmapper_amd.scenarios import load_scenario
 
 g = load_scenario('jupiter_hst_2005')
-sz, P = 1024, 64
+sz, P = 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 64
 e = Engine(0); e.set_geometry(g); x0 = (sz - 1) / 2; e.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
 gen = torch.Generator(device='cuda').manual_seed(5)
 cube = torch.randn((P, sz, sz), generator=gen, device='cuda', dtype=torch.float64)
@@ -19,7 +19,7 @@ for deg in (1.0, 0.1):
     xm = torch.empty((n0, n1), dtype=torch.float64, device='cuda'); ym = torch.empty_like(xm)
     e.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
     out = torch.empty((P, n0, n1), dtype=torch.float64, device='cuda')
-    for interp, kw in (('nearest', {}), ('linear', {}), ('quadratic', {}), ('cubic', {}), (5, {}), ('cubic', {'spline_smoothing': 1.0}), ('smooth', {})):
+    for interp, kw in ((('nearest', {}), ('linear', {}), ('quadratic', {}), ('cubic', {}), (5, {}), ('cubic', {'spline_smoothing': 1.0}), ('smooth', {})) if P <= 64 else (('linear', {}), ('cubic', {}), ('smooth', {}))):
         if interp == 'smooth': e.set_smooth_options(5, 10_000)
         try:
             e.map_cube_device(cube, np.float64, P, xm, ym, n0, n1, out, interp, True, **kw); e.synchronize()

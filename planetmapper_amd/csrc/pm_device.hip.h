@@ -183,7 +183,7 @@ struct PlaneStats {
     unsigned long long n_nan;
     double median;                 // np.nanmedian of the plane (0.0 if nothing finite)
     int all_nan;                   // np.all(np.isnan(plane))
-    int pad_;
+    int needs_median;              // lazy form (pm_launch_clean_lazy): some pixel's clean value IS the median - compute it
 };
 
 // Spline (RectBivariateSpline, s = 0) reprojection: per-axis knots + banded LU of the

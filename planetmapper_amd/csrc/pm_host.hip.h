@@ -26,7 +26,8 @@ void pm_launch_map_xy(const pm::Params &p, const double *lon, const double *lat,
 void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
 void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *dec, unsigned long long n,
                            int ring_only_visible, double *out, hipStream_t s);
-void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s);
+void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, pm::PlaneStats *stats, unsigned int *hist,
+                      hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int shift, int dtype, hipStream_t s);
 void pm_launch_number_blocks(const unsigned char *flags, size_t n_blk, int *tile_sums, int *blkmap, int *blklist, int *total,
@@ -38,6 +39,7 @@ void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, cons
 void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
 void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
+void pm_launch_clean_lazy(const pm::ReprojectArgs &a, double *work, int dtype, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s);
 void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
                         double *c, double *r, hipStream_t s);
 void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s);

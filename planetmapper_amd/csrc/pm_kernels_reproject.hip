@@ -477,20 +477,30 @@ __global__ __launch_bounds__(kBlock) void k_map_limits(const double *x_map, cons
     if (threadIdx.x < 4) limits[threadIdx.x] = sh[threadIdx.x][0];
 }
 
+// mode 0: `stats` hold the plane medians. The lazy form (pm_launch_clean_lazy) - a plane's nanmedian, eight passes over
+// it, is needed only where a non-finite pixel has no finite neighbour, which most data never has: mode 1 cleans with a
+// provisional 0.0 and flags the planes in which some pixel took it (PlaneStats::needs_median); the median kernels then
+// run for flagged planes only (the blocks of the others leave at once), and mode 2 cleans the flagged planes again.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *work, const PlaneStats *stats, int ny, int nx)
+__global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *work, PlaneStats *stats, int ny, int nx, int mode)
 {
     const size_t npx = (size_t)ny * nx;
-    const size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const int pl = blockIdx.y;
-    if (i >= npx) return;
+    if (mode == 2 && !stats[pl].needs_median) return;
+    const double median = mode == 1 ? 0.0 : stats[pl].median;
     bool nm = false;
-    work[(size_t)pl * npx + i] = cleaned_at(cube + (size_t)pl * npx, (long)(i / nx), (long)(i % nx), ny, nx, stats[pl].median, nm);
+    // (grid-stride: the redo pass of the lazy form is launched with a few blocks per plane - nearly all of them leave at once)
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < npx; i += (size_t)gridDim.x * kBlock)
+        work[(size_t)pl * npx + i] = cleaned_at(cube + (size_t)pl * npx, (long)(i / nx), (long)(i % nx), ny, nx, median, nm);
+    if (mode == 1 && nm) atomicOr(&stats[pl].needs_median, 1);
 }
 
 // One lane per (plane, line): solve B c = v along `axis` in place with the banded LU.
 // axis 0: lines are image columns (lanes adjacent in x read one image row per step: coalesced);
-// axis 1: lines are image rows (each lane walks its own row).
+// axis 1: lines are image rows (each lane walks its own row). For 128 planes of 1024^2 axis 1 costs 2.4 times axis 0
+// (2.8 against 1.2 ms) - and so did two LDS-tiled versions of it whose every global access was whole 128-byte lines
+// (64 x 64 and 64 x 16 tiles, 99 VGPRs, no scratch, four waves per SIMD), and so does a 1000-wide plane (not the
+// power-of-two pitch): the lanes' access pattern is not what it waits for. Cause not found (round 4, EXPERIMENTS.md).
 __global__ __launch_bounds__(kBlock) void k_spline_solve(double *work, int n_planes, int ny, int nx, int axis, SplineAxis ax)
 {
     const size_t npx = (size_t)ny * nx;
@@ -856,10 +866,11 @@ __global__ __launch_bounds__(kBlock) void k_sm_eval(const ReprojectArgs a, const
 
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_median_hist(const T *cube, size_t plane_elems, int shift, PlaneStats *stats,
-                                                        unsigned int *hist /* [P][2][256] */)
+                                                        unsigned int *hist /* [P][2][256] */, int lazy)
 {
     __shared__ unsigned int h[2][256];
     const int pl = blockIdx.y;
+    if (lazy && !stats[pl].needs_median) return;  // (the whole block: no plane of the lazy form that did not ask)
     h[0][threadIdx.x] = 0;
     h[1][threadIdx.x] = 0;
     __syncthreads();
@@ -886,9 +897,10 @@ __global__ __launch_bounds__(kBlock) void k_median_hist(const T *cube, size_t pl
 }
 
 // one 256-thread block per plane: pick the bin holding each tracked rank, extend the prefix
-__global__ __launch_bounds__(kBlock) void k_median_pick(int shift, size_t plane_elems, PlaneStats *stats, unsigned int *hist)
+__global__ __launch_bounds__(kBlock) void k_median_pick(int shift, size_t plane_elems, PlaneStats *stats, unsigned int *hist, int lazy)
 {
     const int pl = blockIdx.x;
+    if (lazy && !stats[pl].needs_median) return;  // (its statistics stay zero: median 0.0, all_nan 0 - a plane that is not all NaN)
     unsigned int *g = hist + (size_t)pl * 512;
     __shared__ unsigned long long cum[2][256];
     cum[0][threadIdx.x] = g[threadIdx.x];
@@ -939,15 +951,15 @@ static void launch_reproject_t(const pm::ReprojectArgs &a, hipStream_t s)
 
 template <typename T>
 static void launch_median_t(const void *cube, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
-                            unsigned int *hist, hipStream_t s)
+                            unsigned int *hist, hipStream_t s, int lazy = 0)
 {
     unsigned gx = (unsigned)((plane_elems + pm::kBlock * 16 - 1) / (pm::kBlock * 16));
     if (gx < 1) gx = 1;
     if (gx > 256) gx = 256;
     for (int shift = 56; shift >= 0; shift -= 8) {
         hipLaunchKernelGGL(pm::k_median_hist<T>, dim3(gx, n_planes), dim3(pm::kBlock), 0, s, (const T *)cube,
-                           plane_elems, shift, stats, hist);
-        hipLaunchKernelGGL(pm::k_median_pick, dim3(n_planes), dim3(pm::kBlock), 0, s, shift, plane_elems, stats, hist);
+                           plane_elems, shift, stats, hist, lazy);
+        hipLaunchKernelGGL(pm::k_median_pick, dim3(n_planes), dim3(pm::kBlock), 0, s, shift, plane_elems, stats, hist, lazy);
     }
 }
 
@@ -1070,14 +1082,24 @@ void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable
 }
 
 template <typename T>
-static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, hipStream_t s)
+static void launch_clean_lazy_t(const pm::ReprojectArgs &a, double *work, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s)
 {
     const size_t npx = (size_t)a.ny * a.nx;
-    hipLaunchKernelGGL(pm::k_spline_clean<T>, dim3((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes),
-                       dim3(pm::kBlock), 0, s, (const T *)a.cube, sa.work, a.plane_stats, a.ny, a.nx);
-    size_t l0 = (size_t)a.n_planes * a.nx, l1 = (size_t)a.n_planes * a.ny;
+    const dim3 grid((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes);
+    hipLaunchKernelGGL(pm::k_spline_clean<T>, grid, dim3(pm::kBlock), 0, s, (const T *)a.cube, work, stats, a.ny, a.nx, 1);
+    launch_median_t<T>(a.cube, a.n_planes, npx, stats, hist, s, 1);
+    const dim3 redo(std::min(grid.x, 256u), a.n_planes);
+    hipLaunchKernelGGL(pm::k_spline_clean<T>, redo, dim3(pm::kBlock), 0, s, (const T *)a.cube, work, stats, a.ny, a.nx, 2);
+}
+
+template <typename T>
+static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s)
+{
+    launch_clean_lazy_t<T>(a, sa.work, stats, hist, s);
+    size_t l0 = (size_t)a.n_planes * a.nx;
     hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l0 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
                        sa.work, a.n_planes, a.ny, a.nx, 0, sa.rows);
+    size_t l1 = (size_t)a.n_planes * a.ny;
     hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l1 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
                        sa.work, a.n_planes, a.ny, a.nx, 1, sa.cols);
     hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
@@ -1089,7 +1111,20 @@ static void launch_clean_t(const pm::ReprojectArgs &a, double *work, hipStream_t
 {
     const size_t npx = (size_t)a.ny * a.nx;
     hipLaunchKernelGGL(pm::k_spline_clean<T>, dim3((unsigned)((npx + pm::kBlock - 1) / pm::kBlock), a.n_planes),
-                       dim3(pm::kBlock), 0, s, (const T *)a.cube, work, a.plane_stats, a.ny, a.nx);
+                       dim3(pm::kBlock), 0, s, (const T *)a.cube, work, const_cast<pm::PlaneStats *>(a.plane_stats), a.ny, a.nx, 0);
+}
+// NaN-cleaned f64 copy of a.n_planes planes into `work`, medians computed only for the planes that need theirs.
+// `stats` / `hist` zero-filled by the caller; afterwards `stats` hold all_nan (and the median of the planes that asked).
+void pm_launch_clean_lazy(const pm::ReprojectArgs &a, double *work, int dtype, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s)
+{
+    switch (dtype) {
+    case PM_F64: launch_clean_lazy_t<double>(a, work, stats, hist, s); break;
+    case PM_F32: launch_clean_lazy_t<float>(a, work, stats, hist, s); break;
+    case PM_I16: launch_clean_lazy_t<int16_t>(a, work, stats, hist, s); break;
+    case PM_I32: launch_clean_lazy_t<int32_t>(a, work, stats, hist, s); break;
+    case PM_U8: launch_clean_lazy_t<uint8_t>(a, work, stats, hist, s); break;
+    case PM_U16: launch_clean_lazy_t<uint16_t>(a, work, stats, hist, s); break;
+    }
 }
 // NaN-cleaned f64 copy of a.n_planes planes into `work` (a.plane_stats must hold the medians)
 void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s)
@@ -1161,16 +1196,17 @@ void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, 
     }
 }
 
-// a.plane_stats must already hold the plane statistics (pm_launch_plane_medians)
-void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, hipStream_t s)
+// `stats` (= a.plane_stats) and `hist` zero-filled by the caller: the clean pass fills what it needs of them (lazy form)
+void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, pm::PlaneStats *stats, unsigned int *hist,
+                      hipStream_t s)
 {
     switch (dtype) {
-    case PM_F64: launch_spline_t<double>(a, sa, s); break;
-    case PM_F32: launch_spline_t<float>(a, sa, s); break;
-    case PM_I16: launch_spline_t<int16_t>(a, sa, s); break;
-    case PM_I32: launch_spline_t<int32_t>(a, sa, s); break;
-    case PM_U8: launch_spline_t<uint8_t>(a, sa, s); break;
-    case PM_U16: launch_spline_t<uint16_t>(a, sa, s); break;
+    case PM_F64: launch_spline_t<double>(a, sa, stats, hist, s); break;
+    case PM_F32: launch_spline_t<float>(a, sa, stats, hist, s); break;
+    case PM_I16: launch_spline_t<int16_t>(a, sa, stats, hist, s); break;
+    case PM_I32: launch_spline_t<int32_t>(a, sa, stats, hist, s); break;
+    case PM_U8: launch_spline_t<uint8_t>(a, sa, stats, hist, s); break;
+    case PM_U16: launch_spline_t<uint16_t>(a, sa, stats, hist, s); break;
     }
 }
 

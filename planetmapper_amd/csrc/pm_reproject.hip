@@ -535,8 +535,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         b.plane_stats = ctx->stats;
         PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)np * sizeof(pm::PlaneStats), ctx->stream));
         PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)np * 512 * sizeof(unsigned int), ctx->stream));
-        pm_launch_plane_medians(b.cube, dtype, np, plane_elems, ctx->stats, ctx->hist, ctx->stream);
-        pm_launch_clean(b, ctx->work, dtype, ctx->stream);
+        pm_launch_clean_lazy(b, ctx->work, dtype, ctx->stats, ctx->hist, ctx->stream);
         PM_HIP(ctx, hipMemcpyAsync(stats.data(), ctx->stats, (size_t)np * sizeof(pm::PlaneStats), hipMemcpyDeviceToHost,
                                    ctx->stream));
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));  // cleaned planes + statistics are complete
@@ -607,8 +606,7 @@ int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k
         b.plane_stats = ctx->stats;
         PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)np * sizeof(pm::PlaneStats), ctx->stream));
         PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)np * 512 * sizeof(unsigned int), ctx->stream));
-        pm_launch_plane_medians(b.cube, dtype, np, plane_elems, ctx->stats, ctx->hist, ctx->stream);
-        pm_launch_spline(b, sa, dtype, ctx->stream);
+        pm_launch_spline(b, sa, dtype, ctx->stats, ctx->hist, ctx->stream);
     }
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;

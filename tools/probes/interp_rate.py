@@ -7,7 +7,8 @@ from planetmapper_amd.engine import Engine
 from planetmapper_amd.scenarios import load_scenario
 
 g = load_scenario('jupiter_hst_2005')
-sz, P = 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 64
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+sz = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 e = Engine(0); e.set_geometry(g); x0 = (sz - 1) / 2; e.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
 gen = torch.Generator(device='cuda').manual_seed(5)
 cube = torch.randn((P, sz, sz), generator=gen, device='cuda', dtype=torch.float64)

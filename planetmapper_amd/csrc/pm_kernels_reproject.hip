@@ -389,9 +389,9 @@ __global__ __launch_bounds__(kSphBlock) void k_mapped_data(const Params p, const
 // ------------------------------------------------------------------ spline reprojection
 // scipy RectBivariateSpline(kx, ky, s=0).ev of BodyXY._do_spline_interpolation
 // (body_xy.py:1651-1702) for 'quadratic', 'cubic' and (k0, k1): interpolating tensor-product
-// B-spline. Pipeline per chunk of planes: k_median_* (plane statistics) -> k_spline_clean
-// (NaN-cleaned float64 copy) -> k_spline_solve axis 0, axis 1 (banded LU substitution, in
-// place: samples -> coefficients) -> k_spline_eval.
+// B-spline. Pipeline per chunk of planes: k_spline_clean (NaN-cleaned float64 copy; k_median_* for the planes whose clean
+// values need the plane nanmedian, pm_launch_clean_lazy) -> k_spline_solve_cols (axis 0), k_spline_solve_rows (axis 1)
+// (banded LU substitution, in place: samples -> coefficients) -> k_spline_eval.
 
 // 'smooth' interpolation (BodyXY._do_smooth_interpolation / _pchip_grid_interp2d
 // body_xy.py:1704-1853). The reference materialises the whole oversampled image (up to
@@ -495,81 +495,213 @@ __global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *
     if (mode == 1 && nm) atomicOr(&stats[pl].needs_median, 1);
 }
 
-// One lane per (plane, line): solve B c = v along `axis` in place with the banded LU.
-// axis 0: lines are image columns (lanes adjacent in x read one image row per step: coalesced);
-// axis 1: lines are image rows (each lane walks its own row). For 128 planes of 1024^2 axis 1 costs 2.4 times axis 0
-// (2.8 against 1.2 ms) - and so did two LDS-tiled versions of it whose every global access was whole 128-byte lines
-// (64 x 64 and 64 x 16 tiles, 99 VGPRs, no scratch, four waves per SIMD), and so does a 1000-wide plane (not the
-// power-of-two pitch): the lanes' access pattern is not what it waits for. Cause not found (round 4, EXPERIMENTS.md).
-__global__ __launch_bounds__(kBlock) void k_spline_solve(double *work, int n_planes, int ny, int nx, int axis, SplineAxis ax)
+// Solve B c = v along one axis of every plane in place, with the banded LU of the collocation matrix (unit lower
+// triangle, no pivoting: forward substitution, then back substitution with the last k results kept in registers).
+// A line is 1024 dependent steps; what the kernels are built around is keeping a wave from WAITING at each of them.
+//   * the LU row of a step is the same for every lane: fetched per step it is a scalar load that misses (the table of a
+//     1024-sample axis is 57 KB, every wave is somewhere else in it) - one memory round trip per step. Here the rows of
+//     16 steps come in with the data, 1-3 values per lane, and are read back from LDS;
+//   * the next 16 samples of every line (and their LU rows) are in flight from HBM into registers while the current 16
+//     are worked on;
+//   * axis 1 (lines = image rows: a lane's line is contiguous, the lanes' lines 8 KB apart) goes through a 64 x 16 tile
+//     in LDS: every global access is whole 128-byte lines - four row segments per instruction - instead of 64 different
+//     lines per load instruction, the substitution runs lane-per-row on the tile's 16 values held in registers.
+// Round 4, 128 planes of 1024^2: axis 0 1.18 -> 0.91 ms, axis 1 2.79 -> 0.91 ms (4.7 TB/s of the samples read and written
+// twice). (A first tiled axis 1 WITHOUT the staged LU rows ran in the 2.8 ms of the plain lane-per-row kernel: the round
+// trip per step was the cost, not the access pattern - profiles/EXPERIMENTS.md.)
+constexpr int kSolveRows = 64, kSolveCols = 16, kSolveBand = 11;  // (2 k + 1 <= 11)
+__global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, int n_planes, int ny, int nx, SplineAxis ax)
 {
-    const size_t npx = (size_t)ny * nx;
-    const int lines = axis == 0 ? nx : ny;
-    const size_t tid = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (tid >= (size_t)n_planes * lines) return;
-    const int pl = (int)(tid / lines), line = (int)(tid % lines);
-    double *v = work + (size_t)pl * npx + (axis == 0 ? (size_t)line : (size_t)line * nx);
-    const size_t stride = axis == 0 ? (size_t)nx : 1;
+    __shared__ double tile[kSolveRows][kSolveCols + 1];
+    __shared__ double lu[kSolveCols][kSolveBand];
+    const int lane = threadIdx.x;
+    const int groups = (ny + kSolveRows - 1) / kSolveRows;
+    const int pl = blockIdx.x / groups, r0 = (blockIdx.x % groups) * kSolveRows;
+    const int rows = min(kSolveRows, ny - r0);
+    double *base = work + ((size_t)pl * ny + r0) * nx;
     const int n = ax.n, k = ax.k, w = 2 * k + 1;
-    // forward substitution (unit lower triangle), the last k results kept in registers. Samples
-    // and LU rows are fetched eight at a time so that their load latencies overlap (a line along
-    // image rows then also uses every 64-byte sector it touches in full).
+    const int lr = lane / kSolveCols, lc = lane % kSolveCols;  // this lane's (row within a group of four, column) in the copies
+    constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
     double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int i0 = 0; i0 < n; i0 += 8) {
-        double vb[8], lb[8][5];
+    double v[kSolveCols], g[kSolveRows / 4], glu[kLuRegs];
+    // the next tile is on its way from HBM (into registers) while the current one is worked on
+    auto fetch = [&](int c0) {
+        const int cols = min(kSolveCols, n - c0);
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = (i0 + u < n) ? i0 + u : n - 1;
-            vb[u] = v[(size_t)i * stride];
-            const double *row = ax.lu + (size_t)i * w;
-#pragma unroll
-            for (int q = 1; q <= 5; q++) lb[u][q - 1] = (q <= k) ? row[k - q] : 0.0;
+        for (int it = 0; it < kSolveRows / 4; it++) {
+            const int r = it * 4 + lr;
+            g[it] = (r < rows && lc < cols) ? base[(size_t)r * nx + c0 + lc] : 0.0;
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 + u;
-            if (i < n) {
-                double s = vb[u];
+        for (int e = 0; e < kLuRegs; e++) {
+            const int x = e * kSolveRows + lane;
+            glu[e] = x < cols * w ? ax.lu[(size_t)c0 * w + x] : 0.0;
+        }
+    };
+    auto to_lds = [&](int cols) {
+#pragma unroll
+        for (int it = 0; it < kSolveRows / 4; it++) tile[it * 4 + lr][lc] = g[it];
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int x = e * kSolveRows + lane;
+            if (x < cols * w) lu[x / w][x % w] = glu[e];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) v[j] = tile[lane][j];
+    };
+    auto tile_out = [&](int c0, int cols) {
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) tile[lane][j] = v[j];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kSolveRows / 4; it++) {
+            const int r = it * 4 + lr;
+            if (r < rows && lc < cols) base[(size_t)r * nx + c0 + lc] = tile[r][lc];
+        }
+        __syncthreads();
+    };
+    // forward substitution (unit lower triangle)
+    fetch(0);
+    for (int c0 = 0; c0 < n; c0 += kSolveCols) {
+        const int cols = min(kSolveCols, n - c0);
+        to_lds(cols);
+        if (c0 + kSolveCols < n) fetch(c0 + kSolveCols);
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) {
+            const int i = c0 + j;
+            if (j < cols) {
+                double s = v[j];
 #pragma unroll
                 for (int q = 1; q <= 5; q++)
-                    if (q <= k && i - q >= 0) s -= lb[u][q - 1] * prev[q - 1];
+                    if (q <= k && i - q >= 0) s -= lu[j][k - q] * prev[q - 1];
 #pragma unroll
                 for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
                 prev[0] = s;
-                v[(size_t)i * stride] = s;
+                v[j] = s;
             }
         }
+        tile_out(c0, cols);
+    }
+    // back substitution (the forward pass's stores of the last tile are complete: same wave, program order)
+#pragma unroll
+    for (int q = 0; q < 5; q++) prev[q] = 0.0;
+    const int c_last = ((n - 1) / kSolveCols) * kSolveCols;
+    fetch(c_last);
+    for (int c0 = c_last; c0 >= 0; c0 -= kSolveCols) {
+        const int cols = min(kSolveCols, n - c0);
+        to_lds(cols);
+        if (c0 - kSolveCols >= 0) fetch(c0 - kSolveCols);
+#pragma unroll
+        for (int j = kSolveCols - 1; j >= 0; j--) {
+            const int i = c0 + j;
+            if (j < cols) {
+                double s = v[j];
+#pragma unroll
+                for (int q = 1; q <= 5; q++)
+                    if (q <= k && i + q < n) s -= lu[j][k + q] * prev[q - 1];
+                s /= lu[j][k];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[j] = s;
+            }
+        }
+        tile_out(c0, cols);
+    }
+}
+
+// Axis 0 (lines = image columns) in the same style: one wave takes 64 adjacent columns of a plane, 16 rows at a time - the
+// lanes' loads are coalesced as they stand (no transposition), the LU rows of the 16 steps come through LDS, the next 16
+// rows are in flight while the current ones are worked on.
+__global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(double *work, int n_planes, int ny, int nx, SplineAxis ax)
+{
+    __shared__ double lu[2][kSolveCols][kSolveBand];
+    const int lane = threadIdx.x;
+    const int groups = (nx + kSolveRows - 1) / kSolveRows;
+    const int pl = blockIdx.x / groups, x = (blockIdx.x % groups) * kSolveRows + lane;
+    const bool live = x < nx;
+    double *col = work + (size_t)pl * ny * nx + (live ? x : 0);
+    const int n = ax.n, k = ax.k, w = 2 * k + 1;
+    constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
+    double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double v[kSolveCols], g[kSolveCols], glu[kLuRegs];
+    auto fetch = [&](int i0) {
+        const int cnt = min(kSolveCols, n - i0);
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) g[j] = (live && j < cnt) ? col[(size_t)(i0 + j) * nx] : 0.0;
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int q = e * kSolveRows + lane;
+            glu[e] = q < cnt * w ? ax.lu[(size_t)i0 * w + q] : 0.0;
+        }
+    };
+    auto stage = [&](int buf, int cnt) {
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int q = e * kSolveRows + lane;
+            if (q < cnt * w) lu[buf][q / w][q % w] = glu[e];
+        }
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) v[j] = g[j];
+        __syncthreads();
+    };
+    auto put = [&](int i0, int cnt) {
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++)
+            if (live && j < cnt) col[(size_t)(i0 + j) * nx] = v[j];
+    };
+    int buf = 0;
+    // forward substitution (unit lower triangle)
+    fetch(0);
+    for (int i0 = 0; i0 < n; i0 += kSolveCols, buf ^= 1) {
+        const int cnt = min(kSolveCols, n - i0);
+        stage(buf, cnt);
+        if (i0 + kSolveCols < n) fetch(i0 + kSolveCols);
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) {
+            const int i = i0 + j;
+            if (j < cnt) {
+                double s = v[j];
+#pragma unroll
+                for (int q = 1; q <= 5; q++)
+                    if (q <= k && i - q >= 0) s -= lu[buf][j][k - q] * prev[q - 1];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[j] = s;
+            }
+        }
+        put(i0, cnt);
     }
     // back substitution
 #pragma unroll
     for (int q = 0; q < 5; q++) prev[q] = 0.0;
-    for (int i0 = n - 1; i0 >= 0; i0 -= 8) {
-        double vb[8], ub[8][6];
+    const int i_last = ((n - 1) / kSolveCols) * kSolveCols;
+    fetch(i_last);
+    for (int i0 = i_last; i0 >= 0; i0 -= kSolveCols, buf ^= 1) {
+        const int cnt = min(kSolveCols, n - i0);
+        stage(buf, cnt);
+        if (i0 - kSolveCols >= 0) fetch(i0 - kSolveCols);
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = (i0 - u >= 0) ? i0 - u : 0;
-            vb[u] = v[(size_t)i * stride];
-            const double *row = ax.lu + (size_t)i * w;
-#pragma unroll
-            for (int q = 0; q <= 5; q++) ub[u][q] = (q <= k) ? row[k + q] : 0.0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = i0 - u;
-            if (i >= 0) {
-                double s = vb[u];
+        for (int j = kSolveCols - 1; j >= 0; j--) {
+            const int i = i0 + j;
+            if (j < cnt) {
+                double s = v[j];
 #pragma unroll
                 for (int q = 1; q <= 5; q++)
-                    if (q <= k && i + q < n) s -= ub[u][q] * prev[q - 1];
-                s /= ub[u][0];
+                    if (q <= k && i + q < n) s -= lu[buf][j][k + q] * prev[q - 1];
+                s /= lu[buf][j][k];
 #pragma unroll
                 for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
                 prev[0] = s;
-                v[(size_t)i * stride] = s;
+                v[j] = s;
             }
         }
+        put(i0, cnt);
     }
 }
+
 __device__ __forceinline__ int spline_interval(const SplineAxis &ax, double x)
 {
     // knots are samples (odd k) or sample midpoints (even k): the span follows from floor(x)
@@ -1096,12 +1228,12 @@ template <typename T>
 static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s)
 {
     launch_clean_lazy_t<T>(a, sa.work, stats, hist, s);
-    size_t l0 = (size_t)a.n_planes * a.nx;
-    hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l0 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
-                       sa.work, a.n_planes, a.ny, a.nx, 0, sa.rows);
-    size_t l1 = (size_t)a.n_planes * a.ny;
-    hipLaunchKernelGGL(pm::k_spline_solve, dim3((unsigned)((l1 + pm::kBlock - 1) / pm::kBlock)), dim3(pm::kBlock), 0, s,
-                       sa.work, a.n_planes, a.ny, a.nx, 1, sa.cols);
+    const unsigned cgroups = (unsigned)((a.nx + pm::kSolveRows - 1) / pm::kSolveRows);
+    hipLaunchKernelGGL(pm::k_spline_solve_cols, dim3(cgroups * (unsigned)a.n_planes), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes,
+                       a.ny, a.nx, sa.rows);
+    const unsigned groups = (unsigned)((a.ny + pm::kSolveRows - 1) / pm::kSolveRows);
+    hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(groups * (unsigned)a.n_planes), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes,
+                       a.ny, a.nx, sa.cols);
     hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
                        0, s, a, sa);
 }

@@ -221,8 +221,10 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *   PM_OPT_GENERAL_KERNEL   1: the image planes always go through the general kernel (arbitrary
  *                           rotations, full quadratic motion model, observer anywhere outside the
  *                           body) instead of the spheroid fast path the library selects when its
- *                           guards hold. Results agree within the parity bars; used by the tests
- *                           to cover both kernels. Default 0 (the environment variable
+ *                           guards hold; the MAP planes (pm_backplanes_map, pm_xy_map) go through
+ *                           the J2000 kernel with the general helpers instead of the B0 kernels.
+ *                           Results agree within the parity bars; used by the tests to cover both
+ *                           sets of kernels. Default 0 (with PM_DEBUG_ENV=1 the environment variable
  *                           PM_FORCE_GENERAL=1 sets the default to 1 at pm_create).
  *   PM_OPT_HOST_CHUNK_BYTES bytes per stage of the pipelined host path (PM_MEM_HOST calls move
  *                           data through pinned staging buffers in chunks of this size so that

@@ -1,0 +1,205 @@
+"""
+Row f3 (spline / 'smooth' / smoothing-spline map_img, body_xy.py:1651-1853) AT CUBE SCALE, `-m gpu`: the tiled
+banded solves, the lazy plane medians and the batched smoothing-spline fits are tuned on 1024^2 planes by the dozen,
+so that is where they are held against the oracle here - 1024 x 1024 and 1000 x 1031 (no power-of-two pitch, a last tile
+that is not full) x 42 planes whose clean states interleave: finite; sparse NaN (every NaN has a finite neighbour);
+NaN blocks whose inner pixels have NO finite neighbour (only those planes take the lazy-median redo); +-inf; all NaN.
+NaN masks identical, values <= 1e-9 of scale (f32 input: the same bar - both sides convert the same f32 samples).
+The oracle (serial per plane) runs on the box's cores through a thread pool: ctypes drops the GIL.
+"""
+
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+STATES = ('finite', 'sparse_nan', 'nan_blocks', 'inf', 'all_nan', 'block_and_inf', 'finite')
+
+
+@pytest.fixture(scope='module')
+def engine():
+    from planetmapper_amd.engine import Engine
+
+    e = Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope='module')
+def oracle():
+    from oracle import oracle as o
+
+    return o
+
+
+def oracle_map_cube_mt(oracle, cube, xm, ym, interp, prop, **kw):
+    """oracle.map_cube over plane slices in parallel (planes are independent in every interpolation)"""
+    n = cube.shape[0]
+    workers = max(1, min(n, len(os.sched_getaffinity(0)), 16))
+    bounds = np.linspace(0, n, workers + 1).astype(int)
+    spans = [(a, b) for a, b in zip(bounds[:-1], bounds[1:]) if b > a]
+    with ThreadPoolExecutor(len(spans)) as pool:
+        parts = list(pool.map(lambda ab: oracle.map_cube(cube[ab[0] : ab[1]], xm, ym, interp, prop, **kw), spans))
+    return np.concatenate(parts, axis=0)
+
+
+def make_cube(n_planes, ny, nx, seed, dtype=np.float64, noise=1.0):
+    """planes in every clean state, interleaved (plane p is in state STATES[p % 7])"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:ny, 0:nx]
+    cube = np.empty((n_planes, ny, nx), dtype=np.float64)
+    states = []
+    for p in range(n_planes):
+        st = STATES[p % len(STATES)]
+        states.append(st)
+        pl = np.sin(xx / (7.0 + p)) * np.cos(yy / (11.0 + 0.5 * p)) * (3 + p) + noise * rng.standard_normal((ny, nx))
+        if st == 'sparse_nan':
+            # isolated NaN pixels on a lattice with jitter < 1: no two of them touch, every one has finite neighbours
+            pl[3::7, 2::5] = np.nan
+        elif st == 'nan_blocks':
+            for _ in range(6):
+                i, j = int(rng.integers(0, ny - 40)), int(rng.integers(0, nx - 40))
+                pl[i : i + int(rng.integers(3, 40)), j : j + int(rng.integers(3, 40))] = np.nan
+            pl[0:5, 0:4] = np.nan  # a corner block
+        elif st == 'inf':
+            m = rng.random((ny, nx))
+            pl[m < 0.002] = np.inf
+            pl[m > 0.998] = -np.inf
+        elif st == 'all_nan':
+            pl[:] = np.nan
+        elif st == 'block_and_inf':
+            pl[ny // 2 - 2 : ny // 2 + 3, nx // 3 : nx // 3 + 5] = np.nan  # 5 x 5: the inner 3 x 3 need the median
+            pl[ny // 2, nx // 3 + 2] = np.inf
+            pl[10, 10] = -np.inf
+        cube[p] = pl
+    return cube.astype(dtype), states
+
+
+def setup_maps(engine, oracle, g, ny, nx, deg=1.0):
+    x0, y0 = (nx - 1) / 2, (ny - 1) / 2
+    r0 = 0.45 * min(nx, ny)
+    engine.set_geometry(g)
+    engine.set_disc(x0, y0, r0, 0.3, nx, ny, True)
+    d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny)
+    d.rotation_rad = 0.3
+    lon, lat = oracle.rectangular_grid(g, deg)
+    return oracle.xy_map(g, d, lon, lat)
+
+
+def map_resident(engine, cube, xm, ym, interp, prop, **kw):
+    """the device-resident route (what the kernels were tuned on)"""
+    import torch
+
+    dc = torch.from_numpy(cube).cuda()
+    dx, dy = torch.from_numpy(np.ascontiguousarray(xm)).cuda(), torch.from_numpy(np.ascontiguousarray(ym)).cuda()
+    out = torch.empty((cube.shape[0],) + xm.shape, dtype=torch.float64, device='cuda')
+    engine.map_cube_device(dc, cube.dtype, cube.shape[0], dx, dy, xm.shape[0], xm.shape[1], out, interp, prop, **kw)
+    engine.synchronize()
+    return out.cpu().numpy()
+
+
+def assert_close(a, b, label, bar=1e-9, scale_floor=1.0):
+    assert np.array_equal(np.isnan(a), np.isnan(b)), label
+    assert not np.isinf(a).any(), label
+    fin = np.isfinite(b)
+    assert fin.sum() > 1000 * a.shape[0] // 2, label
+    worst = float(np.max(np.abs(a[fin] - b[fin]) / np.maximum(scale_floor, np.abs(b[fin]))))
+    assert worst <= bar, (label, worst)
+    return worst
+
+
+@pytest.mark.parametrize('ny,nx', [(1024, 1024), (1000, 1031)])
+def test_interpolating_splines_and_smooth_at_cube_scale(engine, oracle, jupiter, ny, nx):
+    n_planes = 42
+    cube, states = make_cube(n_planes, ny, nx, seed=ny + nx)
+    xm, ym = setup_maps(engine, oracle, jupiter, ny, nx)
+    worst = {}
+    for interp in ('quadratic', 'cubic', (1, 3), 5, 'smooth'):
+        if interp == 'smooth':
+            engine.set_smooth_options(5, 10_000)
+        for prop in (True, False):
+            a = map_resident(engine, cube, xm, ym, interp, prop)
+            b = oracle_map_cube_mt(oracle, cube, xm, ym, (interp, interp) if isinstance(interp, int) else interp, prop)
+            for p in range(n_planes):  # per plane: the failure names the clean state
+                w = assert_close(a[p : p + 1], b[p : p + 1], (interp, prop, p, states[p])) if states[p] != 'all_nan' else 0.0
+                worst[str(interp)] = max(worst.get(str(interp), 0.0), w)
+            assert np.isnan(a[[p for p in range(n_planes) if states[p] == 'all_nan']]).all(), (interp, prop)
+    print('\n[cube-scale splines] worst |HIP - oracle| / scale per interpolation:', {k: f'{v:.2e}' for k, v in worst.items()})
+    # the host route (planes through the staging pipeline) gives the resident route's bits
+    for interp in ('cubic', 'smooth'):
+        assert np.array_equal(engine.map_cube(cube[:9], xm, ym, interp, True), map_resident(engine, cube[:9], xm, ym, interp, True),
+                              equal_nan=True), interp
+    # a plane's result does not depend on the planes mapped with it (the lazy-median redo touches flagged planes only)
+    for p in (0, 2, 5, 3):
+        assert np.array_equal(map_resident(engine, cube[p : p + 1], xm, ym, 'cubic', False)[0],
+                              map_resident(engine, cube, xm, ym, 'cubic', False)[p], equal_nan=True), p
+
+
+def test_splines_f32_and_integer_planes_at_cube_scale(engine, oracle, jupiter):
+    ny = nx = 1024
+    cube64, states = make_cube(14, ny, nx, seed=77)
+    xm, ym = setup_maps(engine, oracle, jupiter, ny, nx)
+    c32 = cube64.astype(np.float32)
+    for interp in ('quadratic', 'cubic', (1, 3), 5, 'smooth'):
+        for prop in (True, False):
+            a = map_resident(engine, c32, xm, ym, interp, prop)
+            b = oracle_map_cube_mt(oracle, c32, xm, ym, (interp, interp) if isinstance(interp, int) else interp, prop)
+            assert_close(a, b, ('f32', interp, prop))
+    ci = np.nan_to_num(cube64[:7], nan=0.0, posinf=0.0, neginf=0.0)
+    for dt in (np.int16, np.uint16, np.uint8, np.int32):
+        c = (ci * 10).clip(np.iinfo(dt).min, np.iinfo(dt).max).astype(dt)
+        a = map_resident(engine, c, xm, ym, 'cubic', True)
+        assert_close(a, oracle_map_cube_mt(oracle, c, xm, ym, 'cubic', True), dt)
+
+
+def test_smoothing_splines_on_a_batch_of_planes(engine, oracle, jupiter):
+    """
+    `spline_smoothing > 0` on 12 planes of 512^2 in mixed clean states (and 500 x 523): the knot search of every plane
+    advances in lock-step on the GPU; every plane against the oracle (knots / coefficients = scipy's) to 1e-7 of the
+    data scale, as in test_smoothing_splines_vs_oracle_kats_and_golden.
+    """
+    for ny, nx in ((512, 512), (500, 523)):
+        cube, states = make_cube(12, ny, nx, seed=5 + nx)
+        xm, ym = setup_maps(engine, oracle, jupiter, ny, nx, deg=2.0)
+        npx = ny * nx
+        for interp, s in (('cubic', 1.0 * npx), ('linear', 0.95 * npx), ((2, 3), 1.1 * npx), (5, 40.0 * npx)):
+            for prop in (True, False):
+                a = map_resident(engine, cube, xm, ym, interp, prop, spline_smoothing=s)
+                b = oracle_map_cube_mt(oracle, cube, xm, ym, (interp, interp) if isinstance(interp, int) else interp, prop,
+                                       spline_smoothing=s)
+                assert np.array_equal(np.isnan(a), np.isnan(b)), (interp, s, prop)
+                for p in range(cube.shape[0]):
+                    fin = np.isfinite(b[p])
+                    if states[p] == 'all_nan':
+                        assert not fin.any()
+                        continue
+                    assert fin.sum() > 1000
+                    # (planes with +-inf pixels: the cleaned image carries the plane median there, data scale as the rest)
+                    assert np.max(np.abs(a[p][fin] - b[p][fin])) <= 1e-7 * max(1.0, np.abs(b[p][fin]).max()), (interp, s, prop, p, states[p])
+    # a small s on nearly noise-free data: a long knot search (hundreds of knots per axis) before the fit reaches s.
+    # (s far below the NOISE level is not a test case: FITPACK itself runs into numerically singular knot sets there
+    #  and scipy returns coefficients of 1e99)
+    cube, states = make_cube(8, 256, 256, seed=3, noise=0.004)
+    xm, ym = setup_maps(engine, oracle, jupiter, 256, 256, deg=2.0)
+    a = map_resident(engine, cube, xm, ym, 'cubic', True, spline_smoothing=1.0)
+    b = oracle_map_cube_mt(oracle, cube, xm, ym, 'cubic', True, spline_smoothing=1.0)
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    fin = np.isfinite(b)
+    assert np.max(np.abs(a[fin] - b[fin])) <= 1e-7 * np.abs(b[fin]).max()
+
+
+@pytest.mark.xfail(reason='the per-plane fit sums with atomics: not reproducible run to run until the batched fit lands', strict=False)
+def test_a_smoothing_fit_in_a_batch_equals_the_plane_fitted_alone(engine, oracle, jupiter):
+    """bit for bit: a plane's knot search must not depend on the planes that share its launches"""
+    ny, nx = 500, 523
+    cube, states = make_cube(12, ny, nx, seed=5 + nx)
+    xm, ym = setup_maps(engine, oracle, jupiter, ny, nx, deg=2.0)
+    for interp, s in (('cubic', 1.0 * ny * nx), ((2, 3), 1.1 * ny * nx)):
+        together = map_resident(engine, cube, xm, ym, interp, True, spline_smoothing=s)
+        assert np.array_equal(together, map_resident(engine, cube, xm, ym, interp, True, spline_smoothing=s), equal_nan=True)
+        for p in (0, 2, 3, 4, 5, 11):
+            one = map_resident(engine, cube[p : p + 1], xm, ym, interp, True, spline_smoothing=s)[0]
+            assert np.array_equal(one, together[p], equal_nan=True), (interp, p, states[p])

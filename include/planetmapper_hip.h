@@ -202,7 +202,7 @@ int pm_device_count(void);
  * this library has no CPU fallback.
  * Environment: the library reads PM_RCCL_LIBRARY (pm_comm_*: the collective library to bind) and the launcher's
  * LOCAL_WORLD_SIZE (copy threads per rank). The debug / A-B knobs of tools/ - PM_FORCE_GENERAL, PM_FUSE_PLANES,
- * PM_LT_MODE, PM_HOSTPIPE_TRACE, PM_SM_DEBUG, PM_SM_WORKERS - set the DEFAULTS of the matching pm_set_option()
+ * PM_LT_MODE, PM_HOSTPIPE_TRACE, PM_SM_DEBUG, PM_SM_BATCH_PLANES - set the DEFAULTS of the matching pm_set_option()
  * options at pm_create, and ONLY when PM_DEBUG_ENV=1 is set beside them: without it they are ignored, so a stray
  * variable in a user's shell cannot select another algorithm. */
 pm_ctx *pm_create(int device, int *status);
@@ -290,7 +290,9 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           step on its seed.
  *   PM_OPT_TRACE            mask, on stderr: 1 stage times of every host-path call, 2 the knot / smoothing-parameter
  *                           search of the smoothing splines. Default 0.
- *   PM_OPT_SM_WORKERS       threads the smoothing-spline fits of a cube's planes are dealt to (1 .. 8, default 4).
+ *   PM_OPT_SM_BATCH_PLANES  the most planes of a cube whose smoothing-spline fits (spline_smoothing > 0) advance together
+ *                           in the same launches: 0 (default) = as many as half of the free device memory holds (a plane
+ *                           takes 5 arrays of its own size), 1 .. 4096 = a cap. A plane's result does not depend on it.
  *   PM_OPT_HYBRID_FETCH_PERMILLE read-only: the share of planes (in 1/1000) a hybrid segment (route 4) has the GPU
  *                           fetch on the current problem; 0 while no hybrid has been planned.
  *   PM_OPT_HOST_COPY_THREADS_IN_USE read-only: the copy threads the host pipe of this context runs with (0 before
@@ -335,7 +337,7 @@ typedef enum pm_option {
     PM_OPT_FETCH_BLOCK_BYTES = 15,
     PM_OPT_LT_MODE = 24,
     PM_OPT_TRACE = 25,
-    PM_OPT_SM_WORKERS = 26,
+    PM_OPT_SM_BATCH_PLANES = 26,
     PM_OPT_LAST_LT_PATH = 27,
     PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..4 */
 } pm_option;

@@ -79,7 +79,7 @@ PM_OPT_HYBRID_FETCH_PERMILLE = 14
 PM_OPT_FETCH_BLOCK_BYTES = 15
 PM_OPT_LT_MODE = 24
 PM_OPT_TRACE = 25
-PM_OPT_SM_WORKERS = 26
+PM_OPT_SM_BATCH_PLANES = 26
 PM_OPT_LAST_LT_PATH = 27
 PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..4
 NUM_CUBE_ROUTES = 5

@@ -420,7 +420,7 @@ pm_ctx *pm_create(int device, int *status)
     if (const char *m = pm_debug_env("PM_LT_MODE")) ctx->lt_mode = (m[0] == '1') ? 1 : (m[0] == '2') ? 2 : 0;
     if (pm_debug_env("PM_HOSTPIPE_TRACE")) ctx->trace |= 1;
     if (pm_debug_env("PM_SM_DEBUG")) ctx->trace |= 2;
-    if (const char *w = pm_debug_env("PM_SM_WORKERS")) ctx->sm_worker_count = std::max(1, std::min(std::atoi(w), (int)pm_ctx::kSmWorkers));
+    if (const char *w = pm_debug_env("PM_SM_BATCH_PLANES")) ctx->sm_batch_planes = std::max(0, std::min(std::atoi(w), 4096));
     set(PM_OK);
     return ctx;
 }
@@ -434,11 +434,8 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->flags) (void)hipFree(ctx->flags);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->limits) (void)hipFree(ctx->limits);
-    for (auto &w : ctx->sm_workers) {
-        if (w.arena) (void)hipFree(w.arena);
-        if (w.tables_host) (void)hipHostFree(w.tables_host);
-        if (w.stream) (void)hipStreamDestroy(w.stream);
-    }
+    if (ctx->sm_arena) (void)hipFree(ctx->sm_arena);
+    if (ctx->sm_status_host) (void)hipHostFree(ctx->sm_status_host);
     for (auto &ac : ctx->axis) {
         if (ac.t) (void)hipFree(ac.t);
         if (ac.lu) (void)hipFree(ac.lu);
@@ -513,9 +510,9 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         if (value < 0 || value > 3) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_TRACE takes a mask of 1 (host path) and 2 (smoothing splines)");
         ctx->trace = (int)value;
         return PM_OK;
-    case PM_OPT_SM_WORKERS:
-        if (value < 1 || value > (int64_t)pm_ctx::kSmWorkers) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SM_WORKERS takes 1 .. %d", (int)pm_ctx::kSmWorkers);
-        ctx->sm_worker_count = (int)value;
+    case PM_OPT_SM_BATCH_PLANES:
+        if (value < 0 || value > 4096) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SM_BATCH_PLANES takes 0 (the library's choice) .. 4096");
+        ctx->sm_batch_planes = (int)value;
         return PM_OK;
     case PM_OPT_FETCH_BLOCK_BYTES:
         if (value != 64 && value != 128 && value != 256) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_FETCH_BLOCK_BYTES takes 64, 128 or 256");
@@ -564,7 +561,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_FETCH_BLOCK_BYTES: *value = 1 << ctx->fetch_shift; return PM_OK;
     case PM_OPT_LT_MODE: *value = ctx->lt_mode; return PM_OK;
     case PM_OPT_TRACE: *value = ctx->trace; return PM_OK;
-    case PM_OPT_SM_WORKERS: *value = ctx->sm_worker_count; return PM_OK;
+    case PM_OPT_SM_BATCH_PLANES: *value = ctx->sm_batch_planes; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;

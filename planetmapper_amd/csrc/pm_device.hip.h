@@ -198,31 +198,6 @@ struct SplineArgs {
     SplineAxis rows, cols;  // axis 0 (image y) / axis 1 (image x)
 };
 
-// One direction of a smoothing-spline fit (FITPACK regrid, spline_smoothing > 0) for the current
-// knot set and smoothing parameter p: the host (pm_capi.hip) tabulates the B-spline values of the
-// samples and the triangular band of the QR factor of [A; B / p]; the kernels solve all
-// right-hand sides of that direction in parallel.
-constexpr int kSmBand = 7;  // degree <= 5: band = k + 2
-struct SmoothFitAxis {
-    const double *hb;  // m x 6: the k + 1 non-zero B-splines at sample i
-    const int *lb;     // m: index of the first of them
-    const int *first;  // nc: first / last sample whose B-splines include coefficient j
-    const int *last;
-    const double *R;   // nc x kSmBand: R(j, j + b) at R[j * kSmBand + b]
-    const double *Bp;  // nb x kSmBand: jump rows / p, row r covers coefficients r .. r + k + 1
-    int m, k, nc, nb;
-};
-// Evaluation of a fitted smoothing spline at the map cells
-struct SmoothEvalArgs {
-    const double *ct;        // coefficients, ct[b * nr + a]: column-axis index b, row-axis index a
-    const double *t_rows;    // knots along image rows (axis 0) / columns
-    const double *t_cols;
-    const int *span_rows;    // ny / nx: knot interval of each integer abscissa
-    const int *span_cols;
-    int nr, nc, k_rows, k_cols;
-    int plane;               // plane of the cube / output this fit belongs to
-};
-
 // Arguments of the reprojection kernel (pm_map_cube).
 struct ReprojectArgs {
     const void *cube;     // n_planes x ny x nx elements

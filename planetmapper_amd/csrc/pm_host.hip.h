@@ -40,12 +40,6 @@ void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
 void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
 void pm_launch_clean_lazy(const pm::ReprojectArgs &a, double *work, int dtype, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s);
-void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
-                        double *c, double *r, hipStream_t s);
-void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s);
-void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
-                        double *rowsum, double *colsum, hipStream_t s);
-void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, int dtype, hipStream_t s);
 void pm_launch_plane_medians(const void *cube, int dtype, int n_planes, size_t plane_elems, pm::PlaneStats *stats,
                              unsigned int *hist, hipStream_t s);
 
@@ -95,17 +89,11 @@ struct pm_ctx {
     int smooth_max_size = 10000;
     double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
     double spline_smoothing = 0.0;  // map_img spline_smoothing (FITPACK s), 0 = interpolating splines
-    // smoothing-spline fits: the planes of a cube are fitted by kSmWorkers host threads, each with
-    // its own stream and workspace (a fit is a chain of small launches + a read-back: several
-    // in flight keep the GPU busy)
-    struct SmWorker {
-        hipStream_t stream = nullptr;
-        void *arena = nullptr;        // device workspace of the fits of one plane
-        void *tables_host = nullptr;  // pinned mirror of its table block
-        size_t arena_bytes = 0;
-    };
-    static constexpr int kSmWorkers = 8;  // upper bound; PM_OPT_SM_WORKERS selects fewer (default 4)
-    SmWorker sm_workers[kSmWorkers];
+    // smoothing-spline fits (pm_smoothing.hip): descriptors + per-plane workspace of the planes fitted together
+    void *sm_arena = nullptr;
+    size_t sm_arena_bytes = 0;
+    int *sm_status_host = nullptr;  // pinned: the per-round read-back
+    int sm_batch_planes = 0;        // PM_OPT_SM_BATCH_PLANES: 0 = as many as the workspace budget holds
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined
     bool force_general = false;   // PM_OPT_GENERAL_KERNEL: never take the spheroid fast path
@@ -117,7 +105,6 @@ struct pm_ctx {
     int sparse_frame = -1;       // PM_OPT_SPARSE_FRAME
     int table_cache = 1;         // PM_OPT_BLOCK_TABLE_CACHE
     int trace = 0;               // PM_OPT_TRACE: 1 stage times of the host path, 2 the smoothing-spline search, on stderr
-    int sm_worker_count = 4;     // PM_OPT_SM_WORKERS: threads that run the smoothing-spline fits of a cube's planes
     int fuse_planes = 0;         // PM_OPT_FUSE_PLANES
     int lt_mode = 0;             // PM_OPT_LT_MODE (A/B runs of tools/, the light-time test): 0 closed-form light time of the
                                  // spheroid kernel, 1 the reference's sequence of epochs, 2 Newton step on its seed
@@ -157,7 +144,8 @@ int reproject_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, bool sync_no
 int finish_reproject(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype);
 int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols);
 int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype, const double *limits);
-int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols, double s);
+int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k_rows, int k_cols, double s);  // pm_smoothing.hip
+int ensure_work(pm_ctx *ctx, size_t bytes);
 
 
 // pm_hostpipe.hip: the host <-> HBM leg of PM_MEM_HOST calls

@@ -4,7 +4,6 @@
 //                          propagation and on-the-fly NaN pre-clean
 //   k_median_hist / pick   per-plane nanmedian (radix select) for the pre-clean
 //   k_spline_*             interpolating tensor-product splines (degrees 1..5)
-//   k_sm_*                 smoothing splines (FITPACK regrid fits)
 //   k_reproject_smooth<T>  'smooth' (PCHIP-oversampled) reprojection, evaluated on the fly
 //
 // One lane per (map cell, plane): blockIdx.y = plane, so a wave gathers neighbouring map cells
@@ -788,214 +787,6 @@ __device__ __forceinline__ double key_to_double(unsigned long long k)
     return __longlong_as_double((long long)b);
 }
 
-// ------------------------------------------------------------------ smoothing splines
-// Least squares  [A; B/p] c = [d; 0]  for every right-hand side q of one direction by the
-// corrected semi-normal equations: R'R c = A'd with the host's QR factor R, then one refinement
-// step with the residual (restores the accuracy the normal equations lose: error ~ cond(A) eps
-// instead of cond(A)^2 eps). Three kernels, all coalesced over the right-hand sides q:
-//   k_sm_atr    g = A' r     one lane per (coefficient, q): a banded transposed product, fully parallel
-//   k_sm_subst  R'R x = g    one lane per q: two banded substitutions (the only sequential part,
-//                            nc steps), work vector in LDS when it fits
-//   k_sm_res    r = d - A c  one lane per (sample, q)
-constexpr int kSmChunk = 32;  // samples per lane of k_sm_atr
-__global__ __launch_bounds__(kBlock) void k_sm_atr(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
-                                                   size_t sq, int nrhs, double *__restrict__ g)
-{
-    // One lane per (right-hand side q, chunk of 32 consecutive samples). Consecutive samples
-    // share their k + 1 B-splines or move on by one: the partial sums sit in a register window
-    // that slides with the knot interval and are retired into g (zeroed by the caller) with
-    // atomic adds - a handful per lane whatever the number of knots, so the early fits with
-    // very few coefficients are as parallel as the late ones.
-    const int q = blockIdx.x * kBlock + threadIdx.x;
-    if (q >= nrhs) return;
-    const int i0 = blockIdx.y * kSmChunk, i1 = min(i0 + kSmChunk, a.m);
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0;
-    int cur = a.lb[i0];
-    for (int ib = i0; ib < i1; ib += 8) {
-        double buf[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) buf[u] = in[(size_t)min(ib + u, i1 - 1) * si + q * sq];  // loads in flight together
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int i = ib + u;
-            if (i < i1) {
-                const int l0 = a.lb[i];
-                while (cur < l0) {  // retire the leading partial sum
-                    atomicAdd(&g[(size_t)cur * nrhs + q], s0);
-                    s0 = s1; s1 = s2; s2 = s3; s3 = s4; s4 = s5; s5 = 0.0;
-                    cur++;
-                }
-                const double *h = a.hb + (size_t)i * 6;
-                const double r = buf[u];
-                s0 += h[0] * r;
-                s1 += h[1] * r;
-                if (a.k >= 2) s2 += h[2] * r;
-                if (a.k >= 3) s3 += h[3] * r;
-                if (a.k >= 4) s4 += h[4] * r;
-                if (a.k >= 5) s5 += h[5] * r;
-            }
-        }
-    }
-    atomicAdd(&g[(size_t)cur * nrhs + q], s0);
-    atomicAdd(&g[(size_t)(cur + 1) * nrhs + q], s1);
-    if (a.k >= 2) atomicAdd(&g[(size_t)(cur + 2) * nrhs + q], s2);
-    if (a.k >= 3) atomicAdd(&g[(size_t)(cur + 3) * nrhs + q], s3);
-    if (a.k >= 4) atomicAdd(&g[(size_t)(cur + 4) * nrhs + q], s4);
-    if (a.k >= 5) atomicAdd(&g[(size_t)(cur + 5) * nrhs + q], s5);
-}
-
-__global__ __launch_bounds__(kBlock) void k_sm_res(const SmoothFitAxis a, const double *__restrict__ in, size_t si,
-                                                   size_t sq, int nrhs, const double *__restrict__ c,
-                                                   double *__restrict__ r)
-{
-    const int q = blockIdx.x * kBlock + threadIdx.x;
-    const int i = blockIdx.y;
-    if (q >= nrhs) return;
-    const int l0 = a.lb[i];
-    const double *h = a.hb + (size_t)i * 6;
-    double v = in[(size_t)i * si + q * sq];
-    for (int e = 0; e <= a.k; e++) v -= h[e] * c[(size_t)(l0 + e) * nrhs + q];
-    r[(size_t)i * nrhs + q] = v;
-}
-
-// pass 0: c = (R'R)^-1 g; pass 1: c += (R'R)^-1 (g - (B/p)'(B/p) c)   (g = A'(d - A c) then)
-__global__ __launch_bounds__(kBlock) void k_sm_subst(const SmoothFitAxis a, int nrhs, double *__restrict__ g_glob,
-                                                     double *__restrict__ c_glob, int pass, int use_lds)
-{
-    extern __shared__ double sm_lds[];
-    const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= nrhs) return;
-    const int band = a.k + 2, nc = a.nc;
-    // the work vector of this right-hand side: element j at g[j * st + o]; in LDS (lane-contiguous,
-    // conflict-free) when it fits - the substitutions are chains of dependent updates
-    double *g = use_lds ? sm_lds : g_glob;
-    const size_t st = use_lds ? (size_t)blockDim.x : (size_t)nrhs;
-    const size_t o = use_lds ? (size_t)threadIdx.x : (size_t)q;
-    if (use_lds)
-        for (int j = 0; j < nc; j++) g[j * st + o] = g_glob[(size_t)j * nrhs + q];
-    if (pass)  // the jump rows have a zero right-hand side: their residual is -(B/p) c
-        for (int r = 0; r < a.nb; r++) {
-            const double *b = a.Bp + (size_t)r * kSmBand;
-            double v = 0.0;
-            for (int e = 0; e < band; e++) v += b[e] * c_glob[(size_t)(r + e) * nrhs + q];
-            for (int e = 0; e < band; e++) g[(r + e) * st + o] -= b[e] * v;
-        }
-    // forward substitution R' w = g (w overwrites g), the band of previous values in registers
-    double w1 = 0.0, w2 = 0.0, w3 = 0.0, w4 = 0.0, w5 = 0.0, w6 = 0.0;  // w[j-1] .. w[j-6]
-    for (int j = 0; j < nc; j++) {
-        double sv = g[j * st + o];
-        const double *Rj = a.R + (size_t)j * kSmBand;
-        if (j >= 1) sv -= (Rj - 1 * kSmBand)[1] * w1;
-        if (band > 2 && j >= 2) sv -= (Rj - 2 * kSmBand)[2] * w2;
-        if (band > 3 && j >= 3) sv -= (Rj - 3 * kSmBand)[3] * w3;
-        if (band > 4 && j >= 4) sv -= (Rj - 4 * kSmBand)[4] * w4;
-        if (band > 5 && j >= 5) sv -= (Rj - 5 * kSmBand)[5] * w5;
-        if (band > 6 && j >= 6) sv -= (Rj - 6 * kSmBand)[6] * w6;
-        sv /= Rj[0];
-        g[j * st + o] = sv;
-        w6 = w5; w5 = w4; w4 = w3; w3 = w2; w2 = w1; w1 = sv;
-    }
-    // back substitution R x = w, then c = x (first pass) or c += x
-    double x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0, x5 = 0.0, x6 = 0.0;  // x[j+1] .. x[j+6]
-    for (int j = nc - 1; j >= 0; j--) {
-        double sv = g[j * st + o];
-        const double *Rj = a.R + (size_t)j * kSmBand;
-        sv -= Rj[1] * x1;  // (entries beyond the matrix are stored as zeros)
-        if (band > 2) sv -= Rj[2] * x2;
-        if (band > 3) sv -= Rj[3] * x3;
-        if (band > 4) sv -= Rj[4] * x4;
-        if (band > 5) sv -= Rj[5] * x5;
-        if (band > 6) sv -= Rj[6] * x6;
-        sv /= Rj[0];
-        x6 = x5; x5 = x4; x4 = x3; x3 = x2; x2 = x1; x1 = sv;
-        const size_t ci = (size_t)j * nrhs + q;
-        c_glob[ci] = pass ? c_glob[ci] + sv : sv;
-    }
-}
-
-// out[j * rows + i] = in[i * cols + j] (LDS-tiled)
-__global__ __launch_bounds__(kBlock) void k_transpose(const double *__restrict__ in, double *__restrict__ out, int rows,
-                                                     int cols)
-{
-    __shared__ double tile[16][17];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    int i = blockIdx.y * 16 + ty, j = blockIdx.x * 16 + tx;
-    if (i < rows && j < cols) tile[ty][tx] = in[(size_t)i * cols + j];
-    __syncthreads();
-    i = blockIdx.y * 16 + tx;
-    j = blockIdx.x * 16 + ty;
-    if (i < rows && j < cols) out[(size_t)j * rows + i] = tile[tx][ty];
-}
-
-// Squared residuals of the fitted spline at the image pixels, summed per image row and per
-// image column (the host turns them into fp and the per-knot-interval sums of FITPACK).
-__global__ __launch_bounds__(kBlock) void k_sm_resid(const SmoothFitAxis ay, const SmoothFitAxis ax,
-                                                     const double *__restrict__ z, const double *__restrict__ ct,
-                                                     double *__restrict__ rowsum, double *__restrict__ colsum)
-{
-    const int j = blockIdx.x * kBlock + threadIdx.x;  // image column
-    const int i = blockIdx.y;                         // image row
-    double term = 0.0;
-    if (j < ax.m) {
-        const int la = ay.lb[i], lb = ax.lb[j], nr = ay.nc;
-        const double *hy = ay.hb + (size_t)i * 6, *hx = ax.hb + (size_t)j * 6;
-        double sv = 0.0;
-        for (int b = 0; b <= ax.k; b++) {
-            double r = 0.0;
-            for (int e = 0; e <= ay.k; e++) r += hy[e] * ct[(size_t)(lb + b) * nr + (la + e)];
-            sv += hx[b] * r;
-        }
-        const double d = z[(size_t)i * ax.m + j] - sv;
-        term = d * d;
-        atomicAdd(&colsum[j], term);
-    }
-    // one atomic per wave for the row
-    double rs = term;
-    for (int off = 32; off > 0; off >>= 1) rs += __shfl_down(rs, off, 64);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&rowsum[i], rs);
-}
-
-// bispev of a fitted smoothing spline at the map cells of one plane
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_sm_eval(const ReprojectArgs a, const SmoothEvalArgs e)
-{
-    const int m = blockIdx.x * kBlock + threadIdx.x;
-    if (m >= a.n_map) return;
-    const double nan = __builtin_nan("");
-    const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)e.plane * ny * nx;
-    const double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    bool skip = isnan(x) || isnan(y);
-    if (!skip && a.propagate_nan) {
-        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-            skip = true;
-        } else {
-            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
-                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
-        }
-    }
-    if (!skip) {
-        const double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
-        // the knots are integer abscissae: the span of x is the span of floor(x)
-        const int ly = e.span_rows[(int)yc], lx = e.span_cols[(int)xc];
-        double hy[6], hx[6];
-        SplineAxis ry = {e.t_rows, nullptr, e.nr, e.k_rows}, rx = {e.t_cols, nullptr, e.nc, e.k_cols};
-        spline_basis(ry, yc, ly, hy);
-        spline_basis(rx, xc, lx, hx);
-        double sv = 0.0;
-        for (int q = 0; q <= e.k_cols; q++) {
-            double r = 0.0;
-            for (int p = 0; p <= e.k_rows; p++) r += hy[p] * e.ct[(size_t)(lx - e.k_cols + q) * e.nr + (ly - e.k_rows + p)];
-            sv += hx[q] * r;
-        }
-        val = sv;
-    }
-    a.out[(size_t)e.plane * a.n_map + m] = val;
-}
-
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_median_hist(const T *cube, size_t plane_elems, int shift, PlaneStats *stats,
                                                         unsigned int *hist /* [P][2][256] */, int lazy)
@@ -1268,63 +1059,6 @@ void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStr
     case PM_I32: launch_clean_t<int32_t>(a, work, s); break;
     case PM_U8: launch_clean_t<uint8_t>(a, work, s); break;
     case PM_U16: launch_clean_t<uint16_t>(a, work, s); break;
-    }
-}
-
-// c (nc x nrhs) = least-squares solution for all right-hand sides d(i, q) = in[i * si + q * sq];
-// g (nc x nrhs) and r (m x nrhs) are work arrays
-void pm_launch_sm_solve(const pm::SmoothFitAxis &ax, const double *in, size_t si, size_t sq, int nrhs, double *g,
-                        double *c, double *r, hipStream_t s)
-{
-    // the work vector of a 64-lane workgroup in LDS when it fits (more than 64 KB of dynamic LDS
-    // has to be enabled per kernel)
-    static const size_t lds_limit = [] {
-        const int want = 150 * 1024;
-        return hipFuncSetAttribute((const void *)pm::k_sm_subst, hipFuncAttributeMaxDynamicSharedMemorySize, want) ==
-                       hipSuccess
-                   ? (size_t)want
-                   : (size_t)(64 * 1024);
-    }();
-    const size_t lds = (size_t)ax.nc * 64 * sizeof(double);
-    const bool use_lds = lds <= lds_limit;
-    const dim3 gq((nrhs + pm::kBlock - 1) / pm::kBlock);
-    auto subst = [&](int pass) {
-        if (use_lds)
-            hipLaunchKernelGGL(pm::k_sm_subst, dim3((nrhs + 63) / 64), dim3(64), lds, s, ax, nrhs, g, c, pass, 1);
-        else
-            hipLaunchKernelGGL(pm::k_sm_subst, gq, dim3(pm::kBlock), 0, s, ax, nrhs, g, c, pass, 0);
-    };
-    const dim3 ga(gq.x, (ax.m + pm::kSmChunk - 1) / pm::kSmChunk);
-    const size_t gbytes = (size_t)ax.nc * nrhs * sizeof(double);
-    (void)hipMemsetAsync(g, 0, gbytes, s);
-    hipLaunchKernelGGL(pm::k_sm_atr, ga, dim3(pm::kBlock), 0, s, ax, in, si, sq, nrhs, g);
-    subst(0);
-    hipLaunchKernelGGL(pm::k_sm_res, dim3(gq.x, ax.m), dim3(pm::kBlock), 0, s, ax, in, si, sq, nrhs, c, r);
-    (void)hipMemsetAsync(g, 0, gbytes, s);
-    hipLaunchKernelGGL(pm::k_sm_atr, ga, dim3(pm::kBlock), 0, s, ax, r, (size_t)nrhs, (size_t)1, nrhs, g);
-    subst(1);
-}
-void pm_launch_transpose(const double *in, double *out, int rows, int cols, hipStream_t s)
-{
-    hipLaunchKernelGGL(pm::k_transpose, dim3((cols + 15) / 16, (rows + 15) / 16), dim3(pm::kBlock), 0, s, in, out, rows,
-                       cols);
-}
-void pm_launch_sm_resid(const pm::SmoothFitAxis &ay, const pm::SmoothFitAxis &ax, const double *z, const double *ct,
-                        double *rowsum, double *colsum, hipStream_t s)
-{
-    hipLaunchKernelGGL(pm::k_sm_resid, dim3((ax.m + pm::kBlock - 1) / pm::kBlock, ay.m), dim3(pm::kBlock), 0, s, ay, ax, z,
-                       ct, rowsum, colsum);
-}
-void pm_launch_sm_eval(const pm::ReprojectArgs &a, const pm::SmoothEvalArgs &e, int dtype, hipStream_t s)
-{
-    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock), block(pm::kBlock);
-    switch (dtype) {
-    case PM_F64: hipLaunchKernelGGL(pm::k_sm_eval<double>, grid, block, 0, s, a, e); break;
-    case PM_F32: hipLaunchKernelGGL(pm::k_sm_eval<float>, grid, block, 0, s, a, e); break;
-    case PM_I16: hipLaunchKernelGGL(pm::k_sm_eval<int16_t>, grid, block, 0, s, a, e); break;
-    case PM_I32: hipLaunchKernelGGL(pm::k_sm_eval<int32_t>, grid, block, 0, s, a, e); break;
-    case PM_U8: hipLaunchKernelGGL(pm::k_sm_eval<uint8_t>, grid, block, 0, s, a, e); break;
-    case PM_U16: hipLaunchKernelGGL(pm::k_sm_eval<uint16_t>, grid, block, 0, s, a, e); break;
     }
 }
 

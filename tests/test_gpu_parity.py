@@ -2565,25 +2565,25 @@ def test_debug_knobs_of_the_environment_need_pm_debug_env(jupiter):
     from planetmapper_amd import _lib
     from planetmapper_amd.engine import Engine
 
-    knobs = {'PM_LT_MODE': '2', 'PM_FORCE_GENERAL': '1', 'PM_FUSE_PLANES': '1', 'PM_HOSTPIPE_TRACE': '1', 'PM_SM_WORKERS': '2'}
+    knobs = {'PM_LT_MODE': '2', 'PM_FORCE_GENERAL': '1', 'PM_FUSE_PLANES': '1', 'PM_HOSTPIPE_TRACE': '1', 'PM_SM_BATCH_PLANES': '2'}
     saved = {k: os.environ.get(k) for k in list(knobs) + ['PM_DEBUG_ENV']}
 
     def options():
         eng = Engine(0)
         try:
             return tuple(eng.get_option(o) for o in (_lib.PM_OPT_LT_MODE, _lib.PM_OPT_GENERAL_KERNEL, _lib.PM_OPT_FUSE_PLANES,
-                                                     _lib.PM_OPT_TRACE, _lib.PM_OPT_SM_WORKERS))
+                                                     _lib.PM_OPT_TRACE, _lib.PM_OPT_SM_BATCH_PLANES))
         finally:
             eng.close()
 
     try:
         os.environ.pop('PM_DEBUG_ENV', None)
         os.environ.update(knobs)
-        assert options() == (0, 0, 0, 0, 4)  # ignored
+        assert options() == (0, 0, 0, 0, 0)  # ignored
         os.environ['PM_DEBUG_ENV'] = '1'
         assert options() == (2, 1, 1, 1, 2)  # honoured
         os.environ['PM_DEBUG_ENV'] = '0'
-        assert options() == (0, 0, 0, 0, 4)
+        assert options() == (0, 0, 0, 0, 0)
     finally:
         for k, v in saved.items():
             if v is None:
@@ -2596,7 +2596,7 @@ def test_debug_knobs_of_the_environment_need_pm_debug_env(jupiter):
         with pytest.raises(ValueError):
             eng.set_option(_lib.PM_OPT_LT_MODE, 3)
         with pytest.raises(ValueError):
-            eng.set_option(_lib.PM_OPT_SM_WORKERS, 0)
+            eng.set_option(_lib.PM_OPT_SM_BATCH_PLANES, -1)
         eng.set_option(_lib.PM_OPT_TRACE, 0)
     finally:
         eng.close()

@@ -191,7 +191,6 @@ def test_smoothing_splines_on_a_batch_of_planes(engine, oracle, jupiter):
     assert np.max(np.abs(a[fin] - b[fin])) <= 1e-7 * np.abs(b[fin]).max()
 
 
-@pytest.mark.xfail(reason='the per-plane fit sums with atomics: not reproducible run to run until the batched fit lands', strict=False)
 def test_a_smoothing_fit_in_a_batch_equals_the_plane_fitted_alone(engine, oracle, jupiter):
     """bit for bit: a plane's knot search must not depend on the planes that share its launches"""
     ny, nx = 500, 523

@@ -11,9 +11,9 @@
 //     (SmPlaneDev); k_smb_decide - one wave per plane - consumes the last fit and sets up the next: FITPACK's fpknot adds
 //     knots wave-cooperatively, fprati picks p;
 //   * k_smb_tables / k_smb_factor rebuild what the new knots / p need: B-spline values of the samples, the jump rows
-//     B / p (fpdisc), and the triangular band factor R of [A; B / p] by Givens rotations (fpgivs / fprota) - one lane per
-//     (plane, axis), the rows of both blocks merged by first column so that the rows of R a row meets fit in registers (a
-//     window that slides with the knot interval: R is stored once and never loaded);
+//     B / p (fpdisc), and the triangular band factor R of [A; B / p] by Givens rotations (fpgivs / fprota) - one wave per
+//     (plane, axis), the rows of both blocks merged by first column so that a row meets only k + 2 rows of R: the lanes
+//     of the wave are the stages of a pipeline the rows stream through (R is stored once and never loaded);
 //   * the fit kernels take blockIdx.y / .z = plane: every plane's fit of a round runs in the same launches, each plane
 //     with its own knots. A directional solve is the corrected semi-normal equations R'R c = A'd + one refinement step
 //     with the residual (error ~ cond(A) eps), fused per pass into ONE sweep per right-hand side: the lane walks the
@@ -23,7 +23,9 @@
 //   * the host only sizes the grids: one 16-byte read-back per round (planes still searching, the largest coefficient
 //     counts) - every wave's loops are bounded by that round's own tables, the round loop by FITPACK's own iteration caps.
 // Planes whose search has ended stop taking part (their blocks leave at once); the cube is fitted in batches of as many
-// planes as the workspace budget allows (4 work arrays of a plane each + ~100 KB of tables).
+// planes as the workspace budget allows (6 work arrays of a plane each + ~0.4 MB of tables).
+#include <type_traits>
+
 #include "pm_host.hip.h"
 
 namespace pm {
@@ -40,6 +42,10 @@ struct SmAxisDev {
     double *t;       // n knots (capacity m + k + 2)
     double *fpint;   // residual sum per knot interval (capacity m + 1)
     int *nrdata;     // data points strictly inside each interval (capacity m + 1)
+    // the rows of [A; B / p] merged in the order of their first column (nb > 0): what the refinement pass walks
+    int *mg_src;     // m + nb: sample i, or -(r + 1) for jump row r
+    int *mg_l;       // m + nb: first column of the row
+    double *mg_h;    // (m + nb) x kSmRow: its k + 2 entries
     int m, k, n, nplus, nb, knots_changed;
     __host__ __device__ int nc() const { return n - k - 1; }
     __host__ __device__ int nrint() const { return n - 2 * k - 1; }
@@ -48,6 +54,7 @@ struct SmPlaneDev {
     SmAxisDev y, x;   // FITPACK's "x" = the first array axis = image rows (y here), its "y" = image columns
     const double *z;  // the cleaned plane (ny x nx)
     double *U, *UT, *G, *CT;
+    double *RB;       // residuals of the rows of a direction, (m + nb) x right-hand sides
     double *rowpart, *colpart;  // [tiles_x][ny], [tiles_y][nx]: residual sums per tile column / tile row
     double *rowsum, *colsum;
     double s, acc;
@@ -58,6 +65,21 @@ struct SmPlaneDev {
     int all_nan;  // body_xy.py:1668-1670: the map of an all-NaN image is all NaN
     int plane;    // index in the chunk (cube, output, statistics)
 };
+
+// dst[x] = value(x), x < n, by the NT threads of the workgroup: eight requests in flight per thread (a plain loop of
+// load - store pairs waits out every trip to HBM on its own)
+template <int NT, typename T, typename F>
+__device__ __forceinline__ void sm_stage(T *dst, int n, F &&value)
+{
+    for (int x0 = threadIdx.x; x0 < n; x0 += NT * 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = x0 + u * NT < n ? value(x0 + u * NT) : T();
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (x0 + u * NT < n) dst[x0 + u * NT] = v[u];
+    }
+}
 
 // ------------------------------------------------------------------ the search between two fits
 __device__ __forceinline__ double wave_sum(const double *v, int n, int lane)
@@ -134,12 +156,42 @@ __device__ void sm_account(const SmAxisDev &a, int n, const double *sums, int la
     }
 }
 
+// up to `count` new knots along one axis, its knot arrays worked on in LDS (`lds`: they fit): a new knot is a scan, two
+// reductions and three shifts over them, each a round trip - to LDS a tenth of a microsecond, to HBM one or two
+__device__ bool sm_refine(SmAxisDev &g, int &n, int count, int nmax, int lane, double *smem, int lds)
+{
+    SmAxisDev a = g;
+    const int k = a.k, n0 = n;
+    if (lds) {
+        double *tS = smem, *fS = tS + (a.m + k + 2);
+        int *nS = (int *)(fS + (a.m + 1));
+        for (int i = lane; i < n0; i += 64) tS[i] = g.t[i];
+        for (int i = lane; i < n0 - 2 * k - 1; i += 64) { fS[i] = g.fpint[i]; nS[i] = g.nrdata[i]; }
+        a.t = tS; a.fpint = fS; a.nrdata = nS;
+        __syncthreads();
+    }
+    bool added = false;
+    for (int l = 0; l < count; l++) {  // (FITPACK tries `count` times whether or not an interval can still take a knot; once none can, none will)
+        if (!sm_add_knot(a, n, lane)) break;
+        added = true;
+        if (n == nmax) break;
+    }
+    if (lds && added) {
+        for (int i = lane; i < n; i += 64) g.t[i] = a.t[i];
+        for (int i = lane; i < n - 2 * k - 1; i += 64) { g.fpint[i] = a.fpint[i]; g.nrdata[i] = a.nrdata[i]; }
+    }
+    __syncthreads();
+    return added;
+}
+
 // One wave per plane: close the fit of the last round (residual sums -> fp, per-interval sums), take FITPACK's decision
 // (fpregr: more knots / the next p / finished) and publish what the next fit is. status: [0] planes with a fit to run,
-// [1] / [2] the largest coefficient counts along y / x among them.
+// [1] / [2] the largest coefficient counts along y / x among them, [3] whether any of them fits with p > 0.
+__host__ __device__ inline size_t sm_decide_lds_bytes(int m, int k) { return ((size_t)(m + k + 2) + (size_t)(m + 1)) * sizeof(double) + (size_t)(m + 1) * sizeof(int); }
 __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const PlaneStats *stats, int *status, int first, int tiles_x,
-                                                   int tiles_y)
+                                                   int tiles_y, int lds)
 {
+    extern __shared__ double sm_knots[];
     SmPlaneDev &P = planes[blockIdx.x];
     const int lane = threadIdx.x;
     const double con1 = 0.1, con9 = 0.9, con4 = 0.04;
@@ -221,22 +273,14 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
                 if (!first_axis && nx_n == nmaxx) first_axis = true;
                 lastdi = first_axis ? -1 : 1;
                 // (FITPACK tries nplus times whether or not an interval can still take a knot; once none can, none will)
-                bool added = false;
+                bool added;
                 if (first_axis) {
                     nplus_y = nply;
-                    for (int l = 0; l < nply; l++) {
-                        if (!sm_add_knot(P.y, ny_n, lane)) break;
-                        added = true;
-                        if (ny_n == nmaxy) break;
-                    }
+                    added = sm_refine(P.y, ny_n, nply, nmaxy, lane, sm_knots, lds);
                     changed_y = added;
                 } else {
                     nplus_x = nplx;
-                    for (int l = 0; l < nplx; l++) {
-                        if (!sm_add_knot(P.x, nx_n, lane)) break;
-                        added = true;
-                        if (nx_n == nmaxx) break;
-                    }
+                    added = sm_refine(P.x, nx_n, nplx, nmaxx, lane, sm_knots, lds);
                     changed_x = added;
                 }
                 iter++;
@@ -318,6 +362,7 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
             atomicAdd(&status[0], 1);
             atomicMax(&status[1], ny_n - ky - 1);
             atomicMax(&status[2], nx_n - kx - 1);
+            if (p_fit > 0.0) atomicMax(&status[3], 1);
         }
     }
 }
@@ -383,224 +428,397 @@ __global__ __launch_bounds__(kBlock) void k_smb_tables(SmPlaneDev *planes)
                 a.Bp[(size_t)r * kSmRow + j] = v;
             }
         }
+        // the merged row stream: jump row r after the samples of the knot intervals <= r (this thread wrote the Bp rows
+        // and, if the knots changed, the lb / hb entries it reads here)
+        for (int i = threadIdx.x; i < m; i += kBlock) {
+            const int l0 = a.lb[i], pos = i + min(l0, nb);
+            a.mg_src[pos] = i;
+            a.mg_l[pos] = l0;
+            for (int e = 0; e < kSmRow; e++) a.mg_h[(size_t)pos * kSmRow + e] = e <= k ? a.hb[(size_t)i * 6 + e] : 0.0;
+        }
+        for (int r = threadIdx.x; r < nb; r += kBlock) {
+            const int pos = (int)a.t[k + r + 1] + r;
+            a.mg_src[pos] = -(r + 1);
+            a.mg_l[pos] = r;
+            for (int e = 0; e < kSmRow; e++) a.mg_h[(size_t)pos * kSmRow + e] = a.Bp[(size_t)r * kSmRow + e];
+        }
     }
 }
 
-// Triangular band R of the QR factor of [A; B / p] by Givens rotations (fpgivs / fprota), one lane. FITPACK rotates the
-// collocation rows in first and then each jump row from its first column TO THE END of the band (its fill-in travels:
-// O(nb x nc) rotations). R is unique (positive diagonal), so here the rows of both blocks are merged in the order of their
-// first column instead: a row that enters at coefficient j0 then meets only rows of R that hold nothing beyond column
-// j0 + BAND - 1, and is used up after BAND rotations. Those BAND rows of R live in registers, a window that slides with
-// j0 - a row that falls out of it is final and is stored with the reciprocal of its diagonal (what the substitutions
-// multiply by); nothing of R is ever loaded. The next row of each block is in flight while the current one is rotated in.
-template <int BAND>
-__device__ void sm_factor_axis(const SmAxisDev &a)
+// Triangular band R of the QR factor of [A; B / p] by Givens rotations (fpgivs / fprota). FITPACK rotates the collocation
+// rows in first and then each jump row from its first column TO THE END of the band (its fill-in travels: O(nb x nc)
+// rotations). R is unique (positive diagonal), so here the rows of both blocks are taken in the order of their first column
+// instead (the merged stream of k_smb_tables): a row that enters at coefficient j0 then meets only rows of R that hold
+// nothing beyond column j0 + BAND - 1, and is used up after BAND rotations with the rows j0 .. j0 + BAND - 1 of R.
+// That is a pipeline, and the wave runs it as one: LANE q holds row win0 + q of R in registers and performs the q-th
+// rotation of every row of the stream; a row moves one lane on per tick (DPP), rotated rows follow one another by one tick -
+// by two where the second enters one coefficient further on: then the rows of R move one lane down in its wake, lane 0's
+// row is final and is stored (with the reciprocal of its diagonal, what the substitutions multiply by). Each row of R sees
+// the stream's rows in their order and each stream row sees its BAND rows of R in theirs: the same operations on the same
+// operands as one lane working through the stream alone - in (rows + advances) ticks instead of rows x BAND rotations.
+// Nothing of R is ever loaded.
+__device__ __forceinline__ void sm_givens(double piv, double ww, double &cs, double &sn, double &dd)
 {
-    const int ncf = a.nc(), m = a.m, nb = a.nb, k = a.k;
-    const double *__restrict__ hb = a.hb;
-    const double *__restrict__ Bp = a.Bp;
-    const int *__restrict__ lb = a.lb;
-    double *__restrict__ R = a.R;
-    double W[BAND][BAND], h[BAND], hd[BAND], hj[BAND];
+    // (cs, sn, dd) of the rotation that annihilates piv against the diagonal ww: one reciprocal square root for operands of
+    // ordinary size, FITPACK's scaled form (fpgivs) otherwise
+    const double x2 = fma(piv, piv, ww * ww);
+    if (x2 > 1e-280 && x2 < 1e280) {
+        const double r = rsqrt_fast(x2);
+        dd = x2 * r;
+        cs = ww * r;
+        sn = piv * r;
+    } else {
+        const double store = fabs(piv);
+        dd = (store >= ww) ? store * sqrt(1.0 + (ww / piv) * (ww / piv)) : ww * sqrt(1.0 + (piv / ww) * (piv / ww));
+        cs = ww / dd;
+        sn = piv / dd;
+    }
+}
+// lane l <- lane l - 1 / lane l + 1 of the same row of 16 lanes (0 from beyond it)
+__device__ __forceinline__ int dpp_prev(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+__device__ __forceinline__ int dpp_next(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true); }
+__device__ __forceinline__ double dpp_prev(double v) { return __hiloint2double(dpp_prev(__double2hiint(v)), dpp_prev(__double2loint(v))); }
+__device__ __forceinline__ double dpp_next(double v) { return __hiloint2double(dpp_next(__double2hiint(v)), dpp_next(__double2loint(v))); }
+
+template <int BAND>
+__device__ void sm_factor_stream(const double *rowh, int hs, int we, const int *rowl, int n_rows, double *__restrict__ R, int ncf)
+{
+    const int lane = threadIdx.x;
+    const bool stage = lane < BAND;
+    double w[BAND], h[BAND], ho[BAND];
 #pragma unroll
-    for (int r = 0; r < BAND; r++)
+    for (int b = 0; b < BAND; b++) w[b] = h[b] = ho[b] = 0.0;
+    int tag = 0, to = 0;        // of the row a lane holds: bit 0 it is one, bit 1 it advanced the window, bits 2.. its first column
+    int win0 = 0;               // (lane 0's is the one that counts: rows of R stored so far)
+    int x = 0, prev_l = 0;      // the feeder: the same in every lane
+    bool bubble = false;
+    // the next row of the stream, requested a tick (at least) before lane 0 takes it
+    int nl = 0;
+    double nh[BAND];
+    auto request = [&](int row) {
+        const int rr = min(row, n_rows - 1);
+        nl = rowl[rr];
 #pragma unroll
-        for (int b = 0; b < BAND; b++) W[r][b] = 0.0;
-    int win0 = 0, i = 0, r = 0, lbi = 0;
-    auto fetch_data = [&](int ii) {
-        lbi = lb[ii];
-#pragma unroll
-        for (int e = 0; e < BAND; e++) hd[e] = e <= k ? hb[(size_t)ii * 6 + e] : 0.0;
+        for (int b = 0; b < BAND; b++) nh[b] = b < we ? rowh[(size_t)rr * hs + b] : 0.0;
     };
-    auto fetch_jump = [&](int rr) {
+    request(0);
+    const int guard = 2 * n_rows + 2 * BAND + 8;
+    for (int tick = 0; tick < guard; tick++) {
+        // every row moves one lane on
 #pragma unroll
-        for (int e = 0; e < BAND; e++) hj[e] = Bp[(size_t)rr * kSmRow + e];
-    };
-    auto retire = [&](int j, const double *w) {
+        for (int b = 0; b < BAND; b++) h[b] = dpp_prev(ho[b]);
+        tag = dpp_prev(to);
+        // lane 0 takes the next row of the stream - one tick later if it enters one coefficient further on
+        bool fed = false;
+        if (x < n_rows) {
+            if (nl > prev_l && !bubble) {
+                bubble = true;
+            } else {
+                fed = true;
+                if (lane == 0) {
+                    tag = 1 | (nl > prev_l ? 2 : 0) | (nl << 2);
+#pragma unroll
+                    for (int b = 0; b < BAND; b++) h[b] = nh[b];
+                }
+                prev_l = nl;
+                bubble = false;
+                x++;
+                request(x);
+            }
+        }
+        if (!fed && lane == 0) tag = 0;
+        const int valid = tag & 1, adv = tag & 2, j0 = tag >> 2;
+        if (x >= n_rows && !fed && __builtin_amdgcn_ballot_w64(valid && stage) == 0) break;  // fed and drained
+        // in the wake of a row that advanced the window the rows of R move one lane down
+        const bool shift = valid && adv && stage;
+        if (__builtin_amdgcn_ballot_w64(shift)) {
+            double wn[BAND];
+#pragma unroll
+            for (int b = 0; b < BAND; b++) wn[b] = dpp_next(w[b]);
+            if (shift) {
+                if (lane == 0) {
+#pragma unroll
+                    for (int b = 0; b < BAND; b++) R[(size_t)win0 * kSmRow + b] = w[b];
+                    for (int b = BAND; b < kSmRow - 1; b++) R[(size_t)win0 * kSmRow + b] = 0.0;
+                    R[(size_t)win0 * kSmRow + kSmRow - 1] = 1.0 / w[0];
+                    win0++;
+                }
+#pragma unroll
+                for (int b = 0; b < BAND; b++) w[b] = lane == BAND - 1 ? 0.0 : wn[b];
+            }
+        }
+        // this lane's rotation of the row it holds
+        if (valid && stage && j0 + lane < ncf && h[0] != 0.0) {  // (a row that is used up meets zero pivots from there on)
+            double cs, sn, dd;
+            sm_givens(h[0], w[0], cs, sn, dd);
+            w[0] = dd;
+#pragma unroll
+            for (int b = 1; b < BAND; b++) {
+                const double s1 = h[b], s2 = w[b];
+                w[b] = cs * s2 + sn * s1;
+                h[b] = cs * s1 - sn * s2;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b + 1 < BAND; b++) ho[b] = h[b + 1];
+        ho[BAND - 1] = 0.0;
+        to = tag;
+    }
+    // what is left in the lanes are the last rows of R (the last row enters at ncf - BAND or later: every row is stored)
+    const int base = __builtin_amdgcn_readfirstlane(win0);
+    if (stage && base + lane < ncf) {
+        const int j = base + lane;
 #pragma unroll
         for (int b = 0; b < BAND; b++) R[(size_t)j * kSmRow + b] = w[b];
         for (int b = BAND; b < kSmRow - 1; b++) R[(size_t)j * kSmRow + b] = 0.0;
         R[(size_t)j * kSmRow + kSmRow - 1] = 1.0 / w[0];
-    };
-    fetch_data(0);
-    if (nb > 0) fetch_jump(0);
-    while (i < m || r < nb) {
-        const bool data = i < m && (r >= nb || lbi <= r);
-        int j0;
-        if (data) {
-            j0 = lbi;
-#pragma unroll
-            for (int e = 0; e < BAND; e++) h[e] = hd[e];
-            if (++i < m) fetch_data(i);
-        } else {
-            j0 = r;
-#pragma unroll
-            for (int e = 0; e < BAND; e++) h[e] = hj[e];
-            if (++r < nb) fetch_jump(r);
-        }
-        while (win0 < j0) {
-            retire(win0, W[0]);
-#pragma unroll
-            for (int q = 0; q + 1 < BAND; q++)
-#pragma unroll
-                for (int b = 0; b < BAND; b++) W[q][b] = W[q + 1][b];
-#pragma unroll
-            for (int b = 0; b < BAND; b++) W[BAND - 1][b] = 0.0;
-            win0++;
-        }
-        bool live = true;
-#pragma unroll
-        for (int q = 0; q < BAND; q++) {
-            if (live && j0 + q < ncf) {
-                const double piv = h[0];
-                if (piv != 0.0) {
-                    const double ww = W[q][0], store = fabs(piv);
-                    const double dd = (store >= ww) ? store * sqrt(1.0 + (ww / piv) * (ww / piv)) : ww * sqrt(1.0 + (piv / ww) * (piv / ww));
-                    const double cs = ww / dd, sn = piv / dd;
-                    W[q][0] = dd;
-#pragma unroll
-                    for (int b = 1; b < BAND; b++) {
-                        const double s1 = h[b], s2 = W[q][b];
-                        W[q][b] = cs * s2 + sn * s1;
-                        h[b] = cs * s1 - sn * s2;
-                    }
-                }
-                bool any = false;
-#pragma unroll
-                for (int b = 0; b + 1 < BAND; b++) {
-                    h[b] = h[b + 1];
-                    any |= (h[b] != 0.0);
-                }
-                h[BAND - 1] = 0.0;
-                live = any;
-            }
-        }
     }
-#pragma unroll
-    for (int q = 0; q < BAND; q++)
-        if (win0 + q < ncf) retire(win0 + q, W[q]);  // (the last row enters at ncf - BAND or later: every row of R is stored)
 }
 
-// grid (2 axes, planes), one wave each, lane 0 at work: the band factor(s) of this round's fit
-__global__ __launch_bounds__(64) void k_smb_factor(SmPlaneDev *planes)
+// grid (2 axes, planes), one wave each: the band factor of this round's fit along the axes of degree K (the degree is a
+// constant of the call: one instantiation per degree keeps each within its own registers). The wave first copies the row
+// stream - entries and first columns, compact - into LDS: a row of 40-56 bytes per microsecond-long trip to HBM would leave
+// the pipeline waiting most of the time.
+__host__ __device__ inline size_t sm_factor_lds_bytes(int n_rows, int k) { return (size_t)n_rows * (k + 2) * sizeof(double) + (size_t)n_rows * sizeof(int); }
+constexpr int kFactorBlock = 256;  // (four waves copy the stream into LDS, the first runs the pipeline)
+template <int K>
+__global__ __launch_bounds__(kFactorBlock) void k_smb_factor(SmPlaneDev *planes, int lds)
 {
+    extern __shared__ double sm_rows[];
     SmPlaneDev &P = planes[blockIdx.y];
-    if (!P.active || threadIdx.x != 0) return;
+    if (!P.active) return;
     const SmAxisDev &a = blockIdx.x ? P.x : P.y;
+    if (a.k != K) return;
     if (!a.knots_changed && a.nb == 0) return;  // (the knot search: this axis kept its knots, and with them its factor)
-    switch (a.k) {
-    case 1: sm_factor_axis<3>(a); break;
-    case 2: sm_factor_axis<4>(a); break;
-    case 3: sm_factor_axis<5>(a); break;
-    case 4: sm_factor_axis<6>(a); break;
-    default: sm_factor_axis<7>(a); break;
+    constexpr int BAND = K + 2;
+    const bool merged = a.nb > 0;
+    const int n_rows = a.m + a.nb, hs_g = merged ? kSmRow : 6, we = merged ? BAND : K + 1;
+    const double *rowh_g = merged ? a.mg_h : a.hb;
+    const int *rowl_g = merged ? a.mg_l : a.lb;
+    if (lds) {
+        double *hS = sm_rows;
+        int *lS = (int *)(hS + (size_t)n_rows * BAND);
+        sm_stage<kFactorBlock>(hS, n_rows * BAND, [&](int x) {
+            const int row = x / BAND, e = x - row * BAND;
+            return e < we ? rowh_g[(size_t)row * hs_g + e] : 0.0;
+        });
+        sm_stage<kFactorBlock>(lS, n_rows, [&](int x) { return rowl_g[x]; });
+        __syncthreads();
+        if (threadIdx.x < 64) sm_factor_stream<BAND>(hS, BAND, BAND, lS, n_rows, a.R, a.nc());
+    } else if (threadIdx.x < 64) {
+        sm_factor_stream<BAND>(rowh_g, hs_g, we, rowl_g, n_rows, a.R, a.nc());
     }
 }
 
 // ------------------------------------------------------------------ one directional least-squares solve
 // dir 0: along the image rows' index for every image column (right-hand sides = the nx columns of z, solution U: nr x nx);
 // dir 1: along the image columns' index for every row coefficient (right-hand sides = the nr columns of U', solution
-// C': ncx x nr). pass 0: c = (R'R)^-1 A'd; pass 1: c += (R'R)^-1 (A'(d - A c) - (B/p)'(B/p) c).
+// C': ncx x nr). pass 0: c = (R'R)^-1 A'd; pass 1: c += (R'R)^-1 [A; B/p]' ([d; 0] - [A; B/p] c).
 // One lane per right-hand side q (coalesced over q): the samples are walked once, `s` holds the partial sums of the
 // k + 1 coefficients the current knot interval touches; a coefficient whose last sample has passed is complete and takes
 // its step of the forward substitution R'w = g at once (w -> G); then the back substitution R x = w.
-template <int K>
-__device__ void sm_solve(const SmPlaneDev &P, const SmAxisDev &a, const double *__restrict__ in, int si, int nrhs, double *__restrict__ c,
-                         double *__restrict__ g, int q, int pass)
+// A sweep is ~3 m dependent steps: what it is built around is not WAITING at each of them. Everything that is the same
+// for every lane - the entries and first column of each row, the rows of R - is staged in LDS once per workgroup (compact
+// rows; when it does not fit, the sweep reads the tables where they are) and read four rows at a time; the right-hand
+// side is the only stream from HBM and comes in tiles of 8 requested a tile ahead (so does the work vector on the way
+// back); the column of R a closing needs is requested at the closing before. The second pass takes its residuals from a
+// kernel of its own (k_smb_res: fully parallel) - the jump rows merged among the collocation rows as rows like any other.
+constexpr int kSolveBlock = 256;
+constexpr int kSmTileIn = 8, kSmGroup = 4;
+
+// W: entries per row (k + 1 for the collocation rows alone, k + 2 with the jump rows among them)
+template <int K, int W, bool LDS>
+__device__ __forceinline__ void sm_sweep(const SmAxisDev &a, bool merged, const double *__restrict__ in, int si, int nrhs,
+                                         double *__restrict__ c, double *__restrict__ g, int q, int pass, double *smem)
 {
-    constexpr int BAND = K + 2;
-    const int m = a.m, nc = a.nc(), nb = pass ? a.nb : 0;
-    const double *__restrict__ R = a.R;
-    const double *__restrict__ hb = a.hb;
-    const double *__restrict__ Bp = a.Bp;
-    const int *__restrict__ lb = a.lb;
-    double s[K + 1], w[BAND - 1], vw[BAND];  // w[b]: w_{j-1-b}; vw[b]: v_{j-b} of the jump rows
+    constexpr int BAND = K + 2, TI = kSmTileIn, GR = kSmGroup;
+    const int nc = a.nc(), n_rows = merged ? a.m + a.nb : a.m;
+    const double *rowh_g = merged ? a.mg_h : a.hb;
+    const int *rowl_g = merged ? a.mg_l : a.lb;
+    const int hs_g = merged ? kSmRow : 6, we = merged ? W : K + 1;  // (a collocation row has k + 1 entries, the slot behind them is another row's)
+    const double *rowh = rowh_g, *RT = a.R;
+    const int *rowl = rowl_g;
+    int hs = hs_g, rs = kSmRow, ri = kSmRow - 1;
+    if (LDS) {
+        double *hS = smem, *RS = hS + (size_t)n_rows * W;
+        int *lS = (int *)(RS + (size_t)nc * (BAND + 1));
+        sm_stage<kSolveBlock>(hS, n_rows * W, [&](int x) {
+            const int row = x / W, e = x - row * W;
+            return e < we ? rowh_g[(size_t)row * hs_g + e] : 0.0;
+        });
+        sm_stage<kSolveBlock>(RS, nc * (BAND + 1), [&](int x) {
+            const int j = x / (BAND + 1), b = x - j * (BAND + 1);
+            return a.R[(size_t)j * kSmRow + (b == BAND ? kSmRow - 1 : b)];
+        });
+        sm_stage<kSolveBlock>(lS, n_rows, [&](int x) { return rowl_g[x]; });
+        __syncthreads();
+        rowh = hS; hs = W;
+        RT = RS; rs = BAND + 1; ri = BAND;
+        rowl = lS;
+    }
+    if (q >= nrhs) return;
+    double s[W], w[BAND - 1], rc[BAND - 1], rcinv;  // w[b]: w_{cur-1-b}; rc[b-1] = R(cur - b, cur), rcinv = 1 / R(cur, cur)
 #pragma unroll
-    for (int e = 0; e <= K; e++) s[e] = 0.0;
+    for (int e = 0; e < W; e++) s[e] = 0.0;
 #pragma unroll
     for (int b = 0; b < BAND - 1; b++) w[b] = 0.0;
+    int cur = 0;
+    auto fetch_col = [&](int j) {  // what the closing of coefficient j multiplies by, requested a closing ahead
 #pragma unroll
-    for (int b = 0; b < BAND; b++) vw[b] = 0.0;
-    auto close = [&](int j, double gj) {
-        if (nb) {  // the jump rows have a zero right-hand side: their residual is -(B/p) c
-#pragma unroll
-            for (int b = BAND - 1; b > 0; b--) vw[b] = vw[b - 1];
-            double v = 0.0;
-            if (j < nb) {
-#pragma unroll
-                for (int e = 0; e < BAND; e++) v += Bp[(size_t)j * kSmRow + e] * c[(size_t)(j + e) * nrhs + q];
-            }
-            vw[0] = v;
-#pragma unroll
-            for (int b = 0; b < BAND; b++)
-                if (j - b >= 0 && j - b < nb) gj -= Bp[(size_t)(j - b) * kSmRow + b] * vw[b];
-        }
+        for (int b = 1; b < BAND; b++) rc[b - 1] = (j - b >= 0) ? RT[(size_t)(j - b) * rs + b] : 0.0;
+        rcinv = RT[(size_t)j * rs + ri];
+    };
+    fetch_col(0);
+    auto close = [&](double gj) {  // coefficient `cur` is complete: its step of R'w = g
         double sv = gj;
 #pragma unroll
-        for (int b = 1; b < BAND; b++)
-            if (j - b >= 0) sv -= R[(size_t)(j - b) * kSmRow + b] * w[b - 1];
-        sv *= R[(size_t)j * kSmRow + kSmRow - 1];
-        g[(size_t)j * nrhs + q] = sv;
+        for (int b = BAND - 1; b >= 1; b--) sv -= rc[b - 1] * w[b - 1];  // (the newest w last: the others do not wait for it)
+        sv *= rcinv;
+        g[(size_t)cur * nrhs + q] = sv;
 #pragma unroll
         for (int b = BAND - 2; b > 0; b--) w[b] = w[b - 1];
         w[0] = sv;
+        cur++;
+        if (cur < nc) fetch_col(cur);
     };
-    int cur = 0;
-    for (int i = 0; i < m; i++) {
-        const int l0 = lb[i];
-        while (cur < l0) {
-            close(cur, s[0]);
+    double tin[TI], tnext[TI];
+    auto fetch = [&](int i0) {
 #pragma unroll
-            for (int e = 0; e < K; e++) s[e] = s[e + 1];
-            s[K] = 0.0;
-            cur++;
+        for (int u = 0; u < TI; u++) tnext[u] = (i0 + u < n_rows) ? in[(size_t)(i0 + u) * si + q] : 0.0;
+    };
+    fetch(0);
+    for (int i0 = 0; i0 < n_rows; i0 += TI) {
+#pragma unroll
+        for (int u = 0; u < TI; u++) tin[u] = tnext[u];
+        if (i0 + TI < n_rows) fetch(i0 + TI);
+#pragma unroll
+        for (int gq = 0; gq < TI / GR; gq++) {
+            const int ib = i0 + gq * GR;
+            if (ib < n_rows) {
+                // the tables of four rows at once: one wait instead of eight
+                int l4[GR];
+                double h4[GR][W];
+#pragma unroll
+                for (int u = 0; u < GR; u++) {
+                    const int ii = min(ib + u, n_rows - 1);
+                    l4[u] = rowl[ii];
+#pragma unroll
+                    for (int e = 0; e < W; e++) h4[u][e] = (LDS || e < we) ? rowh[(size_t)ii * hs + e] : 0.0;
+                }
+                if (ib + GR <= n_rows && l4[GR - 1] == cur) {  // no coefficient closes inside the group
+#pragma unroll
+                    for (int u = 0; u < GR; u++)
+#pragma unroll
+                        for (int e = 0; e < W; e++) s[e] += h4[u][e] * tin[gq * GR + u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < GR; u++)
+                        if (ib + u < n_rows) {
+                            while (cur < l4[u]) {
+                                const double g0 = s[0];
+#pragma unroll
+                                for (int e = 0; e + 1 < W; e++) s[e] = s[e + 1];
+                                s[W - 1] = 0.0;
+                                close(g0);
+                            }
+#pragma unroll
+                            for (int e = 0; e < W; e++) s[e] += h4[u][e] * tin[gq * GR + u];
+                        }
+                }
+            }
         }
-        double r = in[(size_t)i * si + q];
-        if (pass) {
-#pragma unroll
-            for (int e = 0; e <= K; e++) r -= hb[(size_t)i * 6 + e] * c[(size_t)(l0 + e) * nrhs + q];
-        }
-#pragma unroll
-        for (int e = 0; e <= K; e++) s[e] += hb[(size_t)i * 6 + e] * r;
     }
 #pragma unroll
-    for (int e = 0; e <= K; e++)
-        if (cur + e < nc) close(cur + e, s[e]);
-    // back substitution R x = w, then c = x (first pass) or c += x
+    for (int e = 0; e < W; e++)
+        if (cur < nc) close(s[e]);
+    // back substitution R x = w, then c = x (first pass) or c += x; w comes back in tiles requested a tile ahead
     double x[BAND - 1];
 #pragma unroll
     for (int b = 0; b < BAND - 1; b++) x[b] = 0.0;
-    for (int j = nc - 1; j >= 0; j--) {
-        double sv = g[(size_t)j * nrhs + q];
+    auto fetch_g = [&](int jt) {
 #pragma unroll
-        for (int b = 1; b < BAND; b++) sv -= R[(size_t)j * kSmRow + b] * x[b - 1];  // (entries beyond the matrix are zeros)
-        sv *= R[(size_t)j * kSmRow + kSmRow - 1];
+        for (int u = 0; u < TI; u++) tnext[u] = g[(size_t)max(jt - u, 0) * nrhs + q];
+    };
+    fetch_g(nc - 1);
+    for (int jt = nc - 1; jt >= 0; jt -= TI) {
 #pragma unroll
-        for (int b = BAND - 2; b > 0; b--) x[b] = x[b - 1];
-        x[0] = sv;
-        const size_t ci = (size_t)j * nrhs + q;
-        c[ci] = pass ? c[ci] + sv : sv;
+        for (int u = 0; u < TI; u++) tin[u] = tnext[u];
+        if (jt - TI >= 0) fetch_g(jt - TI);
+        double cold[TI];
+        if (pass) {
+#pragma unroll
+            for (int u = 0; u < TI; u++) cold[u] = c[(size_t)max(jt - u, 0) * nrhs + q];
+        }
+#pragma unroll
+        for (int u = 0; u < TI; u++) {  // (rows below 0 in the last tile come after the valid ones: computed on row 0's tables, never stored)
+            const int j = max(jt - u, 0);
+            double sv = tin[u];
+#pragma unroll
+            for (int b = BAND - 1; b >= 1; b--) sv -= RT[(size_t)j * rs + b] * x[b - 1];  // (entries beyond the matrix are zeros)
+            sv *= RT[(size_t)j * rs + ri];
+#pragma unroll
+            for (int b = BAND - 2; b > 0; b--) x[b] = x[b - 1];
+            x[0] = sv;
+            if (jt - u >= 0) c[(size_t)j * nrhs + q] = pass ? cold[u] + sv : sv;
+        }
     }
 }
 
-__global__ __launch_bounds__(64) void k_smb_solve(SmPlaneDev *planes, int dir, int pass)
+// LDS the compact tables of a sweep take: rows x entries, the factor, the first columns
+__host__ __device__ inline size_t sm_sweep_lds_bytes(int n_rows, int w, int k, int nc)
 {
+    return ((size_t)n_rows * w + (size_t)nc * (k + 3)) * sizeof(double) + (size_t)n_rows * sizeof(int);
+}
+
+// grid (right-hand sides / 256, planes); pass 0 walks the collocation rows with the data (z, or U' for dir 1), pass 1
+// every row of [A; B / p] with the residuals k_smb_res left in RB
+template <int K, int PASS>
+__global__ __launch_bounds__(kSolveBlock) void k_smb_solve(SmPlaneDev *planes, int dir, int lds)
+{
+    extern __shared__ double sm_tables[];
     const SmPlaneDev &P = planes[blockIdx.y];
     if (!P.active) return;
     const SmAxisDev &a = dir ? P.x : P.y;
     const int nr = P.y.nc();
     const int nrhs = dir ? nr : P.x.m;
-    const int q = blockIdx.x * 64 + threadIdx.x;
-    if (q >= nrhs) return;
-    const double *in = dir ? P.UT : P.z;
-    const int si = dir ? nr : P.x.m;
+    if ((int)(blockIdx.x * kSolveBlock) >= nrhs) return;
+    const int q = blockIdx.x * kSolveBlock + threadIdx.x;
     double *c = dir ? P.CT : P.U;
-    switch (a.k) {
-    case 1: sm_solve<1>(P, a, in, si, nrhs, c, P.G, q, pass); break;
-    case 2: sm_solve<2>(P, a, in, si, nrhs, c, P.G, q, pass); break;
-    case 3: sm_solve<3>(P, a, in, si, nrhs, c, P.G, q, pass); break;
-    case 4: sm_solve<4>(P, a, in, si, nrhs, c, P.G, q, pass); break;
-    default: sm_solve<5>(P, a, in, si, nrhs, c, P.G, q, pass); break;
+    constexpr int W = PASS ? K + 2 : K + 1;
+    const double *in = PASS ? P.RB : (dir ? P.UT : P.z);
+    const int si = PASS ? nrhs : (dir ? nr : P.x.m);
+    const bool merged = PASS && a.nb > 0;
+    if (lds) sm_sweep<K, W, true>(a, merged, in, si, nrhs, c, P.G, q, PASS, sm_tables);
+    else sm_sweep<K, W, false>(a, merged, in, si, nrhs, c, P.G, q, PASS, nullptr);
+}
+
+// residuals of every row of a direction's system after the first pass, in the order the second pass walks them:
+// d - A c for the collocation rows, -(B / p) c for the jump rows. grid (right-hand sides / 256, rows / 4, planes)
+__global__ __launch_bounds__(kBlock) void k_smb_res(SmPlaneDev *planes, int dir)
+{
+    const SmPlaneDev &P = planes[blockIdx.z];
+    if (!P.active) return;
+    const SmAxisDev &a = dir ? P.x : P.y;
+    const int nr = P.y.nc(), nrhs = dir ? nr : P.x.m, nb = a.nb, n_rows = a.m + nb, k = a.k;
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nrhs || (int)blockIdx.y * 4 >= n_rows) return;
+    const double *in = dir ? P.UT : P.z, *c = dir ? P.CT : P.U;
+    const int si = dir ? nr : P.x.m;
+    for (int u = 0; u < 4; u++) {
+        const int x = blockIdx.y * 4 + u;
+        if (x >= n_rows) break;
+        const int src = nb ? a.mg_src[x] : x;
+        double v;
+        if (src >= 0) {
+            v = in[(size_t)src * si + q];
+            const int l0 = a.lb[src];
+            for (int e = 0; e <= k; e++) v -= a.hb[(size_t)src * 6 + e] * c[(size_t)(l0 + e) * nrhs + q];
+        } else {
+            const int r = -src - 1;
+            v = 0.0;
+            for (int e = 0; e < k + 2; e++) v -= a.Bp[(size_t)r * kSmRow + e] * c[(size_t)(r + e) * nrhs + q];
+        }
+        P.RB[(size_t)x * nrhs + q] = v;
     }
 }
 
@@ -623,34 +841,50 @@ __global__ __launch_bounds__(kBlock) void k_smb_transpose(SmPlaneDev *planes)
 
 // Squared residuals of the fitted spline at the pixels of a 64 x 64 tile, summed per image row and per image column of
 // the tile in a fixed order (k_smb_decide adds the tiles up): grid (tiles_x, tiles_y, planes), 4 waves, lane = column.
+// The coefficients the tile's pixels touch - at most (64 + k)^2 - are staged in LDS (read from C' along its contiguous
+// index): a lane's (k + 1)^2 reads per pixel would otherwise be as many gathers with a stride of nr doubles between lanes.
+constexpr int kSmCt = kSmTile + 5;
 __global__ __launch_bounds__(kBlock) void k_smb_resid(SmPlaneDev *planes)
 {
     __shared__ double colacc[4][kSmTile];
+    __shared__ double ct[kSmCt][kSmCt + 2];  // (an odd stride in doubles: lanes that differ in their row do not meet in a bank)
+    __shared__ double hys[kSmTile][6];
+    __shared__ int las[kSmTile];
     const SmPlaneDev &P = planes[blockIdx.z];
     if (!P.active) return;
     const SmAxisDev &ay = P.y, &ax = P.x;
     const int my = ay.m, mx = ax.m, nr = ay.nc(), ky = ay.k, kx = ax.k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int j = blockIdx.x * kSmTile + lane;
+    const int j_first = blockIdx.x * kSmTile, i_first = blockIdx.y * kSmTile;
+    const int c_lo = ax.lb[j_first], c_n = ax.lb[min(j_first + kSmTile, mx) - 1] + kx + 1 - c_lo;
+    const int a_lo = ay.lb[i_first], a_n = ay.lb[min(i_first + kSmTile, my) - 1] + ky + 1 - a_lo;
+    for (int x = threadIdx.x; x < c_n * a_n; x += kBlock) {
+        const int cc = x / a_n, aa = x - cc * a_n;
+        ct[cc][aa] = P.CT[(size_t)(c_lo + cc) * nr + (a_lo + aa)];
+    }
+    for (int x = threadIdx.x; x < kSmTile * 6; x += kBlock) hys[x / 6][x % 6] = ay.hb[(size_t)min(i_first + x / 6, my - 1) * 6 + x % 6];
+    if (threadIdx.x < kSmTile) las[threadIdx.x] = ay.lb[min(i_first + (int)threadIdx.x, my - 1)] - a_lo;
+    __syncthreads();
+    const int j = j_first + lane;
     const bool live = j < mx;
     double hx[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     int lbx = 0;
     if (live) {
-        lbx = ax.lb[j];
+        lbx = ax.lb[j] - c_lo;
         for (int b = 0; b <= kx; b++) hx[b] = ax.hb[(size_t)j * 6 + b];
     }
     double csum = 0.0;
     for (int rr = 0; rr < kSmTile / 4; rr++) {
-        const int i = blockIdx.y * kSmTile + wave * (kSmTile / 4) + rr;
+        const int i = i_first + wave * (kSmTile / 4) + rr;
         if (i >= my) break;
         double term = 0.0;
         if (live) {
-            const int la = ay.lb[i];
-            const double *hy = ay.hb + (size_t)i * 6;
+            const int la = las[i - i_first];
+            const double *hy = hys[i - i_first];
             double sv = 0.0;
             for (int b = 0; b <= kx; b++) {
                 double r = 0.0;
-                for (int e = 0; e <= ky; e++) r += hy[e] * P.CT[(size_t)(lbx + b) * nr + (la + e)];
+                for (int e = 0; e <= ky; e++) r += hy[e] * ct[lbx + b][la + e];
                 sv += hx[b] * r;
             }
             const double d = P.z[(size_t)i * mx + j] - sv;
@@ -726,7 +960,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
     // per-plane workspace: byte offsets inside a plane's slice of the arena
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    struct AxisOff { size_t hb, lb, span, R, Bp, t, fpint, nrdata; } ao[2];
+    struct AxisOff { size_t hb, lb, span, R, Bp, t, fpint, nrdata, mg_src, mg_l, mg_h; } ao[2];
     for (int ax = 0; ax < 2; ax++) {
         const size_t m = (size_t)(ax ? nx : ny), cap = m + 16;
         ao[ax].hb = take(cap * 6 * 8);
@@ -737,10 +971,13 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         ao[ax].t = take(cap * 8);
         ao[ax].fpint = take(cap * 8);
         ao[ax].nrdata = take(cap * 4);
+        ao[ax].mg_src = take(2 * cap * 4);
+        ao[ax].mg_l = take(2 * cap * 4);
+        ao[ax].mg_h = take(2 * cap * kSmRow * 8);
     }
     const size_t o_rowpart = take((size_t)tiles_x * ny * 8), o_colpart = take((size_t)tiles_y * nx * 8);
     const size_t o_rowsum = take((size_t)ny * 8), o_colsum = take((size_t)nx * 8);
-    const size_t o_U = take(npx * 8), o_UT = take(npx * 8), o_G = take(npx * 8), o_CT = take(npx * 8);
+    const size_t o_U = take(npx * 8), o_UT = take(npx * 8), o_G = take(npx * 8), o_CT = take(npx * 8), o_RB = take(2 * npx * 8);
     const size_t per_plane = off;
     // planes whose searches advance together: what half of the free memory (at most 24 GiB) holds, PM_OPT_SM_BATCH_PLANES
     size_t free_b = 0, total_b = 0;
@@ -763,6 +1000,20 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         ctx->sm_arena_bytes = arena_need;
     }
     if (!ctx->sm_status_host) PM_HIP(ctx, hipHostMalloc((void **)&ctx->sm_status_host, 4 * sizeof(int)));
+    // (more than 64 KB of dynamic LDS has to be enabled per kernel)
+    static const size_t lds_limit = [] {
+        const int want = 160 * 1024 - 256;
+        bool ok = true;
+        auto allow = [&](const void *f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess; };
+        allow((const void *)pm::k_smb_solve<1, 0>); allow((const void *)pm::k_smb_solve<1, 1>);
+        allow((const void *)pm::k_smb_solve<2, 0>); allow((const void *)pm::k_smb_solve<2, 1>);
+        allow((const void *)pm::k_smb_solve<3, 0>); allow((const void *)pm::k_smb_solve<3, 1>);
+        allow((const void *)pm::k_smb_solve<4, 0>); allow((const void *)pm::k_smb_solve<4, 1>);
+        allow((const void *)pm::k_smb_solve<5, 0>); allow((const void *)pm::k_smb_solve<5, 1>);
+        allow((const void *)pm::k_smb_factor<1>); allow((const void *)pm::k_smb_factor<2>); allow((const void *)pm::k_smb_factor<3>);
+        allow((const void *)pm::k_smb_factor<4>); allow((const void *)pm::k_smb_factor<5>);
+        return ok ? (size_t)want : (size_t)(64 * 1024);
+    }();
     int rc = ensure_work(ctx, batch * npx * sizeof(double));
     if (rc != PM_OK) return rc;
     rc = ensure_stats(ctx, batch);
@@ -798,12 +1049,16 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
                 A.t = (double *)(sl + ao[ax].t);
                 A.fpint = (double *)(sl + ao[ax].fpint);
                 A.nrdata = (int *)(sl + ao[ax].nrdata);
+                A.mg_src = (int *)(sl + ao[ax].mg_src);
+                A.mg_l = (int *)(sl + ao[ax].mg_l);
+                A.mg_h = (double *)(sl + ao[ax].mg_h);
                 A.m = ax ? nx : ny;
                 A.k = ax ? k_cols : k_rows;
                 A.n = 2 * (A.k + 1);
             }
             d.z = ctx->work + (size_t)pl * plane_elems;
             d.U = (double *)(sl + o_U); d.UT = (double *)(sl + o_UT); d.G = (double *)(sl + o_G); d.CT = (double *)(sl + o_CT);
+            d.RB = (double *)(sl + o_RB);
             d.rowpart = (double *)(sl + o_rowpart); d.colpart = (double *)(sl + o_colpart);
             d.rowsum = (double *)(sl + o_rowsum); d.colsum = (double *)(sl + o_colsum);
             d.s = s;
@@ -813,11 +1068,13 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         PM_HIP(ctx, hipMemcpyAsync(planes, desc.data(), (size_t)np * sizeof(pm::SmPlaneDev), hipMemcpyHostToDevice, st));
         // FITPACK's own caps bound the rounds: ny + nx knot iterations, then 20 steps of p (+ the closing decision)
         const int max_rounds = ny + nx + 20 + 2;
+        const size_t decide_need = std::max(pm::sm_decide_lds_bytes(ny, k_rows), pm::sm_decide_lds_bytes(nx, k_cols));
+        const size_t decide_lds = decide_need <= (size_t)(64 * 1024) ? decide_need : 0;
         int round = 0;
         for (; round < max_rounds; round++) {
             PM_HIP(ctx, hipMemsetAsync(status, 0, 4 * sizeof(int), st));
-            hipLaunchKernelGGL(pm::k_smb_decide, dim3(np), dim3(64), 0, st, planes, (const pm::PlaneStats *)ctx->stats, status,
-                               round == 0 ? 1 : 0, tiles_x, tiles_y);
+            hipLaunchKernelGGL(pm::k_smb_decide, dim3(np), dim3(64), decide_lds, st, planes, (const pm::PlaneStats *)ctx->stats, status,
+                               round == 0 ? 1 : 0, tiles_x, tiles_y, decide_lds ? 1 : 0);
             PM_HIP(ctx, hipMemcpyAsync(ctx->sm_status_host, status, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
             PM_HIP(ctx, hipStreamSynchronize(st));
             const int n_active = ctx->sm_status_host[0], ncy = ctx->sm_status_host[1], ncx = ctx->sm_status_host[2];
@@ -833,12 +1090,41 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
             if (ncy < 1 || ncy > ny || ncx < 1 || ncx > nx)
                 return fail(ctx, PM_ERR_STATE, "smoothing-spline search: coefficient counts (%d, %d) outside the image (%d, %d)", ncy, ncx, ny, nx);
             hipLaunchKernelGGL(pm::k_smb_tables, dim3(2, np), dim3(pm::kBlock), 0, st, planes);
-            hipLaunchKernelGGL(pm::k_smb_factor, dim3(2, np), dim3(64), 0, st, planes);
-            hipLaunchKernelGGL(pm::k_smb_solve, dim3((nx + 63) / 64, np), dim3(64), 0, st, planes, 0, 0);
-            hipLaunchKernelGGL(pm::k_smb_solve, dim3((nx + 63) / 64, np), dim3(64), 0, st, planes, 0, 1);
+            const int any_p = ctx->sm_status_host[3];
+            auto for_degree = [&](int k, auto &&launch) {  // the degree of an axis is a constant of the call
+                switch (k) {
+                case 1: launch(std::integral_constant<int, 1>()); break;
+                case 2: launch(std::integral_constant<int, 2>()); break;
+                case 3: launch(std::integral_constant<int, 3>()); break;
+                case 4: launch(std::integral_constant<int, 4>()); break;
+                default: launch(std::integral_constant<int, 5>()); break;
+                }
+            };
+            {
+                const size_t fy = pm::sm_factor_lds_bytes(ny + (any_p ? ncy : 0), k_rows), fx = pm::sm_factor_lds_bytes(nx + (any_p ? ncx : 0), k_cols);
+                const size_t fb = std::max(fy, fx);
+                auto factor = [&](auto K) {
+                    hipLaunchKernelGGL(pm::k_smb_factor<decltype(K)::value>, dim3(2, np), dim3(pm::kFactorBlock), fb <= lds_limit ? fb : 0, st, planes, fb <= lds_limit ? 1 : 0);
+                };
+                for_degree(k_rows, factor);
+                if (k_cols != k_rows) for_degree(k_cols, factor);
+            }
+            auto solve = [&](int dir) {
+                // the compact tables of the LARGEST fit of the round decide between LDS and the tables where they are
+                const int m = dir ? nx : ny, k = dir ? k_cols : k_rows, ncm = dir ? ncx : ncy, nrhs = dir ? ncy : nx;
+                const int rows1 = m + (any_p ? ncm : 0);
+                const size_t b0 = pm::sm_sweep_lds_bytes(m, k + 1, k, ncm), b1 = pm::sm_sweep_lds_bytes(rows1, k + 2, k, ncm);
+                const dim3 grid((nrhs + pm::kSolveBlock - 1) / pm::kSolveBlock, np), block(pm::kSolveBlock);
+                for_degree(k, [&](auto K) {
+                    constexpr int kk = decltype(K)::value;
+                    hipLaunchKernelGGL((pm::k_smb_solve<kk, 0>), grid, block, b0 <= lds_limit ? b0 : 0, st, planes, dir, b0 <= lds_limit ? 1 : 0);
+                    hipLaunchKernelGGL(pm::k_smb_res, dim3((nrhs + pm::kBlock - 1) / pm::kBlock, (rows1 + 3) / 4, np), dim3(pm::kBlock), 0, st, planes, dir);
+                    hipLaunchKernelGGL((pm::k_smb_solve<kk, 1>), grid, block, b1 <= lds_limit ? b1 : 0, st, planes, dir, b1 <= lds_limit ? 1 : 0);
+                });
+            };
+            solve(0);
             hipLaunchKernelGGL(pm::k_smb_transpose, dim3((nx + 15) / 16, (ncy + 15) / 16, np), dim3(pm::kBlock), 0, st, planes);
-            hipLaunchKernelGGL(pm::k_smb_solve, dim3((ncy + 63) / 64, np), dim3(64), 0, st, planes, 1, 0);
-            hipLaunchKernelGGL(pm::k_smb_solve, dim3((ncy + 63) / 64, np), dim3(64), 0, st, planes, 1, 1);
+            solve(1);
             hipLaunchKernelGGL(pm::k_smb_resid, dim3(tiles_x, tiles_y, np), dim3(pm::kBlock), 0, st, planes);
             PM_HIP(ctx, hipGetLastError());
         }

@@ -19,9 +19,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--seeds', type=int, default=40)
     ap.add_argument('--first', type=int, default=int(time.time()) % 100000 * 1000)
-    ap.add_argument('--only', default='', help='one of discs_fast, reprojection, geometries, light_time_paths')
+    ap.add_argument('--only', default='', help='one of discs_fast, reprojection, geometries, light_time_paths, smoothing')
     args = ap.parse_args()
     import test_gpu_parity as T
+    import test_gpu_splines_cube_scale as S
     from oracle import oracle
     from planetmapper_amd import _lib
     from planetmapper_amd.engine import Engine
@@ -38,7 +39,8 @@ def main():
                   if hasattr(T.test_random_discs_and_frames_fuzz, '__wrapped__') else T.test_random_discs_and_frames_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed')),
                  ('reprojection', lambda: T.test_random_reprojection_fuzz(eng, oracle, jupiter, 'fresh_seed')),
                  ('geometries', lambda: T.test_random_geometries_fuzz(eng, oracle, 'fresh_seed')),
-                 ('light_time_paths', lambda: T.test_random_epochs_body_sizes_and_spins_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed'))]  # fmt: skip
+                 ('light_time_paths', lambda: T.test_random_epochs_body_sizes_and_spins_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed')),
+                 ('smoothing', lambda: S.smoothing_fuzz(eng, oracle, jupiter, seed))]  # fmt: skip
         if args.only:
             cases = [c for c in cases if c[0] == args.only]
         for general in (0, 1):

@@ -202,3 +202,57 @@ def test_a_smoothing_fit_in_a_batch_equals_the_plane_fitted_alone(engine, oracle
         for p in (0, 2, 3, 4, 5, 11):
             one = map_resident(engine, cube[p : p + 1], xm, ym, interp, True, spline_smoothing=s)[0]
             assert np.array_equal(one, together[p], equal_nan=True), (interp, p, states[p])
+
+
+def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
+    """
+    Random small frames, degrees (each axis 1-5), smoothing factors at and above the noise level, planes in mixed clean
+    states, both NaN policies: every plane of a batch against the oracle (1e-7 of the data scale, NaN masks identical)
+    and one plane of the batch against itself fitted alone (bit for bit). (`s` far below the noise is not drawn: FITPACK
+    itself runs into singular knot sets there.) tests/soak_fuzz.py --only smoothing runs it over fresh seeds.
+    """
+    rng = np.random.default_rng(seed)
+    for case in range(n_cases):
+        ny, nx = int(rng.integers(16, 90)), int(rng.integers(16, 90))
+        ky, kx = int(rng.integers(1, 6)), int(rng.integers(1, 6))
+        n_planes = int(rng.integers(2, 7))
+        yy, xx = np.mgrid[0:ny, 0:nx]
+        sigma = float(rng.choice([0.3, 1.0, 4.0]))
+        cube = np.empty((n_planes, ny, nx))
+        for p in range(n_planes):
+            cube[p] = np.sin(xx / rng.uniform(3, 15)) * np.cos(yy / rng.uniform(3, 15)) * rng.uniform(1, 20) + sigma * rng.standard_normal((ny, nx))
+        flavour = int(rng.integers(0, 4))
+        if flavour == 1:
+            cube[0][rng.random((ny, nx)) < 0.03] = np.nan
+        elif flavour == 2 and n_planes > 1:
+            cube[1][ny // 3 : ny // 3 + 4, nx // 4 : nx // 4 + 5] = np.nan
+            cube[0][rng.random((ny, nx)) < 0.01] = np.inf
+        elif flavour == 3:
+            cube[n_planes - 1][:] = np.nan
+        x0, y0 = float(rng.uniform(0.35, 0.65) * nx), float(rng.uniform(0.35, 0.65) * ny)
+        r0 = float(rng.uniform(0.25, 0.6) * min(nx, ny))
+        rot = float(rng.uniform(0, 6.28))
+        engine.set_geometry(jupiter)
+        engine.set_disc(x0, y0, r0, rot, nx, ny, True)
+        lon, lat = oracle.rectangular_grid(jupiter, float(rng.choice([5.0, 9.0, 15.0])))
+        xm, ym = engine.xy_map(lon, lat)
+        if np.isfinite(xm).sum() < 20:
+            continue
+        s = float(rng.uniform(0.8, 3.0)) * ny * nx * sigma * sigma
+        label = (seed, case, ny, nx, (ky, kx), s)
+        for prop in (True, False):
+            a = engine.map_cube(cube, xm, ym, (ky, kx), prop, spline_smoothing=s)
+            b = oracle.map_cube(cube, xm, ym, (ky, kx), prop, spline_smoothing=s)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), label
+            for p in range(n_planes):
+                fin = np.isfinite(b[p])
+                if fin.any():
+                    assert np.max(np.abs(a[p][fin] - b[p][fin])) <= 1e-7 * max(1.0, float(np.abs(cube[p][np.isfinite(cube[p])]).max())), label + (p, prop)
+        p = int(rng.integers(0, n_planes))
+        assert np.array_equal(engine.map_cube(cube[p : p + 1], xm, ym, (ky, kx), True, spline_smoothing=s)[0],
+                              engine.map_cube(cube, xm, ym, (ky, kx), True, spline_smoothing=s)[p], equal_nan=True), label + (p,)
+
+
+@pytest.mark.parametrize('seed', [20261004, 5])
+def test_random_smoothing_spline_fuzz(engine, oracle, jupiter, seed):
+    smoothing_fuzz(engine, oracle, jupiter, seed)

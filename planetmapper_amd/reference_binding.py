@@ -1,0 +1,229 @@
+"""
+The reference-side binding: a `planetmapper.Body` (SPICE does the one-time geometry) in, the engine's geometry block out,
+and the mixin that swaps `BodyXY`'s pixel loops for engine calls.
+
+This is the route by which observers the SPICE-free provider (`geometry.py` / `ephem.py`: text PCK + Chebyshev SPK types
+2 / 3) cannot evaluate - HST, JWST, any spacecraft SPK - reach the engine: everything is asked of SPICE through the
+handful of spiceypy calls below, on the user's machine. `spiceypy` (and `planetmapper`) are imported lazily and only
+there; `tests/test_reference_binding.py` runs the same code against a stand-in for spiceypy built on this repo's own
+ephemeris / PCK readers (`tests/spice_standin.py`) and a duck-typed Body, and holds the block against
+`GeometryBuilder`'s to the bars of the motion-model test (displacement < 1e-9 km over +-4 R/c, rotation increment
+< 1e-13 rad).
+
+What the block holds and where the reference computes it: `planetmapper/body.py:501-606` (`Body.__init__`),
+`planetmapper/base.py:795-839` (`BodyBase.__init__`), include/planetmapper_hip.h (`pm_geometry`).
+
+    from planetmapper_amd.reference_binding import geometry_from_body, HipBackplanes
+    class BodyXY(HipBackplanes, planetmapper.BodyXY): ...
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from .geometry import PMGeometry
+
+J2000 = 'J2000'
+
+
+def _spiceypy():
+    import spiceypy  # noqa: PLC0415 - on the user's machine only
+
+    return spiceypy
+
+
+def _chain(spice, body: int, et: float) -> list[tuple[int, int, int]]:
+    """
+    The segments CSPICE adds up for the SSB position of `body` at `et`: [(body, centre, SPK type), ...] down to the
+    solar system barycentre (spksfs / spkuds). Without those two calls: the standard NAIF chain body -> system
+    barycentre -> SSB, types unknown.
+    """
+    hops = []
+    cur = int(body)
+    try:
+        while cur != 0 and len(hops) < 8:
+            _, descr, _ = spice.spksfs(cur, et, 41)
+            _, centre, _, spk_type, *_ = spice.spkuds(descr)
+            hops.append((cur, int(centre), int(spk_type)))
+            cur = int(centre)
+        if cur == 0:
+            return hops
+    except (AttributeError, NotImplementedError):
+        pass
+    if body == 0:
+        return []
+    centre = int(body) // 100 if int(body) >= 100 else 0
+    return [(int(body), centre, 0)] + ([(centre, 0, 0)] if centre else [])
+
+
+def _series_derivatives(values: np.ndarray, offsets: np.ndarray, h: float) -> tuple[np.ndarray, np.ndarray]:
+    """
+    First and second derivative at offset 0 of the quartic through five samples, `values[k]` taken at `offsets[k]` (~ -2h,
+    -h, 0, h, 2h: the ACTUAL differences of the epochs that were evaluated - epochs are doubles with a quantum of 3e-8 s,
+    which a nominal step would turn into 1e-7 km/s of velocity).
+    """
+    x = offsets / h
+    vand = np.vander(x, 5, increasing=True)
+    coeff = np.linalg.solve(vand, values - values[2])  # (differences of neighbouring positions: exact)
+    return coeff[1] / h, 2.0 * coeff[2] / (h * h)
+
+
+def position_series_derivatives(spice, body: int, et: float) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """
+    (p, dp/dt, d2p/dt2) of the SSB POSITION series of `body` at `et` - the series CSPICE re-evaluates at every light-time
+    epoch (`sincpt`, `illumf`, `spkcpt`), which the kernels replace by p + v d + a d^2 / 2.
+
+    Hop by hop along the chain of segments, so that what is differenced is of the hop's own size (a moon about its
+    planet: 4e5 km, ulp 6e-11 km) and not an SSB vector (1e9 km, ulp 1e-7 km): a type 2 segment's state velocity IS the
+    derivative of its position polynomial (taken as it is; the acceleration from differences of it); any other type (3: a
+    velocity polynomial of its own; 5, 9, 13, ...) is differentiated numerically from positions, five points, a step chosen
+    for the size of the vector (rounding ~ ulp / h, truncation ~ h^4 p^(5) / 30).
+    """
+    p = np.zeros(3)
+    v = np.zeros(3)
+    a = np.zeros(3)
+    for hop, centre, spk_type in _chain(spice, body, et):
+        state, _ = spice.spkgeo(hop, et, J2000, centre)
+        state = np.asarray(state, dtype=float)
+        p += state[:3]
+        size = float(np.linalg.norm(state[:3]))
+        if spk_type == 2:
+            h = 64.0
+            ts = np.array([et - 2 * h, et - h, et, et + h, et + 2 * h])
+            vel = np.array([np.asarray(spice.spkgeo(hop, float(t), J2000, centre)[0], dtype=float)[3:] for t in ts])
+            v += state[3:]
+            a += _series_derivatives(vel, ts - et, h)[0]
+        else:
+            h = float(min(4096.0, max(4.0, 2.0 ** np.ceil(np.log2(7.5e9 * np.spacing(max(size, 1.0)))))))
+            ts = np.array([et - 2 * h, et - h, et, et + h, et + 2 * h])
+            pos = np.array([np.asarray(spice.spkgps(hop, float(t), J2000, centre)[0], dtype=float) for t in ts])
+            dv, da = _series_derivatives(pos, ts - et, h)
+            v += dv
+            a += da
+    return p, v, a
+
+
+def state_velocity_derivative(spice, body: int, et: float) -> np.ndarray:
+    """d/dt of the STATE velocity of `body` wrt the SSB (what `spkcpt`'s velocities follow), five-point differences"""
+    h = 64.0
+    ts = np.array([et - 2 * h, et - h, et, et + h, et + 2 * h])
+    vel = np.array([np.asarray(spice.spkssb(body, float(t), J2000), dtype=float)[3:] for t in ts])
+    return _series_derivatives(vel, ts - et, h)[0]
+
+
+def body_z_rate(spice, frame: str, et: float) -> float:
+    """
+    Angular velocity of `frame` about its own +z axis, rad/s, from the derivative block of sxform('J2000', frame, et) -
+    CSPICE differentiates the IAU model term by term (trigonometric terms of W, RA and Dec included: every moon of
+    pck00010.tpc has them): for an inertial vector i = R' b of a body-fixed b, di/dt = w x i with [w]x = (dR/dt)' R.
+    """
+    xf = np.asarray(spice.sxform(J2000, frame, et), dtype=float)
+    rot, drot = xf[:3, :3], xf[3:, :3]
+    skew = drot.T @ rot
+    w_inertial = np.array([skew[2, 1], skew[0, 2], skew[1, 0]])
+    return float((rot @ w_inertial)[2])
+
+
+def geometry_from_body(body, spice=None) -> PMGeometry:
+    """
+    The engine's geometry block of a reference `planetmapper.Body` (or anything that carries the attributes read here).
+    `spice`: the module to ask (default: spiceypy with the kernels `body` has loaded).
+    """
+    spice = spice if spice is not None else _spiceypy()
+    if getattr(body, 'aberration_correction', 'CN') != 'CN':
+        raise NotImplementedError("the engine evaluates the reference's default aberration correction 'CN' only")
+    if getattr(body, 'observer_frame', J2000) != J2000:
+        raise NotImplementedError("the engine works in the reference's default observer frame 'J2000' only")
+    g = PMGeometry()
+    et, lt = float(body.et), float(body.target_light_time)  # base.py:828-839
+    t0 = et - lt
+    target = int(body.target_body_id)
+    g.et, g.lt_c, g.clight = et, lt, float(spice.clight())
+    g.radii[:] = [float(r) for r in body.radii]  # body.py:521
+    g.T0[:] = [float(x) for x in body._target_obsvec]  # base.py:836
+    # the target centre about t0: position series (what a re-evaluation at et - lt' follows) and what a STATE adds
+    p_t0, v_series, a_series = position_series_derivatives(spice, target, t0)
+    state = np.asarray(spice.spkssb(target, t0, J2000), dtype=float)
+    g.VT[:] = v_series
+    g.AT[:] = a_series
+    g.DVT[:] = state[3:] - v_series
+    g.DAT[:] = state_velocity_derivative(spice, target, t0) - a_series
+    g.VO[:] = np.asarray(spice.spkssb(int(spice.bods2c(body.observer)), et, J2000), dtype=float)[3:]
+    # the illumination source seen from the target centre at t0 (one-way light time)
+    source = getattr(body, 'illumination_source', 'SUN')
+    _, lts = spice.spkpos(source, t0, J2000, 'CN', body.target)
+    ts0 = t0 - float(lts)
+    p_s, v_s, a_s = position_series_derivatives(spice, int(spice.bods2c(source)), ts0)
+    g.ts0 = ts0
+    g.S0[:] = p_s - state[:3]
+    g.VS[:] = v_s
+    g.AS[:] = a_s
+    # orientation: the frame at t0 and its rate about its own z axis (R(t0 + d) = Rz(wdot d) R0)
+    g.R0[:] = np.asarray(spice.pxform(J2000, body.target_frame, t0), dtype=float).ravel()
+    g.wdot = body_z_rate(spice, body.target_frame, t0)
+    # what Body.__init__ has already asked of SPICE (body.py:538-588)
+    g.sub_sp[:] = [float(x) for x in body._subpoint_targvec]
+    g.sub_ray[:] = [float(x) for x in body._subpoint_rayvec]
+    g.sub_obsvec[:] = [float(x) for x in body._subpoint_obsvec]
+    g.sub_et = float(body._subpoint_et)
+    g.sub_dist = float(body.subpoint_distance)
+    normal, const = spice.pl2nvc(body._ring_plane)  # body.py:585
+    g.ring_n[:] = [float(x) for x in normal]
+    g.ring_k = float(const)
+    g.M[:] = np.asarray(body._get_obsvec2angular_matrix(), dtype=float).ravel()  # body.py:1317
+    g.diameter_arcsec = float(body.target_diameter_arcsec)
+    g.km_per_arcsec = float(body.km_per_arcsec)
+    g.np_angle_rad = float(np.deg2rad(body.north_pole_angle()))  # body.py:2985
+    sun_b, _ = spice.spkpos('SUN', t0, body.target_frame, 'LT+S', body.target)  # et2lst, body.py:2364
+    g.lst_sun_lon = float(np.arctan2(sun_b[1], sun_b[0]))
+    g.west_positive = int(body.positive_longitude_direction == 'W')  # body.py:526-535
+    return g
+
+
+class HipBackplanes:
+    """
+    Mixed into the reference's `BodyXY` (before it in the MRO): the pixel loops of `body_xy.py:3195-4085` and `map_img`
+    become engine calls; the reference's cache decorators, registry and argument handling stay as they are.
+    """
+
+    _hip_spice = None  # a module to ask instead of spiceypy (tests)
+
+    def _hip(self):
+        from .engine import Engine  # noqa: PLC0415
+
+        eng = self.__dict__.get('_hip_engine')
+        if eng is None:
+            eng = self.__dict__['_hip_engine'] = Engine(0)
+            eng.set_geometry(geometry_from_body(self, self._hip_spice))  # (et, target and observer of a Body never change)
+        eng.set_disc(self.get_x0(), self.get_y0(), self.get_r0(), self._get_rotation_radians(), self._nx, self._ny, self._optimize_speed)
+        return eng
+
+    def _get_lonlat_img(self):  # body_xy.py:3281
+        o = self._hip().backplanes_img(['LON-GRAPHIC', 'LAT-GRAPHIC'], alt=self._alt_adjustment)
+        return np.stack([o['LON-GRAPHIC'], o['LAT-GRAPHIC']], axis=-1)
+
+    def _get_illumination_gie_img(self):  # body_xy.py:3658
+        o = self._hip().backplanes_img(['PHASE', 'INCIDENCE', 'EMISSION'], alt=self._alt_adjustment)
+        return np.stack([o['PHASE'], o['INCIDENCE'], o['EMISSION']], axis=-1)
+
+    def _get_xy_map(self, **map_kwargs):  # body_xy.py:3478
+        ll = self._get_lonlat_map(**map_kwargs)
+        x, y = self._hip().xy_map(ll[..., 0], ll[..., 1], alt=map_kwargs.get('alt', 0.0))
+        return np.stack([x, y], axis=-1)
+
+    def map_img(self, img, *, interpolation='linear', spline_smoothing=0, propagate_nan=True, smooth_oversample_by=5,
+                smooth_max_oversampled_img_size=10_000, **map_kwargs):  # body_xy.py:1414  # fmt: skip
+        return self._hip().map_cube(img, self.get_x_map(**map_kwargs), self.get_y_map(**map_kwargs), interpolation, propagate_nan,
+                                    smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
+                                    spline_smoothing=spline_smoothing)[0]  # fmt: skip
+
+    def illumination_angles_from_lonlat(self, lon, lat, **kw):  # body.py:2295 (and its siblings)
+        o = self._hip().backplanes_map(['PHASE', 'INCIDENCE', 'EMISSION'], np.atleast_2d(lon), np.atleast_2d(lat))
+        return o['PHASE'], o['INCIDENCE'], o['EMISSION']
+
+    def ring_plane_coordinates(self, ra, dec, only_visible=True):  # body.py:2617
+        q = self._hip().radec_query(ra, dec, ring_only_visible=only_visible)  # (8, ...): q[5:8] = limb_coordinates_from_radec body.py:2040
+        return q[2], q[3], q[4]
+
+    def _get_backplane_imgs_for_saving(self, names):  # observation.py:1269-1279
+        return self._hip().backplanes_img(names, alt=self._alt_adjustment)  # all 26 planes, 2 launches

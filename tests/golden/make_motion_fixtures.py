@@ -14,6 +14,8 @@ epoch, as JSON with every float in hex. Nothing of the reference's source is rea
     motion_mars_earth_2012.json     Mars (499, de410s) from Earth at 0.7 au, 2012-03-15: the fastest apparent
                                     motion and the largest light-time rate the bundled kernels offer
     motion_saturn_earth_2016.json   Saturn barycentre (6) as the centre of a Saturn spheroid, 2016-06-03
+    motion_io_like_earth_2009.json  Io's PCK constants (periodic terms in W, RA, Dec) on Jupiter's ephemeris: the reference-binding test
+    motion_moon_earth_2012.json     the Moon (301, de410s) from Earth: a real moon with its own segment (301 wrt 3) and periodic terms
 (Jupiter / HST 2005 and Saturn / Earth 2005 are the package's own scenarios, planetmapper_amd/data/.)
 """
 
@@ -36,6 +38,9 @@ CASES = [
     ('jupiter_earth_2009', 599, 599, 399, (9.0 * 365.25 + 225.3) * SPD, ('de410s', 'jup120')),
     ('mars_earth_2012', 499, 499, 399, (12.0 * 365.25 + 74.2) * SPD, ('de410s',)),
     ('saturn_earth_2016', 6, 699, 399, (16.0 * 365.25 + 154.6) * SPD, ('de410s',)),
+    # (the bundled kernels hold no moon of Jupiter: Io's orientation model - trigonometric terms in W, RA and Dec - on Jupiter's path)
+    ('io_like_earth_2009', 599, 501, 399, (9.0 * 365.25 + 225.3) * SPD, ('de410s', 'jup120')),
+    ('moon_earth_2012', 301, 301, 399, (12.0 * 365.25 + 74.2) * SPD, ('de410s',)),
 ]
 
 

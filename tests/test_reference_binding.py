@@ -1,0 +1,133 @@
+"""
+The reference-side binding (planetmapper_amd/reference_binding.py) EXECUTED: `geometry_from_body` asks a spiceypy-shaped
+module (tests/spice_standin.py, on this repo's own kernel readers) and a duck-typed Body (the attributes a reference
+`planetmapper.Body` carries after `__init__`, body.py:501-606 / base.py:795-839) and must reproduce the block
+`GeometryBuilder` computes from the same kernel data analytically - to the bars of tests/test_motion_model.py:
+displacement of target and Sun < 1e-9 km over +-4 R/c, rotation increment < 1e-13 rad over the disc's light-time
+span; and (`-m gpu`) a 256^2 frame through the engine from either block inside tests/parity.py.
+Cases: Jupiter / Earth 2009 (SPK type 3 target: state velocity != derivative of the position series), Saturn / Earth
+2016, Mars / Earth 2012 (type 2 chain only), an Io-like moon (periodic terms in W, RA, Dec: the rate about the body's
+own z axis is not the PM[1] coefficient) and the Moon from Earth (a moon with its own segment, 60 radii away).
+"""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+CASES = {
+    'jupiter_earth_2009': ('JUPITER', 'IAU_JUPITER'),
+    'saturn_earth_2016': ('SATURN', 'IAU_SATURN'),
+    'mars_earth_2012': ('MARS', 'IAU_MARS'),
+    'io_like_earth_2009': ('IO', 'IAU_IO'),
+    'moon_earth_2012': ('MOON', 'IAU_MOON'),
+}
+
+
+def build(name):
+    """(fixture, GeometryBuilder's block, the binding's block through the stand-in)"""
+    from planetmapper_amd.ephem import Ephemeris, RotationModel
+    from planetmapper_amd.geometry import GeometryBuilder
+    from planetmapper_amd.reference_binding import geometry_from_body
+    from spice_standin import DuckBody, SpiceStandIn
+
+    d = json.load(open(os.path.join(GOLDEN, f'motion_{name}.json')))
+    eph, rot = Ephemeris.from_json(d['ephemeris']), RotationModel.from_json(d['pck'])
+    g = GeometryBuilder(eph, rot, d['target_id']).build(d['et'], observer_id=d['observer_id'])
+    target, frame = CASES[name]
+    spice = SpiceStandIn(eph, {frame: rot}, {target: d['target_id'], 'SUN': 10, 'EARTH': 399})
+    body = DuckBody(g, target=target, target_id=d['target_id'], observer='EARTH', frame=frame)
+    return d, g, geometry_from_body(body, spice), spice
+
+
+def vec(g, name):
+    return np.array(getattr(g, name)[:])
+
+
+@pytest.mark.parametrize('name', list(CASES))
+def test_binding_reproduces_the_geometry_builder_block(name):
+    d, g, b, spice = build(name)
+    r_c = max(g.radii[:]) / g.clight
+    span = 4.0 * r_c
+    # what Body.__init__ handed over comes back unchanged
+    for f in ('et', 'lt_c', 'clight', 'sub_et', 'sub_dist', 'ring_k', 'diameter_arcsec', 'km_per_arcsec', 'np_angle_rad', 'west_positive'):
+        assert getattr(b, f) == getattr(g, f), f
+    for f in ('radii', 'T0', 'sub_sp', 'sub_ray', 'sub_obsvec', 'ring_n', 'M', 'R0'):
+        assert np.array_equal(vec(b, f), vec(g, f)), f
+    # the motion model: what the kernels add to T0 / S0 over the spans they use
+    worst_t = np.max(np.abs((vec(b, 'VT') - vec(g, 'VT')) * span) + np.abs(vec(b, 'AT') - vec(g, 'AT')) * span * span / 2)
+    worst_s = np.max(np.abs((vec(b, 'VS') - vec(g, 'VS')) * span) + np.abs(vec(b, 'AS') - vec(g, 'AS')) * span * span / 2)
+    assert worst_t < 1e-9, (name, worst_t)  # km: target displacement over +-4 R/c
+    assert worst_s < 1e-9, (name, worst_s)  # km: the Sun's over the same span
+    assert abs(b.ts0 - g.ts0) < 2e-7 and np.max(np.abs(vec(b, 'S0') - vec(g, 'S0'))) < 4e-6, name  # (the Sun moves 0.013 km/s)
+    # the state (radial velocity: 1e-9 km/s bar) and the observer
+    assert np.max(np.abs(vec(b, 'DVT') - vec(g, 'DVT'))) < 1e-10, name
+    assert np.max(np.abs(vec(b, 'DAT') - vec(g, 'DAT'))) * span < 1e-10, name
+    assert np.array_equal(vec(b, 'VO'), vec(g, 'VO')), name
+    # rotation increment Rz(wdot d) over a disc's light-time span (1e-13 rad) and over 4 R/c
+    assert abs(b.wdot - g.wdot) * r_c < 1e-13, (name, b.wdot, g.wdot)
+    assert abs(b.wdot - g.wdot) * span < 4e-13, name
+    assert abs(b.lst_sun_lon - g.lst_sun_lon) < 1e-9, name
+    assert 'spksfs' in spice.calls  # the chain was walked segment by segment
+
+
+@pytest.mark.parametrize('name', ['io_like_earth_2009', 'moon_earth_2012', 'saturn_earth_2016'])
+def test_the_rate_about_the_body_z_axis_is_not_the_pm_coefficient(name):
+    """
+    Missing section 2 of the round-4 verdict: a `wdot` taken from PM[1] alone drops the periodic terms of W (every moon
+    of pck00010.tpc has them) and the pole's precession along the pole: Io 9e-14 rad/s, Saturn 2e-13, the Moon 1e-10 -
+    against a rotation budget of 1e-13 rad over the spans the kernels use. The derivative block of sxform has both.
+    """
+    d, g, b, _ = build(name)
+    pm1 = np.deg2rad(d['pck']['pm'][1]) / 86400.0
+    print(f'\n[{name}] PM[1] alone is {abs(pm1 - g.wdot):.2e} rad/s from the rate about the body z axis; the binding {abs(b.wdot - g.wdot):.2e}')
+    assert abs(pm1 - g.wdot) > 5e-14
+    assert abs(b.wdot - g.wdot) < 1e-3 * abs(pm1 - g.wdot)
+
+
+def test_binding_refuses_what_the_engine_does_not_evaluate():
+    from planetmapper_amd.reference_binding import geometry_from_body
+
+    d, g, b, spice = build('mars_earth_2012')
+    from spice_standin import DuckBody
+
+    body = DuckBody(g, target='MARS', target_id=499, observer='EARTH', frame='IAU_MARS')
+    body.aberration_correction = 'LT+S'
+    with pytest.raises(NotImplementedError):
+        geometry_from_body(body, spice)
+    body.aberration_correction = 'CN'
+    body.observer_frame = 'ECLIPJ2000'
+    with pytest.raises(NotImplementedError):
+        geometry_from_body(body, spice)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['jupiter_earth_2009', 'io_like_earth_2009', 'moon_earth_2012'])
+def test_a_frame_from_the_binding_block_equals_the_frame_from_the_builder_block(name):
+    from parity import compare_planes
+    from planetmapper_amd.engine import Engine
+
+    d, g, b, _ = build(name)
+    names = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH', 'DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER', 'LOCAL-SOLAR-TIME',
+             'RA', 'DEC', 'RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE']  # fmt: skip
+    eng = Engine(0)
+    try:
+        out = {}
+        for key, block in (('builder', g), ('binding', b)):
+            eng.set_geometry(block)
+            eng.set_disc(127.5, 127.5, 100.0, 0.4, 256, 256, True)
+            out[key] = eng.backplanes_img(names)
+        lon, lat = np.meshgrid(np.arange(2.5, 360, 5.0), np.arange(-87.5, 90, 5.0))
+        maps = {}
+        for key, block in (('builder', g), ('binding', b)):
+            eng.set_geometry(block)
+            eng.set_disc(127.5, 127.5, 100.0, 0.4, 256, 256, True)
+            maps[key] = eng.xy_map(lon, lat)
+    finally:
+        eng.close()
+    compare_planes(out['binding'], out['builder'], names, g, plate_scale_arcsec=g.diameter_arcsec / 200.0)
+    for a, c in zip(maps['binding'], maps['builder']):
+        assert np.array_equal(np.isnan(a), np.isnan(c)) and np.nanmax(np.abs(a - c)) < 1e-9

@@ -678,6 +678,28 @@ int pm_set_disc(pm_ctx *ctx, const pm_disc *disc)
     return PM_OK;
 }
 
+// Whether the B0 fast paths apply (k_disc_sph BODY 0 / 1, k_radec_query_b0): an observer well outside the body
+// (|O0| > 2 radii in scaled coordinates; anything else, e.g. a lander, goes through the general kernels), the target's /
+// Sun's acceleration negligible over the light-time span of a disc intercept (|d| <= R / c: fine while A (R/c)^2 / 2 is
+// below 1e-12 of the smallest radius - Jupiter: 6e-9 km of 66 854 km; the ray itself is rounded at 1e-7 km), a spin small
+// enough for the short series a triaxial body is turned with per light-time evaluation, and no PM_OPT_GENERAL_KERNEL.
+static bool fast_path_geometry(const pm_ctx *ctx, const pm::Params &pd)
+{
+    double y2 = 0.0;
+    for (int i = 0; i < 3; i++) y2 += (pd.O0[i] / pd.radii[i]) * (pd.O0[i] / pd.radii[i]);
+    const double rmax = std::fmax(pd.radii[0], std::fmax(pd.radii[1], pd.radii[2]));
+    const double rmin = std::fmin(pd.radii[0], std::fmin(pd.radii[1], pd.radii[2]));
+    const double span = rmax / ctx->geometry.clight;
+    double acc2 = 0.0, accs2 = 0.0;
+    for (int i = 0; i < 3; i++) {
+        acc2 += ctx->geometry.AT[i] * ctx->geometry.AT[i];
+        accs2 += ctx->geometry.AS[i] * ctx->geometry.AS[i];
+    }
+    const bool slow = 0.5 * std::sqrt(std::fmax(acc2, accs2)) * span * span < 1e-12 * rmin;
+    const bool small_spin = std::fabs(ctx->geometry.wdot) * span < 1e-3;
+    return y2 > 4.0 && slow && small_spin && !ctx->force_general;
+}
+
 int pm_backplanes_img(pm_ctx *ctx, uint64_t plane_mask, double alt, double *const *out, int mem)
 {
     if (!ctx) return PM_ERR_INVALID_ARGUMENT;
@@ -738,25 +760,7 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         pd.mask = plane_mask & kDiscBits;
         // spheroids (every planet in pck00010) take the rotation-free fast path, triaxial bodies
         // (most moons) its variant with one small rotation per light-time evaluation
-        // the fast path assumes an observer well outside the body (|O0| > 2 radii in scaled
-        // coordinates); anything else, e.g. a lander, goes through the general kernel
-        double y2 = 0.0;
-        for (int i = 0; i < 3; i++) y2 += (pd.O0[i] / pd.radii[i]) * (pd.O0[i] / pd.radii[i]);
-        // ... and it does not carry the target's / Sun's acceleration over the light-time span of a
-        // disc intercept (|d| <= R / c): fine while A (R/c)^2 / 2 is below 1e-12 of the smallest
-        // radius (Jupiter: 6e-9 km of 66 854 km; the ray itself is rounded at 1e-7 km)
-        const double rmax = std::fmax(pd.radii[0], std::fmax(pd.radii[1], pd.radii[2]));
-        const double rmin = std::fmin(pd.radii[0], std::fmin(pd.radii[1], pd.radii[2]));
-        const double span = rmax / ctx->geometry.clight;
-        double acc2 = 0.0, accs2 = 0.0;
-        for (int i = 0; i < 3; i++) {
-            acc2 += ctx->geometry.AT[i] * ctx->geometry.AT[i];
-            accs2 += ctx->geometry.AS[i] * ctx->geometry.AS[i];
-        }
-        const bool slow = 0.5 * std::sqrt(std::fmax(acc2, accs2)) * span * span < 1e-12 * rmin;
-        // a triaxial body is turned by its spin angle per light-time evaluation with a short series
-        const bool small_spin = std::fabs(ctx->geometry.wdot) * span < 1e-3;
-        const bool spheroid = y2 > 4.0 && slow && small_spin && !ctx->force_general;
+        const bool spheroid = fast_path_geometry(ctx, pd);
         // every plane of the frame from one launch (PM_OPT_FUSE_PLANES): the sky / limb planes ride along
         // (no fused variant where an epoch quantum is visible: those geometries take the QUANT kernels, two launches)
         fused_sky = spheroid && ctx->fuse_planes && (plane_mask & kSkyBits) && !pd.cf_iter && !pd.turn_quantum;
@@ -924,8 +928,10 @@ int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "Cannot adjust surface altitude with non-finite alt value");
     pm::Params p;
     fill_params(ctx, alt, p);
+    // a spheroid seen from outside: the B0 evaluation (k_radec_query_b0); any other body, PM_OPT_GENERAL_KERNEL: J2000
+    const bool b0 = p.radii[0] == p.radii[1] && fast_path_geometry(ctx, p);
     if (mem == PM_MEM_DEVICE) {
-        pm_launch_radec_query(p, ra_deg, dec_deg, n, ring_only_visible, out, ctx->stream);
+        pm_launch_radec_query(p, ra_deg, dec_deg, n, ring_only_visible, out, b0, ctx->stream);
         PM_HIP(ctx, hipGetLastError());
         return PM_OK;
     }
@@ -934,7 +940,7 @@ int pm_radec_query(pm_ctx *ctx, uint64_t n, const double *ra_deg, const double *
     double *base = (double *)ctx->scratch;
     PM_HIP(ctx, hipMemcpyAsync(base, ra_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PM_HIP(ctx, hipMemcpyAsync(base + n, dec_deg, n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    pm_launch_radec_query(p, base, base + n, n, ring_only_visible, base + 2 * n, ctx->stream);
+    pm_launch_radec_query(p, base, base + n, n, ring_only_visible, base + 2 * n, b0, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
     rc = d2h_issue(ctx, ctx->stream, out, base + 2 * n, n * 8 * sizeof(double));
     if (rc != PM_OK) return host_fail(ctx, rc);

@@ -25,7 +25,7 @@ void pm_launch_map(const pm::Params &p, const double *lon, const double *lat, bo
 void pm_launch_map_xy(const pm::Params &p, const double *lon, const double *lat, hipStream_t s);
 void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStream_t s);
 void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *dec, unsigned long long n,
-                           int ring_only_visible, double *out, hipStream_t s);
+                           int ring_only_visible, double *out, bool b0, hipStream_t s);
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, pm::PlaneStats *stats, unsigned int *hist,
                       hipStream_t s);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);

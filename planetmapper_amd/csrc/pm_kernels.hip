@@ -1414,6 +1414,89 @@ __global__ __launch_bounds__(kBlock) void k_radec_query(const Params p_, const d
     for (int k = 0; k < 8; k++) out[(size_t)k * n + i] = o[k];
 }
 
+// The same for a spheroid seen from outside (every planet; the predicate of the image kernels' fast path, pm_capi.hip), in
+// the B0 formulation of k_disc_sph / sky_block / k_map_b0: the ray turned into B0 once (u = R0 ray), sincpt_c 'CN' as the
+// reference's own sequence of light-time epochs in the scaled frame of surfpt_c - the body's spin leaves a spheroid where
+// it is, the target's motion is Y(d) = O0s - VBs d, no rotation per pass - longitude and latitude from the scaled
+// intercept, the ring and limb blocks on the same u (ring_coords_b0 / limb_coords_b0). k_radec_query above, the J2000
+// evaluation with a 3 x 3 rotation per light-time pass and recpgr_c by iteration, serves every other body and
+// PM_OPT_GENERAL_KERNEL (16.7 M points: 2.78 ms).
+__global__ __launch_bounds__(kBlock) void k_radec_query_b0(const Params p_, const double *__restrict__ ra_deg,
+                                                           const double *__restrict__ dec_deg, unsigned long long n,
+                                                           int ring_only_visible, double *__restrict__ out)
+{
+    const Params &p = *(const Params *)kernarg_params();  // constants loaded where they are used (k_map)
+    const unsigned long long i = (unsigned long long)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const double nan = __builtin_nan("");
+    double o[8] = {nan, nan, nan, nan, nan, nan, nan, nan};
+    const double ra = ra_deg[i] * kRad, dec = dec_deg[i] * kRad;
+    const bool given = isfinite(ra) && isfinite(dec);  // body.py:964-967
+    // (a lane without a point carries a harmless ray through the wave-level helpers)
+    const V3 ray = given ? radrec(ra, dec) : (1.0 / (p.g.lt_c * p.g.clight)) * v3(p.g.T0[0], p.g.T0[1], p.g.T0[2]);
+    const V3 u = mxv(p.g.R0, ray);
+    // sincpt_c 'CN' (body.py:1008-1020): the intercept repeated at te = et - lt until the light time moves by
+    // <= 1e-17 |te|, at most 10 passes; no intercept in any pass -> not found
+    const V3 X = {u.x * p.ir[0], u.y * p.ir[1], u.z * p.ir[2]};
+    const double ixx = rcp_fast(dot(X, X));
+    double lt = p.g.lt_c, d = 0.0, k = 0.0, sroot = 0.0;
+    V3 P = {0.0, 0.0, 0.0}, Y = {0.0, 0.0, 0.0};
+    bool hit = given;
+#pragma unroll 1
+    for (int it = 0; it < 10 && hit; it++) {
+        d = (p.g.et - lt) - p.t0;  // two roundings, as the epoch et - lt of the reference has them (first pass: 0 exactly)
+        Y = {fma(-p.VBs[0], d, p.O0s[0]), fma(-p.VBs[1], d, p.O0s[1]), fma(-p.VBs[2], d, p.O0s[2])};
+        const double yx = dot(Y, X);
+        k = yx * ixx;
+        P = {fma(-k, X.x, Y.x), fma(-k, X.y, Y.y), fma(-k, X.z, Y.z)};
+        const double p2 = dot(P, P);
+        if (p2 > 1.0 || yx > 0.0) {  // (the observer is outside: |Y| > 2, host)
+            hit = false;
+            break;
+        }
+        sroot = -sqrt_fast(fmax(0.0, 1.0 - p2) * ixx);
+        const double nlt = (sroot - k) * p.inv_c;  // |u| = 1
+        const double err = fabs(nlt - lt);
+        lt = nlt;
+        if (err <= 1e-17 * fabs(p.g.et - lt)) break;
+    }
+    if (hit) {
+        const V3 Xf = {fma(sroot, X.x, P.x), fma(sroot, X.y, P.y), fma(sroot, X.z, P.z)};
+        // recpgr_c: east longitude in the frame at te = B0 longitude - wdot d, sign by the body's convention
+        const double theta = (Xf.x == 0.0 && Xf.y == 0.0) ? 0.0 : atan2_fast(Xf.y, Xf.x);
+        double l = fma(-p.lon_k[1], d, p.lon_k[0] * theta);
+        if (l < 0.0) l += kTwoPi;
+        const double rho = sqrt_fast(fma(Xf.x, Xf.x, Xf.y * Xf.y));
+        o[0] = l * kDeg;
+        o[1] = atan2_fast<true>(Xf.z * p.a_over_c, rho) * kDeg;
+    }
+    double rr, rl, rd;
+    ring_coords_b0(p, u, rr, rl, rd);
+    if (ring_only_visible && !isnan(rr)) {
+        if (rr - p.radii[0] < 0.0) {
+            rr = rl = rd = nan;  // inside the planet
+        } else if (hit) {
+            // the intercept's distance with one more pass of its light time (point_lt<1>: the point as it stands - the
+            // turn of the body over the 1e-9 s the light time still moves by is 1e-8 km)
+            const double d1 = (p.g.et - lt) - p.t0;
+            const V3 w = {(fma(sroot, X.x, P.x) - fma(-p.VBs[0], d1, p.O0s[0])) * p.radii[0],
+                          (fma(sroot, X.y, P.y) - fma(-p.VBs[1], d1, p.O0s[1])) * p.radii[1],
+                          (fma(sroot, X.z, P.z) - fma(-p.VBs[2], d1, p.O0s[2])) * p.radii[2]};
+            if (norm_f(w) < rd) rr = rl = rd = nan;  // behind the disc
+        }
+    }
+    o[2] = rr;
+    o[3] = rl;
+    o[4] = rd;
+    limb_coords_b0(p, u, o[5], o[6], o[7]);
+    if (!given) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) o[q] = nan;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) out[(size_t)q * n + i] = o[q];
+}
+
 }  // namespace pm
 
 // ------------------------------------------------------------------ launchers (called from pm_capi.hip)
@@ -1499,11 +1582,13 @@ void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStr
 }
 
 void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *dec, unsigned long long n,
-                           int ring_only_visible, double *out, hipStream_t s)
+                           int ring_only_visible, double *out, bool b0, hipStream_t s)
 {
     unsigned long long blocks = (n + pm::kBlock - 1) / pm::kBlock;
-    hipLaunchKernelGGL(pm::k_radec_query, dim3((unsigned)blocks), dim3(pm::kBlock), 0, s, p, ra, dec, n,
-                       ring_only_visible, out);
+    if (b0)
+        hipLaunchKernelGGL(pm::k_radec_query_b0, dim3((unsigned)blocks), dim3(pm::kBlock), 0, s, p, ra, dec, n, ring_only_visible, out);
+    else
+        hipLaunchKernelGGL(pm::k_radec_query, dim3((unsigned)blocks), dim3(pm::kBlock), 0, s, p, ra, dec, n, ring_only_visible, out);
 }
 
 void pm_launch_map_xy(const pm::Params &p, const double *lon, const double *lat, hipStream_t s)

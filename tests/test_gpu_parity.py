@@ -2012,16 +2012,28 @@ def test_radec_query_vs_oracle_and_kats(engine, oracle, jupiter, saturn):
         dec = dec0 + rng.uniform(-span, span, 4000)
         ra[::97] = np.nan
         dec[::89] = np.inf
-        for alt, vis in ((0.0, True), (0.0, False), (2500.0, True)):
-            got = engine.radec_query(ra, dec, alt=alt, ring_only_visible=vis)
-            ref = oracle.radec_query(g, ra, dec, alt=alt, ring_only_visible=vis).T
-            assert np.array_equal(np.isnan(got), np.isnan(ref)), (alt, vis)
-            fin = np.isfinite(ref)
-            d = np.abs(got - ref)
-            d[[0, 3, 5]] = np.minimum(d[[0, 3, 5]], 360.0 - d[[0, 3, 5]])
-            scale = np.array([1e-6, 1e-6, 1e-3, 1e-6, 1e-3, 1e-6, 1e-6, 1e-3])[:, None]  # deg / km
-            assert np.all(d[fin] <= np.broadcast_to(scale, d.shape)[fin]), (alt, vis, np.nanmax(d / scale))
-            assert fin[0].sum() > 100 and fin[2].sum() > 1000
+        # both evaluations: the B0 kernel (the library's choice for a spheroid seen from outside) and the J2000 one behind
+        # PM_OPT_GENERAL_KERNEL, which every other body takes. Bars at the measured deviations x 3 (profiles/r05_radec_query_deviation.txt):
+        # angles of the intercept and the limb point are conditioned like the image planes' (1 / cos e at the limb)
+        from planetmapper_amd import _lib
+
+        for general in (0, 1):
+            engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, general)
+            try:
+                for alt, vis in ((0.0, True), (0.0, False), (2500.0, True)):
+                    got = engine.radec_query(ra, dec, alt=alt, ring_only_visible=vis)
+                    ref = oracle.radec_query(g, ra, dec, alt=alt, ring_only_visible=vis).T
+                    assert np.array_equal(np.isnan(got), np.isnan(ref)), (general, alt, vis)
+                    fin = np.isfinite(ref)
+                    d = np.abs(got - ref)
+                    d[[0, 3, 5]] = np.minimum(d[[0, 3, 5]], 360.0 - d[[0, 3, 5]])
+                    scale = np.array([2e-7, 1e-7, 5e-6, 2e-9, 5e-6, 2e-7, 1e-7, 5e-6])[:, None]  # deg / km
+                    assert np.all(d[fin] <= np.broadcast_to(scale, d.shape)[fin]), (general, alt, vis, np.nanmax(d / scale, axis=1))
+                    for k in (0, 1, 5, 6):
+                        assert np.mean(d[k][fin[k]] < 3e-9) > 0.97, (general, alt, vis, k)
+                    assert fin[0].sum() > 100 and fin[2].sum() > 1000
+            finally:
+                engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
 
 
 @pytest.mark.parametrize('leg', ['fixed_seed', 'fresh_seed'])

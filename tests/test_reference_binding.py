@@ -131,3 +131,62 @@ def test_a_frame_from_the_binding_block_equals_the_frame_from_the_builder_block(
     compare_planes(out['binding'], out['builder'], names, g, plate_scale_arcsec=g.diameter_arcsec / 200.0)
     for a, c in zip(maps['binding'], maps['builder']):
         assert np.array_equal(np.isnan(a), np.isnan(c)) and np.nanmax(np.abs(a - c)) < 1e-9
+
+
+@pytest.mark.gpu
+def test_the_mixin_over_a_duck_typed_bodyxy():
+    """`HipBackplanes` in front of a class with the reference BodyXY's disc accessors and map-grid helper (body_xy.py:818-871,
+    3290-3300): its pixel methods return what the engine returns for the same block and disc, in the reference's shapes"""
+    from planetmapper_amd.engine import Engine
+    from planetmapper_amd.reference_binding import HipBackplanes
+    from spice_standin import DuckBody
+
+    d, g, b, spice = build('jupiter_earth_2009')
+
+    class DuckBodyXY(DuckBody):
+        _nx, _ny, _optimize_speed, _alt_adjustment = 200, 160, True, 0.0
+
+        def get_x0(self): return 99.5
+        def get_y0(self): return 79.5
+        def get_r0(self): return 60.0
+        def _get_rotation_radians(self): return 0.3
+
+        def _get_lonlat_map(self, **kw):
+            lon, lat = np.meshgrid(np.arange(5.0, 360, 10.0)[::-1], np.arange(-85.0, 90, 10.0))
+            return np.stack([lon, lat], axis=-1)
+
+        def get_x_map(self, **kw): return self._get_xy_map(**kw)[..., 0]
+        def get_y_map(self, **kw): return self._get_xy_map(**kw)[..., 1]
+
+    class Bound(HipBackplanes, DuckBodyXY):
+        _hip_spice = spice
+
+    body = Bound(g, target='JUPITER', target_id=599, observer='EARTH', frame='IAU_JUPITER')
+    eng = Engine(0)
+    try:
+        eng.set_geometry(b)
+        eng.set_disc(99.5, 79.5, 60.0, 0.3, 200, 160, True)
+        # (the same plane sets as the mixin asks for: a latitude that rides with the illumination planes comes from the
+        #  normal they need anyway, last-bit different from the one taken alone)
+        ref = eng.backplanes_img(['LON-GRAPHIC', 'LAT-GRAPHIC'])
+        ref.update(eng.backplanes_img(['PHASE', 'INCIDENCE', 'EMISSION']))
+        ll = body._get_lonlat_img()
+        assert ll.shape == (160, 200, 2)
+        assert np.array_equal(ll[..., 0], ref['LON-GRAPHIC'], equal_nan=True) and np.array_equal(ll[..., 1], ref['LAT-GRAPHIC'], equal_nan=True)
+        gie = body._get_illumination_gie_img()
+        for i, n in enumerate(('PHASE', 'INCIDENCE', 'EMISSION')):
+            assert np.array_equal(gie[..., i], ref[n], equal_nan=True), n
+        grid = body._get_lonlat_map()
+        xy = body._get_xy_map()
+        x, y = eng.xy_map(grid[..., 0], grid[..., 1])
+        assert np.array_equal(xy[..., 0], x, equal_nan=True) and np.array_equal(xy[..., 1], y, equal_nan=True)
+        img = np.random.default_rng(0).standard_normal((160, 200))
+        for interp in ('linear', 'cubic'):
+            m = body.map_img(img, interpolation=interp)
+            assert m.shape == grid.shape[:2]
+            assert np.array_equal(m, eng.map_cube(img, x, y, interp, True)[0], equal_nan=True), interp
+        saved = body._get_backplane_imgs_for_saving(['RA', 'DEC', 'EMISSION'])
+        assert np.array_equal(saved['EMISSION'], eng.backplanes_img(['RA', 'DEC', 'EMISSION'])['EMISSION'], equal_nan=True)
+    finally:
+        eng.close()
+        body.__dict__['_hip_engine'].close()

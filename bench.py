@@ -729,8 +729,9 @@ def api_path_section(g, sz: int, device: int) -> dict:
     built on `_get_lonlat_img` / `_get_illumination_gie_img`, :3281, :3658) and
     `Observation.get_mapped_data(degree_interval=1)` (observation.py:826-872) - through the Python shim
     (planetmapper_amd.BodyXY / Observation -> Engine -> ctypes -> C ABI), cold cache every repetition.
-    The five getters are two families, hence two `pm_backplanes_img` calls (2 + 3 planes) into fresh numpy
-    arrays; `host_path.ms_fresh_numpy_arrays` is the same 671 MB through ONE Engine call.
+    The five getters are two families, hence two `pm_backplanes_img` calls (2 + 3 planes), into result arrays the
+    engine recycles between discs (page-locked, their pages long faulted in); `host_path.ms_fresh_numpy_arrays` is the
+    same 671 MB through ONE Engine call into new numpy arrays (a page fault per 4 KiB: 6 of its 16 ms).
     """
     from planetmapper_amd import Observation
 
@@ -764,7 +765,9 @@ def api_path_section(g, sz: int, device: int) -> dict:
         'ms_get_mapped_data': ms(maps),
         'Mpix_s_median': round(sz * sz / float(np.median(tot)) / 1e6, 1),
         'note': 'compare ms_five_backplane_getters with host_path.ms_fresh_numpy_arrays (the same planes through one '
-        'Engine call); get_mapped_data adds the host-resident data plane (134 MB, of which the sampled blocks cross PCIe)',
+        'Engine call into arrays whose pages do not exist yet) and ms_pinned_arrays: the getters write into the page-locked '
+        'arrays the previous disc\'s planes lived in (Engine.plane_buffer: recycled when nobody holds them any more); '
+        'get_mapped_data adds the host-resident data plane (134 MB, of which the sampled blocks cross PCIe)',
     }
 
 

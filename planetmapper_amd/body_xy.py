@@ -221,6 +221,16 @@ class BodyXY:
 
     # ------------------------------------------------------------------ caches
     def _clear_cache(self) -> None:
+        # image planes nobody outside this object refers to go back to the engine's pool of result arrays
+        # (Engine.plane_buffer): the next cold getter writes into memory whose pages exist - and are page-locked
+        recycle = getattr(self._engine, 'recycle_plane', None)
+        buffers = self.__dict__.get('_img_buffers')
+        if recycle is not None and buffers:
+            for key in list(buffers):
+                self._cache.pop(key, None)  # (the read-only view goes first: what is left is the array itself)
+                arr = buffers.pop(key)
+                recycle(arr)
+                del arr
         self._cache.clear()
 
     def _invalidate_disc_parameters(self) -> None:  # body_xy.py:696-698
@@ -419,9 +429,15 @@ class BodyXY:
             if not self._test_if_img_size_valid():
                 # BodyXY._make_empty_img body_xy.py:3166-3168
                 raise ValueError('nx and ny must be positive to create a backplane image')
-            out = self._bind().backplanes_img(missing, alt=alt)
+            eng = self._bind()
+            if hasattr(eng, 'plane_buffer'):
+                out = eng.backplanes_img(missing, alt=alt, recycled=True)
+                self.__dict__.setdefault('_img_buffers', {}).update({('img', n, alt): a for n, a in out.items()})
+            else:
+                out = eng.backplanes_img(missing, alt=alt)
             for n, a in out.items():
                 self._cache[('img', n, alt)] = _readonly(a)
+            del out, a
         return {n: self._cache[('img', n, alt)] for n in names}
 
     def prefetch_backplane_imgs(self, names: Iterable[str] | None = None, *, alt: float = 0.0) -> None:

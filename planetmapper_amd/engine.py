@@ -101,11 +101,18 @@ class Engine:
         self.device = int(device)
         self._disc: PMDisc | None = None
         self._geometry: PMGeometry | None = None
+        # image planes handed to callers of the drop-in surface, recycled once nobody looks at them any more (plane_buffer)
+        self._plane_pool: dict[tuple, list] = {}
+        self._plane_owned: dict[int, int] = {}  # id(array) -> bytes, of the arrays plane_buffer() allocated and that are alive
+        self._plane_bytes = 0
+        self._plane_limit = _plane_pool_limit()
+        self._free_counts = self._calibrate_recycling()
         if general_kernel is not None:
             self.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1 if general_kernel else 0)
 
     # ------------------------------------------------------------------ plumbing
     def close(self) -> None:
+        self._plane_pool = {}
         if getattr(self, '_ctx', None):
             self._lib.pm_destroy(self._ctx)
             self._ctx = None
@@ -193,6 +200,57 @@ class Engine:
         if eng is not None and getattr(eng, '_ctx', None):
             eng._lib.pm_host_free(eng._ctx, ctypes.c_void_p(ptr))
 
+    # ------------------------------------------------------------------ recycled result planes
+    def plane_buffer(self, shape) -> np.ndarray:
+        """
+        A float64 array for a result plane: one that `recycle_plane` took back if there is one of this shape, else a new
+        page-locked one while the pool's budget lasts (PLANETMAPPER_PLANE_POOL_MB, default min(8 GiB, RAM / 8)), else
+        `np.empty`. A fresh pageable array costs the copy threads a page fault per 4 KiB they write - 6 of the 16 ms of
+        the headline frame's five planes; a recycled pinned one takes its plane by DMA, in place (9 ms).
+        """
+        import weakref
+
+        shape = tuple(int(v) for v in shape)
+        free = self._plane_pool.get(shape)
+        if free:
+            return free.pop()
+        nbytes = int(np.prod(shape, dtype=np.int64)) * 8
+        if nbytes < (1 << 20) or self._plane_bytes + nbytes > self._plane_limit:
+            return np.empty(shape, dtype=np.float64)
+        arr = self.pinned_empty(shape)
+        self._plane_owned[id(arr)] = nbytes
+        self._plane_bytes += nbytes
+        weakref.finalize(arr, Engine._forget_plane, weakref.ref(self), id(arr))
+        return arr
+
+    @staticmethod
+    def _forget_plane(engine_ref, key: int) -> None:
+        eng = engine_ref()
+        if eng is not None:
+            eng._plane_bytes -= eng._plane_owned.pop(key, 0)
+
+    def recycle_plane(self, arr, _calibrate: bool = False):
+        """
+        Take a `plane_buffer` array back - if the caller's is the ONLY reference left to it and to the memory behind it
+        (a view a user still holds keeps the owner's count up: then the array is simply left to the garbage collector,
+        and whoever holds it keeps data nobody will overwrite). Call with exactly one reference of your own (a local).
+        """
+        import sys
+
+        base = arr.base
+        counts = (sys.getrefcount(arr), sys.getrefcount(base) if base is not None else 0)
+        if _calibrate:
+            return counts
+        if id(arr) not in self._plane_owned or counts != self._free_counts:
+            return False
+        self._plane_pool.setdefault(arr.shape, []).append(arr)
+        return True
+
+    def _calibrate_recycling(self):
+        # the counts `recycle_plane` sees for an array nobody else refers to, measured through the same calls
+        probe = np.frombuffer(bytearray(16), dtype=np.float64).reshape((2,))
+        return self.recycle_plane(probe, _calibrate=True)
+
     def pinned_copy(self, arr) -> np.ndarray:
         """`arr` copied into a new pinned array (see `pinned_empty`)."""
         arr = np.asarray(arr)
@@ -230,14 +288,14 @@ class Engine:
         self._disc = d
 
     # ------------------------------------------------------------------ image backplanes
-    def backplanes_img(self, names: Iterable[str], alt: float = 0.0) -> dict[str, np.ndarray]:
-        """Compute image-space backplanes into fresh host arrays of shape (ny, nx)."""
+    def backplanes_img(self, names: Iterable[str], alt: float = 0.0, *, recycled: bool = False) -> dict[str, np.ndarray]:
+        """Compute image-space backplanes into fresh host arrays of shape (ny, nx) (`recycled`: into `plane_buffer`s)."""
         names = list(names)
         assert self._disc is not None
         shape = (self._disc.ny, self._disc.nx)
         if shape[0] <= 0 or shape[1] <= 0:
             raise ValueError('nx and ny must be positive to create a backplane image')
-        outs = {n: np.empty(shape, dtype=np.float64) for n in names}
+        outs = {n: (self.plane_buffer(shape) if recycled else np.empty(shape, dtype=np.float64)) for n in names}
         ptrs = (ctypes.c_void_p * NUM_PLANES)()
         for n, a in outs.items():
             ptrs[PLANE_INDEX[n]] = a.ctypes.data
@@ -462,6 +520,19 @@ class Engine:
                 _ptr(out), _lib.PM_MEM_DEVICE,
             )
         )
+
+
+def _plane_pool_limit() -> int:
+    import os
+
+    env = os.environ.get('PLANETMAPPER_PLANE_POOL_MB')
+    if env is not None:
+        return max(0, int(float(env) * (1 << 20)))
+    try:
+        ram = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
+    except (ValueError, OSError):
+        ram = 8 << 30
+    return int(min(8 << 30, ram // 8))
 
 
 def device_count() -> int:

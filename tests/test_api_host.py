@@ -715,3 +715,65 @@ def test_ring_and_grid_wireframe_coordinates_kats(body):
     for (x, y), (ra, dec) in zip(body.visible_lonlat_grid_xy(interval=45, npts=5), got):
         assert close((x, y), body.radec2xy(ra, dec))
     assert close(body.ring_xy(123456.789, npts=3, only_visible=False), body.radec2xy(*body.ring_radec(123456.789, npts=3, only_visible=False)))
+
+
+def test_result_planes_are_recycled_only_when_nobody_holds_them(jupiter):
+    """
+    `Engine.plane_buffer` / `recycle_plane` behind `BodyXY._img_planes` / `_clear_cache`: a cold getter after
+    `set_disc_params` writes into the array the previous disc's plane lived in - unless the caller still holds that
+    plane (the array itself, or any view of it), whose values must then stay what they were (the reference's arrays
+    are independent of each other, body_xy.py:696-698 only drops the cache's reference).
+    """
+    from planetmapper_amd.engine import Engine
+
+    class RecyclingOracleEngine(OracleEngine):
+        """the oracle-backed test double with the real Engine's pool of result arrays (pageable here)"""
+
+        plane_buffer, recycle_plane = Engine.plane_buffer, Engine.recycle_plane
+        _calibrate_recycling, _forget_plane = Engine._calibrate_recycling, staticmethod(Engine._forget_plane)
+
+        def __init__(self):
+            super().__init__()
+            self._plane_pool, self._plane_owned, self._plane_bytes, self._plane_limit = {}, {}, 0, 1 << 40
+            self._free_counts = self._calibrate_recycling()
+            self.lent = []
+
+        def pinned_empty(self, shape, dtype=np.float64):  # (built like Engine.pinned_empty: a reshaped view of a buffer's array)
+            return np.frombuffer(bytearray(int(np.prod(shape)) * 8), dtype=np.float64).reshape(shape)
+
+        def backplanes_img(self, names, alt=0.0, *, recycled=False):
+            out = super().backplanes_img(names, alt)
+            if not recycled:
+                return out
+            res = {}
+            for n, a in out.items():
+                buf = self.plane_buffer(a.shape)
+                buf[...] = a
+                self.lent.append(id(buf))
+                res[n] = buf
+            return res
+
+    eng = RecyclingOracleEngine()
+    body = BodyXY('Jupiter', geometry=jupiter, nx=600, ny=500, engine=eng)  # (planes of 2.4 MB: above the pool's 1 MiB floor)
+    body.set_disc_params(300, 250, 200, 10)
+    lon1 = body.get_lon_img()
+    assert not lon1.flags.writeable and body.get_lon_img() is lon1
+    first = list(eng.lent)  # lon, lat
+    del lon1
+    body.set_disc_params(310, 250, 200, 10)  # nobody holds the planes: both arrays go back to the pool ...
+    lon2 = body.get_lon_img()
+    assert sorted(eng.lent[2:]) == sorted(first)  # ... and are written again
+    keep = lon2[100:110]  # a VIEW of the plane, held by the user
+    values = keep.copy()
+    lat2 = body.get_lat_img()
+    body.set_disc_params(320, 250, 200, 10)
+    lon3 = body.get_lon_img()
+    assert np.array_equal(keep, values, equal_nan=True) and np.array_equal(lat2, lat2.copy(), equal_nan=True)
+    assert not np.array_equal(lon3[100:110], values, equal_nan=True)  # (another disc: other values, in another array)
+    assert len(set(eng.lent[4:]) & set(eng.lent[2:4])) == 0  # neither held array was written again
+    ref = BodyXY('Jupiter', geometry=jupiter, nx=600, ny=500, engine=OracleEngine())
+    ref.set_disc_params(320, 250, 200, 10)
+    assert np.array_equal(lon3, ref.get_lon_img(), equal_nan=True)
+    body.set_img_size(64, 48)  # small planes: plain numpy arrays, nothing pooled
+    body.set_disc_params(30, 20, 15, 0)
+    assert body.get_emission_angle_img().shape == (48, 64)

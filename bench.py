@@ -430,14 +430,14 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
 
     slot = gathered[d.rank]
 
-    def step(fed: bool, pipelined: bool = True):
+    def step(fed: bool, pipelined: bool = True, stages: dict | None = None):
         # the x/y map of the grid, then this rank's planes
         eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
         if pipelined:
             # exchange by exchange: each one mapped and its all-gather started while the next is collected /
             # copied / mapped; a closing agreement on success (distributed.map_cube_sharded_pipelined)
             map_cube_sharded_pipelined(eng, cube_h if fed else cube_d, np.float64, planes, xm, ym, n0, n1, gathered, d.rank, d.world,
-                                       host_cube=fed)
+                                       host_cube=fed, stages=stages)
             return
         # the plain form: map the block, finish it, ONE all-gather of the slots (no callback, no overlap)
         if mine_n > 0:
@@ -449,9 +449,9 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         d.all_gather(gathered, slot)
 
     def run(fed: bool, steps: int, pipelined: bool = True):
-        # (untimed: for a host-fed cube the call that probes the routes and, where a hybrid is a candidate, the four
+        # (untimed: for a host-fed cube the call that probes the routes and, where a hybrid is a candidate, the six
         #  whole calls of its trial - the timed steps run on the route the library has committed to)
-        for _ in range(6 if fed else 2):
+        for _ in range(8 if fed else 2):
             step(fed, pipelined)
         d.barrier()
         own = []
@@ -581,17 +581,75 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
         'block_table_cache_hits': table_hits,
         'fed_equals_resident': same,
     })
+    if real:
+        sec['stages'] = stage_breakdown(eng, lambda st: step(True, True, st), d.sync, d)
     if real and d.world == 1 and mine_n >= 16:
-        sec['shard_proxy'] = shard_proxy(eng, step_fed_n=lambda n_local, n_total: _proxy_step(
-            eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local, n_total, gathered), planes=planes, n0=n0, n1=n1, t_n1=t_fed,
+        sec['shard_proxy'] = shard_proxy(eng, step_fed_n=lambda n_local, n_total, stages=None: _proxy_step(
+            eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local, n_total, gathered, stages), planes=planes, n0=n0, n1=n1, t_n1=t_fed,
             t_n1_median=float(np.median(own_fed)))
     return sec
+
+
+def stage_breakdown(eng, step_with_stages, sync, d=None, reps: int = 5) -> dict:
+    """
+    Where a host-fed step of this rank spends its time: `reps` extra steps (after the timed ones) with PM_OPT_TRACE bit 4
+    on - the library's own stage record of the mapping call (PM_OPT_LAST_STAGE_NS: block-table look-up / build, plan,
+    the first chunk's collection with the link idle, the calling thread's time inside the collections, issue of all
+    chunks, drain of the last DMA and kernels, flag check; device-side sums of the H2D copies and of the kernels) and,
+    around it, what `map_cube_sharded_pipelined` reports (the exchanges still in flight once the mapping is done, the
+    agreement). Medians in ms. `accounted_ms` = the sequential parts (x / y map + sync, tables + plan + issue + drain +
+    finish, exposed exchange, agreement): the rest of `step_ms` is Python and launch overhead.
+    """
+    from planetmapper_amd import _lib
+
+    old = eng.get_option(_lib.PM_OPT_TRACE)
+    eng.set_option(_lib.PM_OPT_TRACE, old | 4)
+    rows = []
+    try:
+        for _ in range(reps):
+            if d is not None:
+                d.barrier()
+            st: dict = {}
+            t = time.perf_counter()
+            step_with_stages(st)
+            sync()
+            st['step'] = (time.perf_counter() - t) * 1e3
+            st.update({'engine_' + k: v for k, v in eng.last_stages_ms().items() if not k.startswith(('exchange', 'agreement', 'sharded'))})
+            rows.append(st)
+    finally:
+        eng.set_option(_lib.PM_OPT_TRACE, old)
+    med = {k: round(float(np.median([r.get(k, 0.0) for r in rows])), 4) for k in rows[0]}
+    accounted = (med['engine_tables'] + med['engine_plan'] + med['engine_issue'] + med['engine_drain'] + med['engine_finish']
+                 + med.get('exchange_exposed', 0.0) + med.get('agreement', 0.0))
+    return {
+        'ms': {
+            'step': med['step'],
+            'block_table_lookup_or_build': med['engine_tables'],
+            'plan': med['engine_plan'],
+            'first_chunk_fill_link_idle': med['engine_first_fill'],
+            'collection_calling_thread': med['engine_collect'],
+            'issue_all_chunks': med['engine_issue'],
+            'drain_last_dma_and_kernels': med['engine_drain'],
+            'flag_check_and_replay': med['engine_finish'],
+            'dma_device_sum': med['engine_dma_device'],
+            'kernels_device_sum': med['engine_kernels_device'],
+            'mapping_call_total': med['engine_total'],
+            'map_call_python': med.get('map_call', 0.0),
+            'exchange_exposed_after_last_kernel': med.get('exchange_exposed', 0.0),
+            'agreement': med.get('agreement', 0.0),
+        },
+        'accounted_ms': round(accounted, 4),
+        'unaccounted_ms': round(med['step'] - accounted, 4),
+        'reps': reps,
+        'note': 'issue_all_chunks contains first_chunk_fill and collection; dma / kernels are device-clock sums that overlap the host '
+        'stages; measured in extra steps with PM_OPT_TRACE bit 4 (which makes the call wait for its exchanges before the agreement)',
+    }
 
 
 _PROXY_SLOTS: dict = {}
 
 
-def _proxy_step(eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local: int, n_total: int, gathered) -> None:
+def _proxy_step(eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local: int, n_total: int, gathered, stages: dict | None = None) -> None:
     """rank 0's step of an N-rank run on this one GPU: its block, exchange by exchange, no collective"""
     from planetmapper_amd.distributed import map_cube_sharded_pipelined
 
@@ -605,7 +663,7 @@ def _proxy_step(eng, lon_d, lat_d, n0, n1, xm, ym, cube_h, n_local: int, n_total
         _PROXY_SLOTS['slots'] = gathered.new_empty((world, n_local, n0, n1))
     slots = _PROXY_SLOTS['slots']
     map_cube_sharded_pipelined(eng, cube_h[:n_local], np.float64, n_total, xm, ym, n0, n1, slots, 0, world, host_cube=True,
-                               pipeline_chunks=True)
+                               pipeline_chunks=True, stages=stages)
 
 
 def shard_proxy(eng, step_fed_n, planes: int, n0: int, n1: int, t_n1: float, t_n1_median: float) -> dict:
@@ -632,9 +690,9 @@ def shard_proxy(eng, step_fed_n, planes: int, n0: int, n1: int, t_n1: float, t_n
             for label, threads in (('cores/N', max(2, cores // n)), ('cores', min(16, cores))):
                 eng.set_option(_lib.PM_OPT_HOST_COPY_THREADS, threads)
                 eng.set_option(_lib.PM_OPT_ROUTE_EXPLORE, 1)  # forget what another thread count measured
-                # (untimed: the call that probes the routes, then - where the probes make a hybrid a candidate - two
+                # (untimed: the call that probes the routes, then - where the probes make a hybrid a candidate - three
                 #  whole calls each by the best single route and by the hybrid, after which the library has committed)
-                for _ in range(6):
+                for _ in range(8):
                     step_fed_n(per, planes)
                 ts = []
                 for _ in range(7):
@@ -650,6 +708,7 @@ def shard_proxy(eng, step_fed_n, planes: int, n0: int, n1: int, t_n1: float, t_n
                     'route_chosen': eng.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE),
                     'route_ns_per_plane': {str(r): eng.get_option(_lib.PM_OPT_ROUTE_NS_PER_PLANE + r) for r in range(_lib.NUM_CUBE_ROUTES)},
                     'rank0_ms': {'median': round(t_med * 1e3, 3), 'min': round(min(ts) * 1e3, 3), 'max': round(max(ts) * 1e3, 3)},
+                    'stages': stage_breakdown(eng, lambda st: step_fed_n(per, planes, st), eng.synchronize),
                     # NOT measured: a model on top of the measured rank-0 time (one assumed link rate, no host contention)
                     'model': {
                         'exposed_allgather_ms_assumed': round(exposed * 1e3, 3),

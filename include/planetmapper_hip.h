@@ -290,9 +290,22 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           step on its seed.
  *   PM_OPT_TRACE            mask, on stderr: 1 stage times of every host-path call, 2 the knot / smoothing-parameter
  *                           search of the smoothing splines. Default 0.
+ *   PM_OPT_TRACE            ... 4: the device-side sums of PM_OPT_LAST_STAGE_NS are collected (a pair of timing events per chunk; a
+ *                           sharded call waits for its exchanges before the agreement, so that the two are timed apart).
  *   PM_OPT_SM_BATCH_PLANES  the most planes of a cube whose smoothing-spline fits (spline_smoothing > 0) advance together
  *                           in the same launches: 0 (default) = as many as half of the free device memory holds (a plane
  *                           takes 5 arrays of its own size), 1 .. 4096 = a cap. A plane's result does not depend on it.
+ *   PM_OPT_LAST_STAGE_NS + k read-only, ns: where the latest host-fed pm_map_cube (PM_MEM_HOST / PM_MEM_HOST_CUBE, nearest /
+ *                           linear) or pm_map_cube_sharded of this context spent its time. Host clock, always recorded:
+ *                           0 the whole pm_map_cube call = 1 + 2 + 5 + 6 + 7; 1 fingerprint of the x / y maps + block-table
+ *                           look-up or build; 2 route plan, layout, scratch; 5 from the first chunk to the last one issued
+ *                           (inside it: 3 until the first byte of the segment is handed to the link - the first chunk's
+ *                           collection, the link idle - and 4 the calling thread inside the copy threads' collections);
+ *                           6 from the last chunk issued until the streams are idle (last DMA, last kernels); 7 flag
+ *                           read-back and nanmedian replay. Device clock, with PM_OPT_TRACE bit 4 only (else 0): 8 the sum of
+ *                           the chunks' H2D copies, 9 the sum of their kernels. pm_map_cube_sharded adds 10 what was left of
+ *                           the exchanges once the mapping had finished (bit 4 only), 11 the agreement (with bit 4 off: the
+ *                           rest of the exchanges + the agreement), 12 the whole sharded call.
  *   PM_OPT_HYBRID_FETCH_PERMILLE read-only: the share of planes (in 1/1000) a hybrid segment (route 4) has the GPU
  *                           fetch on the current problem; 0 while no hybrid has been planned.
  *   PM_OPT_HOST_COPY_THREADS_IN_USE read-only: the copy threads the host pipe of this context runs with (0 before
@@ -339,7 +352,8 @@ typedef enum pm_option {
     PM_OPT_TRACE = 25,
     PM_OPT_SM_BATCH_PLANES = 26,
     PM_OPT_LAST_LT_PATH = 27,
-    PM_OPT_ROUTE_NS_PER_PLANE = 16 /* + route 0..4 */
+    PM_OPT_ROUTE_NS_PER_PLANE = 16, /* + route 0..4 */
+    PM_OPT_LAST_STAGE_NS = 32       /* + stage 0..12, read-only: see below */
 } pm_option;
 int pm_set_option(pm_ctx *ctx, int option, int64_t value);
 int pm_get_option(pm_ctx *ctx, int option, int64_t *value);

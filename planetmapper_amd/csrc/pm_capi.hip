@@ -507,7 +507,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         ctx->lt_mode = (int)value;
         return PM_OK;
     case PM_OPT_TRACE:
-        if (value < 0 || value > 3) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_TRACE takes a mask of 1 (host path) and 2 (smoothing splines)");
+        if (value < 0 || value > 7) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_TRACE takes a mask of 1 (host path), 2 (smoothing splines) and 4 (device-side stage sums)");
         ctx->trace = (int)value;
         return PM_OK;
     case PM_OPT_SM_BATCH_PLANES:
@@ -566,6 +566,10 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;
     case PM_OPT_HYBRID_FETCH_PERMILLE: *value = pipe_hybrid_fetch_permille(ctx); return PM_OK;
+    }
+    if (option >= PM_OPT_LAST_STAGE_NS && option < PM_OPT_LAST_STAGE_NS + 16) {
+        *value = (int64_t)ctx->last_stage_ns[option - PM_OPT_LAST_STAGE_NS];
+        return PM_OK;
     }
     if (option >= PM_OPT_ROUTE_NS_PER_PLANE && option < PM_OPT_ROUTE_NS_PER_PLANE + 5) {
         *value = pipe_route_ns_per_plane(ctx, option - PM_OPT_ROUTE_NS_PER_PLANE);

@@ -12,6 +12,8 @@
 
 #include <mutex>
 
+#include <chrono>
+
 #include "pm_host.hip.h"
 
 namespace {
@@ -301,6 +303,8 @@ int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int 
     }
     double *mine = out_all + (size_t)rank * per_rank * nmap;
     Rccl *r = rccl();
+    const auto clock_ns = [] { return (double)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_sharded = clock_ns();
     // planes of a short last block: NaN padding, so that the gathered buffer is defined everywhere
     int status = PM_OK;
     if (mine_n < per_rank) {
@@ -338,6 +342,14 @@ int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int 
     // communicator): a rank that left with a local error would strand its peers in their receives.
     ex.progress(per_rank);  // whatever has not been sent yet (no planes here, or a failed mapping)
     if (ex.nrc != ncclSuccess) return nccl_fail(ctx, comm, "exchange of mapped planes (ncclSend / ncclRecv)", ex.nrc);
+    const double t_mapped = clock_ns();
+    if (ctx->trace & 4) {
+        // PM_OPT_LAST_STAGE_NS: what of the exchanges is still in flight once the mapping is done (waited for here, so that
+        // the agreement behind it is timed on its own)
+        (void)hipStreamSynchronize(comm->stream);
+        ctx->last_stage_ns[pmh::kStageExchangeExposed] = clock_ns() - t_mapped;
+    }
+    const double t_exchanged = clock_ns();
     if (ex.herr != hipSuccess && status == PM_OK) {
         status = pmh::fail(ctx, PM_ERR_HIP, "ordering the exchange behind the mapping failed: %s", hipGetErrorString(ex.herr));
         first_error = ctx->error;
@@ -356,9 +368,16 @@ int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int 
     if (nrc != ncclSuccess) return nccl_fail(ctx, comm, "ncclAllReduce of the ranks' status", nrc);
     he = hipMemcpyAsync(comm->h_status + 2, comm->d_status + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, comm->stream);
     if (he == hipSuccess) he = hipStreamSynchronize(comm->stream);
-    // (a rank that cannot read the verdict treats the call as failed; it has taken part in every collective)
-    int n_failed = he == hipSuccess ? comm->h_status[2] : -1;
-    const int n_redo = he == hipSuccess ? comm->h_status[3] : 0;
+    if (he != hipSuccess) {
+        // A rank that cannot read the verdict cannot know whether a second exchange follows: peers that read "redo" would
+        // wait in their receives for this rank's block. RCCL does not release remote peers on a local error - the
+        // communicator is torn down instead, as for a failure of the transport itself.
+        (void)nccl_fail(ctx, comm, "reading the ranks' verdict", ncclSuccess);
+        return pmh::fail(ctx, PM_ERR_HIP, "reading the verdict of the ranks failed: %s", hipGetErrorString(he));
+    }
+    ctx->last_stage_ns[pmh::kStageAgreement] = clock_ns() - t_exchanged;
+    int n_failed = comm->h_status[2];
+    const int n_redo = comm->h_status[3];
     if (n_failed == 0 && n_redo > 0) {
         // somebody's planes changed after they had been sent: everybody sends the whole block again
         ex.issue(0, per_rank);
@@ -368,6 +387,8 @@ int pm_map_cube_sharded(pm_ctx *ctx, pm_comm *comm, const void *local_cube, int 
     hipError_t hw = hipEventRecord(comm->ev_done, comm->stream);
     if (hw == hipSuccess) hw = hipStreamWaitEvent(ctx->stream, comm->ev_done, 0);
     if (hw == hipSuccess) hw = hipStreamSynchronize(comm->stream);
+    if (!(ctx->trace & 4)) ctx->last_stage_ns[pmh::kStageExchangeExposed] = 0.0;  // (not separated from the agreement without the trace bit)
+    ctx->last_stage_ns[pmh::kStageShardedTotal] = clock_ns() - t_sharded;
     if (status != PM_OK) {
         ctx->error = first_error;
         return status;

@@ -218,9 +218,9 @@ struct ReprojectArgs {
 // The sparse host path of pm_map_cube (pm_hostpipe.hip; k_mark_blocks / k_fetch_blocks /
 // k_reproject_blocks): the blocks of a plane that the map samples - the same in every plane of the
 // cube - and the table they are collected into. Blocks are 16 bytes when CPU threads collect them
-// into pinned staging (the link then carries little more than the sampled pixels), 256 bytes when
-// the GPU fetches them from pinned host memory itself (the request size PCIe reads run at full rate at).
-constexpr int kBlkShiftHost = 4, kBlkShiftFetch = 8;
+// into pinned staging (the link then carries little more than the sampled pixels), 128 bytes when
+// the GPU fetches them from pinned host memory itself (PM_OPT_FETCH_BLOCK_BYTES: the PCIe read granularity).
+constexpr int kBlkShiftHost = 4;  // (the GPU's own fetch blocks: PM_OPT_FETCH_BLOCK_BYTES, 128 bytes by default)
 struct BlockTable {
     const int *blkmap;   // [plane_bytes >> shift] block of the plane -> row of the table, -1 = not in it
     const int *blklist;  // [n_list] row of the table -> block of the plane (k_fetch_blocks only)

@@ -112,6 +112,9 @@ struct pm_ctx {
     int fetch_shift = 7;         // PM_OPT_FETCH_BLOCK_BYTES: log2 of the blocks the GPU fetches from a pinned cube (routes 2, 4)
     int last_cube_route = -1;    // PM_OPT_LAST_CUBE_ROUTE
     int last_lt_path = 0;        // PM_OPT_LAST_LT_PATH
+    // PM_OPT_LAST_STAGE_NS + k: where the latest host-fed pm_map_cube / pm_map_cube_sharded of this context spent its time, ns
+    // (include/planetmapper_hip.h lists the stages; kStage* below)
+    double last_stage_ns[16] = {};
     int last_redo_planes = 0;    // PM_OPT_LAST_REDO_PLANES: planes of the latest finished pm_map_cube redone with their nanmedian
     // pm_set_chunk_callback: told, on the calling thread, each time the kernels of further planes of a
     // nearest / linear pm_map_cube have been ENQUEUED on the context stream (planes arrive in order)
@@ -121,6 +124,11 @@ struct pm_ctx {
 };
 
 namespace pmh {
+
+enum Stage : int {
+    kStageTotal = 0, kStageTables, kStagePlan, kStageFirstFill, kStageCollect, kStageIssue, kStageDrain, kStageFinish,
+    kStageDmaDevice, kStageKernelDevice, kStageExchangeExposed, kStageAgreement, kStageShardedTotal, kStageCount
+};
 
 // records the message in the context and returns `code`
 int fail(pm_ctx *ctx, int code, const char *fmt, ...);

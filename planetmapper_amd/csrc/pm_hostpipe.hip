@@ -102,6 +102,8 @@ struct HostPipe : HostPool {
     static constexpr int kFq = 4;  // GPU-fetched chunks of a hybrid segment in flight at most (+1: ring of events)
     hipEvent_t ev_f0[kFq] = {}, ev_f1[kFq] = {};  // start / end of each (timing enabled: the fetch rate is measured as it runs)
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;  // (with timing: stage times of a probe chunk)
+    // PM_OPT_TRACE bit 4: device-side durations of every chunk's H2D copy and kernels (start / end per ring slot, timing enabled)
+    hipEvent_t ev_d0[kRing] = {}, ev_d1[kRing] = {}, ev_q0[kRing] = {}, ev_q1[kRing] = {};
     // ---- pinned staging of the H2D leg of block tables collected by the pool (one per ring slot)
     char *in_stage[kRing] = {};
     size_t in_stage_bytes = 0;
@@ -140,8 +142,10 @@ struct HostPipe : HostPool {
         // it is committed only after WHOLE calls by the best single route and by the hybrid have been timed in turn
         int single = -1;            // the best single route by the probes
         bool trial = false;         // whole calls still alternate between `single` and the hybrid
-        double trial_ns[2] = {0.0, 0.0};  // [0] single, [1] hybrid: fastest whole call so far, ns per plane
+        double trial_ns[2] = {0.0, 0.0};  // [0] single, [1] hybrid: the MEDIAN of its three whole calls, ns per plane
+        double trial_samples[2][3] = {};
         int trial_n[2] = {0, 0};
+        double committed_trial_ns = 0.0;  // what the committed route showed in its trial: the trial re-opens if it drifts away
     };
     RouteStats rstats;
     double *d_maps = nullptr;  // the x/y maps of a PM_MEM_HOST call
@@ -184,6 +188,7 @@ static int pipe_get(pm_ctx *ctx, HostPipe **out)
         }
         threads = std::min(16, cores);
     }
+    if (const char *e = pm_debug_env("PM_POOL_SPIN_US")) hp->spin_us = std::max(0, std::atoi(e));  // (A/B of tools/)
     hp->start_workers(threads);
     hp->start_retirer();
     *out = hp;
@@ -515,8 +520,7 @@ inline size_t hybrid_collect_chunk(const pm_ctx *ctx)
 constexpr int kHybridInFlight = 3;
 
 // (hybrid: n_list / shift describe the 16-byte table, n_list_f the fetched one)
-SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, size_t n_list, int shift, bool dst_pinned, size_t n_list_f = 0,
-                     double fetch_share = 0.5)
+SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, size_t n_list, int shift, bool dst_pinned, size_t n_list_f = 0)
 {
     SegLayout L{};
     const size_t nmap = j.nmap;
@@ -534,7 +538,6 @@ SegLayout seg_layout(const pm_ctx *ctx, const CubeJob &j, const Segment &sg, siz
     if (hybrid) {
         // short chunks, dealt out as the segment runs (run_segment): to the GPU while fewer than kHybridInFlight
         // fetched chunks are queued, else to the copy threads
-        (void)fetch_share;
         chunk = std::min<size_t>(hybrid_collect_chunk(ctx), sg.n);
         L.table_row_bytes_f = n_list_f << ctx->fetch_shift;
         // (the closing chunk of a segment may hand the GPU whatever is left after the threads' last share)
@@ -605,6 +608,29 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
     const hipStream_t sk = ctx->stream;
     const size_t nmap = j.nmap;
     const bool hybrid = sg.route == HostPipe::kHybrid;
+    // stage record of the call (PM_OPT_LAST_STAGE_NS): host-side times always, device-side sums with PM_OPT_TRACE bit 4
+    double *const st = ctx->last_stage_ns;
+    const bool dev_times = (ctx->trace & 4) != 0;
+    if (dev_times && !hp->ev_d0[0])
+        for (int i = 0; i < HostPipe::kRing; i++) {
+            PM_HIP(ctx, hipEventCreate(&hp->ev_d0[i]));
+            PM_HIP(ctx, hipEventCreate(&hp->ev_d1[i]));
+            PM_HIP(ctx, hipEventCreate(&hp->ev_q0[i]));
+            PM_HIP(ctx, hipEventCreate(&hp->ev_q1[i]));
+        }
+    bool slot_timed[HostPipe::kRing] = {};
+    auto bank_slot = [&](int slot) -> int {  // the device durations of the chunk that used `slot` last (it has finished)
+        if (!dev_times || !slot_timed[slot]) return PM_OK;
+        float ms = 0.0f;
+        PM_HIP(ctx, hipEventSynchronize(hp->ev_q1[slot]));
+        PM_HIP(ctx, hipEventElapsedTime(&ms, hp->ev_d0[slot], hp->ev_d1[slot]));
+        st[kStageDmaDevice] += (double)ms * 1e6;
+        PM_HIP(ctx, hipEventElapsedTime(&ms, hp->ev_q0[slot], hp->ev_q1[slot]));
+        st[kStageKernelDevice] += (double)ms * 1e6;
+        slot_timed[slot] = false;
+        return PM_OK;
+    };
+    bool first_h2d = true;
     const bool seg_blocks = sg.route == HostPipe::kFetch, seg_host_blocks = sg.route == HostPipe::kCollect;
     char *base = (char *)ctx->scratch;
     char *ring = base + ((2 * nmap * sizeof(double) + 255) & ~(size_t)255);
@@ -638,7 +664,12 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
         // (Tried: ramping the chunks of a collected table up and down - c/8, c/4 ... c ... halves of the rest -
         //  to shorten the pipeline's fill and drain for short blocks. Same-box A/B, 64 and 512 planes, three
         //  process pairs: 2.26-2.86 vs 2.17-2.52 ms and 11.9-16.3 vs 13.0-14.6 ms - inside the run-to-run
-        //  spread of the collecting threads' placement; not kept.)
+        //  spread of the collecting threads' placement; not kept. Round 5, with the stage record (PM_OPT_LAST_STAGE_NS) on a
+        //  64-plane block, 16 threads: a first chunk of 2 planes doubling up to 27 takes "first_fill" from 0.55 to 0.09 ms and
+        //  leaves the call at 2.2 ms, a closing chunk of 3 planes leaves "drain" at 0.55 ms: the DMA of the table (21 us per
+        //  plane) and its collection (22 us) run at the same rate, so the link is always one chunk behind the threads - the
+        //  call is collection + the DMA of its last FULL chunk however the chunks are cut, and every extra chunk costs the
+        //  collection 50-80 us of waking and joining sixteen threads.)
         size_t np = 0;
         for (size_t q0 = 0; q0 < nb; q0 += np, c++) {
             // Hybrid: chunks are dealt out as the segment runs - to the GPU while fewer than kHybridInFlight of its
@@ -698,16 +729,25 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
                 // done) while the DMA of the previous chunk runs
                 char *dslot = ring + (size_t)slot * L.slot_bytes;
                 if (cslot >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipEventSynchronize(hp->ev_in[slot]));
-                const double tg = (stage_ns || hybrid) ? now_ns() : 0.0;
+                if ((rc = bank_slot(slot)) != PM_OK) return rc;
+                const double tg = now_ns();
                 hp->gather(hp->in_stage[slot], j.cube + pl * j.plane_bytes, j.plane_bytes, np, hlist, tab->n_list, tab->shift);
-                if (stage_ns) cpu_stage_ns += now_ns() - tg;
+                const double t_gathered = now_ns();
+                st[kStageCollect] += t_gathered - tg;
+                if (stage_ns) cpu_stage_ns += t_gathered - tg;
                 if (hybrid) {
-                    hy_cpu_ns += now_ns() - tg;
+                    hy_cpu_ns += t_gathered - tg;
                     hy_c_planes += (double)np;
+                }
+                if (first_h2d) {
+                    st[kStageFirstFill] += t_gathered - t_seg0;  // (the link has carried nothing of this segment until now)
+                    first_h2d = false;
                 }
                 if (cslot >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
                 if (stage_ns && cslot == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
+                if (dev_times) PM_HIP(ctx, hipEventRecord(hp->ev_d0[slot], hp->s_in));
                 PM_HIP(ctx, hipMemcpyAsync(dslot, hp->in_stage[slot], np * L.table_row_bytes, hipMemcpyHostToDevice, hp->s_in));
+                if (dev_times) PM_HIP(ctx, hipEventRecord(hp->ev_d1[slot], hp->s_in));
                 if (stage_ns && cslot == 0) {
                     PM_HIP(ctx, hipEventRecord(hp->ev_t1, hp->s_in));
                     timed_events = true;
@@ -719,10 +759,17 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
             } else {
                 char *dslot = ring + (size_t)slot * L.slot_bytes;
                 if (cslot >= (size_t)HostPipe::kRing) PM_HIP(ctx, hipStreamWaitEvent(hp->s_in, hp->ev_k[slot], 0));
+                if ((rc = bank_slot(slot)) != PM_OK) return rc;
                 if (stage_ns && c == 0) PM_HIP(ctx, hipEventRecord(hp->ev_t0, hp->s_in));
+                if (first_h2d) {
+                    st[kStageFirstFill] += now_ns() - t_seg0;
+                    first_h2d = false;
+                }
+                if (dev_times) PM_HIP(ctx, hipEventRecord(hp->ev_d0[slot], hp->s_in));
                 const double tc = stage_ns ? now_ns() : 0.0;
                 PM_HIP(ctx, hipMemcpyAsync(dslot, j.cube + pl * j.plane_bytes, np * j.plane_bytes, hipMemcpyHostToDevice, hp->s_in));
                 if (stage_ns) cpu_stage_ns += now_ns() - tc;  // (pageable planes: the runtime stages them inside the call)
+                if (dev_times) PM_HIP(ctx, hipEventRecord(hp->ev_d1[slot], hp->s_in));
                 if (stage_ns && c == 0) {
                     PM_HIP(ctx, hipEventRecord(hp->ev_t1, hp->s_in));
                     timed_events = true;
@@ -737,10 +784,16 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
             const int fk = (int)(f_head % HostPipe::kFq);
             if (fetch_chunk) PM_HIP(ctx, hipEventRecord(hp->ev_f0[fk], sk));
             if (time_kernel) PM_HIP(ctx, hipEventRecord(hp->ev_t0, sk));
+            const bool slot_chunk = dev_times && !chunk_zero_copy;  // (a chunk that holds a ring slot: its copy and kernels are timed per slot)
+            if (slot_chunk) PM_HIP(ctx, hipEventRecord(hp->ev_q0[slot], sk));
             if (blocks || host_blocks)
                 pm_launch_reproject_blocks(b, tb, j.dtype, sk, /*fetch=*/blocks);
             else
                 pm_launch_reproject(b, j.dtype, sk);
+            if (slot_chunk) {
+                PM_HIP(ctx, hipEventRecord(hp->ev_q1[slot], sk));
+                slot_timed[slot] = true;
+            }
             if (time_kernel) {
                 PM_HIP(ctx, hipEventRecord(hp->ev_t1, sk));
                 timed_events = true;
@@ -780,8 +833,13 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
     }
     // the ring and the events are free for the next segment / the flag check
     if (hybrid && (ctx->trace & 1)) std::fprintf(stderr, "[pm hostpipe]   hybrid: all chunks issued at %.3f ms\n", (now_ns() - t_seg0) * 1e-6);
+    const double t_issued = now_ns();
+    st[kStageIssue] += t_issued - t_seg0;
     PM_HIP(ctx, hipStreamSynchronize(sk));
     PM_HIP(ctx, hipStreamSynchronize(hp->s_in));
+    st[kStageDrain] += now_ns() - t_issued;
+    for (int slot = 0; slot < HostPipe::kRing; slot++)
+        if ((rc = bank_slot(slot)) != PM_OK) return rc;
     if (stage_ns) {
         float ms = 0.0f;
         if (timed_events) PM_HIP(ctx, hipEventElapsedTime(&ms, hp->ev_t0, hp->ev_t1));
@@ -793,6 +851,7 @@ int run_segment(pm_ctx *ctx, HostPipe *hp, const CubeJob &j, const Segment &sg, 
     }
     if (hybrid) {
         if ((rc = retire_fetched(true)) != PM_OK) return rc;
+        st[kStageKernelDevice] += hy_f_ns;  // (the fetched chunks' kernels: their reads over the link are in there)
         if (hybrid_obs) {
             hybrid_obs[0] = hy_cpu_ns;
             hybrid_obs[1] = hy_c_planes;
@@ -823,7 +882,8 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
                                         const double *y_map, size_t nmap, pm::ReprojectArgs a, double *out, bool device_out)
 {
     const bool trace = (ctx->trace & 1) != 0;  // PM_OPT_TRACE: stage times of every call on stderr
-    const double t_call = trace ? now_ns() : 0.0;
+    const double t_call = now_ns();
+    for (int k = 0; k < kStageCount; k++) ctx->last_stage_ns[k] = 0.0;
     HostPipe *hp;
     int rc = pipe_get(ctx, &hp);
     if (rc != PM_OK) return rc;
@@ -891,7 +951,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         have256 = t256.n_list > 0;
     }
 
-    const double t_tables = trace ? now_ns() : 0.0;
+    const double t_tables = now_ns();
     // ---- the plan: segments of planes, each fed by one route
     std::vector<Segment> plan;
     const size_t P = (size_t)n_planes;
@@ -983,7 +1043,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
             if ((sg.route == HostPipe::kFetch || sg.route == HostPipe::kHybrid) && !have256) continue;
             const HostPipe::Table &tt = sg.route == HostPipe::kFetch ? t256 : t16;
             // (the split of a hybrid remainder is not known yet: size it for the widest fetched chunk)
-            const SegLayout L = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned, t256.n_list, plan[i].route < 0 ? 0.95 : rs.hybrid_fetch_share);
+            const SegLayout L = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned, t256.n_list);
             need = std::max(need, L.need);
             if (sg.route == HostPipe::kCollect || sg.route == HostPipe::kHybrid) in_stage_need = std::max(in_stage_need, L.slot_bytes);
             if (plan[i].route >= 0) lay[i] = L;
@@ -1006,7 +1066,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
     else if (dst_pinned)
         PM_HIP(ctx, hipHostGetDevicePointer((void **)&out_dev, (void *)out, 0));
 
-    const double t_plan = trace ? now_ns() : 0.0;
+    const double t_plan = now_ns();
     for (size_t i = 0; i < plan.size(); i++) {
         Segment &sg = plan[i];
         if (sg.n == 0) continue;
@@ -1034,7 +1094,7 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
             }
             sg.route = rs.committed;
             const HostPipe::Table &tt = sg.route == HostPipe::kFetch ? t256 : t16;
-            lay[i] = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned, t256.n_list, rs.hybrid_fetch_share);
+            lay[i] = seg_layout(ctx, j, sg, tt.n_list, tt.shift, dst_pinned, t256.n_list);
         }
         const HostPipe::Table *tt = sg.route == HostPipe::kFetch ? &t256 : &t16;
         const double t_begin = now_ns();
@@ -1055,14 +1115,19 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         }
         if (mode < 0 && rs.trial && !exploring && plan.size() == 1 && P >= 6 * kHybridCollectChunk &&
             (sg.route == HostPipe::kHybrid || sg.route == rs.single)) {
+            // three whole calls per side, judged by their medians (the calls run while other ranks share the link and the
+            // CPUs: one lucky call must not fix the route for the life of the context)
             const int k = sg.route == HostPipe::kHybrid ? 1 : 0;
-            const double v = wall / (double)sg.n;
-            rs.trial_ns[k] = rs.trial_n[k] == 0 ? v : std::min(rs.trial_ns[k], v);
-            rs.trial_n[k]++;
-            if (rs.trial_n[0] >= 2 && rs.trial_n[1] >= 2) {
+            if (rs.trial_n[k] < 3) rs.trial_samples[k][rs.trial_n[k]++] = wall / (double)sg.n;
+            if (rs.trial_n[0] >= 3 && rs.trial_n[1] >= 3) {
+                for (int q = 0; q < 2; q++) {
+                    double *v = rs.trial_samples[q];
+                    rs.trial_ns[q] = std::max(std::min(v[0], v[1]), std::min(std::max(v[0], v[1]), v[2]));
+                }
                 rs.trial = false;
                 // (the hybrid must earn its keep: it also loads the link and the GPU's fetch path)
                 rs.committed = rs.trial_ns[1] < 0.93 * rs.trial_ns[0] ? (int)HostPipe::kHybrid : rs.single;
+                rs.committed_trial_ns = rs.trial_ns[rs.committed == HostPipe::kHybrid ? 1 : 0];
             }
         }
         ctx->last_cube_route = sg.route;
@@ -1078,9 +1143,17 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
                 v = stage / (double)sg.n;
             else if (!exploring && sg.n >= 3 * (lay[i].chunk + lay[i].chunk_f))  // (a running mean once committed, from calls long enough to be pipelines)
                 v = v > 0.0 ? 0.75 * v + 0.25 * wall / (double)sg.n : wall / (double)sg.n;
+            // the route was committed on what the box looked like during its trial: when its running cost has moved 15 % away
+            // from that (other ranks came or went), the next whole calls hold the trial again
+            if (!sg.probe && !exploring && !rs.trial && rs.committed_trial_ns > 0.0 && sg.route == rs.committed && v > 1.15 * rs.committed_trial_ns &&
+                rs.single >= 0 && P >= 6 * kHybridCollectChunk) {
+                rs.trial = true;
+                rs.trial_n[0] = rs.trial_n[1] = 0;
+                rs.committed_trial_ns = 0.0;
+            }
         }
     }
-    const double t_segs = trace ? now_ns() : 0.0;
+    const double t_segs = now_ns();
     // per-plane flags of the whole call: one read-back
     std::vector<int> hflags((size_t)n_planes);
     PM_HIP(ctx, hipMemcpyAsync(hflags.data(), ctx->flags, (size_t)n_planes * sizeof(int), hipMemcpyDeviceToHost, sk));
@@ -1100,6 +1173,14 @@ static int map_cube_host_pipelined_impl(pm_ctx *ctx, const void *cube, int dtype
         double *dout1 = (double *)(dplane + ((j.plane_bytes + 255) & ~(size_t)255));
         rc = redo_with_median(ctx, j, redo, dxm, dym, dplane, dout1);
         if (rc != PM_OK) return rc;
+    }
+    {
+        const double t_end = now_ns();
+        double *st = ctx->last_stage_ns;
+        st[kStageTables] = t_tables - t_call;
+        st[kStagePlan] = t_plan - t_tables;
+        st[kStageFinish] = t_end - t_segs;
+        st[kStageTotal] = t_end - t_call;
     }
     return PM_OK;
 }

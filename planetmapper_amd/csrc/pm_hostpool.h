@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <chrono>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -162,6 +163,21 @@ struct HostPool {
     std::condition_variable cv_work, cv_done;
     std::deque<std::shared_ptr<Job>> queue;  // jobs that may still have parts to hand out
     bool stop = false;
+    // A call feeds the pool a job every few hundred microseconds (a chunk's collection, a staged piece's copy-out): a
+    // thread that went to sleep on the condition variable between two of them comes back 30-60 us late, sixteen of them
+    // one after the other. So a thread with nothing to do keeps looking for `spin_us` before it sleeps.
+    std::atomic<unsigned> posted{0};  // bumped by every post()
+    int spin_us = 150;
+    template <typename Pred>
+    void spin_until(Pred &&ready) const
+    {
+        if (spin_us <= 0) return;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(spin_us);
+        for (int i = 0; !ready(); i++) {
+            _mm_pause();
+            if ((i & 63) == 63 && std::chrono::steady_clock::now() >= deadline) return;
+        }
+    }
 
     void run_part(const Job &j, size_t i)
     {
@@ -238,6 +254,7 @@ struct HostPool {
             std::shared_ptr<Job> j;
             {
                 std::unique_lock<std::mutex> lk(mu);
+                bool spun = false;
                 for (;;) {
                     while (!queue.empty() && queue.front()->next.load(std::memory_order_relaxed) >= queue.front()->nparts)
                         queue.pop_front();
@@ -248,7 +265,17 @@ struct HostPool {
                     // (only with nothing left to hand out: a queued copy-out owns a staging slot that
                     //  nobody else would ever release)
                     if (stop) return;
+                    if (!spun) {
+                        // look a little longer before sleeping (the lock is not held meanwhile)
+                        const unsigned seen = posted.load(std::memory_order_acquire);
+                        lk.unlock();
+                        spin_until([&] { return posted.load(std::memory_order_acquire) != seen; });
+                        lk.lock();
+                        spun = true;
+                        continue;
+                    }
                     cv_work.wait(lk);
+                    spun = false;
                 }
             }
             take_parts(j);
@@ -282,6 +309,7 @@ struct HostPool {
         {
             std::lock_guard<std::mutex> lk(mu);
             queue.push_back(j);
+            posted.fetch_add(1, std::memory_order_release);
         }
         cv_work.notify_all();
     }
@@ -290,6 +318,8 @@ struct HostPool {
     {
         post(j);
         take_parts(j);
+        // (the last parts are in other threads' hands for a few microseconds more)
+        spin_until([&] { return j->finished.load(std::memory_order_acquire) == j->nparts; });
         std::unique_lock<std::mutex> lk(mu);
         cv_done.wait(lk, [&] { return j->done; });
     }

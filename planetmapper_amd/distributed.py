@@ -286,7 +286,8 @@ def map_cube_sharded_device(engine, cube, dtype, n_planes_local: int, x_map, y_m
 
 def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x_map, y_map, n0: int, n1: int, gathered,
                                rank: int, world: int, *, interpolation='linear', propagate_nan=True, group=None,
-                               host_cube: bool = False, gather: bool = True, pipeline_chunks: bool | None = None) -> None:
+                               host_cube: bool = False, gather: bool = True, pipeline_chunks: bool | None = None,
+                               stages: dict | None = None) -> None:
     """
     The plane-sharded cube with the collective PIPELINED behind the mapping - the torch.distributed
     form of `pm_map_cube_sharded` (same protocol, include/planetmapper_hip.h):
@@ -309,6 +310,10 @@ def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x
     `gather=False`: only this rank's slot is written, no collective, errors raise at once.
     `pipeline_chunks=True` keeps the exchange bookkeeping running even when nothing is exchanged (a
     single process timing what one rank of N would do: bench.py's shard proxy).
+    `stages`: a dict that receives where this rank's call spent its time, in ms - `map_call` (the engine call and its
+    finishing `synchronize()`; `Engine.last_stages_ms()` has its inside), `exchange_exposed` (what was left of the
+    all-gathers once the mapping had finished), `agreement`. Asking for it makes the call wait for the device at those
+    points, which it otherwise does not.
     """
     import torch
     import torch.distributed as dist
@@ -362,6 +367,9 @@ def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x
         except Exception as e:  # noqa: BLE001 - must not unwind through the C frames
             state['error'] = e
 
+    import time
+
+    t_begin = time.perf_counter()
     redone = 0
     if mine_n > 0:
         if chunked:
@@ -381,6 +389,9 @@ def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x
         finally:
             if chunked:
                 engine.set_chunk_callback(None)
+    t_mapped = time.perf_counter()
+    if stages is not None:
+        stages.update({'map_call': (t_mapped - t_begin) * 1e3, 'exchange_exposed': 0.0, 'agreement': 0.0})
     if not exchange:
         if state['error'] is not None:
             raise state['error']
@@ -392,10 +403,17 @@ def map_cube_sharded_pipelined(engine, local_cube, dtype, n_planes_total: int, x
         error = error or e
     for w in works:
         w.wait()
+    if stages is not None:
+        if slot.is_cuda:
+            torch.cuda.synchronize(slot.device)
+        stages['exchange_exposed'] = (time.perf_counter() - t_mapped) * 1e3
+    t_exchanged = time.perf_counter()
     verdict = torch.tensor([0 if error is None else 1, 1 if (error is None and redone > 0) else 0], dtype=torch.int32,
                            device=_group_device(group))
     dist.all_reduce(verdict, op=dist.ReduceOp.SUM, group=group)
     n_failed, n_redo = (int(v) for v in verdict.tolist())
+    if stages is not None:
+        stages['agreement'] = (time.perf_counter() - t_exchanged) * 1e3
     if n_failed == 0 and n_redo > 0:
         # somebody's planes changed after they had been sent: everybody gathers the whole block again
         dist.all_gather([torch.empty_like(slot) if r == rank else gathered[r] for r in range(world)], slot, group=group)

@@ -149,6 +149,10 @@ class Engine:
         self._check(self._lib.pm_get_option(self._ctx, int(option), ctypes.byref(v)))
         return int(v.value)
 
+    def last_stages_ms(self) -> dict[str, float]:
+        """`PM_OPT_LAST_STAGE_NS`: where the latest host-fed `map_cube` / sharded call of this engine spent its time, in ms."""
+        return {name: self.get_option(_lib.PM_OPT_LAST_STAGE_NS + k) * 1e-6 for k, name in enumerate(_lib.STAGES)}
+
     def last_redo_planes(self) -> int:
         """planes of the latest finished nearest / linear map_cube that were redone with their nanmedian"""
         return self.get_option(_lib.PM_OPT_LAST_REDO_PLANES)

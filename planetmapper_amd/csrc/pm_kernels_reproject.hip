@@ -509,13 +509,14 @@ __global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *
 // twice). (A first tiled axis 1 WITHOUT the staged LU rows ran in the 2.8 ms of the plain lane-per-row kernel: the round
 // trip per step was the cost, not the access pattern - profiles/EXPERIMENTS.md.)
 constexpr int kSolveRows = 64, kSolveCols = 16, kSolveBand = 11;  // (2 k + 1 <= 11)
-__global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, int n_planes, int ny, int nx, SplineAxis ax)
+__global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, int n_planes, int ny, int nx, SplineAxis ax, const PlaneStats *only_flagged)
 {
     __shared__ double tile[kSolveRows][kSolveCols + 1];
     __shared__ double lu[kSolveCols][kSolveBand];
     const int lane = threadIdx.x;
     const int groups = (ny + kSolveRows - 1) / kSolveRows;
     const int pl = blockIdx.x / groups, r0 = (blockIdx.x % groups) * kSolveRows;
+    if (only_flagged && !only_flagged[pl].needs_median) return;  // (the second round: planes that were cleaned again with their nanmedian)
     const int rows = min(kSolveRows, ny - r0);
     double *base = work + ((size_t)pl * ny + r0) * nx;
     const int n = ax.n, k = ax.k, w = 2 * k + 1;
@@ -613,36 +614,60 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
 // Axis 0 (lines = image columns) in the same style: one wave takes 64 adjacent columns of a plane, 16 rows at a time - the
 // lanes' loads are coalesced as they stand (no transposition), the LU rows of the 16 steps come through LDS, the next 16
 // rows are in flight while the current ones are worked on.
-__global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(double *work, int n_planes, int ny, int nx, SplineAxis ax)
+// The NaN pre-clean rides on the forward pass: the samples come from the cube in its own dtype, a non-finite one is
+// replaced on the way in (cleaned_at: its 3 x 3 neighbours straight from the cube - rare, and cached) - the cleaned plane is
+// never written and read back (two of the ten passes a cubic reprojection makes over a plane). MODE 1 cleans with a
+// provisional 0.0 for pixels without a finite neighbour and flags their planes (PlaneStats::needs_median, the lazy form of
+// k_spline_clean); MODE 2 does the flagged planes again with their nanmedian (the others' blocks leave at once).
+template <typename T, int MODE>
+__global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube, double *work, PlaneStats *stats, int n_planes, int ny, int nx,
+                                                                  SplineAxis ax)
 {
     __shared__ double lu[2][kSolveCols][kSolveBand];
     const int lane = threadIdx.x;
     const int groups = (nx + kSolveRows - 1) / kSolveRows;
     const int pl = blockIdx.x / groups, x = (blockIdx.x % groups) * kSolveRows + lane;
+    if (MODE == 2 && !stats[pl].needs_median) return;
+    const double median = MODE == 2 ? stats[pl].median : 0.0;
+    const T *img = cube + (size_t)pl * ny * nx;
+    bool nm = false;
     const bool live = x < nx;
     double *col = work + (size_t)pl * ny * nx + (live ? x : 0);
     const int n = ax.n, k = ax.k, w = 2 * k + 1;
     constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
     double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double v[kSolveCols], g[kSolveCols], glu[kLuRegs];
+    bool forward = true;  // the forward pass takes its samples from the cube, cleaned; the backward pass from `work`
     auto fetch = [&](int i0) {
         const int cnt = min(kSolveCols, n - i0);
+        if (forward) {
+            // (the raw samples: what a non-finite one becomes is decided when the tile is taken up - a test here would wait
+            //  for every load of the tile that is meant to be in flight while the previous one is worked on)
 #pragma unroll
-        for (int j = 0; j < kSolveCols; j++) g[j] = (live && j < cnt) ? col[(size_t)(i0 + j) * nx] : 0.0;
+            for (int j = 0; j < kSolveCols; j++) g[j] = (live && j < cnt) ? load_as_f64(img, (size_t)(i0 + j) * nx + x) : 0.0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSolveCols; j++) g[j] = (live && j < cnt) ? col[(size_t)(i0 + j) * nx] : 0.0;
+        }
 #pragma unroll
         for (int e = 0; e < kLuRegs; e++) {
             const int q = e * kSolveRows + lane;
             glu[e] = q < cnt * w ? ax.lu[(size_t)i0 * w + q] : 0.0;
         }
     };
-    auto stage = [&](int buf, int cnt) {
+    auto stage = [&](int buf, int cnt, int i0) {
 #pragma unroll
         for (int e = 0; e < kLuRegs; e++) {
             const int q = e * kSolveRows + lane;
             if (q < cnt * w) lu[buf][q / w][q % w] = glu[e];
         }
+        if (forward) {
 #pragma unroll
-        for (int j = 0; j < kSolveCols; j++) v[j] = g[j];
+            for (int j = 0; j < kSolveCols; j++) v[j] = (live && j < cnt) ? cleaned_value(img, g[j], (long)(i0 + j), (long)x, ny, nx, median, nm) : 0.0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSolveCols; j++) v[j] = g[j];
+        }
         __syncthreads();
     };
     auto put = [&](int i0, int cnt) {
@@ -655,7 +680,7 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(double *work, 
     fetch(0);
     for (int i0 = 0; i0 < n; i0 += kSolveCols, buf ^= 1) {
         const int cnt = min(kSolveCols, n - i0);
-        stage(buf, cnt);
+        stage(buf, cnt, i0);
         if (i0 + kSolveCols < n) fetch(i0 + kSolveCols);
 #pragma unroll
         for (int j = 0; j < kSolveCols; j++) {
@@ -673,14 +698,16 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(double *work, 
         }
         put(i0, cnt);
     }
+    if (MODE == 1 && nm) atomicOr(&stats[pl].needs_median, 1);
     // back substitution
+    forward = false;
 #pragma unroll
     for (int q = 0; q < 5; q++) prev[q] = 0.0;
     const int i_last = ((n - 1) / kSolveCols) * kSolveCols;
     fetch(i_last);
     for (int i0 = i_last; i0 >= 0; i0 -= kSolveCols, buf ^= 1) {
         const int cnt = min(kSolveCols, n - i0);
-        stage(buf, cnt);
+        stage(buf, cnt, i0);
         if (i0 - kSolveCols >= 0) fetch(i0 - kSolveCols);
 #pragma unroll
         for (int j = kSolveCols - 1; j >= 0; j--) {
@@ -1018,13 +1045,20 @@ static void launch_clean_lazy_t(const pm::ReprojectArgs &a, double *work, pm::Pl
 template <typename T>
 static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s)
 {
-    launch_clean_lazy_t<T>(a, sa.work, stats, hist, s);
-    const unsigned cgroups = (unsigned)((a.nx + pm::kSolveRows - 1) / pm::kSolveRows);
-    hipLaunchKernelGGL(pm::k_spline_solve_cols, dim3(cgroups * (unsigned)a.n_planes), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes,
-                       a.ny, a.nx, sa.rows);
-    const unsigned groups = (unsigned)((a.ny + pm::kSolveRows - 1) / pm::kSolveRows);
-    hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(groups * (unsigned)a.n_planes), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes,
-                       a.ny, a.nx, sa.cols);
+    const size_t npx = (size_t)a.ny * a.nx;
+    const unsigned cgroups = (unsigned)((a.nx + pm::kSolveRows - 1) / pm::kSolveRows) * (unsigned)a.n_planes;
+    const unsigned rgroups = (unsigned)((a.ny + pm::kSolveRows - 1) / pm::kSolveRows) * (unsigned)a.n_planes;
+    // first round: every plane, cleaned on the way into the axis-0 solve with a provisional 0.0 where a pixel has no finite
+    // neighbour (their planes are flagged) ...
+    hipLaunchKernelGGL((pm::k_spline_solve_cols<T, 1>), dim3(cgroups), dim3(pm::kSolveRows), 0, s, (const T *)a.cube, sa.work, stats, a.n_planes, a.ny,
+                       a.nx, sa.rows);
+    hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(rgroups), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes, a.ny, a.nx, sa.cols, (const pm::PlaneStats *)nullptr);
+    // ... second round: the flagged planes alone, with their nanmedian (the blocks of the others leave at once: most data
+    // never has such a pixel)
+    launch_median_t<T>(a.cube, a.n_planes, npx, stats, hist, s, 1);
+    hipLaunchKernelGGL((pm::k_spline_solve_cols<T, 2>), dim3(cgroups), dim3(pm::kSolveRows), 0, s, (const T *)a.cube, sa.work, stats, a.n_planes, a.ny,
+                       a.nx, sa.rows);
+    hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(rgroups), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes, a.ny, a.nx, sa.cols, (const pm::PlaneStats *)stats);
     hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
                        0, s, a, sa);
 }

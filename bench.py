@@ -1218,6 +1218,10 @@ def headline(args) -> None:
             # ... and if the section HANGS (a collective some rank never joins), every rank gives up after a deadline of
             # its own: rank 0 prints the complete line with the section marked as timed out, and all of them leave with
             # status 0 - the headline of this N is measured and must not be lost to an optional section.
+            # (Status 0 is deliberate. The caller's contract is "one JSON line and the exit status": a non-zero status of one
+            #  rank makes torch.distributed.run tear the group down and report failure - the measured headline of this N
+            #  would be recorded as a failed run. The hang is not hidden: the line says `cube_host.error: timed out ...`,
+            #  and a rank stuck in a collective cannot tear its process group down anyway - os._exit is all that is left.)
             import threading
 
             deadline = float(os.environ.get('PM_BENCH_EXTRAS_TIMEOUT_S', '300'))

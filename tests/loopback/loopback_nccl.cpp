@@ -15,7 +15,9 @@
 // of a group makes progress in turn, so a pair of ranks sending to each other cannot deadlock on a full ring.
 // A wait that sees no progress for PM_LOOPBACK_TIMEOUT_S seconds (default 60) fails with ncclSystemError;
 // ncclCommAbort raises a flag in the segment that fails every rank's pending and future operation (so, unlike
-// RCCL's, an abort here DOES release remote peers - tests of "nobody is left waiting" must not rely on that
+// RCCL's, an abort here DOES release remote peers - unless PM_LOOPBACK_LOCAL_ABORT=1, the mode in which the
+// failing-transport test shows what the peers' progress rests on: the transport's own timeout, nothing else;
+// tests of "nobody is left waiting" must not rely on the flag
 // and assert instead that the protocol itself keeps every rank moving).
 //
 // Fault injection (tests): PM_LOOPBACK_FAIL="<rank>:<nth>" makes the nth ncclSend of that rank (counted per
@@ -385,7 +387,10 @@ int ncclCommAbort(ncclComm_t c)
 {
     if (!c) return ncclSuccess;
     g_stat_aborts.fetch_add(1);
-    if (c->seg) c->seg->aborted.store(1, std::memory_order_release);
+    // PM_LOOPBACK_LOCAL_ABORT=1: like RCCL's, the abort releases nobody but the caller - peers that wait for this rank go on
+    // waiting until the transport's own timeout (PM_LOOPBACK_TIMEOUT_S) fails their operation
+    const char *local = std::getenv("PM_LOOPBACK_LOCAL_ABORT");
+    if (c->seg && !(local && local[0] == '1')) c->seg->aborted.store(1, std::memory_order_release);
     return ncclCommDestroy(c);
 }
 

@@ -88,6 +88,22 @@ def test_c_abi_sharded_cube_survives_a_failing_transport():
     assert rep['loopback_stats[groups,sends,recvs,bytes,allreduces,aborts]'][5] >= 1
 
 
+def test_a_failing_transport_with_an_abort_that_releases_nobody_but_the_caller():
+    """
+    The same failure with PM_LOOPBACK_LOCAL_ABORT=1: the failing rank's ncclCommAbort is local, as RCCL's is. Its peers are
+    in receives from it; what ends their wait is the TRANSPORT's own failure detection (here PM_LOOPBACK_TIMEOUT_S; on real
+    RCCL its watchdog / NCCL_TIMEOUT, if configured - pm_comm adds none of its own) - every rank then returns an error.
+    The protocol guarantees that no rank returns success with an invalid cube, not that a dead link is noticed quickly.
+    """
+    _build_loopback()
+    world = 4
+    p = subprocess.Popen([sys.executable, WORKER, 'capi', '--threads', '--world', str(world), '--cases', 'send_fault', '--deadline', '240'],
+                         env=_env(PM_LOOPBACK_FAIL='1:3', PM_LOOPBACK_TIMEOUT_S='4', PM_LOOPBACK_LOCAL_ABORT='1'), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    (rep,) = _reports([p])
+    assert rep['ok'] and not rep['hung'], rep
+
+
 @pytest.mark.parametrize('world', [2, 4])
 def test_c_abi_sharded_cube_over_the_loopback_transport_processes(world, tmp_path):
     """ranks = processes sharing device 0 (the shape of a real launch: one process per rank)"""

@@ -4,7 +4,7 @@
 // maps a host-resident cube plane by plane and every get_*_img returns a host array
 // (body_xy.py:3166). A drop-in caller therefore sees the PCIe leg, not the kernels - one 4096^2
 // frame is 0.2 ms of GPU work and 671 MB of results. This file makes that leg run at the rate of
-// the link (measured on the MI355X boxes, tools/probe_host_path.hip: 57 GB/s per direction for
+// the link (measured on the MI355X boxes, tools/probes/hip/probe_host_path.hip: 57 GB/s per direction for
 // pinned memory, 49 GB/s each way in duplex):
 //
 //   * results -> pageable caller memory: DMA into a ring of pinned staging buffers; a retire thread
@@ -36,7 +36,7 @@
 //     of the last two (4) - short chunks of planes dealt out as the call runs, to the GPU's fetch while fewer
 //     than two of its chunks are queued, else to the copy threads, who collect while those fetches cross the
 //     link; the split follows the speed of the two legs by itself (64 planes, 2 threads: 3.7-4.6 ms against
-//     5.5-6.0 fetched and 6.3-9.1 collected, box to box; tools/route_ab.py).
+//     5.5-6.0 fetched and 6.3-9.1 collected, box to box; tools/probes/route_ab.py).
 //
 // No compute happens on the CPU here: the threads move bytes (and write the constant NaN where the
 // kernels' own pre-mask says nothing else can be).
@@ -514,7 +514,7 @@ inline size_t hybrid_collect_chunk(const pm_ctx *ctx)
 {
     size_t c = kHybridCollectChunk;
     if (ctx->pipe) c = std::max<size_t>(c, ctx->pipe->workers.size() + 1);
-    if (const char *e = pm_debug_env("PM_HYBRID_CCHUNK")) c = (size_t)std::max(1, std::atoi(e));  // (A/B of tools/route_ab.py)
+    if (const char *e = pm_debug_env("PM_HYBRID_CCHUNK")) c = (size_t)std::max(1, std::atoi(e));  // (A/B of tools/probes/route_ab.py)
     return std::min(c, kHybridCollectChunkMax);
 }
 constexpr int kHybridInFlight = 3;

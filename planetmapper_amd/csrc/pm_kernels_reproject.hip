@@ -176,7 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 
 // ------------------------------------------------------------------ sparse host path: block table
 // A cube in HOST memory mapped onto a coarse grid: what counts is how many bytes cross PCIe and in
-// which request sizes (tools/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of 256 bytes
+// which request sizes (tools/probes/hip/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of 256 bytes
 // and more 55 GB/s; the in-place gather of k_reproject - uncached, so neighbouring waves fetch the
 // same lines again - 32 GB/s of lines). The map touches a fraction of each plane, the SAME blocks in
 // every plane. k_mark_blocks runs the sampling arithmetic once and flags those blocks; k_blocks_*

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
 Where the time of a host-fed cube call goes (config 5 geometry): `PM_DEBUG_ENV=1 PM_HOSTPIPE_TRACE=1 python
-tools/cube_host_probe.py [--planes 512,64] [--threads 16,2] [--chunk-mib 32]` prints the library's own
+tools/probes/cube_host_probe.py [--planes 512,64] [--threads 16,2] [--chunk-mib 32]` prints the library's own
 stage trace (stderr) and the wall time of each step (x/y map + pm_map_cube(PM_MEM_HOST_CUBE) + finish).
 """
 import argparse
@@ -11,7 +11,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 
 
 def main():

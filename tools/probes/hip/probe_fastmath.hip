@@ -1,8 +1,8 @@
 // probe_fastmath.hip -- measures, on the GPU, the error of every function of
 // planetmapper_amd/csrc/pm_fastmath.hip.h against the device libm / IEEE operations.
 //
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probe_fastmath.hip -o tools/probe_fastmath
-//   ./tools/probe_fastmath            # prints one JSON line per function
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probes/hip/probe_fastmath.hip -o tools/probe_fastmath
+//   ./tools/probes/hip/probe_fastmath            # prints one JSON line per function
 //
 // Errors of sqrt / rsqrt / rcp / division are in ulp of the result; the angle functions in
 // absolute radians (their results feed degrees with a parity bar of 1e-9 deg = 1.7e-11 rad).

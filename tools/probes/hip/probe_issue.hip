@@ -2,8 +2,8 @@
 // wave64 FP64 FMA, a 32-bit integer op, a select and a mix of them take when 8 waves share a SIMD.
 // The spheroid image kernel is VALU-bound; this says which instructions are worth removing.
 //
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probe_issue.hip -o tools/probe_issue
-//   ./tools/probe_issue     # one JSON line per mode; ns_per_inst is per wave instruction per SIMD
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 tools/probes/hip/probe_issue.hip -o tools/probe_issue
+//   ./tools/probes/hip/probe_issue     # one JSON line per mode; ns_per_inst is per wave instruction per SIMD
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

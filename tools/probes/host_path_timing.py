@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from planetmapper_amd import _lib  # noqa: E402
 from planetmapper_amd.engine import Engine  # noqa: E402
 from planetmapper_amd.scenarios import load_scenario  # noqa: E402

@@ -2,7 +2,7 @@
 """Time pm_backplanes_img for disc sizes from all-off-disc to all-on-disc (GPU box)."""
 import sys, os, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from planetmapper_amd.engine import Engine
 from planetmapper_amd.scenarios import load_scenario

@@ -9,7 +9,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle  # noqa: E402
 from planetmapper_amd.scenarios import load_scenario  # noqa: E402
 from planetmapper_amd.engine import Engine  # noqa: E402

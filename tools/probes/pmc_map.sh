@@ -1,3 +1,4 @@
+# PMC passes of the map kernels: bash tools/probes/pmc_map.sh
 set -e
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_map
 rm -rf $OUT; mkdir -p $OUT

@@ -1,3 +1,4 @@
+"""Deviation of pm_radec_query (B0 kernel and the J2000 one behind PM_OPT_GENERAL_KERNEL) from the oracle on 200 000 sky points around Jupiter and Saturn: masks, max / p99, share inside 1e-9 deg."""
 import sys; sys.path[:0]=['/root/repo','/root/repo/tests']
 import numpy as np
 from planetmapper_amd.engine import Engine

@@ -3,7 +3,7 @@ Same-process A/B of the host-cube routes (PM_OPT_HOST_CUBE_ROUTE) on the block o
 ceil(512 / N) planes of 1024^2 f64 from pinned host memory -> 1 deg map, device output, for several copy-thread
 counts. Forced routes 2 (GPU fetch), 3 (collected), 4 (hybrid) and the library's own choice (-1), interleaved
 round-robin so that box and clock drift hit all alike; median / min of `--reps` calls each.
-Usage (GPU box): python tools/route_ab.py [--n 8] [--threads 2,4,16] [--reps 9]
+Usage (GPU box): python tools/probes/route_ab.py [--n 8] [--threads 2,4,16] [--reps 9]
 """
 import argparse
 import json
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 
 def main():

@@ -1010,10 +1010,11 @@ __device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double l
     // light time of the point, two passes from the centre value: pos(te) = T(te) + R(te)^T tv, in B0
     // w(d) = VB d + AB d^2 / 2 - O0 + Rz(wdot d)^T tv
     const double wdot = kp->g.wdot;
-    double lt = kp->g.lt_c;
-    V3 w = {0.0, 0.0, 0.0}, q = tv;
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
+    // (the first pass, from the centre's light time, sits at t0 itself - d = (et - lt_c) - t0 = 0 exactly: the point as it
+    //  stands, the bits of the general expression without its sincos and nine FMAs)
+    V3 q = tv, w = {tv.x - kp->O0[0], tv.y - kp->O0[1], tv.z - kp->O0[2]};
+    const double lt = sqrt_fast(dot(w, w)) * kp->inv_c;
+    {
         const double d = (kp->g.et - lt) - kp->t0;
         const double h = 0.5 * d * d;
         const double ang = wdot * d;
@@ -1022,7 +1023,6 @@ __device__ __forceinline__ void map_cell_xy(KParams kp, double lon_deg, double l
         q = {fma(ca, tv.x, -sa * tv.y), fma(sa, tv.x, ca * tv.y), tv.z};
         w = {fma(kp->AB[0], h, fma(kp->VB[0], d, q.x - kp->O0[0])), fma(kp->AB[1], h, fma(kp->VB[1], d, q.y - kp->O0[1])),
              fma(kp->AB[2], h, fma(kp->VB[2], d, q.z - kp->O0[2]))};
-        if (it == 0) lt = sqrt_fast(dot(w, w)) * kp->inv_c;
     }
     // visible <=> the outward normal (q / radii^2, turned like q) faces the observer (at -w from the point)
     const double facing = -fma(q.x * kp->ir[0] * kp->ir[0], w.x, fma(q.y * kp->ir[1] * kp->ir[1], w.y, q.z * kp->ir[2] * kp->ir[2] * w.z));

@@ -1092,10 +1092,14 @@ __global__ __launch_bounds__(kBlock) void k_map_b0(const Params p_, const double
 
     // light time of the point: pos(te) = T(te) + R(te)^T tv, in B0  w(d) = VB d + AB d^2 / 2 - O0 + Rz(wdot d)^T tv
     const double wdot = p.g.wdot;
-    double lt = p.g.lt_c, d = 0.0, sa = 0.0, ca = 1.0;
-    V3 w = {0.0, 0.0, 0.0}, q = tv;
+    // (the first pass starts from the centre's light time: its epoch is t0 itself - d = (et - lt_c) - t0 = 0 exactly, host and
+    //  device form t0 by the same subtraction - so the body has not turned and the target has not moved: the pass is the
+    //  distance of the point as it stands, the same bits as the general expression below without its sincos and nine FMAs)
+    double d = 0.0, sa = 0.0, ca = 1.0;
+    V3 q = tv, w = {tv.x - p.O0[0], tv.y - p.O0[1], tv.z - p.O0[2]};
+    double lt = sqrt_fast(dot(w, w)) * p.inv_c;
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
+    for (int it = 1; it < 4; it++) {
         d = (p.g.et - lt) - p.t0;
         const double h = 0.5 * d * d;
         sincos_tiered<true>(wdot * d, sa, ca);

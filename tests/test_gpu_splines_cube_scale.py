@@ -256,3 +256,26 @@ def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
 @pytest.mark.parametrize('seed', [20261004, 5])
 def test_random_smoothing_spline_fuzz(engine, oracle, jupiter, seed):
     smoothing_fuzz(engine, oracle, jupiter, seed)
+
+
+def test_smoothing_splines_on_axes_too_long_for_lds(engine, oracle, jupiter):
+    """
+    An axis of 3300 samples: its row tables (3300 x 7 x 8 B) do not fit the 160 KB of LDS, its knot arrays not the 64 KB
+    `k_smb_decide` asks for - the sweeps, the factor pipeline and the knot insertion then read the tables where the
+    tables kernel left them (the `lds = 0` variants), while the short axis (520) keeps the LDS ones. Degrees (5, 3) and
+    (2, 4), both orientations, against the oracle as everywhere else (1e-7 of the data scale).
+    """
+    for ny, nx in ((3300, 520), (500, 3290)):
+        cube, states = make_cube(3, ny, nx, seed=ny)
+        xm, ym = setup_maps(engine, oracle, jupiter, ny, nx, deg=3.0)
+        for interp, s in (((5, 3), 1.0 * ny * nx), ((2, 4), 1.05 * ny * nx)):
+            a = map_resident(engine, cube, xm, ym, interp, True, spline_smoothing=s)
+            b = oracle_map_cube_mt(oracle, cube, xm, ym, interp, True, spline_smoothing=s)
+            assert np.array_equal(np.isnan(a), np.isnan(b)), (ny, nx, interp)
+            for p in range(3):
+                fin = np.isfinite(b[p])
+                assert fin.sum() > 100
+                assert np.max(np.abs(a[p][fin] - b[p][fin])) <= 1e-7 * max(1.0, np.abs(b[p][fin]).max()), (ny, nx, interp, p, states[p])
+        # and the interpolating splines at that size (tiled banded solves with long lines)
+        a = map_resident(engine, cube, xm, ym, 'cubic', False)
+        assert_close(a, oracle_map_cube_mt(oracle, cube, xm, ym, 'cubic', False), (ny, nx, 'cubic'))

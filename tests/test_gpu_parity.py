@@ -2612,3 +2612,77 @@ def test_debug_knobs_of_the_environment_need_pm_debug_env(jupiter):
         eng.set_option(_lib.PM_OPT_TRACE, 0)
     finally:
         eng.close()
+
+
+@pytest.mark.gpu
+def test_result_planes_of_the_shim_are_recycled_on_the_real_engine(jupiter):
+    """
+    tests/test_api_host.py's recycling test against the real engine: the planes of a cold getter live in page-locked arrays of
+    the engine's pool; after `set_disc_params` they are written again - unless the caller still holds one, which then keeps its
+    values while the new plane goes elsewhere.
+    """
+    from planetmapper_amd import BodyXY
+    from planetmapper_amd.engine import Engine
+
+    eng = Engine(0)
+    try:
+        body = BodyXY('Jupiter', geometry=jupiter, nx=700, ny=600, engine=eng)
+        body.set_disc_params(350, 300, 250, 10)
+        lon = body.get_lon_img()
+        first = lon.ctypes.data
+        assert not lon.flags.writeable and eng._plane_bytes == 2 * 700 * 600 * 8  # lon + lat, both from the pool
+        del lon
+        body.set_disc_params(352, 300, 250, 10)
+        assert sum(len(v) for v in eng._plane_pool.values()) == 2
+        lon2 = body.get_lon_img()
+        lat2 = body.get_lat_img()
+        assert {lon2.ctypes.data, lat2.ctypes.data} >= {first} and sum(len(v) for v in eng._plane_pool.values()) == 0
+        kept = lon2[:, 300:310]
+        values = kept.copy()
+        del lon2
+        body.set_disc_params(380, 300, 250, 10)
+        lon3 = body.get_lon_img()
+        assert lon3.ctypes.data != kept.ctypes.data - 300 * 8 and np.array_equal(kept, values, equal_nan=True)
+        ref = eng.backplanes_img(['LON-GRAPHIC', 'LAT-GRAPHIC'])
+        assert np.array_equal(lon3, ref['LON-GRAPHIC'], equal_nan=True)
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_stage_record_of_a_host_fed_cube_call(engine, jupiter):
+    """PM_OPT_LAST_STAGE_NS: the sequential stages add up to the call; device-side sums only with PM_OPT_TRACE bit 4"""
+    import time
+
+    import torch
+
+    from planetmapper_amd import _lib
+
+    sz, planes = 512, 40
+    engine.set_geometry(jupiter)
+    engine.set_disc(255.5, 255.5, 200.0, 0.1, sz, sz, True)
+    lon, lat = np.meshgrid(np.arange(1.0, 360, 2.0)[::-1], np.arange(-89.0, 90, 2.0))
+    xm, ym = engine.xy_map(lon, lat)
+    dx, dy = torch.from_numpy(xm).cuda(), torch.from_numpy(ym).cuda()
+    cube = engine.pinned_empty((planes, sz, sz))
+    cube[...] = np.random.default_rng(2).standard_normal(cube.shape)
+    out = torch.empty((planes,) + xm.shape, dtype=torch.float64, device='cuda')
+    for trace in (0, 4):
+        engine.set_option(_lib.PM_OPT_TRACE, trace)
+        try:
+            for _ in range(3):
+                t = time.perf_counter()
+                engine.map_cube_host_to_device(cube, dx, dy, xm.shape[0], xm.shape[1], out)
+                engine.synchronize()
+                wall = (time.perf_counter() - t) * 1e3
+            st = engine.last_stages_ms()
+        finally:
+            engine.set_option(_lib.PM_OPT_TRACE, 0)
+        parts = st['tables'] + st['plan'] + st['issue'] + st['drain'] + st['finish']
+        assert 0 < st['total'] <= wall * 1.05 and abs(parts - st['total']) <= 0.05 * st['total'] + 0.02, (st, wall)
+        assert st['first_fill'] <= st['issue'] + 1e-6 and st['collect'] <= st['issue'] + 1e-6
+        if trace:
+            assert st['kernels_device'] > 0 and (st['dma_device'] > 0 or engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) in (1, 2))
+        else:
+            assert st['dma_device'] == 0 and (st['kernels_device'] == 0 or engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) == 4)
+    assert np.array_equal(out.cpu().numpy(), engine.map_cube(np.array(cube), xm, ym, 'linear', True), equal_nan=True)

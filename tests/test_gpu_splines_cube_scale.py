@@ -279,3 +279,22 @@ def test_smoothing_splines_on_axes_too_long_for_lds(engine, oracle, jupiter):
         # and the interpolating splines at that size (tiled banded solves with long lines)
         a = map_resident(engine, cube, xm, ym, 'cubic', False)
         assert_close(a, oracle_map_cube_mt(oracle, cube, xm, ym, 'cubic', False), (ny, nx, 'cubic'))
+
+
+def test_smoothing_batches_capped_by_the_option_give_the_same_planes(engine, oracle, jupiter):
+    """PM_OPT_SM_BATCH_PLANES caps the planes fitted together: a cube then takes several batches - the same bits as one"""
+    from planetmapper_amd import _lib
+
+    ny, nx = 300, 260
+    cube, states = make_cube(7, ny, nx, seed=9)
+    xm, ym = setup_maps(engine, oracle, jupiter, ny, nx, deg=3.0)
+    s = 1.0 * ny * nx
+    whole = map_resident(engine, cube, xm, ym, 'cubic', True, spline_smoothing=s)
+    try:
+        for cap in (1, 3):
+            engine.set_option(_lib.PM_OPT_SM_BATCH_PLANES, cap)
+            assert engine.get_option(_lib.PM_OPT_SM_BATCH_PLANES) == cap
+            assert np.array_equal(map_resident(engine, cube, xm, ym, 'cubic', True, spline_smoothing=s), whole, equal_nan=True), cap
+            assert np.array_equal(engine.map_cube(cube, xm, ym, 'cubic', True, spline_smoothing=s), whole, equal_nan=True), cap
+    finally:
+        engine.set_option(_lib.PM_OPT_SM_BATCH_PLANES, 0)

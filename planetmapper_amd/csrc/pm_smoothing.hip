@@ -793,32 +793,65 @@ __global__ __launch_bounds__(kSolveBlock) void k_smb_solve(SmPlaneDev *planes, i
 }
 
 // residuals of every row of a direction's system after the first pass, in the order the second pass walks them:
-// d - A c for the collocation rows, -(B / p) c for the jump rows. grid (right-hand sides / 256, rows / 4, planes)
+// d - A c for the collocation rows, -(B / p) c for the jump rows. grid (right-hand sides / 256, rows / 16, planes): a
+// workgroup takes 16 consecutive rows - their entries and first columns through LDS - and each lane carries the k + 2
+// coefficients the current row touches in registers: rows come in the order of their first column, so the window moves
+// on by one coefficient (one load) where the row stream does, and not at all while the rows share a knot interval.
+constexpr int kResRows = 16;
 __global__ __launch_bounds__(kBlock) void k_smb_res(SmPlaneDev *planes, int dir)
 {
+    __shared__ double hs[kResRows][kSmRow];
+    __shared__ int l0s[kResRows], srcs[kResRows];
     const SmPlaneDev &P = planes[blockIdx.z];
     if (!P.active) return;
     const SmAxisDev &a = dir ? P.x : P.y;
-    const int nr = P.y.nc(), nrhs = dir ? nr : P.x.m, nb = a.nb, n_rows = a.m + nb, k = a.k;
-    const int q = blockIdx.x * kBlock + threadIdx.x;
-    if (q >= nrhs || (int)blockIdx.y * 4 >= n_rows) return;
-    const double *in = dir ? P.UT : P.z, *c = dir ? P.CT : P.U;
-    const int si = dir ? nr : P.x.m;
-    for (int u = 0; u < 4; u++) {
-        const int x = blockIdx.y * 4 + u;
-        if (x >= n_rows) break;
-        const int src = nb ? a.mg_src[x] : x;
-        double v;
-        if (src >= 0) {
-            v = in[(size_t)src * si + q];
-            const int l0 = a.lb[src];
-            for (int e = 0; e <= k; e++) v -= a.hb[(size_t)src * 6 + e] * c[(size_t)(l0 + e) * nrhs + q];
-        } else {
-            const int r = -src - 1;
-            v = 0.0;
-            for (int e = 0; e < k + 2; e++) v -= a.Bp[(size_t)r * kSmRow + e] * c[(size_t)(r + e) * nrhs + q];
+    const int nr = P.y.nc(), nrhs = dir ? nr : P.x.m, nb = a.nb, n_rows = a.m + nb, k = a.k, nc = a.nc();
+    const int x0 = blockIdx.y * kResRows;
+    if ((int)(blockIdx.x * kBlock) >= nrhs || x0 >= n_rows) return;
+    const int rows = min(kResRows, n_rows - x0);
+    if (threadIdx.x < kResRows * kSmRow) {
+        const int u = threadIdx.x / kSmRow, e = threadIdx.x % kSmRow;
+        if (u < rows) {
+            const int x = x0 + u, src = nb ? a.mg_src[x] : x;
+            double h = 0.0;
+            if (nb) h = a.mg_h[(size_t)x * kSmRow + e];
+            else if (e <= k) h = a.hb[(size_t)src * 6 + e];
+            hs[u][e] = h;
+            if (e == 0) {
+                l0s[u] = nb ? a.mg_l[x] : a.lb[src];
+                srcs[u] = src;
+            }
         }
-        P.RB[(size_t)x * nrhs + q] = v;
+    }
+    __syncthreads();
+    const int q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= nrhs) return;
+    const double *__restrict__ in = dir ? P.UT : P.z;
+    const double *__restrict__ c = dir ? P.CT : P.U;
+    const int si = dir ? nr : P.x.m;
+    constexpr int CW = 7;  // k + 2 <= 7 coefficients under a row
+    const int width = k + 2;
+    int cur = l0s[0];
+    double cw[CW];
+#pragma unroll
+    for (int e = 0; e < CW; e++) cw[e] = (e < width && cur + e < nc) ? c[(size_t)(cur + e) * nrhs + q] : 0.0;
+    for (int u = 0; u < rows; u++) {
+        const int l0 = l0s[u];
+        while (cur < l0) {
+#pragma unroll
+            for (int e = 0; e + 1 < CW; e++) cw[e] = cw[e + 1];
+            cur++;
+            // (the entry that comes into reach: position width - 1 of the window)
+            const double fresh = (cur + width - 1 < nc) ? c[(size_t)(cur + width - 1) * nrhs + q] : 0.0;
+#pragma unroll
+            for (int e = 0; e < CW; e++)
+                if (e == width - 1) cw[e] = fresh;
+        }
+        const int src = srcs[u];
+        double v = src >= 0 ? in[(size_t)src * si + q] : 0.0;
+#pragma unroll
+        for (int e = 0; e < CW; e++) v -= hs[u][e] * cw[e];  // (entries beyond the row's own are zeros)
+        P.RB[(size_t)(x0 + u) * nrhs + q] = v;
     }
 }
 
@@ -1118,7 +1151,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
                 for_degree(k, [&](auto K) {
                     constexpr int kk = decltype(K)::value;
                     hipLaunchKernelGGL((pm::k_smb_solve<kk, 0>), grid, block, b0 <= lds_limit ? b0 : 0, st, planes, dir, b0 <= lds_limit ? 1 : 0);
-                    hipLaunchKernelGGL(pm::k_smb_res, dim3((nrhs + pm::kBlock - 1) / pm::kBlock, (rows1 + 3) / 4, np), dim3(pm::kBlock), 0, st, planes, dir);
+                    hipLaunchKernelGGL(pm::k_smb_res, dim3((nrhs + pm::kBlock - 1) / pm::kBlock, (rows1 + pm::kResRows - 1) / pm::kResRows, np), dim3(pm::kBlock), 0, st, planes, dir);
                     hipLaunchKernelGGL((pm::k_smb_solve<kk, 1>), grid, block, b1 <= lds_limit ? b1 : 0, st, planes, dir, b1 <= lds_limit ? 1 : 0);
                 });
             };

@@ -121,20 +121,43 @@ __device__ bool sm_add_knot(SmAxisDev &a, int &n, int lane)
     }
     if (number == 0x7fffffff) return false;
     const int maxpt = a.nrdata[number];
-    int before = 0;
-    for (int j = lane; j < number; j += 64) before += a.nrdata[j] + 1;
-    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off, 64);
-    const int ihalf = maxpt / 2 + 1, nrx = 1 + before + ihalf;  // 1-based data index: abscissa nrx - 1
+    // the new knot: ihalf data points beyond the interval's left knot (FITPACK counts the points before it, maxbeg - knots
+    // are sample abscissae here, so that count is the left knot itself)
+    const int ihalf = maxpt / 2 + 1, at = (int)a.t[number + k] + ihalf;
     __syncthreads();
-    shift_up(a.fpint, number + 1, nri - 1, lane);
-    shift_up(a.nrdata, number + 1, nri - 1, lane);
-    shift_up(a.t, number + k + 1, n - 1, lane);
+    // one step up for everything behind the interval: the k + 1 topmost knots first (they have no interval of their own),
+    // then fpint / nrdata [j] together with t[j + k], from the top in blocks of 64
+    {
+        const int idx = n - 1 - lane;
+        double v = 0.0;
+        if (lane <= k && idx >= number + k + 1) v = a.t[idx];
+        __syncthreads();
+        if (lane <= k && idx >= number + k + 1) a.t[idx + 1] = v;
+    }
+    for (int top = nri - 1; top >= number + 1; top -= 64) {
+        const int j = top - lane;
+        const bool mine = j >= number + 1;
+        double vf = 0.0, vt = 0.0;
+        int vn = 0;
+        if (mine) {
+            vf = a.fpint[j];
+            vn = a.nrdata[j];
+            vt = a.t[j + k];
+        }
+        __syncthreads();
+        if (mine) {
+            a.fpint[j + 1] = vf;
+            a.nrdata[j + 1] = vn;
+            a.t[j + k + 1] = vt;
+        }
+    }
+    __syncthreads();
     if (lane == 0) {
         a.nrdata[number] = ihalf - 1;
         a.nrdata[number + 1] = maxpt - ihalf;
         a.fpint[number] = best * (double)(ihalf - 1) / (double)maxpt;
         a.fpint[number + 1] = best * (double)(maxpt - ihalf) / (double)maxpt;
-        a.t[number + k + 1] = (double)(nrx - 1);
+        a.t[number + k + 1] = (double)at;
     }
     n += 1;
     __syncthreads();

@@ -301,10 +301,14 @@ def _protocol_worker(rank: int, world: int, port: int, tmpdir: str) -> None:
             # planes redone with their nanmedian after they were sent: everybody gathers once more
             eng.redo_planes = 1 if rank == 0 else 0
             gathered = torch.full((world, per_rank, n0, n1), -7.0, dtype=torch.float64)
+            stages: dict = {}
             D.map_cube_sharded_pipelined(eng, cube[a:b].copy(), np.float64, planes, xm, ym, n0, n1, gathered, rank, world,
-                                         host_cube=True)
+                                         host_cube=True, stages=stages)
             eng.redo_planes = 0
             assert np.array_equal(gathered.reshape(-1, n0, n1).numpy()[:planes], expect, equal_nan=True)
+            # the stage record of the call (bench.py `stages`): the mapping call, what was left of the exchanges, the agreement
+            assert set(stages) == {'map_call', 'exchange_exposed', 'agreement'} and all(v >= 0.0 for v in stages.values())
+            assert stages['map_call'] > 0.0 and stages['agreement'] > 0.0
             # ---- (e) a rank whose mapping raises: nobody hangs, every rank raises
             class Boom(RuntimeError):
                 pass

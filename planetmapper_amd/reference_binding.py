@@ -180,14 +180,36 @@ def geometry_from_body(body, spice=None) -> PMGeometry:
     return g
 
 
+def _freeze(v):
+    """hashable stand-in for a keyword value of a mapping function (the reference turns arrays into nested tuples, base.py:41)"""
+    if isinstance(v, np.ndarray):
+        return ('__ndarray__', v.shape, v.tobytes())
+    if isinstance(v, (list, tuple)):
+        return tuple(_freeze(x) for x in v)
+    return v
+
+
+def _readonly(a: np.ndarray) -> np.ndarray:
+    v = a.view()
+    v.setflags(write=False)
+    return v
+
+
 class HipBackplanes:
     """
-    Mixed into the reference's `BodyXY` (before it in the MRO): the pixel loops of `body_xy.py:3195-4085` and `map_img`
-    become engine calls; the reference's cache decorators, registry and argument handling stay as they are.
+    Mixed into the reference's `BodyXY` (before it in the MRO): the pixel loops of `body_xy.py:3195-4190` and `map_img`
+    become engine calls. Results are cached where the reference caches them - image-space producers in the Body's own
+    `_cache` (emptied by its `_clear_cache()` whenever the disc changes, keyed with the altitude adjustment like
+    `_cache_clearable_alt_dependent_result`, body.py:255-272), map-space producers in `_stable_cache` (base.py:91-112) - and
+    handed out as read-only arrays (`_return_readonly_array`, base.py:115-138). The registry, `get_backplane_img / map`,
+    the map-grid helpers (`_get_lonlat_map` with every projection), `_AdjustedSurfaceAltitude` and the argument handling
+    stay the reference's. Names and return shapes follow the reference method each override replaces (line numbers in
+    `_IMG_FAMILIES` / `_MAP_FAMILIES`).
     """
 
     _hip_spice = None  # a module to ask instead of spiceypy (tests)
 
+    # ------------------------------------------------------------------ the engine, bound to this body's geometry and disc
     def _hip(self):
         from .engine import Engine  # noqa: PLC0415
 
@@ -198,20 +220,30 @@ class HipBackplanes:
         eng.set_disc(self.get_x0(), self.get_y0(), self.get_r0(), self._get_rotation_radians(), self._nx, self._ny, self._optimize_speed)
         return eng
 
-    def _get_lonlat_img(self):  # body_xy.py:3281
-        o = self._hip().backplanes_img(['LON-GRAPHIC', 'LAT-GRAPHIC'], alt=self._alt_adjustment)
-        return np.stack([o['LON-GRAPHIC'], o['LAT-GRAPHIC']], axis=-1)
+    def _hip_img_family(self, names: tuple) -> dict:
+        """the planes of one image-space family: one launch, cached until the disc (or the altitude adjustment) changes"""
+        alt = float(getattr(self, '_alt_adjustment', 0.0))
+        key = ('_hip_img', names, alt)
+        if key not in self._cache:
+            out = self._hip().backplanes_img(list(names), alt=alt)
+            self._cache[key] = {n: _readonly(a) for n, a in out.items()}
+        return self._cache[key]
 
-    def _get_illumination_gie_img(self):  # body_xy.py:3658
-        o = self._hip().backplanes_img(['PHASE', 'INCIDENCE', 'EMISSION'], alt=self._alt_adjustment)
-        return np.stack([o['PHASE'], o['INCIDENCE'], o['EMISSION']], axis=-1)
+    def _hip_map_family(self, names: tuple, map_kwargs: dict) -> dict:
+        """the planes of one map-space family on the grid the reference builds for `map_kwargs` (stable: no disc dependence)"""
+        key = ('_hip_map', names, frozenset((k, _freeze(v)) for k, v in map_kwargs.items()))
+        xy = 'PIXEL-X' in names  # (pixel coordinates of map cells DO depend on the disc: the reference's _get_xy_map is clearable)
+        cache = self._cache if xy else self._stable_cache
+        if xy:
+            key = key + (self.get_x0(), self.get_y0(), self.get_r0(), self._get_rotation_radians())
+        if key not in cache:
+            ll = self._get_lonlat_map(**map_kwargs)  # (the reference's own grid: every projection it knows)
+            out = self._hip().backplanes_map(list(names), ll[..., 0], ll[..., 1], alt=float(map_kwargs.get('alt', 0.0)))
+            cache[key] = {n: _readonly(a) for n, a in out.items()}
+        return cache[key]
 
-    def _get_xy_map(self, **map_kwargs):  # body_xy.py:3478
-        ll = self._get_lonlat_map(**map_kwargs)
-        x, y = self._hip().xy_map(ll[..., 0], ll[..., 1], alt=map_kwargs.get('alt', 0.0))
-        return np.stack([x, y], axis=-1)
-
-    def map_img(self, img, *, interpolation='linear', spline_smoothing=0, propagate_nan=True, smooth_oversample_by=5,
+    # ------------------------------------------------------------------ reprojection and the point forms
+    def map_img(self, img, *, interpolation='linear', propagate_nan=True, warn_nan=False, spline_smoothing=0, smooth_oversample_by=5,
                 smooth_max_oversampled_img_size=10_000, **map_kwargs):  # body_xy.py:1414  # fmt: skip
         return self._hip().map_cube(img, self.get_x_map(**map_kwargs), self.get_y_map(**map_kwargs), interpolation, propagate_nan,
                                     smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
@@ -227,3 +259,72 @@ class HipBackplanes:
 
     def _get_backplane_imgs_for_saving(self, names):  # observation.py:1269-1279
         return self._hip().backplanes_img(names, alt=self._alt_adjustment)  # all 26 planes, 2 launches
+
+
+# The reference's producers and what replaces them. (method, planes, how the planes are put together: 'stack' -> one
+# (.., .., n) array like the reference's `_get_*_img`, 'tuple' -> a tuple of arrays, 'one' -> the plane itself.)
+_IMG_FAMILIES = (
+    ('_get_lonlat_img', ('LON-GRAPHIC', 'LAT-GRAPHIC'), 'stack'),  # body_xy.py:3284
+    ('_get_lonlat_centric_img', ('LON-CENTRIC', 'LAT-CENTRIC'), 'stack'),  # :3349
+    ('_get_radec_img', ('RA', 'DEC'), 'stack'),  # :3413
+    ('_get_km_xy_img', ('KM-X', 'KM-Y'), 'stack'),  # :3547
+    ('_get_illumination_gie_img', ('PHASE', 'INCIDENCE', 'EMISSION'), 'stack'),  # :3661
+    ('get_azimuth_angle_img', ('PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH'), 'AZIMUTH'),  # :3744
+    ('get_local_solar_time_img', ('LON-GRAPHIC', 'LAT-GRAPHIC', 'LOCAL-SOLAR-TIME'), 'LOCAL-SOLAR-TIME'),  # :3790 (an et2lst call per pixel)
+    ('get_distance_img', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'), 'DISTANCE'),  # :3870 (from _get_state_imgs :3832)
+    ('get_radial_velocity_img', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'), 'RADIAL-VELOCITY'),  # :3898
+    ('get_doppler_img', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'), 'DOPPLER'),  # :3938
+    ('_get_limb_coordinate_imgs', ('LIMB-LON-GRAPHIC', 'LIMB-LAT-GRAPHIC', 'LIMB-DISTANCE'), 'stack'),  # :3967 (lon, lat, dist)
+    ('_get_ring_plane_coordinate_imgs', ('RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE'), 'tuple'),  # :4061
+)
+_MAP_FAMILIES = (
+    ('_get_xy_map', ('PIXEL-X', 'PIXEL-Y'), 'stack'),  # :3482
+    ('_get_lonlat_centric_map', ('LON-CENTRIC', 'LAT-CENTRIC'), 'stack'),  # :3359
+    ('_get_radec_map', ('RA', 'DEC'), 'stack'),  # :3423
+    ('_get_km_xy_map', ('KM-X', 'KM-Y'), 'stack'),  # :3557
+    ('get_phase_angle_map', ('PHASE', 'INCIDENCE', 'EMISSION'), 'PHASE'),  # :3687 (columns of _get_illumf_map :3671)
+    ('get_incidence_angle_map', ('PHASE', 'INCIDENCE', 'EMISSION'), 'INCIDENCE'),  # :3709
+    ('get_emission_angle_map', ('PHASE', 'INCIDENCE', 'EMISSION'), 'EMISSION'),  # :3731
+    ('get_azimuth_angle_map', ('PHASE', 'INCIDENCE', 'EMISSION', 'AZIMUTH'), 'AZIMUTH'),  # :3767
+    ('get_local_solar_time_map', ('LOCAL-SOLAR-TIME',), 'LOCAL-SOLAR-TIME'),  # :3812
+    ('get_distance_map', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'), 'DISTANCE'),  # :3883 (from _get_state_maps :3851)
+    ('get_radial_velocity_map', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'), 'RADIAL-VELOCITY'),  # :3919
+    ('get_doppler_map', ('DISTANCE', 'RADIAL-VELOCITY', 'DOPPLER'), 'DOPPLER'),  # :3951
+    ('_get_limb_coordinate_maps', ('LIMB-LON-GRAPHIC', 'LIMB-LAT-GRAPHIC', 'LIMB-DISTANCE'), 'stack'),  # :3979
+    ('_get_ring_plane_coordinate_maps', ('RING-RADIUS', 'RING-LON-GRAPHIC', 'RING-DISTANCE'), 'tuple'),  # :4090
+)
+
+
+def _assemble(planes: dict, names: tuple, how: str):
+    if how == 'stack':
+        return _readonly(np.stack([planes[n] for n in names], axis=-1))
+    if how == 'tuple':
+        return tuple(planes[n] for n in names)
+    return planes[how]
+
+
+def _make_img_override(method: str, names: tuple, how: str):
+    def override(self):
+        key = ('_hip_out', method, float(getattr(self, '_alt_adjustment', 0.0)))
+        if key not in self._cache:  # (the assembled form is cached too: `get_lon_img()[...] is get_lon_img()[...]`-style identity holds)
+            self._cache[key] = _assemble(self._hip_img_family(names), names, how)
+        return self._cache[key]
+
+    override.__name__ = method
+    override.__doc__ = f'planetmapper.BodyXY.{method}: {", ".join(names)} from one engine launch'
+    return override
+
+
+def _make_map_override(method: str, names: tuple, how: str):
+    def override(self, **map_kwargs):
+        return _assemble(self._hip_map_family(names, map_kwargs), names, how)
+
+    override.__name__ = method
+    override.__doc__ = f'planetmapper.BodyXY.{method}: {", ".join(names)} of the map grid from one engine launch'
+    return override
+
+
+for _method, _names, _how in _IMG_FAMILIES:
+    setattr(HipBackplanes, _method, _make_img_override(_method, _names, _how))
+for _method, _names, _how in _MAP_FAMILIES:
+    setattr(HipBackplanes, _method, _make_map_override(_method, _names, _how))

@@ -135,10 +135,14 @@ def test_a_frame_from_the_binding_block_equals_the_frame_from_the_builder_block(
 
 @pytest.mark.gpu
 def test_the_mixin_over_a_duck_typed_bodyxy():
-    """`HipBackplanes` in front of a class with the reference BodyXY's disc accessors and map-grid helper (body_xy.py:818-871,
-    3290-3300): its pixel methods return what the engine returns for the same block and disc, in the reference's shapes"""
+    """
+    `HipBackplanes` in front of a class with the reference BodyXY's disc accessors, caches and map-grid helper
+    (body_xy.py:818-871, 3290-3300; base.py:58-112): every producer it overrides returns what the engine returns for the same
+    block and disc, in the reference's shapes, read-only, cached where the reference caches (image space: until the Body's
+    `_cache` is cleared, per altitude adjustment; map space: `_stable_cache`, per set of map keywords).
+    """
     from planetmapper_amd.engine import Engine
-    from planetmapper_amd.reference_binding import HipBackplanes
+    from planetmapper_amd.reference_binding import _IMG_FAMILIES, _MAP_FAMILIES, HipBackplanes
     from spice_standin import DuckBody
 
     d, g, b, spice = build('jupiter_earth_2009')
@@ -146,13 +150,22 @@ def test_the_mixin_over_a_duck_typed_bodyxy():
     class DuckBodyXY(DuckBody):
         _nx, _ny, _optimize_speed, _alt_adjustment = 200, 160, True, 0.0
 
-        def get_x0(self): return 99.5
-        def get_y0(self): return 79.5
-        def get_r0(self): return 60.0
-        def _get_rotation_radians(self): return 0.3
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            self._cache, self._stable_cache = {}, {}
+            self.disc = [99.5, 79.5, 60.0, 0.3]
 
-        def _get_lonlat_map(self, **kw):
-            lon, lat = np.meshgrid(np.arange(5.0, 360, 10.0)[::-1], np.arange(-85.0, 90, 10.0))
+        def get_x0(self): return self.disc[0]
+        def get_y0(self): return self.disc[1]
+        def get_r0(self): return self.disc[2]
+        def _get_rotation_radians(self): return self.disc[3]
+
+        def set_x0(self, x0):  # body_xy.py:696-700: a new disc empties the clearable cache
+            self.disc[0] = x0
+            self._cache.clear()
+
+        def _get_lonlat_map(self, degree_interval=10.0, **kw):
+            lon, lat = np.meshgrid(np.arange(degree_interval / 2, 360, degree_interval)[::-1], np.arange(-90 + degree_interval / 2, 90, degree_interval))
             return np.stack([lon, lat], axis=-1)
 
         def get_x_map(self, **kw): return self._get_xy_map(**kw)[..., 0]
@@ -166,25 +179,51 @@ def test_the_mixin_over_a_duck_typed_bodyxy():
     try:
         eng.set_geometry(b)
         eng.set_disc(99.5, 79.5, 60.0, 0.3, 200, 160, True)
-        # (the same plane sets as the mixin asks for: a latitude that rides with the illumination planes comes from the
-        #  normal they need anyway, last-bit different from the one taken alone)
-        ref = eng.backplanes_img(['LON-GRAPHIC', 'LAT-GRAPHIC'])
-        ref.update(eng.backplanes_img(['PHASE', 'INCIDENCE', 'EMISSION']))
-        ll = body._get_lonlat_img()
-        assert ll.shape == (160, 200, 2)
-        assert np.array_equal(ll[..., 0], ref['LON-GRAPHIC'], equal_nan=True) and np.array_equal(ll[..., 1], ref['LAT-GRAPHIC'], equal_nan=True)
-        gie = body._get_illumination_gie_img()
-        for i, n in enumerate(('PHASE', 'INCIDENCE', 'EMISSION')):
-            assert np.array_equal(gie[..., i], ref[n], equal_nan=True), n
+        # ---- image space: every overridden producer against the engine's planes of the same family
+        for method, names, how in _IMG_FAMILIES:
+            ref = eng.backplanes_img(list(names))
+            got = getattr(body, method)()
+            assert got is getattr(body, method)(), method  # cached
+            if how == 'stack':
+                assert got.shape == (160, 200, len(names)) and not got.flags.writeable, method
+                parts = [got[..., i] for i in range(len(names))]
+            elif how == 'tuple':
+                assert isinstance(got, tuple) and len(got) == len(names), method
+                parts = list(got)
+            else:
+                parts, names = [got], (how,)
+            for part, n in zip(parts, names):
+                assert part.shape == (160, 200) and not part.flags.writeable and np.array_equal(part, ref[n], equal_nan=True), (method, n)
+        assert np.isfinite(body.get_local_solar_time_img()).sum() > 1000 and np.isfinite(body._get_ring_plane_coordinate_imgs()[0]).sum() > 1000
+        # ---- the clearable cache: a new disc gives new planes, an altitude adjustment its own entry
+        lon_before = body._get_lonlat_img()
+        body.set_x0(104.5)
+        eng.set_disc(104.5, 79.5, 60.0, 0.3, 200, 160, True)
+        lon_after = body._get_lonlat_img()
+        assert lon_after is not lon_before and np.array_equal(lon_after[..., 0], eng.backplanes_img(['LON-GRAPHIC', 'LAT-GRAPHIC'])['LON-GRAPHIC'], equal_nan=True)
+        body._alt_adjustment = 2500.0
+        hi = body._get_illumination_gie_img()
+        assert np.array_equal(hi[..., 2], eng.backplanes_img(['PHASE', 'INCIDENCE', 'EMISSION'], alt=2500.0)['EMISSION'], equal_nan=True)
+        body._alt_adjustment = 0.0
+        assert body._get_illumination_gie_img() is not hi
+        # ---- map space, on the grid the (duck) reference builds for the keywords
+        for kw in ({}, {'degree_interval': 15.0}, {'degree_interval': 15.0, 'alt': 1000.0}):
+            grid = body._get_lonlat_map(**kw)
+            for method, names, how in _MAP_FAMILIES:
+                ref = eng.backplanes_map(list(names), grid[..., 0], grid[..., 1], alt=kw.get('alt', 0.0))
+                got = getattr(body, method)(**kw)
+                parts = [got[..., i] for i in range(len(names))] if how == 'stack' else (list(got) if how == 'tuple' else [got])
+                for part, n in zip(parts, names if how in ('stack', 'tuple') else (how,)):
+                    assert part.shape == grid.shape[:2] and not part.flags.writeable and np.array_equal(part, ref[n], equal_nan=True), (method, n, kw)
+        assert len([k for k in body._stable_cache if k[0] == '_hip_map']) >= 3 * 5  # kept per set of keywords ...
+        assert any(k[0] == '_hip_map' and 'PIXEL-X' in k[1] for k in body._cache)  # ... but the x / y map goes with the disc
+        # ---- map_img through the overridden x / y map
         grid = body._get_lonlat_map()
-        xy = body._get_xy_map()
         x, y = eng.xy_map(grid[..., 0], grid[..., 1])
-        assert np.array_equal(xy[..., 0], x, equal_nan=True) and np.array_equal(xy[..., 1], y, equal_nan=True)
         img = np.random.default_rng(0).standard_normal((160, 200))
         for interp in ('linear', 'cubic'):
             m = body.map_img(img, interpolation=interp)
-            assert m.shape == grid.shape[:2]
-            assert np.array_equal(m, eng.map_cube(img, x, y, interp, True)[0], equal_nan=True), interp
+            assert m.shape == grid.shape[:2] and np.array_equal(m, eng.map_cube(img, x, y, interp, True)[0], equal_nan=True), interp
         saved = body._get_backplane_imgs_for_saving(['RA', 'DEC', 'EMISSION'])
         assert np.array_equal(saved['EMISSION'], eng.backplanes_img(['RA', 'DEC', 'EMISSION'])['EMISSION'], equal_nan=True)
     finally:

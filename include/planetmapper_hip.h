@@ -294,7 +294,7 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           sharded call waits for its exchanges before the agreement, so that the two are timed apart).
  *   PM_OPT_SM_BATCH_PLANES  the most planes of a cube whose smoothing-spline fits (spline_smoothing > 0) advance together
  *                           in the same launches: 0 (default) = as many as half of the free device memory holds (a plane
- *                           takes 5 arrays of its own size), 1 .. 4096 = a cap. A plane's result does not depend on it.
+ *                           takes 7 float64 arrays of its own size), 1 .. 4096 = a cap. A plane's result does not depend on it.
  *   PM_OPT_LAST_STAGE_NS + k read-only, ns: where the latest host-fed pm_map_cube (PM_MEM_HOST / PM_MEM_HOST_CUBE, nearest /
  *                           linear) or pm_map_cube_sharded of this context spent its time. Host clock, always recorded:
  *                           0 the whole pm_map_cube call = 1 + 2 + 5 + 6 + 7; 1 fingerprint of the x / y maps + block-table

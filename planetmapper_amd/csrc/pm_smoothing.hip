@@ -18,8 +18,8 @@
 //     with its own knots. A directional solve is the corrected semi-normal equations R'R c = A'd + one refinement step
 //     with the residual (error ~ cond(A) eps), fused per pass into ONE sweep per right-hand side: the lane walks the
 //     samples once, a register window holds the k + 1 partial sums of A'd that are still open, each sum that closes is
-//     fed straight into the forward substitution; the back substitution follows. No atomics anywhere: a plane's result is
-//     the same bits whatever shares its launches (tests/test_gpu_splines_cube_scale.py);
+//     fed straight into the forward substitution; the back substitution follows (the second pass takes its residuals from k_smb_res,
+//     jump rows merged among the others). No atomics: a plane's result is the same bits whatever shares its launches (tests/test_gpu_splines_cube_scale.py);
 //   * the host only sizes the grids: one 16-byte read-back per round (planes still searching, the largest coefficient
 //     counts) - every wave's loops are bounded by that round's own tables, the round loop by FITPACK's own iteration caps.
 // Planes whose search has ended stop taking part (their blocks leave at once); the cube is fitted in batches of as many

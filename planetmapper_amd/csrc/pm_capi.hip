@@ -1046,7 +1046,7 @@ int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes, const do
     double limits[4] = {INFINITY, -INFINITY, INFINITY, -INFINITY};
     if (smooth && mem == PM_MEM_DEVICE) {
         // footprint of the map on the image: tiny reduction + 32-byte read-back
-        if (!ctx->limits) PM_HIP(ctx, hipMalloc((void **)&ctx->limits, 4 * sizeof(double)));
+        if (!ctx->limits) PM_HIP(ctx, hipMalloc((void **)&ctx->limits, 4 * (1 + pm::kMapLimitsBlocks) * sizeof(double)));
         pm_launch_map_limits(x_map, y_map, (int)nmap, ctx->limits, ctx->stream);
         PM_HIP(ctx, hipMemcpyAsync(limits, ctx->limits, sizeof(limits), hipMemcpyDeviceToHost, ctx->stream));
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -233,6 +233,7 @@ struct BlockTable {
 // One axis of the oversampled grid of 'smooth' interpolation (get_xy_pchip
 // body_xy.py:1724-1741): the original pixel coordinates first..last, optionally refined
 // to `num` points with numpy.linspace arithmetic (i * step + first, last point exact).
+constexpr int kMapLimitsBlocks = 1024;  // pm_launch_map_limits: at most this many partial results
 struct SmoothAxis {
     int first, last;  // trimmed original range [first, last] (pixels within 5 of the map's footprint)
     int num;          // grid points
@@ -241,6 +242,8 @@ struct SmoothAxis {
 };
 struct SmoothArgs {
     SmoothAxis x, y;
+    int general;  // PM_OPT_GENERAL_KERNEL: every cell takes the gap-aware form (the cross-check of the 4 x 4 form)
+    int planes_per_lane;  // set by the launcher
 };
 __device__ __forceinline__ double smooth_grid(const SmoothAxis &ax, int i)
 {
@@ -251,7 +254,7 @@ __device__ __forceinline__ double smooth_grid(const SmoothAxis &ax, int i)
 // interval i with grid[i] <= v < grid[i+1] (last interval closed), grid[0] <= v <= grid[num-1]
 __device__ __forceinline__ int smooth_interval(const SmoothAxis &ax, double v)
 {
-    int i = ax.oversampled ? (int)floor((v - (double)ax.first) / ax.step) : (int)floor(v) - ax.first;
+    int i = ax.oversampled ? (int)floor(div_fast(v - (double)ax.first, ax.step)) : (int)floor(v) - ax.first;  // (a first guess)
     i = i < 0 ? 0 : (i > ax.num - 2 ? ax.num - 2 : i);
     while (i > 0 && v < smooth_grid(ax, i)) i--;
     while (i < ax.num - 2 && v >= smooth_grid(ax, i + 1)) i++;
@@ -261,15 +264,21 @@ __device__ __forceinline__ int smooth_interval(const SmoothAxis &ax, double v)
 // scipy.interpolate.PchipInterpolator restated piecewise (oracle: pchip_1d): Fritsch-Carlson
 // derivative at an interior sample / Moler's three-point rule at an end sample
 __device__ __forceinline__ double pchip_sign(double v) { return (double)((v > 0.0) - (v < 0.0)); }
+// (The kernel that calls these is bound by their arithmetic. Samples without gaps are one pixel apart: a division by 1.0
+//  is the identity and is skipped, bit for bit; the others use the Newton division of pm_fastmath.hip.h, within an ulp of
+//  the IEEE quotient - the oracle, which restates scipy's arithmetic to the bit, stays the checker at 1e-9 relative.)
+__device__ __forceinline__ double pchip_over(double a, double h) { return h == 1.0 ? a : div_fast(a, h); }
 __device__ __forceinline__ double pchip_interior(double h0, double h1, double m0, double m1)
 {
-    if (pchip_sign(m0) != pchip_sign(m1) || m0 == 0.0 || m1 == 0.0) return 0.0;
+    // zero unless the slopes are both positive or both negative (scipy: sign(m0) != sign(m1) | m0 == 0 | m1 == 0; slopes of
+    // finite samples are never NaN) - four compares instead of two sign() values and three
+    if (!(m0 > 0.0 ? m1 > 0.0 : (m0 < 0.0 && m1 < 0.0))) return 0.0;
     const double w1 = 2.0 * h1 + h0, w2 = h1 + 2.0 * h0;
-    return 1.0 / ((w1 / m0 + w2 / m1) / (w1 + w2));
+    return rcp_fast(div_fast(div_fast(w1, m0) + div_fast(w2, m1), w1 + w2));
 }
 __device__ __forceinline__ double pchip_edge(double h0, double h1, double m0, double m1)
 {
-    const double d = ((2.0 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+    const double d = div_fast((2.0 * h0 + h1) * m0 - h0 * m1, h0 + h1);
     if (pchip_sign(d) != pchip_sign(m0)) return 0.0;
     if (pchip_sign(m0) != pchip_sign(m1) && fabs(d) > 3.0 * fabs(m0)) return 3.0 * m0;
     return d;
@@ -279,16 +288,16 @@ __device__ __forceinline__ double pchip_edge(double h0, double h1, double m0, do
 __device__ __forceinline__ double pchip_piece(bool has_a, double xa, double ya, double xb, double yb, double xc,
                                               double yc, bool has_d, double xd, double yd, double v)
 {
-    const double h = xc - xb, slope = (yc - yb) / h;
+    const double h = xc - xb, slope = pchip_over(yc - yb, h);
     double db = slope, dc = slope;  // two samples in all: straight line
     if (has_a || has_d) {
         const double hab = xb - xa, hcd = xd - xc;
-        const double mab = has_a ? (yb - ya) / hab : 0.0, mcd = has_d ? (yd - yc) / hcd : 0.0;
+        const double mab = has_a ? pchip_over(yb - ya, hab) : 0.0, mcd = has_d ? pchip_over(yd - yc, hcd) : 0.0;
         db = has_a ? pchip_interior(hab, h, mab, slope) : pchip_edge(h, hcd, slope, mcd);
         dc = has_d ? pchip_interior(h, hcd, slope, mcd) : pchip_edge(h, hab, slope, mab);
     }
-    const double t = (db + dc - 2.0 * slope) / h;
-    const double c0 = t / h, c1 = (slope - db) / h - t;
+    const double t = pchip_over(db + dc - 2.0 * slope, h);
+    const double c0 = pchip_over(t, h), c1 = pchip_over(slope - db, h) - t;
     const double s = v - xb;
     double z = s, res = yb;
     res += db * z;
@@ -298,6 +307,30 @@ __device__ __forceinline__ double pchip_piece(bool has_a, double xa, double ya, 
     res += c0 * z;
     return res;
 }
+// The piece on [b, b+1] of four consecutive finite samples one pixel apart (ya, yb, yc, yd): pchip_piece's arithmetic for
+// has_a = has_d = true and h = hab = hcd = 1, split into the coefficients (the same for every point of the piece) and the
+// evaluation at s = v - b.
+struct PchipUnitPiece {
+    double yb, db, c1, c0;
+    __device__ __forceinline__ PchipUnitPiece(double ya, double yb_, double yc, double yd) : yb(yb_)
+    {
+        const double slope = yc - yb, mab = yb - ya, mcd = yd - yc;
+        db = pchip_interior(1.0, 1.0, mab, slope);
+        const double dc = pchip_interior(1.0, 1.0, slope, mcd);
+        c0 = db + dc - 2.0 * slope;
+        c1 = (slope - db) - c0;
+    }
+    __device__ __forceinline__ double operator()(double s) const
+    {
+        double z = s, res = yb;
+        res += db * z;
+        z *= s;
+        res += c1 * z;
+        z *= s;
+        res += c0 * z;
+        return res;
+    }
+};
 // PCHIP through the finite samples val(lo..hi) (integer abscissae), evaluated at v;
 // NaN outside the first..last finite sample (extrapolate=False) or with < 2 of them.
 // Only the <= 4 finite samples around v are looked up.

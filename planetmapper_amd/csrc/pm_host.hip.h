@@ -36,7 +36,8 @@ void pm_launch_hash_maps(const double *x_map, const double *y_map, int n, unsign
 void pm_launch_reproject_blocks(const pm::ReprojectArgs &a, const pm::BlockTable &t, int dtype, hipStream_t s, bool fetch);
 void pm_launch_mapped_data(const pm::Params &p, const pm::ReprojectArgs &a, const double *lon, const double *lat, double *xo,
                            double *yo, int dtype, hipStream_t s);
-void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s);
+dim3 pm_smooth_grid(int n_map, int n_planes);
+void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, unsigned *redo, hipStream_t s);
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s);
 void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStream_t s);
 void pm_launch_clean_lazy(const pm::ReprojectArgs &a, double *work, int dtype, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s);
@@ -87,7 +88,7 @@ struct pm_ctx {
     // 'smooth' interpolation options (map_img smooth_oversample_by / smooth_max_oversampled_img_size)
     int smooth_oversample_by = 5;
     int smooth_max_size = 10000;
-    double *limits = nullptr;  // 4 doubles: nanmin / nanmax of the x and y maps
+    double *limits = nullptr;  // nanmin / nanmax of the x and y maps (4 doubles), then the partial values of pm_launch_map_limits
     double spline_smoothing = 0.0;  // map_img spline_smoothing (FITPACK s), 0 = interpolating splines
     // smoothing-spline fits (pm_smoothing.hip): descriptors + per-plane workspace of the planes fitted together
     void *sm_arena = nullptr;

@@ -399,66 +399,145 @@ __global__ __launch_bounds__(kSphBlock) void k_mapped_data(const Params p, const
 // fine-grid nodes around its sample: node (r, k) = column PCHIP at ys[r] over the rows whose
 // row PCHIP at xs[k] is finite, each of those a PCHIP over the finite pixels of the row.
 // Work scales with the map, not with the oversampled image, and nothing is staged in HBM.
+// Two kernels. k_reproject_smooth_window does the common case, some five times cheaper than the general one: the fine grid
+// is finer than the pixels, so the two fine nodes of an axis lie in one pixel cell [j, j+1] (the second possibly ON its far
+// edge, where a PCHIP returns the sample itself), and the 4 x 4 pixels around the cell are finite and inside the trimmed
+// range. Then all four nodes are built from the same four row pieces (coefficients once per row, evaluated at both xq)
+// and two column pieces - 6 sets of coefficients instead of 20, with the arithmetic of pchip_piece. A lane keeps its cell
+// for sm.planes_per_lane planes (blockIdx.y counts groups of planes): where the cell lies on the fine grid - two interval
+// searches, four nodes, the bilinear weights - is the same for every plane. A (cell, plane) it cannot do (gaps, the
+// range's edge) gets kSmoothRedo, a NaN no arithmetic produces, and the workgroup's byte of `redo` is set;
+// k_reproject_smooth_gaps, the gap-aware form, then visits the flagged workgroups and computes those.
+// (One kernel with both forms ran at the registers of the general one - 80, and 203 with the loop over planes.)
+constexpr unsigned long long kSmoothRedo = 0x7ff85a5a5a5a5a5aull;
+
+struct SmoothCell {
+    double xk0, xk1, yr0, yr1, fx, fy;
+    bool inside;
+    __device__ __forceinline__ SmoothCell(const ReprojectArgs &a, const SmoothArgs &sm, double x, double y)
+    {
+        // propagate_nan: NaN where the sample lies outside the image (or one of the up to four pixels around it is NaN)
+        const bool skip = isnan(x) || (a.propagate_nan && (x < 0.0 || y < 0.0 || x > a.nx - 1 || y > a.ny - 1));
+        // RegularGridInterpolator(bounds_error=False, fill_value=nan)
+        inside = !skip && x >= (double)sm.x.first && x <= (double)sm.x.last && y >= (double)sm.y.first && y <= (double)sm.y.last;
+        const int k = inside ? smooth_interval(sm.x, x) : 0, r = inside ? smooth_interval(sm.y, y) : 0;
+        xk0 = smooth_grid(sm.x, k), xk1 = smooth_grid(sm.x, k + 1);
+        yr0 = smooth_grid(sm.y, r), yr1 = smooth_grid(sm.y, r + 1);
+        fx = (x - xk0) / (xk1 - xk0), fy = (y - yr0) / (yr1 - yr0);
+    }
+    __device__ __forceinline__ double blend(double f00, double f01, double f10, double f11) const
+    {
+        return f00 * (1.0 - fy) * (1.0 - fx) + f01 * (1.0 - fy) * fx + f10 * fy * (1.0 - fx) + f11 * fy * fx;
+    }
+};
+
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_reproject_smooth(const ReprojectArgs a, const SmoothArgs sm)
+__global__ __launch_bounds__(kBlock) void k_reproject_smooth_window(const ReprojectArgs a, const SmoothArgs sm, unsigned *redo)
 {
     const int m = blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
+    const int nx = a.nx;
+    const bool live = m < a.n_map;
+    const SmoothCell c(a, sm, live ? a.x_map[m] : __builtin_nan(""), live ? a.y_map[m] : __builtin_nan(""));
+    const int jx = (int)floor(c.xk0), iy = (int)floor(c.yr0);
+    const bool window = c.inside && c.xk1 <= jx + 1.0 && c.yr1 <= iy + 1.0 && jx - 1 >= sm.x.first && jx + 2 <= sm.x.last &&
+                        iy - 1 >= sm.y.first && iy + 2 <= sm.y.last;
+    const double sx0 = c.xk0 - (double)jx, sx1 = c.xk1 - (double)jx, sy0 = c.yr0 - (double)iy, sy1 = c.yr1 - (double)iy;
+    const bool x_edge = c.xk1 == jx + 1.0, y_edge = c.yr1 == iy + 1.0;
+    const size_t corner = window ? (size_t)(iy - 1) * nx + (jx - 1) : 0;
+    bool todo = false;
+    for (int q = 0; q < sm.planes_per_lane; q++) {
+        const int pl = blockIdx.y * sm.planes_per_lane + q;
+        if (pl >= a.n_planes || !live) break;
+        const T *img = (const T *)a.cube + (size_t)pl * a.ny * nx;
+        double val = __builtin_nan("");
+        if (c.inside) {
+            bool fast = window;
+            if (fast) {
+                // (propagate_nan's test of the pixels around the sample is made with this one: floor(x) and ceil(x) are jx
+                //  or jx + 1, those pixels are among the sixteen)
+                double g0[4], g1[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const size_t at = corner + (size_t)i * nx;
+                    const double wa = load_as_f64(img, at), wb = load_as_f64(img, at + 1), wc = load_as_f64(img, at + 2),
+                                 wd = load_as_f64(img, at + 3);
+                    const PchipUnitPiece row(wa, wb, wc, wd);
+                    g0[i] = row(sx0);
+                    g1[i] = x_edge ? wc : row(sx1);
+                    fast = fast && isfinite(wa) && isfinite(wb) && isfinite(wc) && isfinite(wd) && isfinite(g0[i]) && isfinite(g1[i]);
+                }
+                const PchipUnitPiece c0(g0[0], g0[1], g0[2], g0[3]), c1(g1[0], g1[1], g1[2], g1[3]);
+                val = c.blend(c0(sy0), c1(sy0), y_edge ? g0[2] : c0(sy1), y_edge ? g1[2] : c1(sy1));
+            }
+            if (!fast) {
+                val = __longlong_as_double((long long)kSmoothRedo);
+                todo = true;
+            }
+        }
+        a.out[(size_t)pl * a.n_map + m] = val;
+    }
+    // (the order of the list is that of arrival; the results do not depend on it)
+    const int any = __syncthreads_or(todo);
+    if (threadIdx.x == 0 && any) redo[1 + atomicAdd(redo, 1u)] = blockIdx.y * gridDim.x + blockIdx.x;
+}
+
+template <typename T>
+__device__ __forceinline__ void smooth_gaps_block(const ReprojectArgs &a, const SmoothArgs &sm, bool flagged_only, unsigned bx, unsigned group)
+{
+    const int m = bx * kBlock + threadIdx.x;
     if (m >= a.n_map) return;
     const double nan = __builtin_nan("");
     const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
     const double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    bool skip = isnan(x);
-    if (!skip && a.propagate_nan) {
-        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-            skip = true;
-        } else {
-            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
+#pragma unroll 1
+    for (int q = 0; q < sm.planes_per_lane; q++) {
+        const int pl = group * sm.planes_per_lane + q;
+        if (pl >= a.n_planes) break;
+        double *out = a.out + (size_t)pl * a.n_map + m;
+        if (flagged_only && (unsigned long long)__double_as_longlong(*out) != kSmoothRedo) continue;
+        const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
+        const SmoothCell c(a, sm, x, y);
+        bool skip = !c.inside;
+        if (!skip && a.propagate_nan) {
+            const long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
+            const long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
             skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
                    isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
         }
-    }
-    // RegularGridInterpolator(bounds_error=False, fill_value=nan)
-    const double x_lo = (double)sm.x.first, x_hi = (double)sm.x.last;
-    const double y_lo = (double)sm.y.first, y_hi = (double)sm.y.last;
-    if (!skip && x >= x_lo && x <= x_hi && y >= y_lo && y <= y_hi) {
-        const int k = smooth_interval(sm.x, x), r = smooth_interval(sm.y, y);
-        const double xk0 = smooth_grid(sm.x, k), xk1 = smooth_grid(sm.x, k + 1);
-        const double yr0 = smooth_grid(sm.y, r), yr1 = smooth_grid(sm.y, r + 1);
-        auto node = [&](double xq, double yq) {
-            auto column = [&](int i) {
-                auto row = [&](int j) { return load_as_f64(img, (size_t)i * nx + j); };
-                return pchip_gappy(row, sm.x.first, sm.x.last, xq);
+        double val = nan;
+        if (!skip) {
+            auto node = [&](double xq, double yq) {
+                auto column = [&](int i) {
+                    auto row = [&](int j) { return load_as_f64(img, (size_t)i * nx + j); };
+                    return pchip_gappy(row, sm.x.first, sm.x.last, xq);
+                };
+                return pchip_gappy(column, sm.y.first, sm.y.last, yq);
             };
-            return pchip_gappy(column, sm.y.first, sm.y.last, yq);
-        };
-        const double f00 = node(xk0, yr0), f01 = node(xk1, yr0), f10 = node(xk0, yr1), f11 = node(xk1, yr1);
-        const double fx = (x - xk0) / (xk1 - xk0), fy = (y - yr0) / (yr1 - yr0);
-        val = f00 * (1.0 - fy) * (1.0 - fx) + f01 * (1.0 - fy) * fx + f10 * fy * (1.0 - fx) + f11 * fy * fx;
+            const double f00 = node(c.xk0, c.yr0), f01 = node(c.xk1, c.yr0), f10 = node(c.xk0, c.yr1), f11 = node(c.xk1, c.yr1);
+            val = c.blend(f00, f01, f10, f11);
+        }
+        *out = val;
     }
-    a.out[(size_t)pl * a.n_map + m] = val;
 }
 
-// nanmin / nanmax of the x and y maps (one block): limits[0..3] = xmin, xmax, ymin, ymax;
-// +inf / -inf when no cell is visible.
-__global__ __launch_bounds__(kBlock) void k_map_limits(const double *x_map, const double *y_map, int n, double *limits)
+// The workgroups of the window kernel's grid (grid_x by n_groups) listed in redo[1 .. redo[0]], a fixed number of blocks
+// striding through the list; redo == nullptr: every (cell, plane) (PM_OPT_GENERAL_KERNEL: the cross-check of the window form).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reproject_smooth_gaps(const ReprojectArgs a, const SmoothArgs sm, const unsigned *redo,
+                                                                  unsigned grid_x, unsigned n_groups)
 {
-    __shared__ double sh[4][kBlock];
-    double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-        const double x = x_map[i], y = y_map[i];
-        if (!isnan(x)) {
-            xmin = fmin(xmin, x);
-            xmax = fmax(xmax, x);
-        }
-        if (!isnan(y)) {
-            ymin = fmin(ymin, y);
-            ymax = fmax(ymax, y);
-        }
+    const unsigned count = redo ? redo[0] : grid_x * n_groups;
+    for (unsigned at = blockIdx.x; at < count; at += gridDim.x) {
+        const unsigned id = redo ? redo[1 + at] : at;
+        smooth_gaps_block<T>(a, sm, redo != nullptr, id % grid_x, id / grid_x);
     }
+}
+
+// nanmin / nanmax of the x and y maps: limits[0..3] = xmin, xmax, ymin, ymax; +inf / -inf when no cell is visible.
+// Two stages - every block leaves its four values in partial[4 * block], a last block folds those. (Round 5: the single
+// block this used to be took 3.5 ms over the 6.5 M cells of a 0.1 deg map - as long as the smooth interpolation of 32 planes.)
+__device__ __forceinline__ void limits_fold(double (&sh)[4][kBlock], double xmin, double xmax, double ymin, double ymax, double *out)
+{
     sh[0][threadIdx.x] = xmin;
     sh[1][threadIdx.x] = xmax;
     sh[2][threadIdx.x] = ymin;
@@ -473,7 +552,36 @@ __global__ __launch_bounds__(kBlock) void k_map_limits(const double *x_map, cons
         }
         __syncthreads();
     }
-    if (threadIdx.x < 4) limits[threadIdx.x] = sh[threadIdx.x][0];
+    if (threadIdx.x < 4) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+__global__ __launch_bounds__(kBlock) void k_map_limits(const double *x_map, const double *y_map, int n, double *partial)
+{
+    __shared__ double sh[4][kBlock];
+    double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
+    for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < (size_t)n; i += (size_t)gridDim.x * kBlock) {
+        const double x = x_map[i], y = y_map[i];
+        if (!isnan(x)) {
+            xmin = fmin(xmin, x);
+            xmax = fmax(xmax, x);
+        }
+        if (!isnan(y)) {
+            ymin = fmin(ymin, y);
+            ymax = fmax(ymax, y);
+        }
+    }
+    limits_fold(sh, xmin, xmax, ymin, ymax, partial + 4 * (size_t)blockIdx.x);
+}
+__global__ __launch_bounds__(kBlock) void k_map_limits_fold(const double *partial, int n_blocks, double *limits)
+{
+    __shared__ double sh[4][kBlock];
+    double xmin = __builtin_inf(), xmax = -__builtin_inf(), ymin = __builtin_inf(), ymax = -__builtin_inf();
+    for (int b = threadIdx.x; b < n_blocks; b += kBlock) {  // (fmin / fmax drop nothing here: partials are never NaN)
+        xmin = fmin(xmin, partial[4 * b]);
+        xmax = fmax(xmax, partial[4 * b + 1]);
+        ymin = fmin(ymin, partial[4 * b + 2]);
+        ymax = fmax(ymax, partial[4 * b + 3]);
+    }
+    limits_fold(sh, xmin, xmax, ymin, ymax, limits);
 }
 
 // mode 0: `stats` hold the plane medians. The lazy form (pm_launch_clean_lazy) - a plane's nanmedian, eight passes over
@@ -913,28 +1021,51 @@ static void launch_median_t(const void *cube, int n_planes, size_t plane_elems, 
     }
 }
 
-template <typename T>
-static void launch_smooth_t(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, hipStream_t s)
+// planes per lane: as many as leave a few thousand workgroups, at most 4 (64 planes on a 0.1 deg map: 229 us a plane
+// with 1, 201 with 2, 190 with 4, 240 with 16); `redo` holds 1 + grid.x * grid.y unsigned
+dim3 pm_smooth_grid(int n_map, int n_planes)
 {
-    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes);
-    hipLaunchKernelGGL(pm::k_reproject_smooth<T>, grid, dim3(pm::kBlock), 0, s, a, sm);
+    const long blocks_x = (n_map + pm::kBlock - 1) / pm::kBlock;
+    long ppl = blocks_x * n_planes / 4096;
+    ppl = ppl < 1 ? 1 : (ppl > 4 ? 4 : ppl);
+    if (const char *e = getenv("PM_SMOOTH_PPL")) ppl = atoi(e);
+    return dim3((unsigned)blocks_x, (unsigned)((n_planes + ppl - 1) / ppl));
 }
 
-void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, hipStream_t s)
+template <typename T>
+static void launch_smooth_t(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, unsigned *redo, hipStream_t s)
+{
+    dim3 grid = pm_smooth_grid(a.n_map, a.n_planes);
+    pm::SmoothArgs smp = sm;
+    smp.planes_per_lane = (a.n_planes + (int)grid.y - 1) / (int)grid.y;
+    const size_t total = (size_t)grid.x * grid.y;
+    if (!sm.general) {
+        (void)hipMemsetAsync(redo, 0, sizeof(unsigned), s);
+        hipLaunchKernelGGL(pm::k_reproject_smooth_window<T>, grid, dim3(pm::kBlock), 0, s, a, smp, redo);
+    }
+    hipLaunchKernelGGL(pm::k_reproject_smooth_gaps<T>, dim3((unsigned)(total < 2048 ? total : 2048)), dim3(pm::kBlock), 0, s, a, smp,
+                       sm.general ? nullptr : redo, grid.x, grid.y);
+}
+
+void pm_launch_reproject_smooth(const pm::ReprojectArgs &a, const pm::SmoothArgs &sm, int dtype, unsigned *redo, hipStream_t s)
 {
     switch (dtype) {
-    case PM_F64: launch_smooth_t<double>(a, sm, s); break;
-    case PM_F32: launch_smooth_t<float>(a, sm, s); break;
-    case PM_I16: launch_smooth_t<int16_t>(a, sm, s); break;
-    case PM_I32: launch_smooth_t<int32_t>(a, sm, s); break;
-    case PM_U8: launch_smooth_t<uint8_t>(a, sm, s); break;
-    case PM_U16: launch_smooth_t<uint16_t>(a, sm, s); break;
+    case PM_F64: launch_smooth_t<double>(a, sm, redo, s); break;
+    case PM_F32: launch_smooth_t<float>(a, sm, redo, s); break;
+    case PM_I16: launch_smooth_t<int16_t>(a, sm, redo, s); break;
+    case PM_I32: launch_smooth_t<int32_t>(a, sm, redo, s); break;
+    case PM_U8: launch_smooth_t<uint8_t>(a, sm, redo, s); break;
+    case PM_U16: launch_smooth_t<uint16_t>(a, sm, redo, s); break;
     }
 }
 
+// `limits`: 4 * (1 + pm::kMapLimitsBlocks) doubles - the result, then the blocks' partial values
 void pm_launch_map_limits(const double *x_map, const double *y_map, int n, double *limits, hipStream_t s)
 {
-    hipLaunchKernelGGL(pm::k_map_limits, dim3(1), dim3(pm::kBlock), 0, s, x_map, y_map, n, limits);
+    int nb = (n + 8 * pm::kBlock - 1) / (8 * pm::kBlock);
+    nb = nb < 1 ? 1 : (nb > pm::kMapLimitsBlocks ? pm::kMapLimitsBlocks : nb);
+    hipLaunchKernelGGL(pm::k_map_limits, dim3(nb), dim3(pm::kBlock), 0, s, x_map, y_map, n, limits + 4);
+    hipLaunchKernelGGL(pm::k_map_limits_fold, dim3(1), dim3(pm::kBlock), 0, s, limits + 4, nb, limits);
 }
 
 template <typename T>

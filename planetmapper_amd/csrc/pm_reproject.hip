@@ -134,7 +134,13 @@ int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype
         !smooth_axis(a.ny, limits[2], limits[3], ctx->smooth_oversample_by, ctx->smooth_max_size, sm.y))
         return fail(ctx, PM_ERR_INVALID_ARGUMENT,
                     "smooth interpolation needs at least two image pixels per axis near the mapped region");
-    pm_launch_reproject_smooth(a, sm, dtype, ctx->stream);
+    sm.general = ctx->force_general ? 1 : 0;
+    sm.planes_per_lane = 1;
+    const dim3 grid = pm_smooth_grid(a.n_map, a.n_planes);
+    // the list of the workgroups with cells left to the gap-aware kernel
+    const int rc = ensure_work(ctx, (1 + (size_t)grid.x * grid.y) * sizeof(unsigned));
+    if (rc != PM_OK) return rc;
+    pm_launch_reproject_smooth(a, sm, dtype, (unsigned *)ctx->work, ctx->stream);
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
 }

@@ -138,6 +138,36 @@ def test_interpolating_splines_and_smooth_at_cube_scale(engine, oracle, jupiter,
                               map_resident(engine, cube, xm, ym, 'cubic', False)[p], equal_nan=True), p
 
 
+def test_smooth_interpolation_4x4_form_gives_the_gap_aware_form_bits(engine, oracle, jupiter):
+    """
+    k_reproject_smooth builds a cell's four fine-grid nodes from the 4 x 4 finite pixels around it where it can (six sets of
+    PCHIP coefficients) and from the gap-aware search otherwise (twenty): both are the same arithmetic, so the output must
+    not depend on which one a cell took. `PM_OPT_GENERAL_KERNEL` sends every cell through the gap-aware form. Oversampling 1
+    puts every second fine node ON a pixel (the 4 x 4 form returns the sample there), 5 and 3 put them inside the cells.
+    """
+    from planetmapper_amd import _lib
+
+    ny, nx = 500, 523
+    cube, states = make_cube(14, ny, nx, seed=31)
+    cube32 = cube.astype(np.float32)
+    xm, ym = setup_maps(engine, oracle, jupiter, ny, nx, deg=0.5)
+    try:
+        for oversample, max_size in ((5, 10_000), (1, 10_000), (3, 10_000), (5, 700)):
+            engine.set_smooth_options(oversample, max_size)
+            for c in (cube, cube32):
+                for prop in (True, False):
+                    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
+                    a = map_resident(engine, c, xm, ym, 'smooth', prop)
+                    engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1)
+                    b = map_resident(engine, c, xm, ym, 'smooth', prop)
+                    assert np.array_equal(a, b, equal_nan=True), (oversample, max_size, c.dtype, prop,
+                                                                  float(np.nanmax(np.abs(a - b))))
+                    assert np.isfinite(a).sum() > 1000 * 6
+    finally:
+        engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
+        engine.set_smooth_options(5, 10_000)
+
+
 def test_splines_f32_and_integer_planes_at_cube_scale(engine, oracle, jupiter):
     ny = nx = 1024
     cube64, states = make_cube(14, ny, nx, seed=77)

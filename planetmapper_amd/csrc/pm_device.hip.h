@@ -274,7 +274,10 @@ __device__ __forceinline__ double pchip_interior(double h0, double h1, double m0
     // finite samples are never NaN) - four compares instead of two sign() values and three
     if (!(m0 > 0.0 ? m1 > 0.0 : (m0 < 0.0 && m1 < 0.0))) return 0.0;
     const double w1 = 2.0 * h1 + h0, w2 = h1 + 2.0 * h0;
-    return rcp_fast(div_fast(div_fast(w1, m0) + div_fast(w2, m1), w1 + w2));
+    // the weighted harmonic mean (w1 + w2) / (w1 / m0 + w2 / m1) with ONE division: m0 / (w1 m1 + w2 m0) is below 1 / w2
+    // (the slopes have one sign), so nothing overflows that the four-division form would not. (The fma is spelt out: which
+    // of the two products the compiler fuses must not depend on the caller - the two smooth kernels give the same bits.)
+    return (w1 + w2) * div_fast(m0, __builtin_fma(w1, m1, w2 * m0)) * m1;
 }
 __device__ __forceinline__ double pchip_edge(double h0, double h1, double m0, double m1)
 {

@@ -4,10 +4,12 @@
 //                          propagation and on-the-fly NaN pre-clean
 //   k_median_hist / pick   per-plane nanmedian (radix select) for the pre-clean
 //   k_spline_*             interpolating tensor-product splines (degrees 1..5)
-//   k_reproject_smooth<T>  'smooth' (PCHIP-oversampled) reprojection, evaluated on the fly
+//   k_reproject_smooth_*   'smooth' (PCHIP-oversampled) reprojection, evaluated on the fly (4 x 4 window form + gap-aware form)
 //
 // One lane per (map cell, plane): blockIdx.y = plane, so a wave gathers neighbouring map cells
-// from ONE plane and stores coalesced along the map row.
+// from ONE plane and stores coalesced along the map row. (Keeping a lane's cell for a few planes - the cell's coordinates
+// are two thirds of a plane's traffic on a fine map - pays in the smooth kernel only: k_reproject ran no faster with 4
+// planes a lane, 29.4 us a plane of a 0.1 deg map, and slower with the loop at one.)
 #include "pm_device.hip.h"
 
 namespace pm {
@@ -17,6 +19,28 @@ template <typename T>
 __device__ __forceinline__ double load_as_f64(const T *p, size_t i)
 {
     return (double)p[i];
+}
+
+// p[i .. i+3] in as few load instructions as the element size allows (the address is aligned to the element only: gfx950
+// takes global loads of 16 bytes at any dword address). The gathers of the fine-map kernels are bound by the number of
+// load instructions the texture path takes in, not by bytes.
+template <typename T>
+__device__ __forceinline__ void load4_as_f64(const T *p, size_t i, double &a, double &b, double &c, double &d)
+{
+    typedef T Quad __attribute__((ext_vector_type(4), aligned(sizeof(T) < 4 ? sizeof(T) : 4)));
+    const Quad v = *(const Quad *)(p + i);
+    a = (double)v.x;
+    b = (double)v.y;
+    c = (double)v.z;
+    d = (double)v.w;
+}
+template <typename T>
+__device__ __forceinline__ void load2_as_f64(const T *p, size_t i, double &a, double &b)
+{
+    typedef T Pair __attribute__((ext_vector_type(2), aligned(sizeof(T) < 4 ? sizeof(T) : 4)));
+    const Pair v = *(const Pair *)(p + i);
+    a = (double)v.x;
+    b = (double)v.y;
 }
 
 // Value the reference would interpolate from at pixel (i, j): the pixel itself if finite,
@@ -459,8 +483,8 @@ __global__ __launch_bounds__(kBlock) void k_reproject_smooth_window(const Reproj
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const size_t at = corner + (size_t)i * nx;
-                    const double wa = load_as_f64(img, at), wb = load_as_f64(img, at + 1), wc = load_as_f64(img, at + 2),
-                                 wd = load_as_f64(img, at + 3);
+                    double wa, wb, wc, wd;
+                    load4_as_f64(img, at, wa, wb, wc, wd);
                     const PchipUnitPiece row(wa, wb, wc, wd);
                     g0[i] = row(sx0);
                     g1[i] = x_edge ? wc : row(sx1);
@@ -851,59 +875,97 @@ __device__ __forceinline__ int spline_interval(const SplineAxis &ax, double x)
     while (l > ax.k && x < ax.t[l]) l--;
     return l;
 }
-__device__ __forceinline__ void spline_basis(const SplineAxis &ax, double x, int l, double *h)
+// The k + 1 B-splines that are non-zero on span l at x (de Boor's recurrence, fitpack fpbspl). Loops of fixed length with
+// the degree as a guard - the degree is the same for every lane, the guards are scalar branches - so that h stays in
+// registers (indexed by the degree it lived in scratch memory).
+__device__ __forceinline__ void spline_basis(const SplineAxis &ax, double x, int l, double (&h)[6])
 {
     double hh[6];
     h[0] = 1.0;
-    for (int j = 1; j <= ax.k; j++) {
-        for (int i = 0; i < j; i++) hh[i] = h[i];
-        h[0] = 0.0;
-        for (int i = 1; i <= j; i++) {
-            const int li = l + i, lj = li - j;
-            const double f = hh[i - 1] / (ax.t[li] - ax.t[lj]);
-            h[i - 1] += f * (ax.t[li] - x);
-            h[i] = f * (x - ax.t[lj]);
+#pragma unroll
+    for (int j = 1; j <= 5; j++) {
+        if (j <= ax.k) {
+#pragma unroll
+            for (int i = 0; i < j; i++) hh[i] = h[i];
+            h[0] = 0.0;
+#pragma unroll
+            for (int i = 1; i <= j; i++) {
+                const int li = l + i, lj = li - j;
+                const double tli = ax.t[li], tlj = ax.t[lj];
+                const double f = hh[i - 1] / (tli - tlj);
+                h[i - 1] += f * (tli - x);
+                h[i] = f * (x - tlj);
+            }
         }
     }
 }
+// A lane keeps its cell for `planes_per_lane` planes (blockIdx.y counts groups of planes, pm_smooth_grid): the span and the
+// B-spline values of the cell - two searches, 2 x k (k + 1) / 2 divisions, the knots - are the same for every plane, which
+// leaves (kr + 1) (kc + 1) coefficients and as many multiply-adds per plane. (Round 5, cubic, 64 planes on a 0.1 deg map:
+// 137 us a plane with one plane per lane and the arrays in scratch.)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_spline_eval(const ReprojectArgs a, const SplineArgs sa)
+__global__ __launch_bounds__(kBlock) void k_spline_eval(const ReprojectArgs a, const SplineArgs sa, int planes_per_lane)
 {
     const int m = blockIdx.x * kBlock + threadIdx.x;
-    const int pl = blockIdx.y;
     if (m >= a.n_map) return;
     const double nan = __builtin_nan("");
-    const int nx = a.nx, ny = a.ny;
-    const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
-    const double *c = sa.work + (size_t)pl * ny * nx;
-    double x = a.x_map[m], y = a.y_map[m];
-    double val = nan;
-    bool skip = isnan(x) || a.plane_stats[pl].all_nan;
-    if (!skip && a.propagate_nan) {
-        if (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1) {
-            skip = true;
-        } else {
-            long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
-            long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
-            skip = isnan(load_as_f64(img, (size_t)ja * nx + ia)) || isnan(load_as_f64(img, (size_t)ja * nx + ib)) ||
-                   isnan(load_as_f64(img, (size_t)jb * nx + ia)) || isnan(load_as_f64(img, (size_t)jb * nx + ib));
-        }
-    }
-    if (!skip) {
+    const int nx = a.nx, ny = a.ny, kr = sa.rows.k, kc = sa.cols.k;
+    const double x = a.x_map[m], y = a.y_map[m];
+    const bool cell = !isnan(x) && !(a.propagate_nan && (x < 0.0 || y < 0.0 || x > nx - 1 || y > ny - 1));
+    // propagate_nan: the (up to) four pixels around the sample
+    const long ia = (long)fmax(floor(x), 0.0), ib = (long)fmin(ceil(x), nx - 1.0);
+    const long ja = (long)fmax(floor(y), 0.0), jb = (long)fmin(ceil(y), ny - 1.0);
+    const long ic = ia < nx - 2 ? ia : nx - 2;
+    double hy[6], hx[6];
+    size_t corner = 0;
+    if (cell) {
         const double xc = fmin(fmax(x, 0.0), nx - 1.0), yc = fmin(fmax(y, 0.0), ny - 1.0);
-        double hy[6], hx[6];
         const int ly = spline_interval(sa.rows, yc), lx = spline_interval(sa.cols, xc);
         spline_basis(sa.rows, yc, ly, hy);
         spline_basis(sa.cols, xc, lx, hx);
-        double s = 0.0;
-        for (int p = 0; p <= sa.rows.k; p++) {
-            double r = 0.0;
-            for (int q = 0; q <= sa.cols.k; q++) r += hx[q] * c[(size_t)(ly - sa.rows.k + p) * nx + (lx - sa.cols.k + q)];
-            s += hy[p] * r;
-        }
-        val = s;
+        corner = (size_t)(ly - kr) * nx + (lx - kc);
     }
-    a.out[(size_t)pl * a.n_map + m] = val;
+    for (int g = 0; g < planes_per_lane; g++) {
+        const int pl = blockIdx.y * planes_per_lane + g;
+        if (pl >= a.n_planes) break;
+        const T *img = (const T *)a.cube + (size_t)pl * ny * nx;
+        const double *c = sa.work + (size_t)pl * ny * nx + corner;
+        double val = nan;
+        if (cell) {
+            // (the pixels of the NaN test and the coefficients are fetched together - one memory round trip a plane, not two;
+            //  every address is inside the plane whatever the test says)
+            bool skip = a.plane_stats[pl].all_nan;
+            if (a.propagate_nan) {
+                // pixels ia and ib of a row in one load: both are ic or ic + 1 (ib is ia or ia + 1)
+                double v0, v1, w0, w1;
+                load2_as_f64(img, (size_t)ja * nx + ic, v0, v1);
+                load2_as_f64(img, (size_t)jb * nx + ic, w0, w1);
+                skip = (int)skip | (int)isnan(ia == ic ? v0 : v1) | (int)isnan(ib == ic ? v0 : v1) | (int)isnan(ia == ic ? w0 : w1) |
+                       (int)isnan(ib == ic ? w0 : w1);
+            }
+            double s = 0.0;
+#pragma unroll
+            for (int p = 0; p <= 5; p++) {
+                if (p <= kr) {
+                    // (pairs of coefficients per load where the degree has both)
+                    double r = 0.0, c0, c1;
+#pragma unroll
+                    for (int q = 0; q <= 4; q += 2) {
+                        if (q + 1 <= kc) {
+                            load2_as_f64(c, (size_t)p * nx + q, c0, c1);
+                            r += hx[q] * c0;
+                            r += hx[q + 1] * c1;
+                        } else if (q <= kc) {
+                            r += hx[q] * c[(size_t)p * nx + q];
+                        }
+                    }
+                    s += hy[p] * r;
+                }
+            }
+            val = skip ? nan : s;
+        }
+        a.out[(size_t)pl * a.n_map + m] = val;
+    }
 }
 
 // ------------------------------------------------------------------ per-plane nanmedian
@@ -1000,6 +1062,16 @@ __global__ __launch_bounds__(kBlock) void k_median_pick(int shift, size_t plane_
 
 extern "C++" {
 
+// 'smooth' and the spline evaluation: planes per lane - as many as leave a few thousand workgroups, at most 8 (65 planes on a 0.1 deg map: 104 us a
+// plane with 1, 79 with 2, 68 with 4, 61 with 8); `redo` holds 1 + grid.x * grid.y unsigned
+dim3 pm_smooth_grid(int n_map, int n_planes)
+{
+    const long blocks_x = (n_map + pm::kBlock - 1) / pm::kBlock;
+    long ppl = blocks_x * n_planes / 4096;
+    ppl = ppl < 1 ? 1 : (ppl > 8 ? 8 : ppl);
+    return dim3((unsigned)blocks_x, (unsigned)((n_planes + ppl - 1) / ppl));
+}
+
 template <typename T>
 static void launch_reproject_t(const pm::ReprojectArgs &a, hipStream_t s)
 {
@@ -1019,17 +1091,6 @@ static void launch_median_t(const void *cube, int n_planes, size_t plane_elems, 
                            plane_elems, shift, stats, hist, lazy);
         hipLaunchKernelGGL(pm::k_median_pick, dim3(n_planes), dim3(pm::kBlock), 0, s, shift, plane_elems, stats, hist, lazy);
     }
-}
-
-// planes per lane: as many as leave a few thousand workgroups, at most 4 (64 planes on a 0.1 deg map: 229 us a plane
-// with 1, 201 with 2, 190 with 4, 240 with 16); `redo` holds 1 + grid.x * grid.y unsigned
-dim3 pm_smooth_grid(int n_map, int n_planes)
-{
-    const long blocks_x = (n_map + pm::kBlock - 1) / pm::kBlock;
-    long ppl = blocks_x * n_planes / 4096;
-    ppl = ppl < 1 ? 1 : (ppl > 4 ? 4 : ppl);
-    if (const char *e = getenv("PM_SMOOTH_PPL")) ppl = atoi(e);
-    return dim3((unsigned)blocks_x, (unsigned)((n_planes + ppl - 1) / ppl));
 }
 
 template <typename T>
@@ -1190,8 +1251,8 @@ static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa
     hipLaunchKernelGGL((pm::k_spline_solve_cols<T, 2>), dim3(cgroups), dim3(pm::kSolveRows), 0, s, (const T *)a.cube, sa.work, stats, a.n_planes, a.ny,
                        a.nx, sa.rows);
     hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(rgroups), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes, a.ny, a.nx, sa.cols, (const pm::PlaneStats *)stats);
-    hipLaunchKernelGGL(pm::k_spline_eval<T>, dim3((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes), dim3(pm::kBlock),
-                       0, s, a, sa);
+    const dim3 egrid = pm_smooth_grid(a.n_map, a.n_planes);
+    hipLaunchKernelGGL(pm::k_spline_eval<T>, egrid, dim3(pm::kBlock), 0, s, a, sa, (a.n_planes + (int)egrid.y - 1) / (int)egrid.y);
 }
 
 template <typename T>

@@ -222,7 +222,8 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           rotations, full quadratic motion model, observer anywhere outside the
  *                           body) instead of the spheroid fast path the library selects when its
  *                           guards hold; the MAP planes (pm_backplanes_map, pm_xy_map) go through
- *                           the J2000 kernel with the general helpers instead of the B0 kernels.
+ *                           the J2000 kernel with the general helpers instead of the B0 kernels;
+ *                           'smooth' reprojection takes the gap-aware PCHIP form at every cell.
  *                           Results agree within the parity bars; used by the tests to cover both
  *                           sets of kernels. Default 0 (with PM_DEBUG_ENV=1 the environment variable
  *                           PM_FORCE_GENERAL=1 sets the default to 1 at pm_create).

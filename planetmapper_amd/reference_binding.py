@@ -229,6 +229,15 @@ class HipBackplanes:
             self._cache[key] = {n: _readonly(a) for n, a in out.items()}
         return self._cache[key]
 
+    def _hip_lonlat_grids(self, map_kwargs: dict) -> tuple:
+        """the reference's own grid (`_get_lonlat_map`: every projection it knows) as two contiguous arrays, cut out of the
+        interleaved (n0, n1, 2) array once per grid - the two strided copies are 15 ms on a 0.1 deg grid"""
+        key = ('_hip_lonlat', frozenset((k, _freeze(v)) for k, v in map_kwargs.items() if k != 'alt'))
+        if key not in self._stable_cache:
+            ll = self._get_lonlat_map(**map_kwargs)
+            self._stable_cache[key] = (_readonly(np.ascontiguousarray(ll[..., 0])), _readonly(np.ascontiguousarray(ll[..., 1])))
+        return self._stable_cache[key]
+
     def _hip_map_family(self, names: tuple, map_kwargs: dict) -> dict:
         """the planes of one map-space family on the grid the reference builds for `map_kwargs` (stable: no disc dependence)"""
         key = ('_hip_map', names, frozenset((k, _freeze(v)) for k, v in map_kwargs.items()))
@@ -237,8 +246,8 @@ class HipBackplanes:
         if xy:
             key = key + (self.get_x0(), self.get_y0(), self.get_r0(), self._get_rotation_radians())
         if key not in cache:
-            ll = self._get_lonlat_map(**map_kwargs)  # (the reference's own grid: every projection it knows)
-            out = self._hip().backplanes_map(list(names), ll[..., 0], ll[..., 1], alt=float(map_kwargs.get('alt', 0.0)))
+            lon, lat = self._hip_lonlat_grids(map_kwargs)
+            out = self._hip().backplanes_map(list(names), lon, lat, alt=float(map_kwargs.get('alt', 0.0)))
             cache[key] = {n: _readonly(a) for n, a in out.items()}
         return cache[key]
 

@@ -136,11 +136,18 @@ int reproject_smooth_resident(pm_ctx *ctx, const pm::ReprojectArgs &a, int dtype
                     "smooth interpolation needs at least two image pixels per axis near the mapped region");
     sm.general = ctx->force_general ? 1 : 0;
     sm.planes_per_lane = 1;
-    const dim3 grid = pm_smooth_grid(a.n_map, a.n_planes);
-    // the list of the workgroups with cells left to the gap-aware kernel
-    const int rc = ensure_work(ctx, (1 + (size_t)grid.x * grid.y) * sizeof(unsigned));
-    if (rc != PM_OK) return rc;
-    pm_launch_reproject_smooth(a, sm, dtype, (unsigned *)ctx->work, ctx->stream);
+    const size_t plane_bytes = (size_t)a.ny * a.nx * dtype_size(dtype);
+    for (int p0 = 0; p0 < a.n_planes; p0 += 32768) {  // (blockIdx.y: at most 65535 groups of planes per launch)
+        pm::ReprojectArgs b = a;
+        b.n_planes = std::min(32768, a.n_planes - p0);
+        b.cube = (const char *)a.cube + (size_t)p0 * plane_bytes;
+        b.out = a.out + (size_t)p0 * a.n_map;
+        const dim3 grid = pm_smooth_grid(b.n_map, b.n_planes);
+        // the list of the workgroups with cells left to the gap-aware kernel
+        const int rc = ensure_work(ctx, (1 + (size_t)grid.x * grid.y) * sizeof(unsigned));
+        if (rc != PM_OK) return rc;
+        pm_launch_reproject_smooth(b, sm, dtype, (unsigned *)ctx->work, ctx->stream);
+    }
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;
 }

@@ -226,6 +226,32 @@ def test_generate_map_coordinates(body):
     assert body.get_lon_map(projection='manual', lon_coords=[-10, 370], lat_coords=[0])[0].tolist() == [350, 10]
 
 
+def test_lonlat_grids_are_the_interleaved_map_cut_once(body):
+    """
+    body_xy.py:3290-3300: `_get_lonlat_map` is (n0, n1, 2), longitudes modulo 360, non-finite -> NaN, read-only, cached for
+    good. The engine takes the two contiguous grids (`_get_lonlat_grids`): the same values, cut once per grid, and what the
+    map planes are computed from.
+    """
+    for kw in (dict(degree_interval=30), dict(degree_interval=45, xlim=(100, 250), ylim=(0, 90)), dict(projection='orthographic', size=7),
+               dict(projection='manual', lon_coords=np.array([[-10.0, 370.0, np.inf]]), lat_coords=np.array([[0.0, 1.0, 2.0]]))):
+        lon, lat = body._get_lonlat_grids(**kw)
+        ll = body._get_lonlat_map(**kw)
+        assert ll.shape == lon.shape + (2,) and lon.flags.c_contiguous and lat.flags.c_contiguous
+        assert np.array_equal(ll[..., 0], lon, equal_nan=True) and np.array_equal(ll[..., 1], lat, equal_nan=True)
+        assert not lon.flags.writeable and not lat.flags.writeable and not ll.flags.writeable
+        assert body._get_lonlat_grids(**kw)[0] is lon and body._get_lonlat_map(**kw) is ll  # cached
+        fin = np.isfinite(lon)
+        assert ((lon[fin] >= 0) & (lon[fin] < 360)).all() and not np.isinf(ll).any()
+        assert np.array_equal(body.get_lon_map(**kw), lon, equal_nan=True) or kw.get('projection') == 'orthographic'
+    lon, _ = body._get_lonlat_grids(projection='manual', lon_coords=np.array([[-10.0, 370.0, np.inf]]), lat_coords=np.array([[0.0, 1.0, 2.0]]))
+    assert lon[0, :2].tolist() == [350.0, 10.0] and np.isnan(lon[0, 2])
+    # the grids are their own arrays: the caller's coordinates are not frozen or changed by the cache
+    mine = np.array([[0.0, 90.0]])
+    body._get_lonlat_grids(projection='manual', lon_coords=mine, lat_coords=mine)
+    mine[0, 0] = 5.0
+    assert mine.flags.writeable
+
+
 IMAGE = np.array(
     [
         [0.0, 100.0, -1.0, 2.2, 3.3, 4.4],

@@ -190,7 +190,7 @@ struct PlaneStats {
 // collocation matrix, built on the host (pm_capi.hip), resident in device memory.
 struct SplineAxis {
     const double *t;   // n + k + 1 knots
-    const double *lu;  // n x (2k + 1) banded LU (unit lower), entry (i, j) at lu[i*(2k+1) + (j-i+k)]
+    const double *lu;  // n x (2k + 1) banded LU (unit lower), entry (i, j) at lu[i*(2k+1) + (j-i+k)]; the RECIPROCAL of U's diagonal at j = i
     int n, k;
 };
 struct SplineArgs {

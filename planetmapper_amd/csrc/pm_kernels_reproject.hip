@@ -627,7 +627,8 @@ __global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *
 }
 
 // Solve B c = v along one axis of every plane in place, with the banded LU of the collocation matrix (unit lower
-// triangle, no pivoting: forward substitution, then back substitution with the last k results kept in registers).
+// triangle, no pivoting, the diagonal of U stored as its reciprocal: forward substitution, then back substitution with the
+// last k results kept in registers).
 // A line is 1024 dependent steps; what the kernels are built around is keeping a wave from WAITING at each of them.
 //   * the LU row of a step is the same for every lane: fetched per step it is a scalar load that misses (the table of a
 //     1024-sample axis is 57 KB, every wave is somewhere else in it) - one memory round trip per step. Here the rows of
@@ -641,6 +642,18 @@ __global__ __launch_bounds__(kBlock) void k_spline_clean(const T *cube, double *
 // twice). (A first tiled axis 1 WITHOUT the staged LU rows ran in the 2.8 ms of the plain lane-per-row kernel: the round
 // trip per step was the cost, not the access pattern - profiles/EXPERIMENTS.md.)
 constexpr int kSolveRows = 64, kSolveCols = 16, kSolveBand = 11;  // (2 k + 1 <= 11)
+constexpr int kSolveRpi = 64 / kSolveCols;  // rows of a tile per load instruction of the axis-1 kernel
+// A workgroup of these kernels is ONE wave: what its lanes exchange through LDS needs the order of the wave's own LDS
+// instructions, which the hardware keeps, and no barrier. __syncthreads() also waits for every global store the wave has
+// issued (vmcnt(0)) - here the 16 rows just written, a full memory round trip per tile that nothing else hides when a
+// plane is alone: one plane of 1024^2 took 0.65 + 0.57 ms in the two solves.
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <int K>
 __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, int n_planes, int ny, int nx, SplineAxis ax, const PlaneStats *only_flagged)
 {
     __shared__ double tile[kSolveRows][kSolveCols + 1];
@@ -651,17 +664,18 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
     if (only_flagged && !only_flagged[pl].needs_median) return;  // (the second round: planes that were cleaned again with their nanmedian)
     const int rows = min(kSolveRows, ny - r0);
     double *base = work + ((size_t)pl * ny + r0) * nx;
-    const int n = ax.n, k = ax.k, w = 2 * k + 1;
+    const int n = ax.n;
+    constexpr int w = 2 * K + 1;
     const int lr = lane / kSolveCols, lc = lane % kSolveCols;  // this lane's (row within a group of four, column) in the copies
     constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
     double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    double v[kSolveCols], g[kSolveRows / 4], glu[kLuRegs];
+    double v[kSolveCols], g[kSolveRows / kSolveRpi], glu[kLuRegs];
     // the next tile is on its way from HBM (into registers) while the current one is worked on
     auto fetch = [&](int c0) {
         const int cols = min(kSolveCols, n - c0);
 #pragma unroll
-        for (int it = 0; it < kSolveRows / 4; it++) {
-            const int r = it * 4 + lr;
+        for (int it = 0; it < kSolveRows / kSolveRpi; it++) {
+            const int r = it * kSolveRpi + lr;
             g[it] = (r < rows && lc < cols) ? base[(size_t)r * nx + c0 + lc] : 0.0;
         }
 #pragma unroll
@@ -672,26 +686,92 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
     };
     auto to_lds = [&](int cols) {
 #pragma unroll
-        for (int it = 0; it < kSolveRows / 4; it++) tile[it * 4 + lr][lc] = g[it];
+        for (int it = 0; it < kSolveRows / kSolveRpi; it++) tile[it * kSolveRpi + lr][lc] = g[it];
 #pragma unroll
         for (int e = 0; e < kLuRegs; e++) {
             const int x = e * kSolveRows + lane;
             if (x < cols * w) lu[x / w][x % w] = glu[e];
         }
-        __syncthreads();
+        wave_sync();
 #pragma unroll
         for (int j = 0; j < kSolveCols; j++) v[j] = tile[lane][j];
     };
     auto tile_out = [&](int c0, int cols) {
 #pragma unroll
         for (int j = 0; j < kSolveCols; j++) tile[lane][j] = v[j];
-        __syncthreads();
+        wave_sync();
 #pragma unroll
-        for (int it = 0; it < kSolveRows / 4; it++) {
-            const int r = it * 4 + lr;
+        for (int it = 0; it < kSolveRows / kSolveRpi; it++) {
+            const int r = it * kSolveRpi + lr;
             if (r < rows && lc < cols) base[(size_t)r * nx + c0 + lc] = tile[r][lc];
         }
-        __syncthreads();
+        wave_sync();
+    };
+    // One step of a substitution, straight-line: the degree is a template argument, and the terms that would reach
+    // outside the matrix need no test - the band is stored with zeros there and `prev` starts as zeros, so they subtract
+    // an exact 0. (With the degree and those tests at run time every multiply-add sat in a basic block of its own
+    // behind an LDS read it waited for: ~60 cycles per term, 700 per step - the whole cost of a plane that is alone.)
+    // The terms are taken farthest first: the result of the step before enters the LAST multiply-add, so a step's place in
+    // the line's chain of dependent operations is one multiply-add (and one multiplication by the reciprocal diagonal on the
+    // way back), whatever the degree.
+    auto fwd_step = [&](int j) {
+        double s = v[j];
+#pragma unroll
+        for (int q = K; q >= 1; q--) s -= lu[j][K - q] * prev[q - 1];
+#pragma unroll
+        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+        prev[0] = s;
+        v[j] = s;
+    };
+    auto back_step = [&](int j) {
+        double s = v[j];
+#pragma unroll
+        for (int q = K; q >= 1; q--) s -= lu[j][K + q] * prev[q - 1];
+        s *= lu[j][K];
+#pragma unroll
+        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+        prev[0] = s;
+        v[j] = s;
+    };
+    // Eight steps of a full tile at a time: their LU entries are read from LDS together, AHEAD of the chain (left to
+    // itself the compiler reads each step's entries right where it uses them, and every step waits for LDS).
+    constexpr int kRun = 8;
+    auto fwd_run = [&](int j0) {
+        double l[kRun][K];
+#pragma unroll
+        for (int j = 0; j < kRun; j++)
+#pragma unroll
+            for (int q = 1; q <= K; q++) l[j][q - 1] = lu[j0 + j][K - q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kRun; j++) {
+            double s = v[j0 + j];
+#pragma unroll
+            for (int q = K; q >= 1; q--) s -= l[j][q - 1] * prev[q - 1];
+#pragma unroll
+            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+            prev[0] = s;
+            v[j0 + j] = s;
+        }
+    };
+    auto back_run = [&](int j0) {  // steps j0 + kRun - 1 down to j0
+        double l[kRun][K + 1];
+#pragma unroll
+        for (int j = kRun - 1; j >= 0; j--)
+#pragma unroll
+            for (int q = 0; q <= K; q++) l[j][q] = lu[j0 + j][K + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = kRun - 1; j >= 0; j--) {
+            double s = v[j0 + j];
+#pragma unroll
+            for (int q = K; q >= 1; q--) s -= l[j][q] * prev[q - 1];
+            s *= l[j][0];
+#pragma unroll
+            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+            prev[0] = s;
+            v[j0 + j] = s;
+        }
     };
     // forward substitution (unit lower triangle)
     fetch(0);
@@ -699,19 +779,13 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
         const int cols = min(kSolveCols, n - c0);
         to_lds(cols);
         if (c0 + kSolveCols < n) fetch(c0 + kSolveCols);
+        if (cols == kSolveCols) {
 #pragma unroll
-        for (int j = 0; j < kSolveCols; j++) {
-            const int i = c0 + j;
-            if (j < cols) {
-                double s = v[j];
+            for (int j0 = 0; j0 < kSolveCols; j0 += kRun) fwd_run(j0);
+        } else {
 #pragma unroll
-                for (int q = 1; q <= 5; q++)
-                    if (q <= k && i - q >= 0) s -= lu[j][k - q] * prev[q - 1];
-#pragma unroll
-                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-                prev[0] = s;
-                v[j] = s;
-            }
+            for (int j = 0; j < kSolveCols; j++)
+                if (j < cols) fwd_step(j);
         }
         tile_out(c0, cols);
     }
@@ -724,20 +798,13 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
         const int cols = min(kSolveCols, n - c0);
         to_lds(cols);
         if (c0 - kSolveCols >= 0) fetch(c0 - kSolveCols);
+        if (cols == kSolveCols) {
 #pragma unroll
-        for (int j = kSolveCols - 1; j >= 0; j--) {
-            const int i = c0 + j;
-            if (j < cols) {
-                double s = v[j];
+            for (int j0 = kSolveCols - kRun; j0 >= 0; j0 -= kRun) back_run(j0);
+        } else {
 #pragma unroll
-                for (int q = 1; q <= 5; q++)
-                    if (q <= k && i + q < n) s -= lu[j][k + q] * prev[q - 1];
-                s /= lu[j][k];
-#pragma unroll
-                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-                prev[0] = s;
-                v[j] = s;
-            }
+            for (int j = kSolveCols - 1; j >= 0; j--)
+                if (j < cols) back_step(j);
         }
         tile_out(c0, cols);
     }
@@ -751,7 +818,7 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
 // never written and read back (two of the ten passes a cubic reprojection makes over a plane). MODE 1 cleans with a
 // provisional 0.0 for pixels without a finite neighbour and flags their planes (PlaneStats::needs_median, the lazy form of
 // k_spline_clean); MODE 2 does the flagged planes again with their nanmedian (the others' blocks leave at once).
-template <typename T, int MODE>
+template <typename T, int MODE, int K>
 __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube, double *work, PlaneStats *stats, int n_planes, int ny, int nx,
                                                                   SplineAxis ax)
 {
@@ -765,7 +832,8 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
     bool nm = false;
     const bool live = x < nx;
     double *col = work + (size_t)pl * ny * nx + (live ? x : 0);
-    const int n = ax.n, k = ax.k, w = 2 * k + 1;
+    const int n = ax.n;
+    constexpr int w = 2 * K + 1;
     constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
     double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     double v[kSolveCols], g[kSolveCols], glu[kLuRegs];
@@ -800,12 +868,70 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
 #pragma unroll
             for (int j = 0; j < kSolveCols; j++) v[j] = g[j];
         }
-        __syncthreads();
+        wave_sync();
     };
     auto put = [&](int i0, int cnt) {
 #pragma unroll
         for (int j = 0; j < kSolveCols; j++)
             if (live && j < cnt) col[(size_t)(i0 + j) * nx] = v[j];
+    };
+    // (straight-line steps, as in k_spline_solve_rows)
+    auto fwd_step = [&](int b, int j) {
+        double s = v[j];
+#pragma unroll
+        for (int q = K; q >= 1; q--) s -= lu[b][j][K - q] * prev[q - 1];
+#pragma unroll
+        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+        prev[0] = s;
+        v[j] = s;
+    };
+    auto back_step = [&](int b, int j) {
+        double s = v[j];
+#pragma unroll
+        for (int q = K; q >= 1; q--) s -= lu[b][j][K + q] * prev[q - 1];
+        s *= lu[b][j][K];
+#pragma unroll
+        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+        prev[0] = s;
+        v[j] = s;
+    };
+    constexpr int kRun = 8;  // (as in k_spline_solve_rows)
+    auto fwd_run = [&](int b, int j0) {
+        double l[kRun][K];
+#pragma unroll
+        for (int j = 0; j < kRun; j++)
+#pragma unroll
+            for (int q = 1; q <= K; q++) l[j][q - 1] = lu[b][j0 + j][K - q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < kRun; j++) {
+            double s = v[j0 + j];
+#pragma unroll
+            for (int q = K; q >= 1; q--) s -= l[j][q - 1] * prev[q - 1];
+#pragma unroll
+            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+            prev[0] = s;
+            v[j0 + j] = s;
+        }
+    };
+    auto back_run = [&](int b, int j0) {
+        double l[kRun][K + 1];
+#pragma unroll
+        for (int j = kRun - 1; j >= 0; j--)
+#pragma unroll
+            for (int q = 0; q <= K; q++) l[j][q] = lu[b][j0 + j][K + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = kRun - 1; j >= 0; j--) {
+            double s = v[j0 + j];
+#pragma unroll
+            for (int q = K; q >= 1; q--) s -= l[j][q] * prev[q - 1];
+            s *= l[j][0];
+#pragma unroll
+            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+            prev[0] = s;
+            v[j0 + j] = s;
+        }
     };
     int buf = 0;
     // forward substitution (unit lower triangle)
@@ -814,19 +940,13 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
         const int cnt = min(kSolveCols, n - i0);
         stage(buf, cnt, i0);
         if (i0 + kSolveCols < n) fetch(i0 + kSolveCols);
+        if (cnt == kSolveCols) {
 #pragma unroll
-        for (int j = 0; j < kSolveCols; j++) {
-            const int i = i0 + j;
-            if (j < cnt) {
-                double s = v[j];
+            for (int j0 = 0; j0 < kSolveCols; j0 += kRun) fwd_run(buf, j0);
+        } else {
 #pragma unroll
-                for (int q = 1; q <= 5; q++)
-                    if (q <= k && i - q >= 0) s -= lu[buf][j][k - q] * prev[q - 1];
-#pragma unroll
-                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-                prev[0] = s;
-                v[j] = s;
-            }
+            for (int j = 0; j < kSolveCols; j++)
+                if (j < cnt) fwd_step(buf, j);
         }
         put(i0, cnt);
     }
@@ -841,20 +961,13 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
         const int cnt = min(kSolveCols, n - i0);
         stage(buf, cnt, i0);
         if (i0 - kSolveCols >= 0) fetch(i0 - kSolveCols);
+        if (cnt == kSolveCols) {
 #pragma unroll
-        for (int j = kSolveCols - 1; j >= 0; j--) {
-            const int i = i0 + j;
-            if (j < cnt) {
-                double s = v[j];
+            for (int j0 = kSolveCols - kRun; j0 >= 0; j0 -= kRun) back_run(buf, j0);
+        } else {
 #pragma unroll
-                for (int q = 1; q <= 5; q++)
-                    if (q <= k && i + q < n) s -= lu[buf][j][k + q] * prev[q - 1];
-                s /= lu[buf][j][k];
-#pragma unroll
-                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-                prev[0] = s;
-                v[j] = s;
-            }
+            for (int j = kSolveCols - 1; j >= 0; j--)
+                if (j < cnt) back_step(buf, j);
         }
         put(i0, cnt);
     }
@@ -1242,15 +1355,40 @@ static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa
     const unsigned rgroups = (unsigned)((a.ny + pm::kSolveRows - 1) / pm::kSolveRows) * (unsigned)a.n_planes;
     // first round: every plane, cleaned on the way into the axis-0 solve with a provisional 0.0 where a pixel has no finite
     // neighbour (their planes are flagged) ...
-    hipLaunchKernelGGL((pm::k_spline_solve_cols<T, 1>), dim3(cgroups), dim3(pm::kSolveRows), 0, s, (const T *)a.cube, sa.work, stats, a.n_planes, a.ny,
-                       a.nx, sa.rows);
-    hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(rgroups), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes, a.ny, a.nx, sa.cols, (const pm::PlaneStats *)nullptr);
+    auto cols_pass = [&](auto mode) {
+        constexpr int M = decltype(mode)::value;
+        auto go = [&](auto kk) {
+            hipLaunchKernelGGL((pm::k_spline_solve_cols<T, M, decltype(kk)::value>), dim3(cgroups), dim3(pm::kSolveRows), 0, s, (const T *)a.cube,
+                               sa.work, stats, a.n_planes, a.ny, a.nx, sa.rows);
+        };
+        switch (sa.rows.k) {
+        case 1: go(std::integral_constant<int, 1>()); break;
+        case 2: go(std::integral_constant<int, 2>()); break;
+        case 3: go(std::integral_constant<int, 3>()); break;
+        case 4: go(std::integral_constant<int, 4>()); break;
+        default: go(std::integral_constant<int, 5>()); break;
+        }
+    };
+    auto rows_pass = [&](const pm::PlaneStats *only_flagged) {
+        auto go = [&](auto kk) {
+            hipLaunchKernelGGL(pm::k_spline_solve_rows<decltype(kk)::value>, dim3(rgroups), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes, a.ny,
+                               a.nx, sa.cols, only_flagged);
+        };
+        switch (sa.cols.k) {
+        case 1: go(std::integral_constant<int, 1>()); break;
+        case 2: go(std::integral_constant<int, 2>()); break;
+        case 3: go(std::integral_constant<int, 3>()); break;
+        case 4: go(std::integral_constant<int, 4>()); break;
+        default: go(std::integral_constant<int, 5>()); break;
+        }
+    };
+    cols_pass(std::integral_constant<int, 1>());
+    rows_pass(nullptr);
     // ... second round: the flagged planes alone, with their nanmedian (the blocks of the others leave at once: most data
     // never has such a pixel)
     launch_median_t<T>(a.cube, a.n_planes, npx, stats, hist, s, 1);
-    hipLaunchKernelGGL((pm::k_spline_solve_cols<T, 2>), dim3(cgroups), dim3(pm::kSolveRows), 0, s, (const T *)a.cube, sa.work, stats, a.n_planes, a.ny,
-                       a.nx, sa.rows);
-    hipLaunchKernelGGL(pm::k_spline_solve_rows, dim3(rgroups), dim3(pm::kSolveRows), 0, s, sa.work, a.n_planes, a.ny, a.nx, sa.cols, (const pm::PlaneStats *)stats);
+    cols_pass(std::integral_constant<int, 2>());
+    rows_pass(stats);
     const dim3 egrid = pm_smooth_grid(a.n_map, a.n_planes);
     hipLaunchKernelGGL(pm::k_spline_eval<T>, egrid, dim3(pm::kBlock), 0, s, a, sa, (a.n_planes + (int)egrid.y - 1) / (int)egrid.y);
 }

@@ -50,6 +50,8 @@ int ensure_axis(pm_ctx *ctx, int which, int n, int k, pm::SplineAxis &out)
                 for (int j = p + 1; j <= p + k && j < n; j++) a[(size_t)i * w + (j - i + k)] -= f * a[(size_t)p * w + (j - p + k)];
             }
         }
+        // the back substitution multiplies by the reciprocal of the diagonal (a division would sit in the chain of every step)
+        for (int p = 0; p < n; p++) a[(size_t)p * w + k] = 1.0 / a[(size_t)p * w + k];
         PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
         if (ac.t) PM_HIP(ctx, hipFree(ac.t));
         if (ac.lu) PM_HIP(ctx, hipFree(ac.lu));

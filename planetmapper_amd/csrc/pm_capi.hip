@@ -436,6 +436,7 @@ void pm_destroy(pm_ctx *ctx)
     if (ctx->limits) (void)hipFree(ctx->limits);
     if (ctx->sm_arena) (void)hipFree(ctx->sm_arena);
     if (ctx->sm_status_host) (void)hipHostFree(ctx->sm_status_host);
+    if (ctx->spline_ev) (void)hipEventDestroy(ctx->spline_ev);
     for (auto &ac : ctx->axis) {
         if (ac.t) (void)hipFree(ac.t);
         if (ac.lu) (void)hipFree(ac.lu);

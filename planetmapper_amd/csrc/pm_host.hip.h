@@ -27,7 +27,7 @@ void pm_launch_transform(const pm::Params &p, const pm::TransformArgs &t, hipStr
 void pm_launch_radec_query(const pm::Params &p, const double *ra, const double *dec, unsigned long long n,
                            int ring_only_visible, double *out, bool b0, hipStream_t s);
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, pm::PlaneStats *stats, unsigned int *hist,
-                      hipStream_t s);
+                      hipStream_t s, int stage);
 void pm_launch_reproject(const pm::ReprojectArgs &a, int dtype, hipStream_t s);
 void pm_launch_mark_blocks(const pm::ReprojectArgs &a, unsigned char *flags, int shift, int dtype, hipStream_t s);
 void pm_launch_number_blocks(const unsigned char *flags, size_t n_blk, int *tile_sums, int *blkmap, int *blklist, int *total,
@@ -93,7 +93,8 @@ struct pm_ctx {
     // smoothing-spline fits (pm_smoothing.hip): descriptors + per-plane workspace of the planes fitted together
     void *sm_arena = nullptr;
     size_t sm_arena_bytes = 0;
-    int *sm_status_host = nullptr;  // pinned: the per-round read-back
+    int *sm_status_host = nullptr;  // pinned: the per-round read-back (smoothing splines); [0] also the interpolating splines' "a plane asked for its median"
+    hipEvent_t spline_ev = nullptr; // after the axis-0 solve of reproject_spline_resident
     int sm_batch_planes = 0;        // PM_OPT_SM_BATCH_PLANES: 0 = as many as the workspace budget holds
     int map_seq = 0;        // sequence number of the latest pm_map_cube call
     int checked_seq = 0;    // calls up to this number have had their flags examined

@@ -950,7 +950,10 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
         }
         put(i0, cnt);
     }
-    if (MODE == 1 && nm) atomicOr(&stats[pl].needs_median, 1);
+    if (MODE == 1 && nm) {
+        atomicOr(&stats[pl].needs_median, 1);
+        stats[n_planes].needs_median = 1;  // (the element behind the planes': some plane of the launch asked)
+    }
     // back substitution
     forward = false;
 #pragma unroll
@@ -1348,7 +1351,8 @@ static void launch_clean_lazy_t(const pm::ReprojectArgs &a, double *work, pm::Pl
 }
 
 template <typename T>
-static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s)
+static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, pm::PlaneStats *stats, unsigned int *hist, hipStream_t s,
+                            int stage)
 {
     const size_t npx = (size_t)a.ny * a.nx;
     const unsigned cgroups = (unsigned)((a.nx + pm::kSolveRows - 1) / pm::kSolveRows) * (unsigned)a.n_planes;
@@ -1382,15 +1386,19 @@ static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa
         default: go(std::integral_constant<int, 5>()); break;
         }
     };
-    cols_pass(std::integral_constant<int, 1>());
-    rows_pass(nullptr);
-    // ... second round: the flagged planes alone, with their nanmedian (the blocks of the others leave at once: most data
-    // never has such a pixel)
-    launch_median_t<T>(a.cube, a.n_planes, npx, stats, hist, s, 1);
-    cols_pass(std::integral_constant<int, 2>());
-    rows_pass(stats);
-    const dim3 egrid = pm_smooth_grid(a.n_map, a.n_planes);
-    hipLaunchKernelGGL(pm::k_spline_eval<T>, egrid, dim3(pm::kBlock), 0, s, a, sa, (a.n_planes + (int)egrid.y - 1) / (int)egrid.y);
+    if (stage == 0) {
+        cols_pass(std::integral_constant<int, 1>());
+    } else if (stage == 1) {
+        rows_pass(nullptr);
+    } else if (stage == 2) {
+        // ... second round: the flagged planes alone, with their nanmedian (the blocks of the others leave at once)
+        launch_median_t<T>(a.cube, a.n_planes, npx, stats, hist, s, 1);
+        cols_pass(std::integral_constant<int, 2>());
+        rows_pass(stats);
+    } else {
+        const dim3 egrid = pm_smooth_grid(a.n_map, a.n_planes);
+        hipLaunchKernelGGL(pm::k_spline_eval<T>, egrid, dim3(pm::kBlock), 0, s, a, sa, (a.n_planes + (int)egrid.y - 1) / (int)egrid.y);
+    }
 }
 
 template <typename T>
@@ -1426,17 +1434,20 @@ void pm_launch_clean(const pm::ReprojectArgs &a, double *work, int dtype, hipStr
     }
 }
 
-// `stats` (= a.plane_stats) and `hist` zero-filled by the caller: the clean pass fills what it needs of them (lazy form)
+// `stats` (= a.plane_stats, n_planes + 1 elements) and `hist` zero-filled by the caller: the clean pass fills what it needs of
+// them (lazy form). Stages, in this order: 0 the axis-0 solve of every plane (flags the planes that need their nanmedian, and
+// stats[n_planes].needs_median if any does), 1 the axis-1 solve, 2 the second round for the flagged planes (medians, both
+// solves: the caller may leave it out when nothing was flagged - most data), 3 the evaluation at the map cells.
 void pm_launch_spline(const pm::ReprojectArgs &a, const pm::SplineArgs &sa, int dtype, pm::PlaneStats *stats, unsigned int *hist,
-                      hipStream_t s)
+                      hipStream_t s, int stage)
 {
     switch (dtype) {
-    case PM_F64: launch_spline_t<double>(a, sa, stats, hist, s); break;
-    case PM_F32: launch_spline_t<float>(a, sa, stats, hist, s); break;
-    case PM_I16: launch_spline_t<int16_t>(a, sa, stats, hist, s); break;
-    case PM_I32: launch_spline_t<int32_t>(a, sa, stats, hist, s); break;
-    case PM_U8: launch_spline_t<uint8_t>(a, sa, stats, hist, s); break;
-    case PM_U16: launch_spline_t<uint16_t>(a, sa, stats, hist, s); break;
+    case PM_F64: launch_spline_t<double>(a, sa, stats, hist, s, stage); break;
+    case PM_F32: launch_spline_t<float>(a, sa, stats, hist, s, stage); break;
+    case PM_I16: launch_spline_t<int16_t>(a, sa, stats, hist, s, stage); break;
+    case PM_I32: launch_spline_t<int32_t>(a, sa, stats, hist, s, stage); break;
+    case PM_U8: launch_spline_t<uint8_t>(a, sa, stats, hist, s, stage); break;
+    case PM_U16: launch_spline_t<uint16_t>(a, sa, stats, hist, s, stage); break;
     }
 }
 

@@ -170,8 +170,10 @@ int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k
     if (chunk > 32768) chunk = 32768;
     rc = ensure_work(ctx, chunk * plane_elems * sizeof(double));
     if (rc != PM_OK) return rc;
-    rc = ensure_stats(ctx, chunk);
+    rc = ensure_stats(ctx, chunk + 1);
     if (rc != PM_OK) return rc;
+    if (!ctx->sm_status_host) PM_HIP(ctx, hipHostMalloc((void **)&ctx->sm_status_host, 4 * sizeof(int)));
+    if (!ctx->spline_ev) PM_HIP(ctx, hipEventCreateWithFlags(&ctx->spline_ev, hipEventDisableTiming));
     sa.work = ctx->work;
     for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += chunk) {
         const int np = (int)std::min(chunk, (size_t)a.n_planes - p0);
@@ -180,9 +182,20 @@ int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k
         b.cube = (const char *)a.cube + p0 * plane_elems * dtype_size(dtype);
         b.out = a.out + p0 * a.n_map;
         b.plane_stats = ctx->stats;
-        PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)np * sizeof(pm::PlaneStats), ctx->stream));
-        PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)np * 512 * sizeof(unsigned int), ctx->stream));
-        pm_launch_spline(b, sa, dtype, ctx->stats, ctx->hist, ctx->stream);
+        // The second round (nanmedian of the planes with a pixel that has no finite neighbour, their solves again) is
+        // eighteen launches that leave at once for most data - 80 us of the 0.5 ms a plane alone takes. Whether any plane
+        // asked is known after the axis-0 solve: its flag comes back while the axis-1 solve runs.
+        PM_HIP(ctx, hipMemsetAsync(ctx->stats, 0, (size_t)(np + 1) * sizeof(pm::PlaneStats), ctx->stream));
+        pm_launch_spline(b, sa, dtype, ctx->stats, ctx->hist, ctx->stream, 0);
+        PM_HIP(ctx, hipMemcpyAsync(ctx->sm_status_host, &ctx->stats[np].needs_median, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        PM_HIP(ctx, hipEventRecord(ctx->spline_ev, ctx->stream));
+        pm_launch_spline(b, sa, dtype, ctx->stats, ctx->hist, ctx->stream, 1);
+        PM_HIP(ctx, hipEventSynchronize(ctx->spline_ev));
+        if (ctx->sm_status_host[0]) {
+            PM_HIP(ctx, hipMemsetAsync(ctx->hist, 0, (size_t)np * 512 * sizeof(unsigned int), ctx->stream));
+            pm_launch_spline(b, sa, dtype, ctx->stats, ctx->hist, ctx->stream, 2);
+        }
+        pm_launch_spline(b, sa, dtype, ctx->stats, ctx->hist, ctx->stream, 3);
     }
     PM_HIP(ctx, hipGetLastError());
     return PM_OK;

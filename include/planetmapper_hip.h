@@ -487,7 +487,10 @@ int pm_backplanes_map(pm_ctx *ctx, uint64_t plane_mask, const double *lon_deg,
  * PM_MEM_DEVICE: asynchronous (no host round trip per call); planes that turn out to
  * need the nanmedian are completed by the next pm_synchronize(), until which cube / maps /
  * out must stay valid; if another pm_map_cube was enqueued in between, pm_synchronize()
- * reports PM_ERR_STATE instead. Calls with propagate_nan == 0 complete synchronously.
+ * reports PM_ERR_STATE instead. Calls with propagate_nan == 0 complete synchronously. The spline
+ * interpolations wait on the host for their first solve (whether a plane needs its nanmedian decides
+ * what is launched next) and 'smooth' for the footprint of the map; the rest of their work is
+ * enqueued like the other modes'.
  */
 int pm_map_cube(pm_ctx *ctx, const void *cube, int dtype, int n_planes,
                 const double *x_map, const double *y_map, int n0, int n1,

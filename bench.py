@@ -22,6 +22,8 @@ Beside the headline line the same JSON object carries (rank 0, after the timed r
   host_path                         PCIe-inclusive time of the same frame into numpy arrays
   api_path                          the same through the drop-in surface: BodyXY.get_*_img() x 5 +
                                     Observation.get_mapped_data(), cold cache, Python shim included
+  interpolations                    every interpolation of map_img on a resident cube: us per plane of 1024^2
+                                    onto the 1 deg and a 0.1 deg map (N = 1)
   cube_host                         BASELINE config 5, the north star's scaling case: a 512-plane
                                     1024^2 f64 cube in HOST memory, planes sharded over the ranks,
                                     each rank feeding its block over its own PCIe link, the mapped
@@ -830,6 +832,55 @@ def api_path_section(g, sz: int, device: int) -> dict:
     }
 
 
+def interpolations_section(device: int, g, planes: int = 64, sz: int = 1024) -> dict:
+    """
+    Every interpolation of BodyXY.map_img (body_xy.py:1414-1904) on a cube resident in HBM: microseconds per plane of
+    `sz`^2 onto the 1 deg map (180 x 360) and onto a 0.1 deg map (1800 x 3600 = 6.48 M cells), `planes` planes per call,
+    and the cubic of ONE plane (a batch of splines costs what its chain of dependent steps costs). Results stay on the
+    device; the smoothing-spline search is left to tools/probes/smoothing_rate.py (seconds per call).
+    """
+    import torch
+
+    from planetmapper_amd.engine import Engine
+
+    x0 = (sz - 1) / 2
+    eng = Engine(device)
+    eng.set_geometry(g)
+    eng.set_disc(x0, x0, 0.9 * x0, 0.0, sz, sz, True)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    cube = torch.randn((planes, sz, sz), generator=gen, device='cuda', dtype=torch.float64)
+    torch.cuda.synchronize()
+    out = {'workload': f'{planes} planes of {sz}x{sz} f64 resident in HBM, results left on the device', 'us_per_plane': {}}
+    for deg in (1.0, 0.1):
+        lon_g, lat_g = rectangular_grid(g.west_positive, deg)
+        n0, n1 = lon_g.shape
+        lon_d, lat_d = torch.from_numpy(lon_g).cuda(), torch.from_numpy(lat_g).cuda()
+        xm = torch.empty((n0, n1), dtype=torch.float64, device='cuda')
+        ym = torch.empty_like(xm)
+        torch.cuda.synchronize()
+        eng.xy_map_device(lon_d, lat_d, n0, n1, xm, ym)
+        res = torch.empty((planes, n0, n1), dtype=torch.float64, device='cuda')
+        row = {}
+        for interp in ('nearest', 'linear', 'quadratic', 'cubic', 5, 'smooth'):
+            if interp == 'smooth':
+                eng.set_smooth_options(5, 10_000)
+            for n_pl, key in ((planes, str(interp)),) + (((1, 'cubic, one plane'),) if interp == 'cubic' else ()):
+                eng.map_cube_device(cube, np.float64, n_pl, xm, ym, n0, n1, res, interp, True)
+                eng.synchronize()
+                reps = 5
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    eng.map_cube_device(cube, np.float64, n_pl, xm, ym, n0, n1, res, interp, True)
+                eng.synchronize()
+                row[key] = round((time.perf_counter() - t0) / reps / n_pl * 1e6, 1)
+        out['us_per_plane'][f'{deg} deg map ({n0}x{n1})'] = row
+        del res, xm, ym, lon_d, lat_d
+    eng.close()
+    del cube
+    torch.cuda.empty_cache()
+    return out
+
+
 def shared_gpu_section(args) -> dict:
     """
     The N-rank code of the sharded host-fed cube, EXECUTED on this one GPU: for N = 2 and 4 this process starts
@@ -1237,6 +1288,10 @@ def headline(args) -> None:
         if d.world == 1 and d.rank == 0:
             line['host_path'] = host_path_section(eng, g, sz)
             line['api_path'] = api_path_section(g, sz, d.local_rank)
+            try:
+                line['interpolations'] = interpolations_section(d.local_rank, g)
+            except Exception as e:  # noqa: BLE001
+                line['interpolations'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         try:
             sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50)
         except Exception as e:  # noqa: BLE001

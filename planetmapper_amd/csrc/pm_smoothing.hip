@@ -1140,6 +1140,15 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
                     pm::SmPlaneDev d0;
                     PM_HIP(ctx, hipMemcpy(&d0, planes + pl, sizeof(d0), hipMemcpyDeviceToHost));
                     std::fprintf(stderr, "   plane %d: phase %d knots=(%d,%d) next p=%g last fp=%.17g\n", pl, d0.phase, d0.y.n, d0.x.n, d0.p, d0.fp);
+                    if (ctx->trace & 1) {  // (with bit 0 as well: the interior knots themselves)
+                        for (const pm::SmAxisDev *ax : {&d0.y, &d0.x}) {
+                            std::vector<double> t((size_t)ax->n);
+                            PM_HIP(ctx, hipMemcpy(t.data(), ax->t, t.size() * sizeof(double), hipMemcpyDeviceToHost));
+                            std::fprintf(stderr, "      %c knots:", ax == &d0.y ? 'y' : 'x');
+                            for (int i = ax->k + 1; i < ax->n - ax->k - 1; i++) std::fprintf(stderr, " %g", t[(size_t)i]);
+                            std::fprintf(stderr, "\n");
+                        }
+                    }
                 }
             }
             if (n_active == 0) break;

@@ -248,6 +248,10 @@ def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
     states, both NaN policies: every plane of a batch against the oracle (1e-7 of the data scale, NaN masks identical)
     and one plane of the batch against itself fitted alone (bit for bit). (`s` far below the noise is not drawn: FITPACK
     itself runs into singular knot sets there.) tests/soak_fuzz.py --only smoothing runs it over fresh seeds.
+    A known corner of that soak (1 fit in ~9 600, seed 111241): when fpknot has to choose between intervals whose residual
+    shares are equal in exact arithmetic (proportional splits of one interval), the last bit of a residual sum decides, and
+    the device's tiled sum does not have the serial sum's last bit - one knot lands elsewhere, the fit is another spline that
+    passes FITPACK's acceptance test (profiles/EXPERIMENTS_r05.md).
     """
     rng = np.random.default_rng(seed)
     for case in range(n_cases):

@@ -290,7 +290,7 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           reference's own sequence of epochs for every pixel, 2 that sequence shortened by a Newton
  *                           step on its seed.
  *   PM_OPT_TRACE            mask, on stderr: 1 stage times of every host-path call, 2 the knot / smoothing-parameter
- *                           search of the smoothing splines. Default 0.
+ *                           search of the smoothing splines (with 1 as well: the knots of the first planes). Default 0.
  *   PM_OPT_TRACE            ... 4: the device-side sums of PM_OPT_LAST_STAGE_NS are collected (a pair of timing events per chunk; a
  *                           sharded call waits for its exchanges before the agreement, so that the two are timed apart).
  *   PM_OPT_SM_BATCH_PLANES  the most planes of a cube whose smoothing-spline fits (spline_smoothing > 0) advance together

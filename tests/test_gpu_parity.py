@@ -2686,3 +2686,18 @@ def test_stage_record_of_a_host_fed_cube_call(engine, jupiter):
         else:
             assert st['dma_device'] == 0 and (st['kernels_device'] == 0 or engine.get_option(_lib.PM_OPT_LAST_CUBE_ROUTE) == 4)
     assert np.array_equal(out.cpu().numpy(), engine.map_cube(np.array(cube), xm, ym, 'linear', True), equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_bench_interpolations_section(jupiter):
+    """bench.py's `interpolations` record (N = 1): every map_img mode on both maps, times positive and in the order the
+    work implies (a fine map costs more than the 1 deg map; one plane alone costs more per plane than a batch)"""
+    import bench
+
+    rec = bench.interpolations_section(0, jupiter, planes=6, sz=256)
+    assert set(rec) == {'workload', 'us_per_plane'} and len(rec['us_per_plane']) == 2
+    coarse, fine = (rec['us_per_plane'][k] for k in sorted(rec['us_per_plane'], key=lambda k: float(k.split()[0]), reverse=True))
+    assert set(coarse) == set(fine) == {'nearest', 'linear', 'quadratic', 'cubic', 'cubic, one plane', '5', 'smooth'}
+    assert all(v > 0 for v in coarse.values()) and all(v > 0 for v in fine.values())
+    assert fine['linear'] > coarse['linear'] and fine['smooth'] > coarse['smooth']
+    assert coarse['cubic, one plane'] > coarse['cubic']

@@ -296,6 +296,14 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *   PM_OPT_SM_BATCH_PLANES  the most planes of a cube whose smoothing-spline fits (spline_smoothing > 0) advance together
  *                           in the same launches: 0 (default) = as many as half of the free device memory holds (a plane
  *                           takes 7 float64 arrays of its own size), 1 .. 4096 = a cap. A plane's result does not depend on it.
+ *   PM_OPT_SPLINE_SEGMENT   the interpolating-spline solves of pm_map_cube (degrees 1-5, spline_smoothing = 0) run one
+ *                           lane per image line - a chain of 2 n dependent steps per axis, which leaves most of the
+ *                           chip idle when the planes of a call are few and large. 0 (default): such calls (fewer
+ *                           waves than SIMDs) cut every line into segments whose substitutions start a few dozen samples
+ *                           early (the factors' recursion forgets geometrically: the same steps on the same operands, a
+ *                           second workspace of the planes' size); -1: never; n >= 64: segments of n samples (rounded up
+ *                           to 16) for every call. A/B and the test that holds the two forms to each other.
+ *   PM_OPT_LAST_SPLINE_SEGMENT read-only: the axis-0 segment length of the latest spline call, 0 = one lane per line.
  *   PM_OPT_LAST_STAGE_NS + k read-only, ns: where the latest host-fed pm_map_cube (PM_MEM_HOST / PM_MEM_HOST_CUBE, nearest /
  *                           linear) or pm_map_cube_sharded of this context spent its time. Host clock, always recorded:
  *                           0 the whole pm_map_cube call = 1 + 2 + 5 + 6 + 7; 1 fingerprint of the x / y maps + block-table
@@ -353,6 +361,8 @@ typedef enum pm_option {
     PM_OPT_TRACE = 25,
     PM_OPT_SM_BATCH_PLANES = 26,
     PM_OPT_LAST_LT_PATH = 27,
+    PM_OPT_SPLINE_SEGMENT = 28,
+    PM_OPT_LAST_SPLINE_SEGMENT = 29,
     PM_OPT_ROUTE_NS_PER_PLANE = 16, /* + route 0..4 */
     PM_OPT_LAST_STAGE_NS = 32       /* + stage 0..12, read-only: see below */
 } pm_option;

@@ -515,6 +515,11 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
         if (value < 0 || value > 4096) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SM_BATCH_PLANES takes 0 (the library's choice) .. 4096");
         ctx->sm_batch_planes = (int)value;
         return PM_OK;
+    case PM_OPT_SPLINE_SEGMENT:
+        if (value < -1 || value > (1 << 20) || (value > 0 && value < 64))
+            return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_SPLINE_SEGMENT takes 0 (the library's choice), -1 (never) or a segment length >= 64");
+        ctx->spline_segment = (int)value;
+        return PM_OK;
     case PM_OPT_FETCH_BLOCK_BYTES:
         if (value != 64 && value != 128 && value != 256) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "PM_OPT_FETCH_BLOCK_BYTES takes 64, 128 or 256");
         ctx->fetch_shift = value == 64 ? 6 : value == 128 ? 7 : 8;
@@ -531,6 +536,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_LAST_LT_PATH:
     case PM_OPT_HOST_COPY_THREADS_IN_USE:
     case PM_OPT_HYBRID_FETCH_PERMILLE:
+    case PM_OPT_LAST_SPLINE_SEGMENT:
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "option %d is read-only", option);
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -563,6 +569,8 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_LT_MODE: *value = ctx->lt_mode; return PM_OK;
     case PM_OPT_TRACE: *value = ctx->trace; return PM_OK;
     case PM_OPT_SM_BATCH_PLANES: *value = ctx->sm_batch_planes; return PM_OK;
+    case PM_OPT_SPLINE_SEGMENT: *value = ctx->spline_segment; return PM_OK;
+    case PM_OPT_LAST_SPLINE_SEGMENT: *value = ctx->last_spline_segment; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;

@@ -196,7 +196,16 @@ struct SplineAxis {
 struct SplineArgs {
     double *work;  // n_planes x ny x nx cleaned image -> B-spline coefficients (in place)
     SplineAxis rows, cols;  // axis 0 (image y) / axis 1 (image x)
+    // the segmented solves of few, large planes (k_spline_seg_*): samples per segment along axis 0 / axis 1 (0: the
+    // one-lane-per-line solves, in place), and the second buffer their forward passes write into
+    int seg_rows = 0, seg_cols = 0;
+    double *work2 = nullptr;
 };
+// How far before (beyond) a segment its forward (backward) substitution starts: the homogeneous recursion of the factors decays
+// by the symbol's root per step (degree 2: 0.172, 3: 0.268, 4: 0.361, 5: 0.431) - what is left at the segment is < 4e-24.
+constexpr int kSolveLines = 64;        // lines per wave of the spline solves
+constexpr long kSolveFillWaves = 1024;  // one wave per SIMD of the chip (256 CUs x 4)
+__host__ __device__ inline int spline_warm(int k) { return k <= 1 ? 16 : k == 2 ? 32 : k <= 4 ? 48 : 64; }
 
 // Arguments of the reprojection kernel (pm_map_cube).
 struct ReprojectArgs {

@@ -653,6 +653,93 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// The 16 steps of a tile (cnt < 16: the last tile of a line), straight-line: the degree is a template argument, and the terms
+// that would reach outside the matrix need no test - the band is stored with zeros there and `prev` starts as zeros, so they
+// subtract an exact 0. (With the degree and those tests at run time every multiply-add sat in a basic block of its own
+// behind an LDS read it waited for: ~60 cycles per term, 700 per step - the whole cost of a plane that is alone.)
+// The terms are taken farthest first: the result of the step before enters the LAST multiply-add, so a step's place in
+// the line's chain of dependent operations is one multiply-add (and one multiplication by the reciprocal diagonal on the
+// way back), whatever the degree. Eight steps of a full tile at a time: their LU entries are read from LDS together, AHEAD
+// of the chain (left to itself the compiler reads each step's entries right where it uses them, and every step waits for
+// LDS). One definition for the line solves and the segmented ones: the same instructions, the same bits.
+template <int K>
+__device__ __forceinline__ void solve_fwd_tile(double (&v)[kSolveCols], double (&prev)[5], const double (*lu)[kSolveBand], int cnt)
+{
+    constexpr int kRun = 8;
+    if (cnt == kSolveCols) {
+#pragma unroll
+        for (int j0 = 0; j0 < kSolveCols; j0 += kRun) {
+            double l[kRun][K];
+#pragma unroll
+            for (int j = 0; j < kRun; j++)
+#pragma unroll
+                for (int q = 1; q <= K; q++) l[j][q - 1] = lu[j0 + j][K - q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < kRun; j++) {
+                double s = v[j0 + j];
+#pragma unroll
+                for (int q = K; q >= 1; q--) s -= l[j][q - 1] * prev[q - 1];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[j0 + j] = s;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++)
+            if (j < cnt) {
+                double s = v[j];
+#pragma unroll
+                for (int q = K; q >= 1; q--) s -= lu[j][K - q] * prev[q - 1];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[j] = s;
+            }
+    }
+}
+template <int K>
+__device__ __forceinline__ void solve_back_tile(double (&v)[kSolveCols], double (&prev)[5], const double (*lu)[kSolveBand], int cnt)
+{
+    constexpr int kRun = 8;
+    if (cnt == kSolveCols) {
+#pragma unroll
+        for (int j0 = kSolveCols - kRun; j0 >= 0; j0 -= kRun) {
+            double l[kRun][K + 1];
+#pragma unroll
+            for (int j = kRun - 1; j >= 0; j--)
+#pragma unroll
+                for (int q = 0; q <= K; q++) l[j][q] = lu[j0 + j][K + q];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = kRun - 1; j >= 0; j--) {
+                double s = v[j0 + j];
+#pragma unroll
+                for (int q = K; q >= 1; q--) s -= l[j][q] * prev[q - 1];
+                s *= l[j][0];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[j0 + j] = s;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = kSolveCols - 1; j >= 0; j--)
+            if (j < cnt) {
+                double s = v[j];
+#pragma unroll
+                for (int q = K; q >= 1; q--) s -= lu[j][K + q] * prev[q - 1];
+                s *= lu[j][K];
+#pragma unroll
+                for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
+                prev[0] = s;
+                v[j] = s;
+            }
+    }
+}
 template <int K>
 __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, int n_planes, int ny, int nx, SplineAxis ax, const PlaneStats *only_flagged)
 {
@@ -707,86 +794,13 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
         }
         wave_sync();
     };
-    // One step of a substitution, straight-line: the degree is a template argument, and the terms that would reach
-    // outside the matrix need no test - the band is stored with zeros there and `prev` starts as zeros, so they subtract
-    // an exact 0. (With the degree and those tests at run time every multiply-add sat in a basic block of its own
-    // behind an LDS read it waited for: ~60 cycles per term, 700 per step - the whole cost of a plane that is alone.)
-    // The terms are taken farthest first: the result of the step before enters the LAST multiply-add, so a step's place in
-    // the line's chain of dependent operations is one multiply-add (and one multiplication by the reciprocal diagonal on the
-    // way back), whatever the degree.
-    auto fwd_step = [&](int j) {
-        double s = v[j];
-#pragma unroll
-        for (int q = K; q >= 1; q--) s -= lu[j][K - q] * prev[q - 1];
-#pragma unroll
-        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-        prev[0] = s;
-        v[j] = s;
-    };
-    auto back_step = [&](int j) {
-        double s = v[j];
-#pragma unroll
-        for (int q = K; q >= 1; q--) s -= lu[j][K + q] * prev[q - 1];
-        s *= lu[j][K];
-#pragma unroll
-        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-        prev[0] = s;
-        v[j] = s;
-    };
-    // Eight steps of a full tile at a time: their LU entries are read from LDS together, AHEAD of the chain (left to
-    // itself the compiler reads each step's entries right where it uses them, and every step waits for LDS).
-    constexpr int kRun = 8;
-    auto fwd_run = [&](int j0) {
-        double l[kRun][K];
-#pragma unroll
-        for (int j = 0; j < kRun; j++)
-#pragma unroll
-            for (int q = 1; q <= K; q++) l[j][q - 1] = lu[j0 + j][K - q];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < kRun; j++) {
-            double s = v[j0 + j];
-#pragma unroll
-            for (int q = K; q >= 1; q--) s -= l[j][q - 1] * prev[q - 1];
-#pragma unroll
-            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-            prev[0] = s;
-            v[j0 + j] = s;
-        }
-    };
-    auto back_run = [&](int j0) {  // steps j0 + kRun - 1 down to j0
-        double l[kRun][K + 1];
-#pragma unroll
-        for (int j = kRun - 1; j >= 0; j--)
-#pragma unroll
-            for (int q = 0; q <= K; q++) l[j][q] = lu[j0 + j][K + q];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = kRun - 1; j >= 0; j--) {
-            double s = v[j0 + j];
-#pragma unroll
-            for (int q = K; q >= 1; q--) s -= l[j][q] * prev[q - 1];
-            s *= l[j][0];
-#pragma unroll
-            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-            prev[0] = s;
-            v[j0 + j] = s;
-        }
-    };
     // forward substitution (unit lower triangle)
     fetch(0);
     for (int c0 = 0; c0 < n; c0 += kSolveCols) {
         const int cols = min(kSolveCols, n - c0);
         to_lds(cols);
         if (c0 + kSolveCols < n) fetch(c0 + kSolveCols);
-        if (cols == kSolveCols) {
-#pragma unroll
-            for (int j0 = 0; j0 < kSolveCols; j0 += kRun) fwd_run(j0);
-        } else {
-#pragma unroll
-            for (int j = 0; j < kSolveCols; j++)
-                if (j < cols) fwd_step(j);
-        }
+        solve_fwd_tile<K>(v, prev, lu, cols);
         tile_out(c0, cols);
     }
     // back substitution (the forward pass's stores of the last tile are complete: same wave, program order)
@@ -798,14 +812,7 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_rows(double *work, 
         const int cols = min(kSolveCols, n - c0);
         to_lds(cols);
         if (c0 - kSolveCols >= 0) fetch(c0 - kSolveCols);
-        if (cols == kSolveCols) {
-#pragma unroll
-            for (int j0 = kSolveCols - kRun; j0 >= 0; j0 -= kRun) back_run(j0);
-        } else {
-#pragma unroll
-            for (int j = kSolveCols - 1; j >= 0; j--)
-                if (j < cols) back_step(j);
-        }
+        solve_back_tile<K>(v, prev, lu, cols);
         tile_out(c0, cols);
     }
 }
@@ -875,64 +882,6 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
         for (int j = 0; j < kSolveCols; j++)
             if (live && j < cnt) col[(size_t)(i0 + j) * nx] = v[j];
     };
-    // (straight-line steps, as in k_spline_solve_rows)
-    auto fwd_step = [&](int b, int j) {
-        double s = v[j];
-#pragma unroll
-        for (int q = K; q >= 1; q--) s -= lu[b][j][K - q] * prev[q - 1];
-#pragma unroll
-        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-        prev[0] = s;
-        v[j] = s;
-    };
-    auto back_step = [&](int b, int j) {
-        double s = v[j];
-#pragma unroll
-        for (int q = K; q >= 1; q--) s -= lu[b][j][K + q] * prev[q - 1];
-        s *= lu[b][j][K];
-#pragma unroll
-        for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-        prev[0] = s;
-        v[j] = s;
-    };
-    constexpr int kRun = 8;  // (as in k_spline_solve_rows)
-    auto fwd_run = [&](int b, int j0) {
-        double l[kRun][K];
-#pragma unroll
-        for (int j = 0; j < kRun; j++)
-#pragma unroll
-            for (int q = 1; q <= K; q++) l[j][q - 1] = lu[b][j0 + j][K - q];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < kRun; j++) {
-            double s = v[j0 + j];
-#pragma unroll
-            for (int q = K; q >= 1; q--) s -= l[j][q - 1] * prev[q - 1];
-#pragma unroll
-            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-            prev[0] = s;
-            v[j0 + j] = s;
-        }
-    };
-    auto back_run = [&](int b, int j0) {
-        double l[kRun][K + 1];
-#pragma unroll
-        for (int j = kRun - 1; j >= 0; j--)
-#pragma unroll
-            for (int q = 0; q <= K; q++) l[j][q] = lu[b][j0 + j][K + q];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = kRun - 1; j >= 0; j--) {
-            double s = v[j0 + j];
-#pragma unroll
-            for (int q = K; q >= 1; q--) s -= l[j][q] * prev[q - 1];
-            s *= l[j][0];
-#pragma unroll
-            for (int q = 4; q > 0; q--) prev[q] = prev[q - 1];
-            prev[0] = s;
-            v[j0 + j] = s;
-        }
-    };
     int buf = 0;
     // forward substitution (unit lower triangle)
     fetch(0);
@@ -940,14 +889,7 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
         const int cnt = min(kSolveCols, n - i0);
         stage(buf, cnt, i0);
         if (i0 + kSolveCols < n) fetch(i0 + kSolveCols);
-        if (cnt == kSolveCols) {
-#pragma unroll
-            for (int j0 = 0; j0 < kSolveCols; j0 += kRun) fwd_run(buf, j0);
-        } else {
-#pragma unroll
-            for (int j = 0; j < kSolveCols; j++)
-                if (j < cnt) fwd_step(buf, j);
-        }
+        solve_fwd_tile<K>(v, prev, lu[buf], cnt);
         put(i0, cnt);
     }
     if (MODE == 1 && nm) {
@@ -964,15 +906,204 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
         const int cnt = min(kSolveCols, n - i0);
         stage(buf, cnt, i0);
         if (i0 - kSolveCols >= 0) fetch(i0 - kSolveCols);
-        if (cnt == kSolveCols) {
+        solve_back_tile<K>(v, prev, lu[buf], cnt);
+        put(i0, cnt);
+    }
+}
+
+// ------------------------------------------------------------------ the same solves for planes that are few and large
+// One lane per line makes a line's 2 n steps ONE chain: a 4096^2 plane alone is 64 waves (of the chip's 1024 SIMDs), each
+// waiting through 8192 dependent steps per axis. The factors of a B-spline collocation matrix forget: away from the ends
+// of a line L's multipliers and U's rows are the constants of a Toeplitz band whose recursion has the symbol's roots INSIDE
+// the unit circle (degree 2: 0.172, 3: 0.268, 4: 0.361, 5: 0.431 per step), so a substitution started `warm` steps early
+// with zeros for the values before it carries, when it reaches the segment it is meant for, an error of root^warm
+// (<= 4e-24 of the values with pm_spline_warm's lengths) - far below half an ulp: the steps of the segment are the serial
+// substitution's operations on the serial substitution's operands, and the results its bits (measured: bit-equal on every
+// sample of the cube-scale tests; the tests hold the two forms to 1e-14 of scale). A line is cut into segments of `seg`
+// samples (a multiple of the tile of 16), one wave takes 64 lines of one segment: forward from `warm` before the segment
+// (from the line's start if that is nearer: exact), backward from `warm` beyond it (from the line's end if the start would
+// fall into its last tile). The backward pass of a segment needs the forward results of the `warm` samples beyond it, which
+// are another wave's: forward and backward are two launches, from one buffer into the other (pm_launch_spline, stages 4-7).
+// where a segment's backward pass starts: the tile that ends `warm` beyond the segment, or the line's last tile
+__device__ __forceinline__ int seg_back_top(int n, int e0, int warm)
+{
+    const int i_last = ((n - 1) / kSolveCols) * kSolveCols;
+    return e0 + warm >= i_last ? i_last : e0 + warm - kSolveCols;
+}
+
+// Axis 0, one direction of one segment of 64 adjacent columns. Forward: samples from the cube, cleaned (MODE as in
+// k_spline_solve_cols), results into `dst`; backward: from `src` into `dst`.
+template <typename T, int MODE, int K, bool BACK>
+__global__ __launch_bounds__(kSolveRows) void k_spline_seg_cols(const T *cube, const double *src, double *dst, PlaneStats *stats, int n_planes, int ny,
+                                                                int nx, SplineAxis ax, int seg, int warm)
+{
+    __shared__ double lu[2][kSolveCols][kSolveBand];
+    const int lane = threadIdx.x;
+    const int n = ax.n;
+    const int groups = (nx + kSolveRows - 1) / kSolveRows, nseg = (n + seg - 1) / seg;
+    unsigned b = blockIdx.x;
+    const int sg = b % nseg;
+    b /= nseg;
+    const int pl = b / groups, x = (b % groups) * kSolveRows + lane;
+    if (MODE == 2 && !stats[pl].needs_median) return;
+    const double median = MODE == 2 ? stats[pl].median : 0.0;
+    const size_t plane = (size_t)pl * ny * nx;
+    const T *img = cube + plane;
+    bool nm = false;
+    const bool live = x < nx;
+    const double *in = src + plane + (live ? x : 0);
+    double *out = dst + plane + (live ? x : 0);
+    constexpr int w = 2 * K + 1;
+    constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
+    double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double v[kSolveCols], g[kSolveCols], glu[kLuRegs];
+    auto fetch = [&](int i0) {
+        const int cnt = min(kSolveCols, n - i0);
+        if (!BACK) {
 #pragma unroll
-            for (int j0 = kSolveCols - kRun; j0 >= 0; j0 -= kRun) back_run(buf, j0);
+            for (int j = 0; j < kSolveCols; j++) g[j] = (live && j < cnt) ? load_as_f64(img, (size_t)(i0 + j) * nx + x) : 0.0;
         } else {
 #pragma unroll
-            for (int j = kSolveCols - 1; j >= 0; j--)
-                if (j < cnt) back_step(buf, j);
+            for (int j = 0; j < kSolveCols; j++) g[j] = (live && j < cnt) ? in[(size_t)(i0 + j) * nx] : 0.0;
         }
-        put(i0, cnt);
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int q = e * kSolveRows + lane;
+            glu[e] = q < cnt * w ? ax.lu[(size_t)i0 * w + q] : 0.0;
+        }
+    };
+    auto stage = [&](int buf, int cnt, int i0) {
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int q = e * kSolveRows + lane;
+            if (q < cnt * w) lu[buf][q / w][q % w] = glu[e];
+        }
+        if (!BACK) {
+#pragma unroll
+            for (int j = 0; j < kSolveCols; j++) v[j] = (live && j < cnt) ? cleaned_value(img, g[j], (long)(i0 + j), (long)x, ny, nx, median, nm) : 0.0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < kSolveCols; j++) v[j] = g[j];
+        }
+        wave_sync();
+    };
+    auto put = [&](int i0, int cnt) {
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++)
+            if (live && j < cnt) out[(size_t)(i0 + j) * nx] = v[j];
+    };
+    const int s0 = sg * seg, e0 = min(n, s0 + seg);
+    int buf = 0;
+    if (!BACK) {
+        const int begin = max(0, s0 - warm);
+        fetch(begin);
+        for (int i0 = begin; i0 < e0; i0 += kSolveCols, buf ^= 1) {
+            const int cnt = min(kSolveCols, n - i0);
+            stage(buf, cnt, i0);
+            if (i0 + kSolveCols < e0) fetch(i0 + kSolveCols);
+            solve_fwd_tile<K>(v, prev, lu[buf], cnt);
+            if (i0 >= s0) put(i0, cnt);
+        }
+        if (MODE == 1 && nm) {
+            atomicOr(&stats[pl].needs_median, 1);
+            stats[n_planes].needs_median = 1;
+        }
+    } else {
+        const int top = seg_back_top(n, e0, warm);
+        fetch(top);
+        for (int i0 = top; i0 >= s0; i0 -= kSolveCols, buf ^= 1) {
+            const int cnt = min(kSolveCols, n - i0);
+            stage(buf, cnt, i0);
+            if (i0 - kSolveCols >= s0) fetch(i0 - kSolveCols);
+            solve_back_tile<K>(v, prev, lu[buf], cnt);
+            if (i0 < e0) put(i0, cnt);
+        }
+    }
+}
+
+// Axis 1, one direction of one segment of 64 image rows (the 64 x 16 tile of k_spline_solve_rows), from `src` into `dst`.
+template <int K, bool BACK>
+__global__ __launch_bounds__(kSolveRows) void k_spline_seg_rows(const double *src, double *dst, int n_planes, int ny, int nx, SplineAxis ax,
+                                                                const PlaneStats *only_flagged, int seg, int warm)
+{
+    __shared__ double tile[kSolveRows][kSolveCols + 1];
+    __shared__ double lu[kSolveCols][kSolveBand];
+    const int lane = threadIdx.x;
+    const int n = ax.n;
+    const int groups = (ny + kSolveRows - 1) / kSolveRows, nseg = (n + seg - 1) / seg;
+    unsigned b = blockIdx.x;
+    const int sg = b % nseg;
+    b /= nseg;
+    const int pl = b / groups, r0 = (b % groups) * kSolveRows;
+    if (only_flagged && !only_flagged[pl].needs_median) return;
+    const int rows = min(kSolveRows, ny - r0);
+    const size_t first = ((size_t)pl * ny + r0) * nx;
+    const double *in = src + first;
+    double *out = dst + first;
+    constexpr int w = 2 * K + 1;
+    const int lr = lane / kSolveCols, lc = lane % kSolveCols;
+    constexpr int kLuRegs = (kSolveCols * kSolveBand + kSolveRows - 1) / kSolveRows;
+    double prev[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    double v[kSolveCols], g[kSolveRows / kSolveRpi], glu[kLuRegs];
+    auto fetch = [&](int c0) {
+        const int cols = min(kSolveCols, n - c0);
+#pragma unroll
+        for (int it = 0; it < kSolveRows / kSolveRpi; it++) {
+            const int r = it * kSolveRpi + lr;
+            g[it] = (r < rows && lc < cols) ? in[(size_t)r * nx + c0 + lc] : 0.0;
+        }
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int x = e * kSolveRows + lane;
+            glu[e] = x < cols * w ? ax.lu[(size_t)c0 * w + x] : 0.0;
+        }
+    };
+    auto to_lds = [&](int cols) {
+#pragma unroll
+        for (int it = 0; it < kSolveRows / kSolveRpi; it++) tile[it * kSolveRpi + lr][lc] = g[it];
+#pragma unroll
+        for (int e = 0; e < kLuRegs; e++) {
+            const int x = e * kSolveRows + lane;
+            if (x < cols * w) lu[x / w][x % w] = glu[e];
+        }
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < kSolveCols; j++) v[j] = tile[lane][j];
+    };
+    auto tile_out = [&](int c0, int cols, bool keep) {
+        if (keep) {
+#pragma unroll
+            for (int j = 0; j < kSolveCols; j++) tile[lane][j] = v[j];
+            wave_sync();
+#pragma unroll
+            for (int it = 0; it < kSolveRows / kSolveRpi; it++) {
+                const int r = it * kSolveRpi + lr;
+                if (r < rows && lc < cols) out[(size_t)r * nx + c0 + lc] = tile[r][lc];
+            }
+        }
+        wave_sync();
+    };
+    const int s0 = sg * seg, e0 = min(n, s0 + seg);
+    if (!BACK) {
+        const int begin = max(0, s0 - warm);
+        fetch(begin);
+        for (int c0 = begin; c0 < e0; c0 += kSolveCols) {
+            const int cols = min(kSolveCols, n - c0);
+            to_lds(cols);
+            if (c0 + kSolveCols < e0) fetch(c0 + kSolveCols);
+            solve_fwd_tile<K>(v, prev, lu, cols);
+            tile_out(c0, cols, c0 >= s0);
+        }
+    } else {
+        const int top = seg_back_top(n, e0, warm);
+        fetch(top);
+        for (int c0 = top; c0 >= s0; c0 -= kSolveCols) {
+            const int cols = min(kSolveCols, n - c0);
+            to_lds(cols);
+            if (c0 - kSolveCols >= s0) fetch(c0 - kSolveCols);
+            solve_back_tile<K>(v, prev, lu, cols);
+            tile_out(c0, cols, c0 < e0);
+        }
     }
 }
 
@@ -1386,15 +1517,56 @@ static void launch_spline_t(const pm::ReprojectArgs &a, const pm::SplineArgs &sa
         default: go(std::integral_constant<int, 5>()); break;
         }
     };
+    // the segmented forms (sa.seg_rows / seg_cols > 0: few, large planes): forward into work2, backward into work, per axis
+    auto with_degree = [&](int k, auto &&go) {
+        switch (k) {
+        case 1: go(std::integral_constant<int, 1>()); break;
+        case 2: go(std::integral_constant<int, 2>()); break;
+        case 3: go(std::integral_constant<int, 3>()); break;
+        case 4: go(std::integral_constant<int, 4>()); break;
+        default: go(std::integral_constant<int, 5>()); break;
+        }
+    };
+    auto cols_seg = [&](auto mode) {
+        constexpr int M = decltype(mode)::value;
+        const unsigned blocks = cgroups * (unsigned)((a.ny + sa.seg_rows - 1) / sa.seg_rows);
+        const int warm = pm::spline_warm(sa.rows.k);
+        with_degree(sa.rows.k, [&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            hipLaunchKernelGGL((pm::k_spline_seg_cols<T, M, K, false>), dim3(blocks), dim3(pm::kSolveRows), 0, s, (const T *)a.cube,
+                               (const double *)nullptr, sa.work2, stats, a.n_planes, a.ny, a.nx, sa.rows, sa.seg_rows, warm);
+            hipLaunchKernelGGL((pm::k_spline_seg_cols<double, M, K, true>), dim3(blocks), dim3(pm::kSolveRows), 0, s, (const double *)nullptr,
+                               (const double *)sa.work2, sa.work, stats, a.n_planes, a.ny, a.nx, sa.rows, sa.seg_rows, warm);
+        });
+    };
+    auto rows_seg = [&](const pm::PlaneStats *only_flagged) {
+        const unsigned blocks = rgroups * (unsigned)((a.nx + sa.seg_cols - 1) / sa.seg_cols);
+        const int warm = pm::spline_warm(sa.cols.k);
+        with_degree(sa.cols.k, [&](auto kk) {
+            constexpr int K = decltype(kk)::value;
+            hipLaunchKernelGGL((pm::k_spline_seg_rows<K, false>), dim3(blocks), dim3(pm::kSolveRows), 0, s, (const double *)sa.work, sa.work2,
+                               a.n_planes, a.ny, a.nx, sa.cols, only_flagged, sa.seg_cols, warm);
+            hipLaunchKernelGGL((pm::k_spline_seg_rows<K, true>), dim3(blocks), dim3(pm::kSolveRows), 0, s, (const double *)sa.work2, sa.work,
+                               a.n_planes, a.ny, a.nx, sa.cols, only_flagged, sa.seg_cols, warm);
+        });
+    };
+    const bool segmented = sa.seg_rows > 0;
     if (stage == 0) {
-        cols_pass(std::integral_constant<int, 1>());
+        if (segmented) cols_seg(std::integral_constant<int, 1>());
+        else cols_pass(std::integral_constant<int, 1>());
     } else if (stage == 1) {
-        rows_pass(nullptr);
+        if (segmented) rows_seg(nullptr);
+        else rows_pass(nullptr);
     } else if (stage == 2) {
         // ... second round: the flagged planes alone, with their nanmedian (the blocks of the others leave at once)
         launch_median_t<T>(a.cube, a.n_planes, npx, stats, hist, s, 1);
-        cols_pass(std::integral_constant<int, 2>());
-        rows_pass(stats);
+        if (segmented) {
+            cols_seg(std::integral_constant<int, 2>());
+            rows_seg(stats);
+        } else {
+            cols_pass(std::integral_constant<int, 2>());
+            rows_pass(stats);
+        }
     } else {
         const dim3 egrid = pm_smooth_grid(a.n_map, a.n_planes);
         hipLaunchKernelGGL(pm::k_spline_eval<T>, egrid, dim3(pm::kBlock), 0, s, a, sa, (a.n_planes + (int)egrid.y - 1) / (int)egrid.y);

@@ -168,13 +168,37 @@ int reproject_spline_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, int k
     if (chunk < 1) chunk = 1;
     if (chunk > (size_t)a.n_planes) chunk = (size_t)a.n_planes;
     if (chunk > 32768) chunk = 32768;
-    rc = ensure_work(ctx, chunk * plane_elems * sizeof(double));
+    // Few, large planes: with one lane per line the chunk is `chunk * n / 64` waves, each a chain of 2 n dependent steps. Under
+    // one wave per SIMD the lines are cut into segments (k_spline_seg_*: the same steps on the same operands, a second
+    // buffer) - as many as bring the launch to ~2 waves per SIMD, of 64 .. 256 samples (measured, profiles/EXPERIMENTS_r06.md:
+    // shorter segments re-read more warm-up samples, longer ones leave the chain long; from one wave per SIMD up the
+    // line solves are as fast or faster).
+    auto segment = [&](int lines, int n) {
+        if (ctx->spline_segment < 0) return 0;
+        if (ctx->spline_segment > 0) return std::min((ctx->spline_segment + 15) / 16 * 16, (n + 15) / 16 * 16);
+        const long waves = (long)chunk * ((lines + pm::kSolveLines - 1) / pm::kSolveLines);
+        if (waves >= pm::kSolveFillWaves || n < 256) return 0;
+        const long pieces = (2 * pm::kSolveFillWaves + waves - 1) / waves;
+        const int seg = (int)(((n + pieces - 1) / pieces + 15) / 16 * 16);
+        return std::min(std::max(seg, 64), 256);
+    };
+    sa.seg_rows = segment(a.nx, a.ny);
+    sa.seg_cols = segment(a.ny, a.nx);
+    // (one form for both axes: the segmented passes go from buffer to buffer)
+    if (!sa.seg_rows != !sa.seg_cols) {
+        if (!sa.seg_rows) sa.seg_rows = (a.ny + 15) / 16 * 16;
+        if (!sa.seg_cols) sa.seg_cols = (a.nx + 15) / 16 * 16;
+    }
+    ctx->last_spline_segment = sa.seg_rows;
+    const size_t chunk_bytes = chunk * plane_elems * sizeof(double);
+    rc = ensure_work(ctx, chunk_bytes * (sa.seg_rows ? 2 : 1));
     if (rc != PM_OK) return rc;
     rc = ensure_stats(ctx, chunk + 1);
     if (rc != PM_OK) return rc;
     if (!ctx->sm_status_host) PM_HIP(ctx, hipHostMalloc((void **)&ctx->sm_status_host, 4 * sizeof(int)));
     if (!ctx->spline_ev) PM_HIP(ctx, hipEventCreateWithFlags(&ctx->spline_ev, hipEventDisableTiming));
     sa.work = ctx->work;
+    if (sa.seg_rows) sa.work2 = ctx->work + chunk * plane_elems;
     for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += chunk) {
         const int np = (int)std::min(chunk, (size_t)a.n_planes - p0);
         pm::ReprojectArgs b = a;

@@ -138,6 +138,77 @@ def test_interpolating_splines_and_smooth_at_cube_scale(engine, oracle, jupiter,
                               map_resident(engine, cube, xm, ym, 'cubic', False)[p], equal_nan=True), p
 
 
+def test_segmented_spline_solves_give_the_line_solves_results(engine, oracle, jupiter):
+    """
+    Few, large planes: the banded solves cut every line into segments whose substitutions start `warm` samples early
+    (k_spline_seg_*, PM_OPT_SPLINE_SEGMENT). The factors' recursion forgets geometrically, so a segment's steps are the
+    serial substitution's operations on - to 4e-24 - its operands, and both forms run the same tile code: the results are
+    held here to be the one-lane-per-line form's BITS, on every degree, clean state, dtype and on sizes whose last tile /
+    last segment are not full.
+    """
+    from planetmapper_amd import _lib
+
+    def both(cube, xm, ym, interp, prop, seg):
+        engine.set_option(_lib.PM_OPT_SPLINE_SEGMENT, -1)
+        a = map_resident(engine, cube, xm, ym, interp, prop)
+        assert engine.get_option(_lib.PM_OPT_LAST_SPLINE_SEGMENT) == 0
+        engine.set_option(_lib.PM_OPT_SPLINE_SEGMENT, seg)
+        b = map_resident(engine, cube, xm, ym, interp, prop)
+        assert engine.get_option(_lib.PM_OPT_LAST_SPLINE_SEGMENT) > 0
+        return a, b
+
+    total = 0
+    try:
+        for ny, nx, n_planes, segs in ((1000, 1031, 7, (64, 112, 256)), (517, 300, 7, (64, 128)), (1024, 1024, 3, (64, 512, 2048))):
+            cube, states = make_cube(n_planes, ny, nx, seed=ny * 3 + nx)
+            xm, ym = setup_maps(engine, oracle, jupiter, ny, nx)
+            for interp in ('quadratic', 'cubic', (1, 3), (4, 2), 5):
+                for prop, seg in zip((True, False, True), segs):
+                    a, b = both(cube, xm, ym, interp, prop, seg)
+                    assert np.array_equal(np.isnan(a), np.isnan(b)), (ny, nx, interp, seg)
+                    fin = np.isfinite(a)
+                    assert fin.sum() > 1000 * n_planes // 2
+                    assert np.array_equal(a, b, equal_nan=True), (ny, nx, interp, seg, float(np.nanmax(np.abs(a - b))))
+                    total += int(fin.sum())
+            # other sample types take the same route (the forward pass of axis 0 reads the cube in its own dtype)
+            c32 = cube.astype(np.float32)
+            a, b = both(c32, xm, ym, 'cubic', False, segs[0])
+            assert np.array_equal(a, b, equal_nan=True)
+            ci = (np.nan_to_num(cube[:2], nan=0.0, posinf=0.0, neginf=0.0) * 10).clip(-30000, 30000).astype(np.int16)
+            a, b = both(ci, xm, ym, 'cubic', True, segs[0])
+            assert np.array_equal(a, b, equal_nan=True)
+        print(f'\n[segmented solves] bit-identical to the line solves on {total} mapped samples')
+        # the library's own choice: few planes of a large image are segmented, a batch that fills the chip is not
+        engine.set_option(_lib.PM_OPT_SPLINE_SEGMENT, 0)
+        cube, _ = make_cube(1, 1024, 1024, seed=9)
+        xm, ym = setup_maps(engine, oracle, jupiter, 1024, 1024)
+        map_resident(engine, cube, xm, ym, 'cubic', True)
+        assert engine.get_option(_lib.PM_OPT_LAST_SPLINE_SEGMENT) >= 64
+        small, _ = make_cube(2, 200, 200, seed=9)
+        xs, ys = setup_maps(engine, oracle, jupiter, 200, 200)
+        map_resident(engine, small, xs, ys, 'cubic', True)
+        assert engine.get_option(_lib.PM_OPT_LAST_SPLINE_SEGMENT) == 0
+    finally:
+        engine.set_option(_lib.PM_OPT_SPLINE_SEGMENT, 0)
+
+
+@pytest.mark.parametrize('n_planes,ny,nx', [(1, 4096, 4096), (2, 2048, 3000)])
+def test_interpolating_splines_on_a_few_large_planes(engine, oracle, jupiter, n_planes, ny, nx):
+    """the headline frame size as ONE plane (and two planes of 2048 x 3000): the segmented solves against the oracle"""
+    from planetmapper_amd import _lib
+
+    cube, states = make_cube(n_planes, ny, nx, seed=ny + nx + 1)
+    cube[0, 100:140, 200:260] = np.nan  # a block whose inner pixels need the plane's nanmedian when cleaned
+    xm, ym = setup_maps(engine, oracle, jupiter, ny, nx)
+    worst = {}
+    for interp, prop in (('cubic', True), ('cubic', False), ('quadratic', False), (5, True)):
+        a = map_resident(engine, cube, xm, ym, interp, prop)
+        assert engine.get_option(_lib.PM_OPT_LAST_SPLINE_SEGMENT) >= 64
+        b = oracle_map_cube_mt(oracle, cube, xm, ym, (interp, interp) if isinstance(interp, int) else interp, prop)
+        worst[f'{interp}/{prop}'] = assert_close(a, b, (interp, prop))
+    print('\n[few large planes] worst |HIP - oracle| / scale:', {k: f'{v:.2e}' for k, v in worst.items()})
+
+
 def test_smooth_interpolation_4x4_form_gives_the_gap_aware_form_bits(engine, oracle, jupiter):
     """
     k_reproject_smooth builds a cell's four fine-grid nodes from the 4 x 4 finite pixels around it where it can (six sets of

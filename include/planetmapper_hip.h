@@ -304,6 +304,12 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           second workspace of the planes' size); -1: never; n >= 64: segments of n samples (rounded up
  *                           to 16) for every call. A/B and the test that holds the two forms to each other.
  *   PM_OPT_LAST_SPLINE_SEGMENT read-only: the axis-0 segment length of the latest spline call, 0 = one lane per line.
+ *   PM_OPT_LAST_SM_KNIFE_EDGES read-only: planes of the latest smoothing-spline call (spline_smoothing > 0) whose knot
+ *                           search chose between knot intervals whose residual shares are equal in exact arithmetic and
+ *                           ordered only by the rounding of FITPACK's `fpmax * an / am` products - a choice scipy itself
+ *                           makes by the last bit of a sum of ~10^3 squared residuals (a one-ulp change of one input pixel
+ *                           flips it; the two outcomes are both smoothing splines FITPACK accepts, percent-level apart).
+ *                           0 = every decision of the search was the reference's own beyond rounding.
  *   PM_OPT_LAST_STAGE_NS + k read-only, ns: where the latest host-fed pm_map_cube (PM_MEM_HOST / PM_MEM_HOST_CUBE, nearest /
  *                           linear) or pm_map_cube_sharded of this context spent its time. Host clock, always recorded:
  *                           0 the whole pm_map_cube call = 1 + 2 + 5 + 6 + 7; 1 fingerprint of the x / y maps + block-table
@@ -363,6 +369,7 @@ typedef enum pm_option {
     PM_OPT_LAST_LT_PATH = 27,
     PM_OPT_SPLINE_SEGMENT = 28,
     PM_OPT_LAST_SPLINE_SEGMENT = 29,
+    PM_OPT_LAST_SM_KNIFE_EDGES = 30,
     PM_OPT_ROUTE_NS_PER_PLANE = 16, /* + route 0..4 */
     PM_OPT_LAST_STAGE_NS = 32       /* + stage 0..12, read-only: see below */
 } pm_option;

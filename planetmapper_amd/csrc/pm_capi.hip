@@ -537,6 +537,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_HOST_COPY_THREADS_IN_USE:
     case PM_OPT_HYBRID_FETCH_PERMILLE:
     case PM_OPT_LAST_SPLINE_SEGMENT:
+    case PM_OPT_LAST_SM_KNIFE_EDGES:
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "option %d is read-only", option);
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -571,6 +572,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_SM_BATCH_PLANES: *value = ctx->sm_batch_planes; return PM_OK;
     case PM_OPT_SPLINE_SEGMENT: *value = ctx->spline_segment; return PM_OK;
     case PM_OPT_LAST_SPLINE_SEGMENT: *value = ctx->last_spline_segment; return PM_OK;
+    case PM_OPT_LAST_SM_KNIFE_EDGES: *value = ctx->last_sm_knife_edges; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;
@@ -683,9 +685,10 @@ int pm_set_disc(pm_ctx *ctx, const pm_disc *disc)
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "disc parameters must be finite");
     if (!(disc->r0 > 0.0)) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "r0 must be greater than zero");
     if (disc->nx < 0 || disc->ny < 0) return fail(ctx, PM_ERR_INVALID_ARGUMENT, "nx and ny must be non-negative");
-    // the image kernels address a row with a 32-bit byte offset and put rows on gridDim.y
-    if (disc->nx > (1 << 28) || disc->ny > 65535)
-        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image size is limited to nx <= 2^28, ny <= 65535");
+    // the image kernels address a row with a 32-bit byte offset (rows go on gridDim.y: frames taller than a launch's 65 535
+    // rows are mapped in row blocks, pm_backplanes_img_rows)
+    if (disc->nx > (1 << 28) || disc->ny > (1 << 30))
+        return fail(ctx, PM_ERR_INVALID_ARGUMENT, "image size is limited to nx <= 2^28, ny <= 2^30");
     ctx->disc = *disc;
     ctx->have_disc = true;
     return PM_OK;
@@ -763,6 +766,17 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
             if ((plane_mask >> i) & 1) p.out[i] = (double *)ctx->scratch + (size_t)(k++) * npx;
     }
 
+    // gridDim.y holds at most 65 535 rows: a taller frame (body_xy.py:3166 knows no limit) goes in blocks of rows, each a
+    // launch of its own with its own row order - a pixel's value depends on its coordinates only
+    constexpr int kRowsPerLaunch = 32768;
+    const pm::Params p_all = p;
+    for (int b0 = 0; b0 < n_rows; b0 += kRowsPerLaunch) {
+    const int nb = std::min(kRowsPerLaunch, n_rows - b0);
+    p = p_all;
+    p.y_off = row_begin + b0;
+    set_row_order(p, nb);
+    for (int i = 0; i < PM_NUM_PLANES; i++)
+        if ((plane_mask >> i) & 1) p.out[i] = p_all.out[i] + (size_t)b0 * d.nx;
     bool fused_sky = false;
     if (plane_mask & kDiscBits) {
         int flags = 0;
@@ -797,6 +811,8 @@ int pm_backplanes_img_rows(pm_ctx *ctx, uint64_t plane_mask, double alt, int row
         ps.mask = plane_mask & kSkyBits;
         pm_launch_sky(ps, (plane_mask & kLimbBits) != 0, ctx->stream);
     }
+    }  // (row blocks)
+    p = p_all;
     PM_HIP(ctx, hipGetLastError());
 
     if (mem != PM_MEM_DEVICE) {

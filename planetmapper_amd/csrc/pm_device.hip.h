@@ -202,10 +202,12 @@ struct SplineArgs {
     double *work2 = nullptr;
 };
 // How far before (beyond) a segment its forward (backward) substitution starts: the homogeneous recursion of the factors decays
-// by the symbol's root per step (degree 2: 0.172, 3: 0.268, 4: 0.361, 5: 0.431) - what is left at the segment is < 4e-24.
+// by the symbol's root per step (degree 2: 0.172, 3: 0.268, 4: 0.361, 5: 0.431) - what is left at the segment is < 1e-34 of the
+// values. (1e-22 is not enough for the SAME BITS: a perturbation of that size changes the rounding of one operation in ~2e5,
+// and a cube has millions of segment starts - the first lengths, 32 / 48 / 48 / 64, left one sample of 1.1 million an ulp off.)
 constexpr int kSolveLines = 64;        // lines per wave of the spline solves
 constexpr long kSolveFillWaves = 1024;  // one wave per SIMD of the chip (256 CUs x 4)
-__host__ __device__ inline int spline_warm(int k) { return k <= 1 ? 16 : k == 2 ? 32 : k <= 4 ? 48 : 64; }
+__host__ __device__ inline int spline_warm(int k) { return k <= 1 ? 16 : k == 2 ? 48 : k == 3 ? 64 : k == 4 ? 80 : 96; }
 
 // Arguments of the reprojection kernel (pm_map_cube).
 struct ReprojectArgs {

@@ -917,9 +917,9 @@ __global__ __launch_bounds__(kSolveRows) void k_spline_solve_cols(const T *cube,
 // of a line L's multipliers and U's rows are the constants of a Toeplitz band whose recursion has the symbol's roots INSIDE
 // the unit circle (degree 2: 0.172, 3: 0.268, 4: 0.361, 5: 0.431 per step), so a substitution started `warm` steps early
 // with zeros for the values before it carries, when it reaches the segment it is meant for, an error of root^warm
-// (<= 4e-24 of the values with pm_spline_warm's lengths) - far below half an ulp: the steps of the segment are the serial
-// substitution's operations on the serial substitution's operands, and the results its bits (measured: bit-equal on every
-// sample of the cube-scale tests; the tests hold the two forms to 1e-14 of scale). A line is cut into segments of `seg`
+// (<= 1e-35 of the values with spline_warm's lengths) - so far below half an ulp that it changes the rounding of no
+// operation: the steps of the segment are the serial substitution's operations on the serial substitution's operands, and
+// the results its bits (tests/test_gpu_splines_cube_scale.py holds the two forms to each other bit for bit). A line is cut into segments of `seg`
 // samples (a multiple of the tile of 16), one wave takes 64 lines of one segment: forward from `warm` before the segment
 // (from the line's start if that is nearer: exact), backward from `warm` beyond it (from the line's end if the start would
 // fall into its last tile). The backward pass of a segment needs the forward results of the `warm` samples beyond it, which

@@ -42,6 +42,8 @@ struct SmAxisDev {
     double *t;       // n knots (capacity m + k + 2)
     double *fpint;   // residual sum per knot interval (capacity m + 1)
     int *nrdata;     // data points strictly inside each interval (capacity m + 1)
+    int *twin;       // != 0 and equal for the two halves of an interval fpknot split down the middle (their shares are the
+                     // same product: equal in any arithmetic); 0 for sums that come from a fit (capacity m + 1)
     // the rows of [A; B / p] merged in the order of their first column (nb > 0): what the refinement pass walks
     int *mg_src;     // m + nb: sample i, or -(r + 1) for jump row r
     int *mg_l;       // m + nb: first column of the row
@@ -64,6 +66,7 @@ struct SmPlaneDev {
     int active;   // a fit is wanted this round
     int all_nan;  // body_xy.py:1668-1670: the map of an all-NaN image is all NaN
     int plane;    // index in the chunk (cube, output, statistics)
+    int knife_edge;  // the knot search took a decision between intervals whose residual shares tie to rounding (sm_add_knot)
 };
 
 // dst[x] = value(x), x < n, by the NT threads of the workgroup: eight requests in flight per thread (a plain loop of
@@ -105,7 +108,16 @@ __device__ __forceinline__ void shift_up(T *a, int lo, int hi, int lane)
 }
 
 // fpknot: a new knot at the middle data point of the interval with the largest residual sum (one wave)
-__device__ bool sm_add_knot(SmAxisDev &a, int &n, int lane)
+// `remaining`: the knots this round may still add, this one included. *knife_edge is set when the choice made here is one
+// the reference makes by rounding noise: fpknot's shares of a split interval (fpint = fpmax * an / am) are EQUAL in exact
+// arithmetic for several intervals at once (F/2 * 4/10 and F * 9/20 * 4/9, say) and differ in their last bits by the
+// rounding of those products - i.e. by the last bit of F, a sum of ~10^3 squared residuals that no implementation with
+// other coefficient arithmetic than FITPACK's serial Givens sequence has to the bit (a one-ulp change of ONE input pixel
+// flips scipy's own choice: tests/test_smoothing_knife_edge.py). Counted: intervals within 4 ulp of the largest sum that
+// could take a knot, other than the twin of an interval split down the middle (SmAxisDev::twin - the same product on both
+// sides: equal in FITPACK too, the first wins there as here); the edge is real when the round cannot give every one of
+// them a knot.
+__device__ bool sm_add_knot(SmAxisDev &a, int &n, int lane, int remaining, int *knife_edge)
 {
     const int k = a.k, nri = n - 2 * k - 1;
     double best = 0.0;
@@ -120,6 +132,18 @@ __device__ bool sm_add_knot(SmAxisDev &a, int &n, int lane)
         if (ob > best || (ob == best && oi < number)) { best = ob; number = oi; }
     }
     if (number == 0x7fffffff) return false;
+    {
+        const double near = best * (1.0 - 0x1p-50);
+        int others = 0;
+        for (int j = lane; j < nri; j += 64) {
+            const double v = a.fpint[j];
+            const int tw = a.twin[j];
+            const bool twin = tw != 0 && tw == a.twin[number];
+            others += (j != number && a.nrdata[j] != 0 && v >= near && !twin) ? 1 : 0;
+        }
+        for (int off = 32; off > 0; off >>= 1) others += __shfl_xor(others, off, 64);
+        if (others >= remaining) *knife_edge = 1;
+    }
     const int maxpt = a.nrdata[number];
     // the new knot: ihalf data points beyond the interval's left knot (FITPACK counts the points before it, maxbeg - knots
     // are sample abscissae here, so that count is the left knot itself)
@@ -138,16 +162,18 @@ __device__ bool sm_add_knot(SmAxisDev &a, int &n, int lane)
         const int j = top - lane;
         const bool mine = j >= number + 1;
         double vf = 0.0, vt = 0.0;
-        int vn = 0;
+        int vn = 0, vw = 0;
         if (mine) {
             vf = a.fpint[j];
             vn = a.nrdata[j];
+            vw = a.twin[j];
             vt = a.t[j + k];
         }
         __syncthreads();
         if (mine) {
             a.fpint[j + 1] = vf;
             a.nrdata[j + 1] = vn;
+            a.twin[j + 1] = vw;
             a.t[j + k + 1] = vt;
         }
     }
@@ -157,6 +183,7 @@ __device__ bool sm_add_knot(SmAxisDev &a, int &n, int lane)
         a.nrdata[number + 1] = maxpt - ihalf;
         a.fpint[number] = best * (double)(ihalf - 1) / (double)maxpt;
         a.fpint[number + 1] = best * (double)(maxpt - ihalf) / (double)maxpt;
+        a.twin[number] = a.twin[number + 1] = (ihalf - 1 == maxpt - ihalf) ? n : 0;  // (n, the knot count before this one: unique per split)
         a.t[number + k + 1] = (double)at;
     }
     n += 1;
@@ -176,32 +203,33 @@ __device__ void sm_account(const SmAxisDev &a, int n, const double *sums, int la
         for (int i = lo + 1; i <= hi; i++) acc += sums[i];
         if (num < nri - 1) acc += 0.5 * sums[hi + 1];
         a.fpint[num] = acc;
+        a.twin[num] = 0;
     }
 }
 
 // up to `count` new knots along one axis, its knot arrays worked on in LDS (`lds`: they fit): a new knot is a scan, two
 // reductions and three shifts over them, each a round trip - to LDS a tenth of a microsecond, to HBM one or two
-__device__ bool sm_refine(SmAxisDev &g, int &n, int count, int nmax, int lane, double *smem, int lds)
+__device__ bool sm_refine(SmAxisDev &g, int &n, int count, int nmax, int lane, double *smem, int lds, int *knife_edge)
 {
     SmAxisDev a = g;
     const int k = a.k, n0 = n;
     if (lds) {
         double *tS = smem, *fS = tS + (a.m + k + 2);
-        int *nS = (int *)(fS + (a.m + 1));
+        int *nS = (int *)(fS + (a.m + 1)), *wS = nS + (a.m + 1);
         for (int i = lane; i < n0; i += 64) tS[i] = g.t[i];
-        for (int i = lane; i < n0 - 2 * k - 1; i += 64) { fS[i] = g.fpint[i]; nS[i] = g.nrdata[i]; }
-        a.t = tS; a.fpint = fS; a.nrdata = nS;
+        for (int i = lane; i < n0 - 2 * k - 1; i += 64) { fS[i] = g.fpint[i]; nS[i] = g.nrdata[i]; wS[i] = g.twin[i]; }
+        a.t = tS; a.fpint = fS; a.nrdata = nS; a.twin = wS;
         __syncthreads();
     }
     bool added = false;
     for (int l = 0; l < count; l++) {  // (FITPACK tries `count` times whether or not an interval can still take a knot; once none can, none will)
-        if (!sm_add_knot(a, n, lane)) break;
+        if (!sm_add_knot(a, n, lane, min(count - l, nmax - n), knife_edge)) break;
         added = true;
         if (n == nmax) break;
     }
     if (lds && added) {
         for (int i = lane; i < n; i += 64) g.t[i] = a.t[i];
-        for (int i = lane; i < n - 2 * k - 1; i += 64) { g.fpint[i] = a.fpint[i]; g.nrdata[i] = a.nrdata[i]; }
+        for (int i = lane; i < n - 2 * k - 1; i += 64) { g.fpint[i] = a.fpint[i]; g.nrdata[i] = a.nrdata[i]; g.twin[i] = a.twin[i]; }
     }
     __syncthreads();
     return added;
@@ -210,7 +238,7 @@ __device__ bool sm_refine(SmAxisDev &g, int &n, int count, int nmax, int lane, d
 // One wave per plane: close the fit of the last round (residual sums -> fp, per-interval sums), take FITPACK's decision
 // (fpregr: more knots / the next p / finished) and publish what the next fit is. status: [0] planes with a fit to run,
 // [1] / [2] the largest coefficient counts along y / x among them, [3] whether any of them fits with p > 0.
-__host__ __device__ inline size_t sm_decide_lds_bytes(int m, int k) { return ((size_t)(m + k + 2) + (size_t)(m + 1)) * sizeof(double) + (size_t)(m + 1) * sizeof(int); }
+__host__ __device__ inline size_t sm_decide_lds_bytes(int m, int k) { return ((size_t)(m + k + 2) + (size_t)(m + 1)) * sizeof(double) + 2 * (size_t)(m + 1) * sizeof(int); }
 __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const PlaneStats *stats, int *status, int first, int tiles_x,
                                                    int tiles_y, int lds)
 {
@@ -230,6 +258,7 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
     int iter = P.iter, it2 = P.it2, lastdi = P.lastdi, poly = P.poly, ich1 = P.ich1, ich3 = P.ich3;
     int nplus_y = P.y.nplus, nplus_x = P.x.nplus;
     const double s = P.s, acc = P.acc;
+    int knife_edge = 0;
     if (first) {
         const int all_nan = stats[P.plane].all_nan;
         if (lane == 0) P.all_nan = all_nan;
@@ -243,6 +272,8 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
             P.x.nrdata[0] = mx - 2;
             P.y.fpint[0] = 0.0;
             P.x.fpint[0] = 0.0;
+            P.y.twin[0] = 0;
+            P.x.twin[0] = 0;
         }
         changed_y = changed_x = true;
         fp = fp0 = fpold = reducy = reducx = fpms = 0.0;
@@ -252,7 +283,7 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
         iter = it2 = lastdi = ich1 = ich3 = 0;
         nplus_y = nplus_x = 0;
         poly = 1;
-        if (lane == 0) P.fits = 0;
+        if (lane == 0) { P.fits = 0; P.knife_edge = 0; }
     } else {
         // the residual sums of the fit, tile partials added in a fixed order
         for (int i = lane; i < my; i += 64) {
@@ -299,11 +330,11 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
                 bool added;
                 if (first_axis) {
                     nplus_y = nply;
-                    added = sm_refine(P.y, ny_n, nply, nmaxy, lane, sm_knots, lds);
+                    added = sm_refine(P.y, ny_n, nply, nmaxy, lane, sm_knots, lds, &knife_edge);
                     changed_y = added;
                 } else {
                     nplus_x = nplx;
-                    added = sm_refine(P.x, nx_n, nplx, nmaxx, lane, sm_knots, lds);
+                    added = sm_refine(P.x, nx_n, nplx, nmaxx, lane, sm_knots, lds, &knife_edge);
                     changed_x = added;
                 }
                 iter++;
@@ -370,6 +401,10 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
     const double p_fit = (phase == 1) ? p : -1.0;
     const int nri_y = ny_n - 2 * ky - 1, nri_x = nx_n - 2 * kx - 1;
     if (lane == 0) {
+        if (knife_edge && !P.knife_edge) {
+            P.knife_edge = 1;
+            atomicAdd(&status[8], 1);  // (status[8]: zeroed once per call, not per round)
+        }
         P.phase = phase;
         P.active = phase != 2;
         P.y.n = ny_n; P.x.n = nx_n;
@@ -1016,7 +1051,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
     // per-plane workspace: byte offsets inside a plane's slice of the arena
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    struct AxisOff { size_t hb, lb, span, R, Bp, t, fpint, nrdata, mg_src, mg_l, mg_h; } ao[2];
+    struct AxisOff { size_t hb, lb, span, R, Bp, t, fpint, nrdata, twin, mg_src, mg_l, mg_h; } ao[2];
     for (int ax = 0; ax < 2; ax++) {
         const size_t m = (size_t)(ax ? nx : ny), cap = m + 16;
         ao[ax].hb = take(cap * 6 * 8);
@@ -1027,6 +1062,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         ao[ax].t = take(cap * 8);
         ao[ax].fpint = take(cap * 8);
         ao[ax].nrdata = take(cap * 4);
+        ao[ax].twin = take(cap * 4);
         ao[ax].mg_src = take(2 * cap * 4);
         ao[ax].mg_l = take(2 * cap * 4);
         ao[ax].mg_h = take(2 * cap * kSmRow * 8);
@@ -1057,7 +1093,8 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
     }
     if (!ctx->sm_status_host) PM_HIP(ctx, hipHostMalloc((void **)&ctx->sm_status_host, 4 * sizeof(int)));
     // (more than 64 KB of dynamic LDS has to be enabled per kernel)
-    static const size_t lds_limit = [] {
+    // (HIP keeps function attributes per device: once per context, after pm's hipSetDevice - not once per process)
+    if (!ctx->sm_lds_limit) ctx->sm_lds_limit = [] {
         const int want = 160 * 1024 - 256;
         bool ok = true;
         auto allow = [&](const void *f) { ok = ok && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess; };
@@ -1070,6 +1107,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         allow((const void *)pm::k_smb_factor<4>); allow((const void *)pm::k_smb_factor<5>);
         return ok ? (size_t)want : (size_t)(64 * 1024);
     }();
+    const size_t lds_limit = ctx->sm_lds_limit;
     int rc = ensure_work(ctx, batch * npx * sizeof(double));
     if (rc != PM_OK) return rc;
     rc = ensure_stats(ctx, batch);
@@ -1081,6 +1119,8 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
     const hipStream_t st = ctx->stream;
     std::vector<pm::SmPlaneDev> desc(batch);
     const size_t plane_elems = npx;
+    PM_HIP(ctx, hipMemsetAsync(status + 8, 0, sizeof(int), st));
+    ctx->last_sm_knife_edges = 0;
     for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += batch) {
         const int np = (int)std::min(batch, (size_t)a.n_planes - p0);
         pm::ReprojectArgs b = a;
@@ -1105,6 +1145,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
                 A.t = (double *)(sl + ao[ax].t);
                 A.fpint = (double *)(sl + ao[ax].fpint);
                 A.nrdata = (int *)(sl + ao[ax].nrdata);
+                A.twin = (int *)(sl + ao[ax].twin);
                 A.mg_src = (int *)(sl + ao[ax].mg_src);
                 A.mg_l = (int *)(sl + ao[ax].mg_l);
                 A.mg_h = (double *)(sl + ao[ax].mg_h);
@@ -1204,6 +1245,9 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         case PM_U16: hipLaunchKernelGGL(pm::k_smb_eval<uint16_t>, ge, bl, 0, st, b, (const pm::SmPlaneDev *)planes); break;
         }
         PM_HIP(ctx, hipGetLastError());
+        PM_HIP(ctx, hipMemcpyAsync(ctx->sm_status_host, status + 8, sizeof(int), hipMemcpyDeviceToHost, st));
+        PM_HIP(ctx, hipStreamSynchronize(st));
+        ctx->last_sm_knife_edges = ctx->sm_status_host[0];  // (cumulative over the batches of the call)
         // (`desc` is rewritten for the next batch: the upload above must have been consumed - it has, every round synchronised)
     }
     return PM_OK;

@@ -19,6 +19,8 @@ What the block holds and where the reference computes it: `planetmapper/body.py:
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from .geometry import PMGeometry
@@ -210,13 +212,23 @@ class HipBackplanes:
     _hip_spice = None  # a module to ask instead of spiceypy (tests)
 
     # ------------------------------------------------------------------ the engine, bound to this body's geometry and disc
-    def _hip(self):
-        from .engine import Engine  # noqa: PLC0415
+    _hip_device = None  # the GPU of this process: None = LOCAL_RANK where the launcher left every card visible, else 0
 
-        eng = self.__dict__.get('_hip_engine')
-        if eng is None:
-            eng = self.__dict__['_hip_engine'] = Engine(0)
-            eng.set_geometry(geometry_from_body(self, self._hip_spice))  # (et, target and observer of a Body never change)
+    def _hip(self):
+        """the process's ONE context on this rank's device (shared with every other body, like the native BodyXY's),
+        pointed at this body's geometry block - which is all a body keeps - and at its disc"""
+        from .body_xy import _shared_engine  # noqa: PLC0415
+        from .engine import device_count  # noqa: PLC0415
+
+        device = self._hip_device
+        if device is None:
+            local = int(os.environ.get('LOCAL_RANK', '0') or 0)
+            device = local if 0 <= local < device_count() else 0
+        eng = _shared_engine(int(device))
+        g = self.__dict__.get('_hip_geometry')
+        if g is None:
+            g = self.__dict__['_hip_geometry'] = geometry_from_body(self, self._hip_spice)  # (et, target and observer of a Body never change)
+        eng.set_geometry(g)
         eng.set_disc(self.get_x0(), self.get_y0(), self.get_r0(), self._get_rotation_radians(), self._nx, self._ny, self._optimize_speed)
         return eng
 
@@ -258,12 +270,29 @@ class HipBackplanes:
                                     smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
                                     spline_smoothing=spline_smoothing)[0]  # fmt: skip
 
-    def illumination_angles_from_lonlat(self, lon, lat, **kw):  # body.py:2295 (and its siblings)
-        o = self._hip().backplanes_map(['PHASE', 'INCIDENCE', 'EMISSION'], np.atleast_2d(lon), np.atleast_2d(lat))
-        return o['PHASE'], o['INCIDENCE'], o['EMISSION']
+    def illumination_angles_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):  # body.py:2295
+        """
+        (phase, incidence, emission) in degrees: floats for a scalar point like the reference's, arrays of the inputs'
+        broadcast shape for arrays (the reference takes scalars only). `alt` there is the height of the POINT above the
+        unadjusted ellipsoid (lonlat2targvec -> pgrrec), not the altitude adjustment of the backplanes, and planetocentric
+        input goes through the reference's own conversion: both stay the reference's scalar SPICE path.
+        """
+        if alt != 0.0 or planetocentric:
+            return super().illumination_angles_from_lonlat(lon, lat, alt=alt, planetocentric=planetocentric)
+        scalar = np.ndim(lon) == 0 and np.ndim(lat) == 0
+        lon_b, lat_b = np.broadcast_arrays(np.asarray(lon, dtype=np.float64), np.asarray(lat, dtype=np.float64))
+        if lon_b.size == 0:
+            return tuple(np.empty(lon_b.shape) for _ in range(3))
+        o = self._hip().backplanes_map(['PHASE', 'INCIDENCE', 'EMISSION'], np.ascontiguousarray(lon_b.reshape(1, -1)),
+                                       np.ascontiguousarray(lat_b.reshape(1, -1)))
+        res = tuple(o[n].reshape(lon_b.shape) for n in ('PHASE', 'INCIDENCE', 'EMISSION'))
+        return tuple(float(r) for r in res) if scalar else res
 
     def ring_plane_coordinates(self, ra, dec, only_visible=True):  # body.py:2617
+        """(ring_radius, ring_longitude, ring_distance): floats for a scalar sky point like the reference's, arrays for arrays"""
         q = self._hip().radec_query(ra, dec, ring_only_visible=only_visible)  # (8, ...): q[5:8] = limb_coordinates_from_radec body.py:2040
+        if np.ndim(ra) == 0 and np.ndim(dec) == 0:
+            return float(q[2]), float(q[3]), float(q[4])
         return q[2], q[3], q[4]
 
     def _get_backplane_imgs_for_saving(self, names):  # observation.py:1269-1279

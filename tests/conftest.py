@@ -47,15 +47,49 @@ def jupiter_info():
     return scenario_info('jupiter_hst_2005')
 
 
+_ALL_SEEDS: dict = {}     # every seed drawn in this session, and those of tests that failed: the LAST lines of the run
+_FAILED_SEEDS: dict = {}  # (pytest_terminal_summary) - a truncated tail of the log still names them
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _ALL_SEEDS:
+        terminalreporter.write_line('fuzz seeds of this run: ' + ', '.join(f'{n}={s}' for n, s in _ALL_SEEDS.items()))
+    if _FAILED_SEEDS:
+        terminalreporter.write_line('FAILED with a fresh seed - replay: ' + '; '.join(f'PM_FUZZ_SEED={s} python -m pytest tests -m gpu -k {n}' for n, s in _FAILED_SEEDS.items()))
+
+
+_FRESH_SEEDS: dict = {}  # seeds drawn by the test that is running (pytest_runtest_call below puts them into a failure's message)
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_call(item):
+    """
+    A fresh-seed leg that fails must NAME its seed where every reader of the run sees it - the one-line summary
+    (`FAILED ...::test[fresh_seed] - AssertionError: [replay: PM_FUZZ_SEED=...] ...`), not only captured stdout or a log
+    file the driver does not collect: the seed is put in front of the exception's own message.
+    """
+    _FRESH_SEEDS.clear()
+    outcome = yield
+    if outcome.excinfo is not None and _FRESH_SEEDS:
+        exc = outcome.excinfo[1]
+        tag = '[' + ', '.join(f'PM_FUZZ_SEED={s}' for s in _FRESH_SEEDS.values()) + '] '
+        _FAILED_SEEDS.update(_FRESH_SEEDS)
+        first = exc.args[0] if exc.args else ''
+        exc.args = (tag + (first if isinstance(first, str) else repr(first)),) + tuple(exc.args[1:])
+
+
 def fresh_seed(test_name: str) -> int:
     """
     Seed of the per-run leg of a fuzz test: from PM_FUZZ_SEED if set (to replay a failure), else from the
-    clock. Printed (pytest -s / the failure report shows it) and appended to gpurun_out/fuzz_seeds.log.
+    clock. Printed, appended to gpurun_out/fuzz_seeds.log, and - if the test fails - put in front of the failure's own
+    message (pytest_runtest_call above).
     """
     import time
 
     env = os.environ.get('PM_FUZZ_SEED')
     seed = int(env) if env else int(time.time_ns() % (2**32))
+    _FRESH_SEEDS[test_name] = seed
+    _ALL_SEEDS[test_name] = seed
     line = f'{test_name}: PM_FUZZ_SEED={seed}'
     print('\n[fuzz] ' + line)
     out = os.path.join(REPO, 'gpurun_out')

@@ -267,3 +267,76 @@ def compare_planes(out: dict, ref: dict, names, g, min_flat_fraction=None, plate
             floor = min_flat(g)[n] if min_flat_fraction is None else min_flat_fraction
             assert flat >= floor, (n, flat, floor, geometry_class(g))
     return stats
+
+
+# ---------------------------------------------------------------- against the reference's own golden planes
+# What an implementation is held to where the expected values are the REFERENCE's (tests/data/outputs/*.fits, real CSPICE):
+# the tighter of (a) the conditioned bars above, evaluated on the golden planes themselves, and (b) the flat bars the
+# restatement was first pinned with (round 1-5: `TIGHT`) - RA / Dec 1e-12 deg, PHASE 1e-12 deg, DOPPLER 1e-14 are far
+# inside the conditioned numbers. Measured (oracle and HIP vs the 13 golden files): worst pixel at <= 0.5 of this bar.
+GOLDEN_FLAT = {
+    'LON-GRAPHIC': 1e-8, 'LAT-GRAPHIC': 1e-8, 'LON-CENTRIC': 1e-8, 'LAT-CENTRIC': 1e-8,
+    'RA': 1e-12, 'DEC': 1e-12, 'PIXEL-X': 1e-9, 'PIXEL-Y': 1e-9,
+    'KM-X': 1e-5, 'KM-Y': 1e-5, 'ANGULAR-X': 1e-8, 'ANGULAR-Y': 1e-8,
+    'PHASE': 1e-12, 'INCIDENCE': 1e-8, 'EMISSION': 1e-8, 'AZIMUTH': 1e-8,
+    'LOCAL-SOLAR-TIME': 0.0, 'DISTANCE': 1e-5, 'RADIAL-VELOCITY': 1e-9, 'DOPPLER': 1e-14,
+    'LIMB-DISTANCE': 1e-5, 'LIMB-LON-GRAPHIC': 1e-7, 'LIMB-LAT-GRAPHIC': 1e-7,
+    'RING-RADIUS': 1e-3, 'RING-LON-GRAPHIC': 1e-7, 'RING-DISTANCE': 1e-3,
+}  # fmt: skip
+
+
+def check_against_golden(out: dict, gold, names, g, what: str = '', report: bool = True) -> dict:
+    """
+    `out` (oracle or HIP planes) against the reference's golden planes: identical NaN masks, the reference's own rule
+    (tests/test_observation.py:1203-1258: rtol 1e-5, atol 1e-6), and per pixel min(conditioned bar from the golden planes,
+    GOLDEN_FLAT). Returns and prints {plane: worst |diff| / bar}.
+    """
+    gold = {n: np.asarray(gold[n], dtype=float) for n in (gold.files if hasattr(gold, 'files') else gold)}
+    planes = {n: gold[n] for n in gold if gold[n].ndim == 2}
+    tol = tolerances(planes, g)
+    ratios = {}
+    for n in names:
+        a, b = np.asarray(out[n], dtype=float), gold[n]
+        assert a.shape == b.shape, (what, n)
+        assert np.array_equal(np.isnan(a), np.isnan(b)), f'{what} {n}: NaN mask differs from the golden plane'
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True), (what, n)
+        fin = np.isfinite(b)
+        if not fin.any():
+            ratios[n] = 0.0
+            continue
+        d = np.abs(a - b)
+        if 'LON' in n or n == 'RA':
+            d = _wrap(d)
+        rel = 1e-11 * np.nanmax(np.abs(b)) if n in ('RING-RADIUS', 'RING-DISTANCE', 'DISTANCE') else 0.0
+        bar = np.minimum(np.broadcast_to(tol[n], d.shape), GOLDEN_FLAT[n] + rel) if n in tol else np.full(d.shape, GOLDEN_FLAT[n] + rel)
+        if n == 'LOCAL-SOLAR-TIME':
+            assert np.nanmax(d) == 0.0, (what, n, float(np.nanmax(d)))
+            ratios[n] = 0.0
+            continue
+        r = np.where(fin, d / np.maximum(bar, 1e-300), 0.0)
+        ratios[n] = float(r.max())
+        if ratios[n] > 1.0:
+            i = np.unravel_index(int(np.argmax(r)), r.shape)
+            raise AssertionError(f'{what} {n}: |diff| = {d[i]:.3e} > bar = {bar[i]:.3e} at {i} (got {a[i]!r}, golden {b[i]!r})')
+    if report:
+        top = sorted(ratios.items(), key=lambda kv: -kv[1])[:4]
+        print(f'\n[golden {what}] worst |diff| / bar: ' + ', '.join(f'{k} {v:.2f}' for k, v in top))
+    return ratios
+
+
+def check_mapped_against_golden(mapped, ref, interpolation, what: str = '') -> float:
+    """
+    A mapped cube against the golden one (PRIMARY of tests/data/outputs/map_*.fits; input values up to 1e4, x / y maps
+    good to 4e-11 px): NaN masks identical, the reference's own rule, 'nearest' exactly equal, every other interpolation
+    within 1e-8 absolute (measured, oracle and HIP: 0.6-1.9e-9).
+    """
+    mapped, ref = np.asarray(mapped, dtype=float), np.asarray(ref, dtype=float)
+    assert mapped.shape == ref.shape, what
+    assert np.array_equal(np.isnan(mapped), np.isnan(ref)), f'{what}: NaN mask of the mapped cube differs from the golden one'
+    assert np.allclose(mapped, ref, rtol=1e-5, atol=1e-6, equal_nan=True), what
+    worst = float(np.nanmax(np.abs(mapped - ref))) if np.isfinite(ref).any() else 0.0
+    if interpolation == 'nearest':
+        assert np.array_equal(mapped, ref, equal_nan=True), what
+    else:
+        assert worst <= 1e-8, (what, worst)
+    return worst

@@ -31,6 +31,7 @@ def main():
     jupiter, saturn = load_scenario('jupiter_hst_2005'), load_scenario('saturn_earth_2005')
     eng = Engine(0)
     failures = []
+    knife_edges = []  # smoothing fits the library itself reported as decided by rounding noise in the reference, beyond the bar
     t0 = time.time()
     for k in range(args.seeds):
         seed = args.first + k
@@ -40,7 +41,7 @@ def main():
                  ('reprojection', lambda: T.test_random_reprojection_fuzz(eng, oracle, jupiter, 'fresh_seed')),
                  ('geometries', lambda: T.test_random_geometries_fuzz(eng, oracle, 'fresh_seed')),
                  ('light_time_paths', lambda: T.test_random_epochs_body_sizes_and_spins_fuzz(eng, oracle, jupiter, saturn, 'fresh_seed')),
-                 ('smoothing', lambda: S.smoothing_fuzz(eng, oracle, jupiter, seed))]  # fmt: skip
+                 ('smoothing', lambda: knife_edges.extend(S.smoothing_fuzz(eng, oracle, jupiter, seed)))]  # fmt: skip
         if args.only:
             cases = [c for c in cases if c[0] == args.only]
         for general in (0, 1):
@@ -58,7 +59,11 @@ def main():
             print(json.dumps({'done': k + 1, 'failures': len(failures), 'seconds': round(time.time() - t0, 1)}), flush=True)
     eng.set_option(_lib.PM_OPT_GENERAL_KERNEL, 0)
     eng.close()
-    print(json.dumps({'seeds': args.seeds, 'first': args.first, 'failures': len(failures), 'seconds': round(time.time() - t0, 1)}), flush=True)
+    for ke in knife_edges:
+        print(json.dumps({'knife_edge': [str(v) for v in ke]}), flush=True)
+    print(json.dumps({'seeds': args.seeds, 'first': args.first, 'failures': len(failures), 'reported_knife_edges_beyond_bar': len(knife_edges),
+                      'smoothing_plane_fits': getattr(S.smoothing_fuzz, 'calls', 0), 'of_them_reported_as_knife_edges': getattr(S.smoothing_fuzz, 'flagged', 0),
+                      'seconds': round(time.time() - t0, 1)}), flush=True)
     return 1 if failures else 0
 
 

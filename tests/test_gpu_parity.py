@@ -75,24 +75,16 @@ def _library_choice(engine):
         engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, forced)
 
 
-def _check_golden(out, gold, names):
+def _check_golden(out, gold, names, g, what):
     """
-    HIP against the reference's golden planes DIRECTLY: NaN masks identical, the reference's own comparison
-    rule (tests/test_observation.py:1255: atol 1e-6, rtol 1e-5) and the tight bars the CPU oracle is held to
-    against the same files (tests/test_oracle_golden.py TIGHT: 1e-8 deg, 1e-5 km, 1e-9 km/s ...).
+    HIP against the reference's golden planes DIRECTLY (real CSPICE output): NaN masks identical, the reference's own
+    comparison rule (tests/test_observation.py:1255: atol 1e-6, rtol 1e-5), and per pixel the tighter of the conditioned
+    1e-9 deg evaluated on the GOLDEN planes and the flat bars of rounds 1-5 (tests/parity.py check_against_golden; the
+    worst pixel / bar of every file is printed).
     """
-    from test_oracle_golden import TIGHT
+    from parity import check_against_golden
 
-    for n in names:
-        a, b = out[n], np.asarray(gold[n], dtype=float)
-        assert np.array_equal(np.isnan(a), np.isnan(b)), n
-        assert np.allclose(a, b, rtol=1e-5, atol=1e-6, equal_nan=True), n
-        if np.isfinite(b).any():
-            d = np.abs(a - b)
-            if 'LON' in n or n == 'RA':
-                d = np.minimum(d, 360.0 - d)
-            rel = 1e-11 * np.nanmax(np.abs(b)) if n in ('RING-RADIUS', 'RING-DISTANCE', 'DISTANCE') else 0.0
-            assert np.nanmax(d) <= TIGHT[n] + rel, (n, float(np.nanmax(d)))
+    return check_against_golden(out, gold, names, g, f'HIP {what}')
 
 
 def _golden_setup(engine, g):
@@ -105,7 +97,7 @@ def test_golden_nav_all_planes(engine, oracle, jupiter):
     gold = np.load(os.path.join(GOLDEN, 'golden_test_nav.npz'))
     _golden_setup(engine, jupiter)
     out = engine.backplanes_img(oracle.PLANE_NAMES)
-    _check_golden(out, gold, oracle.PLANE_NAMES)
+    _check_golden(out, gold, oracle.PLANE_NAMES, jupiter, 'test_nav')
     ref = oracle.backplanes_img(jupiter, oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10), oracle.PLANE_NAMES)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter)
 
@@ -114,7 +106,7 @@ def test_golden_nav_alt(engine, oracle, jupiter):
     gold = np.load(os.path.join(GOLDEN, 'golden_test_nav_alt.npz'))
     _golden_setup(engine, jupiter)
     out = engine.backplanes_img(oracle.PLANE_NAMES, alt=34567.8912)
-    _check_golden(out, gold, oracle.PLANE_NAMES)
+    _check_golden(out, gold, oracle.PLANE_NAMES, jupiter, 'test_nav_alt')
 
 
 @pytest.mark.parametrize(
@@ -131,13 +123,14 @@ def test_golden_maps(engine, oracle, jupiter, name, interp, alt):
     _golden_setup(engine, jupiter)
     lon, lat = gold['LON-GRAPHIC'], gold['LAT-GRAPHIC']
     out = engine.backplanes_map(oracle.PLANE_NAMES, lon, lat, alt=alt)
-    _check_golden(out, gold, oracle.PLANE_NAMES)
+    _check_golden(out, gold, oracle.PLANE_NAMES, jupiter, name)
     disc = oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10)
     ref = oracle.backplanes_map(jupiter, disc, oracle.PLANE_NAMES, lon, lat, alt=alt)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter, r0=3.9)
     mapped = engine.map_cube(cube, out['PIXEL-X'], out['PIXEL-Y'], interp, True)
-    assert np.array_equal(np.isnan(mapped), np.isnan(gold['PRIMARY']))
-    assert np.allclose(mapped, gold['PRIMARY'], rtol=1e-5, atol=1e-6, equal_nan=True)
+    from parity import check_mapped_against_golden
+
+    check_mapped_against_golden(mapped, gold['PRIMARY'], interp, f'HIP {name}')
     ref_mapped = oracle.map_cube(cube, out['PIXEL-X'], out['PIXEL-Y'], interp, True)
     assert np.array_equal(np.isnan(mapped), np.isnan(ref_mapped))
     assert np.nanmax(np.abs(mapped - ref_mapped), initial=0.0) <= 1e-12
@@ -223,6 +216,44 @@ def test_no_optimize_speed_and_ragged_sizes(engine_fg, oracle, jupiter):
     d.rotation_rad = 1.0
     ref = oracle.backplanes_img(jupiter, d, oracle.PLANE_NAMES, alt=1234.5)
     _compare(out, ref, oracle.PLANE_NAMES, jupiter)
+
+
+def test_a_frame_taller_than_one_launch(engine_fg, oracle, jupiter):
+    """
+    70 000 x 64: more rows than gridDim.y holds (65 535) - the reference's loop (body_xy.py:3155-3166) has no limit; the
+    library maps such a frame in row blocks. A strip through a disc of 30 000 px radius: limb at both ends, all 26 planes,
+    whole frame and a row window that straddles the block boundary; into host memory (sparse bands) and device memory.
+    """
+    import torch
+
+    nx, ny = 64, 70_000
+    x0, y0, r0, rot = 20.3, 34_000.7, 30_000.0, 0.4
+    engine_fg.set_geometry(jupiter)
+    engine_fg.set_disc(x0, y0, r0, rot, nx, ny, True)
+    d = oracle.make_disc(x0, y0, r0, 0.0, nx, ny)
+    d.rotation_rad = rot
+    ref = oracle.backplanes_img(jupiter, d, oracle.PLANE_NAMES)
+    out = engine_fg.backplanes_img(oracle.PLANE_NAMES)
+    assert out['LON-GRAPHIC'].shape == (ny, nx) and 0.8 < np.isfinite(ref['LON-GRAPHIC']).mean() < 0.9
+    # (at 30 000 px per radius the strip resolves the sub-observer point to 1e-5 rad of emission: within a few pixels of it
+    #  the azimuth - pi - acos(q / (sin e sin i)) - is conditioned beyond the capped bar of tests/parity.py; those pixels,
+    #  emission < 0.01 deg, are held to 0.05 deg, the rest of the plane to the bar like every other plane)
+    core = ref['EMISSION'] < 0.01
+    assert 0 < core.sum() < 200
+    az_out, az_ref = out['AZIMUTH'].copy(), ref['AZIMUTH'].copy()
+    assert np.array_equal(np.isnan(az_out), np.isnan(az_ref)) and np.nanmax(np.abs(az_out[core] - az_ref[core])) < 0.05
+    az_out[core] = az_ref[core]
+    _compare({**out, 'AZIMUTH': az_out}, ref, oracle.PLANE_NAMES, jupiter, r0=r0)
+    names = ['LON-GRAPHIC', 'EMISSION', 'RA', 'RING-RADIUS']
+    bufs = {n: torch.full((ny, nx), 7.0, dtype=torch.float64, device='cuda') for n in names}
+    engine_fg.backplanes_img_device(bufs)
+    engine_fg.synchronize()
+    for n in names:
+        assert np.array_equal(bufs[n].cpu().numpy(), out[n], equal_nan=True), n
+    lo, n_rows = 30_000, 36_000  # (crosses row 32 768 of the frame and is itself more than one block)
+    win = engine_fg.backplanes_img_rows(names, lo, n_rows)
+    for n in names:
+        assert np.array_equal(win[n], out[n][lo : lo + n_rows], equal_nan=True), n
 
 
 def test_saturn_rings_divergent_path(engine_fg, oracle, saturn):
@@ -398,13 +429,13 @@ def test_projected_golden_maps_through_the_hip_map_kernel(jupiter, oracle, name,
     for n in body.backplanes:
         if n in gold.files:
             got[n] = body.get_backplane_map(n, **kw)
-            assert np.array_equal(np.isnan(got[n]), np.isnan(gold[n])), n
-            assert np.allclose(got[n], gold[n], rtol=1e-5, atol=1e-6, equal_nan=True), n
+    _check_golden(got, gold, list(got), jupiter, name)
     _compare(got, ref, list(got), jupiter, r0=3.9)
     cube = np.load(os.path.join(GOLDEN, 'input_cube.npz'))['data']
     mapped = body.map_img(cube, **kw)
-    assert np.array_equal(np.isnan(mapped), np.isnan(gold['PRIMARY']))
-    assert np.allclose(mapped, gold['PRIMARY'], rtol=1e-5, atol=1e-6, equal_nan=True)
+    from parity import check_mapped_against_golden
+
+    check_mapped_against_golden(mapped, gold['PRIMARY'], 'linear', f'HIP {name}')
 
 
 def test_nan_preclean_and_median_paths(engine, oracle, jupiter):
@@ -905,8 +936,9 @@ def test_spline_interpolation_vs_oracle_and_goldens(engine, oracle, jupiter):
     for name in ('quadratic', 'cubic'):
         gold = np.load(os.path.join(GOLDEN, f'golden_map_rectangular_{name}.npz'))['PRIMARY']
         got = obs.get_mapped_data(name, degree_interval=30)
-        assert np.array_equal(np.isnan(got), np.isnan(gold)), name
-        assert np.allclose(got, gold, rtol=1e-5, atol=1e-6, equal_nan=True), name
+        from parity import check_mapped_against_golden
+
+        check_mapped_against_golden(got, gold, name, f'HIP map_rectangular_{name}')
     sz = 200
     x0 = y0 = (sz - 1) / 2
     engine.set_geometry(jupiter)
@@ -970,8 +1002,9 @@ def test_smooth_interpolation_vs_oracle_kats_and_golden(engine, oracle, jupiter)
     obs.set_disc_params(2.5, 3.1, 3.9, 123.456)
     gold = np.load(os.path.join(GOLDEN, 'golden_map_rectangular_smooth.npz'))['PRIMARY']
     got = obs.get_mapped_data('smooth', degree_interval=30)
-    assert np.array_equal(np.isnan(got), np.isnan(gold))
-    assert np.allclose(got, gold, rtol=1e-5, atol=1e-6, equal_nan=True)
+    from parity import check_mapped_against_golden
+
+    check_mapped_against_golden(got, gold, 'smooth', 'HIP map_rectangular_smooth')
 
     sz = 200
     x0 = y0 = (sz - 1) / 2

@@ -171,6 +171,9 @@ def test_the_mixin_over_a_duck_typed_bodyxy():
         def get_x_map(self, **kw): return self._get_xy_map(**kw)[..., 0]
         def get_y_map(self, **kw): return self._get_xy_map(**kw)[..., 1]
 
+        def illumination_angles_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):  # body.py:2295: the scalar SPICE path
+            return ('the reference\'s own', lon, lat, alt, planetocentric)
+
     class Bound(HipBackplanes, DuckBodyXY):
         _hip_spice = spice
 
@@ -226,6 +229,29 @@ def test_the_mixin_over_a_duck_typed_bodyxy():
             assert m.shape == grid.shape[:2] and np.array_equal(m, eng.map_cube(img, x, y, interp, True)[0], equal_nan=True), interp
         saved = body._get_backplane_imgs_for_saving(['RA', 'DEC', 'EMISSION'])
         assert np.array_equal(saved['EMISSION'], eng.backplanes_img(['RA', 'DEC', 'EMISSION'])['EMISSION'], equal_nan=True)
+        # ---- the point forms: floats for a scalar point like the reference's (body.py:2295, 2617), arrays for arrays; a point
+        # above the surface or planetocentric input is the reference's own scalar path (`alt` there is not the backplanes' adjustment)
+        ref = eng.backplanes_map(['PHASE', 'INCIDENCE', 'EMISSION'], np.array([[150.0, 12.5]]), np.array([[-3.0, 40.0]]))
+        got = body.illumination_angles_from_lonlat(150.0, -3.0)
+        assert all(type(v) is float for v in got) and got == tuple(float(ref[n][0, 0]) for n in ('PHASE', 'INCIDENCE', 'EMISSION'))
+        assert f'{got[0]:.1f}'  # (what the (1, 1) arrays of round 5 broke)
+        arr = body.illumination_angles_from_lonlat(np.array([150.0, 12.5]), np.array([-3.0, 40.0]))
+        assert all(a.shape == (2,) for a in arr) and np.array_equal(arr[2], ref['EMISSION'][0], equal_nan=True)
+        assert body.illumination_angles_from_lonlat(np.zeros((0, 3)), np.zeros((0, 3)))[0].shape == (0, 3)
+        assert body.illumination_angles_from_lonlat(150.0, -3.0, alt=12.0) == ('the reference\'s own', 150.0, -3.0, 12.0, False)
+        assert body.illumination_angles_from_lonlat(150.0, -3.0, planetocentric=True) == ('the reference\'s own', 150.0, -3.0, 0.0, True)
+        ra0, dec0 = float(np.nanmean(saved['RA'])), float(np.nanmean(saved['DEC']))
+        for vis in (True, False):
+            q = eng.radec_query(np.array([ra0 + 0.004, ra0]), np.array([dec0, dec0 + 0.003]), ring_only_visible=vis)
+            one = body.ring_plane_coordinates(ra0 + 0.004, dec0, only_visible=vis)
+            assert all(type(v) is float for v in one) and np.array_equal(one, q[2:5, 0], equal_nan=True)
+            many = body.ring_plane_coordinates(np.array([ra0 + 0.004, ra0]), np.array([dec0, dec0 + 0.003]), only_visible=vis)
+            assert all(np.array_equal(m, q[2 + i], equal_nan=True) for i, m in enumerate(many))
+        # ---- one context per device for every bound body (the native BodyXY's), a body keeps its geometry block only
+        from planetmapper_amd.body_xy import _shared_engine
+
+        assert body._hip() is _shared_engine(0) and '_hip_engine' not in body.__dict__ and '_hip_geometry' in body.__dict__
+        other = Bound(g, target='JUPITER', target_id=599, observer='EARTH', frame='IAU_JUPITER')
+        assert other._hip() is body._hip()
     finally:
         eng.close()
-        body.__dict__['_hip_engine'].close()

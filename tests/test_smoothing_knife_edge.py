@@ -1,0 +1,71 @@
+"""
+What the reference itself does at the one smoothing-spline fit of the round-5 soak that the device does not reproduce
+(`spline_smoothing > 0`, body_xy.py:1673-1680 -> scipy RectBivariateSpline -> FITPACK regrid). CPU only, scipy only.
+
+FITPACK's fpknot gives a round's new knots to the intervals with the largest residual sums, and after each knot splits the
+interval's sum in proportion to the points on either side (`fpint = fpmax * an / am`). On this plane three intervals end
+up with shares that are all F / 5 in exact arithmetic; which of them takes the round's last knot - row 51 or row 61 - is
+the rounding of those products, i.e. the last bit of F, a sum of ~1 600 squared residuals. The tests below show that
+scipy's own answer is on that edge: moving ONE pixel of the 6 384 by ONE ulp gives the other knot and a spline 7e-3 of the
+data scale away - both with a residual inside FITPACK's acceptance band |fp - s| <= 1e-3 s. No implementation whose
+coefficient arithmetic is not FITPACK's serial Givens sequence to the bit can be on scipy's side of such an edge by anything
+but chance; the library reports these searches instead (PM_OPT_LAST_SM_KNIFE_EDGES; the GPU side of this fixture is
+tests/test_gpu_splines_cube_scale.py::test_smoothing_knife_edge_is_reported_and_lands_on_one_of_scipys_two_answers).
+Fixture: tests/golden/make_smoothing_knife_edge_fixture.py.
+"""
+import os
+
+import numpy as np
+import pytest
+from scipy.interpolate import RectBivariateSpline
+
+FIXTURE = os.path.join(os.path.dirname(__file__), 'golden', 'smoothing_knife_edge.npz')
+
+
+@pytest.fixture(scope='module')
+def case():
+    fx = np.load(FIXTURE)
+    return fx['plane'], (int(fx['degrees'][0]), int(fx['degrees'][1])), float(fx['s']), fx
+
+
+def fit(z, k, s):
+    return RectBivariateSpline(np.arange(z.shape[0]), np.arange(z.shape[1]), z, kx=k[0], ky=k[1], s=s)
+
+
+def test_scipys_knot_choice_flips_under_a_one_ulp_change_of_one_pixel(case):
+    plane, k, s, fx = case
+    base = fit(plane, k, s)
+    ty, tx = base.get_knots()
+    assert np.array_equal(ty, fx['knots_y']) and np.array_equal(tx, fx['knots_x'])
+    assert 61.0 in ty and 51.0 not in ty
+    yy, xx = np.mgrid[0 : plane.shape[0] - 1 : 40j, 0 : plane.shape[1] - 1 : 40j]
+    scale = float(np.abs(plane).max())
+    for i, j, direction in fx['flips']:
+        z = plane.copy()
+        z[i, j] = np.nextafter(z[i, j], np.inf * direction)
+        assert 0 < abs(z[i, j] - plane[i, j]) <= abs(np.spacing(plane[i, j]))
+        other = fit(z, k, s)
+        ty2, tx2 = other.get_knots()
+        assert np.array_equal(tx2, tx)
+        assert sorted(set(ty2) - set(ty)) == [51.0] and sorted(set(ty) - set(ty2)) == [61.0], (i, j)
+        # both are smoothing splines FITPACK accepts for this s ...
+        for sp in (base, other):
+            assert abs(sp.get_residual() - s) <= 1e-3 * s
+        # ... and they are not the same function: percent-level apart on a data scale of ~15
+        apart = float(np.max(np.abs(base.ev(yy, xx) - other.ev(yy, xx)))) / scale
+        assert 1e-3 < apart < 5e-2, apart
+
+
+def test_the_edge_is_rare_not_everywhere(case):
+    """most one-ulp changes leave scipy's fit where it is (the fixture's search found 3 flips in 443 single-pixel trials)"""
+    plane, k, s, fx = case
+    assert 100 <= int(fx['trials']) <= 3000
+    base_y = fit(plane, k, s).get_knots()[0]
+    r = np.random.default_rng(1)
+    same = 0
+    for _ in range(25):
+        z = plane.copy()
+        i, j = int(r.integers(0, plane.shape[0])), int(r.integers(0, plane.shape[1]))
+        z[i, j] = np.nextafter(z[i, j], np.inf)
+        same += bool(np.array_equal(fit(z, k, s).get_knots()[0], base_y))
+    assert same >= 22

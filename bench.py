@@ -36,7 +36,7 @@ Beside the headline line the same JSON object carries (rank 0, after the timed r
                                     gloo group: correctness + host-side contention, not scaling)
 At N > 1 rank 0 prints the headline line BEFORE these sections start (marked `extras: pending`) and the complete
 line after them; a section that hangs is abandoned after PM_BENCH_EXTRAS_TIMEOUT_S (300 s) with the complete
-line printed and exit status 0.
+line printed (the section marked `timed out`) and exit status 75 - the headline stands, the status says a section was lost.
 
 Usage:  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frame|saturn|all26|cube|cube-host]
 `--gpus N` with N > 1 launches itself: unless it already runs under torch.distributed.run
@@ -66,6 +66,7 @@ if REPO not in sys.path:
 HEADLINE = ['LON-GRAPHIC', 'LAT-GRAPHIC', 'PHASE', 'INCIDENCE', 'EMISSION']
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64
+EXTRAS_TIMED_OUT_STATUS = 75  # EX_TEMPFAIL: an optional N > 1 section was abandoned at its deadline; the headline line is complete
 METRIC = 'Mpix/s full backplane set (lat/lon/inc/emi/phase) + map-reproject, 4096^2 frame'
 
 
@@ -123,7 +124,19 @@ def self_launch(args) -> int:
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')  # dmabuf IPC: RCCL needs it on this pool
     env.setdefault('OMP_NUM_THREADS', '1')
-    return subprocess.run(cmd, env=env).returncode
+    # torch.distributed.run reports ANY non-zero exit of a rank as its own status 1: a rank that leaves with a status that
+    # means something (EXTRAS_TIMED_OUT_STATUS) also notes it in this file, and the launcher's 1 is translated back
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        env['PM_BENCH_STATUS_FILE'] = os.path.join(tmp, 'status')
+        rc = subprocess.run(cmd, env=env).returncode
+        if rc != 0 and os.path.exists(env['PM_BENCH_STATUS_FILE']):
+            try:
+                rc = int(open(env['PM_BENCH_STATUS_FILE']).read().strip() or rc)
+            except ValueError:
+                pass
+    return rc
 
 
 # ------------------------------------------------------------------ helpers
@@ -1267,20 +1280,29 @@ def headline(args) -> None:
         watchdog = None
         if d.world > 1:
             # ... and if the section HANGS (a collective some rank never joins), every rank gives up after a deadline of
-            # its own: rank 0 prints the complete line with the section marked as timed out, and all of them leave with
-            # status 0 - the headline of this N is measured and must not be lost to an optional section.
-            # (Status 0 is deliberate. The caller's contract is "one JSON line and the exit status": a non-zero status of one
-            #  rank makes torch.distributed.run tear the group down and report failure - the measured headline of this N
-            #  would be recorded as a failed run. The hang is not hidden: the line says `cube_host.error: timed out ...`,
-            #  and a rank stuck in a collective cannot tear its process group down anyway - os._exit is all that is left.)
+            # its own: rank 0 prints the complete line with the section marked as timed out, and every rank leaves with
+            # EXTRAS_TIMED_OUT_STATUS (75, EX_TEMPFAIL) - a status of its own, neither success nor a crash: the headline of
+            # this N is on stdout twice by then (the `extras: pending` line before the section, the complete line now), and a
+            # caller that looks at the status learns that a section was abandoned. Rank 0 leaves first; the other ranks wait
+            # a little longer, so that the launcher (which tears the group down at the first non-zero exit) cannot cut rank 0
+            # off before its line is out. (A rank stuck in a collective cannot tear its process group down: os._exit is all
+            # that is left.)
             import threading
 
             deadline = float(os.environ.get('PM_BENCH_EXTRAS_TIMEOUT_S', '300'))
 
             def bail() -> None:
                 if d.rank == 0:
-                    print(json.dumps(dict(line, cube_host={'error': f'timed out after {deadline:.0f} s: section abandoned'})), flush=True)
-                os._exit(0)
+                    print(json.dumps(dict(line, cube_host={'error': f'timed out after {deadline:.0f} s: section abandoned',
+                                                           'exit_status': EXTRAS_TIMED_OUT_STATUS})), flush=True)
+                    sys.stdout.flush()
+                    note = os.environ.get('PM_BENCH_STATUS_FILE')  # (self_launch: the launcher turns every rank status into 1)
+                    if note:
+                        with open(note, 'w') as f:
+                            f.write(str(EXTRAS_TIMED_OUT_STATUS))
+                else:
+                    time.sleep(2.0)
+                os._exit(EXTRAS_TIMED_OUT_STATUS)
 
             watchdog = threading.Timer(deadline, bail)
             watchdog.daemon = True

@@ -15,29 +15,20 @@
 #include <chrono>
 
 #include "pm_host.hip.h"
+#include "pm_rccl_abi.h"
 
 namespace {
 
-// the part of rccl.h this file needs (RCCL 2.x ABI)
-typedef struct ncclComm *ncclComm_t;
-struct ncclUniqueId {
-    char internal[128];
-};
-enum { ncclSuccess = 0, ncclInt32 = 2, ncclFloat64 = 8, ncclSum = 0 };
+// the part of rccl.h this file needs: pm_rccl_abi.h (checked against the installed header by tests/rccl_abi_check.cpp)
+using ncclComm_t = pm_rccl::Comm;
+using ncclUniqueId = pm_rccl::UniqueId;
+enum { ncclSuccess = pm_rccl::Success, ncclInt32 = pm_rccl::Int32, ncclFloat64 = pm_rccl::Float64, ncclSum = pm_rccl::Sum };
 
 struct Rccl {
     void *handle = nullptr;
-    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
-    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
-    int (*CommDestroy)(ncclComm_t) = nullptr;
-    int (*CommAbort)(ncclComm_t) = nullptr;
-    int (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
-    int (*GroupStart)() = nullptr;
-    int (*GroupEnd)() = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
+#define PM_RCCL_MEMBER(name, symbol) pm_rccl::name##_t name = nullptr;
+    PM_RCCL_SYMBOLS(PM_RCCL_MEMBER)
+#undef PM_RCCL_MEMBER
     std::string error;
 };
 
@@ -66,17 +57,9 @@ Rccl *rccl()
             if (!p && r.error.empty()) r.error = std::string("RCCL lacks ") + n;
             return p;
         };
-        r.GetUniqueId = (int (*)(ncclUniqueId *))sym("ncclGetUniqueId");
-        r.CommInitRank = (int (*)(ncclComm_t *, int, ncclUniqueId, int))sym("ncclCommInitRank");
-        r.CommDestroy = (int (*)(ncclComm_t))sym("ncclCommDestroy");
-        r.CommAbort = (int (*)(ncclComm_t))sym("ncclCommAbort");
-        r.AllGather = (int (*)(const void *, void *, size_t, int, ncclComm_t, hipStream_t))sym("ncclAllGather");
-        r.AllReduce = (int (*)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclAllReduce");
-        r.Send = (int (*)(const void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclSend");
-        r.Recv = (int (*)(void *, size_t, int, int, ncclComm_t, hipStream_t))sym("ncclRecv");
-        r.GroupStart = (int (*)())sym("ncclGroupStart");
-        r.GroupEnd = (int (*)())sym("ncclGroupEnd");
-        r.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+#define PM_RCCL_BIND(name, symbol) r.name = (pm_rccl::name##_t)sym(symbol);
+        PM_RCCL_SYMBOLS(PM_RCCL_BIND)
+#undef PM_RCCL_BIND
     });
     return &r;
 }

@@ -45,10 +45,28 @@ def uneven_planes(world: int) -> int:
     return {2: 1, 3: 4}.get(world, 2 * world - 3)
 
 
+_SHARED: dict = {}  # ranks that are THREADS of one process share the cube and its one-rank reference (config 5: 4 GiB each)
+_SHARED_LOCK = threading.Lock()
+
+
+def shared(key, make):
+    with _SHARED_LOCK:
+        if key not in _SHARED:
+            _SHARED.clear()  # (one case at a time: the previous case's cube and reference go)
+            _SHARED[key] = make()
+        return _SHARED[key]
+
+
 def make_cube(planes: int, sz: int, redo_plane: int | None):
     rng = np.random.default_rng(4242)
-    cube = rng.standard_normal((planes, sz, sz)) + 2.0
-    cube[rng.random(cube.shape) < 2e-3] = np.nan
+    if planes * sz * sz > (1 << 27):  # (plane by plane: the masks of a 4 GiB cube are 4.5 GiB more)
+        cube = np.empty((planes, sz, sz))
+        for p in range(planes):
+            cube[p] = rng.standard_normal((sz, sz)) + 2.0
+            cube[p][rng.random((sz, sz)) < 2e-3] = np.nan
+    else:
+        cube = rng.standard_normal((planes, sz, sz)) + 2.0
+        cube[rng.random(cube.shape) < 2e-3] = np.nan
     if redo_plane is not None:
         # an -inf block: the pixels in its interior have no finite neighbour and take the plane's nanmedian -
         # the plane is mapped, flagged, and redone behind the pipeline AFTER its exchange may have started
@@ -110,9 +128,12 @@ def capi_rank(rank: int, world: int, uid: bytes, args, report: dict) -> None:
                     planes = uneven_planes(world)
                 if case == 'redo':
                     redo = planes // 2
-                cube = make_cube(planes, args.size, redo)
+                if args.threads:
+                    cube, ref = shared((case, planes, args.size, redo), lambda: (lambda c: (c, reference(eng, c, dxm, dym, n0, n1)))(make_cube(planes, args.size, redo)))
+                else:
+                    cube = make_cube(planes, args.size, redo)
+                    ref = reference(eng, cube, dxm, dym, n0, n1)
                 a, b, per_rank = shard_bounds(planes, world, rank)
-                ref = reference(eng, cube, dxm, dym, n0, n1)
                 out = torch.full((world, per_rank, n0, n1), -7.0, dtype=torch.float64, device='cuda')
                 block = np.ascontiguousarray(cube[a:b])
                 if case in ('device', 'uneven', 'redo', 'fail', 'send_fault'):

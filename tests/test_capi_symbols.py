@@ -99,28 +99,39 @@ def test_missing_rccl_is_an_error_code_not_a_crash():
     assert f'rc {_lib.PM_ERR_UNSUPPORTED}' in r.stdout
 
 
-def test_hand_declared_rccl_abi_matches_the_installed_header():
+def test_hand_declared_rccl_abi_matches_the_installed_header(tmp_path):
     """
-    pm_comm.hip binds RCCL at run time and declares the part of rccl.h it needs by hand (no link-time dependency):
-    the enum values and the unique-id size there must be those of the installed header, and every symbol it asks
-    dlsym for must be declared there.
+    pm_comm.hip binds RCCL at run time through hand declarations (planetmapper_amd/csrc/pm_rccl_abi.h: no build- or
+    link-time dependency). tests/rccl_abi_check.cpp includes them NEXT TO the installed <rccl/rccl.h> and static_asserts
+    sizeof / alignof(ncclUniqueId), the enum values and sizes, and every bound prototype: compiled here (the compiler, not
+    a regular expression, reads the header) - and once more with a wrong prototype and a wrong constant, which must not compile.
     """
     import re
+    import shutil
+    import subprocess
 
     header = '/opt/rocm/include/rccl/rccl.h'
-    if not os.path.exists(header):
-        pytest.skip('no rccl.h on this machine')
-    h = open(header).read()
-    src = open(os.path.join(REPO, 'planetmapper_amd', 'csrc', 'pm_comm.hip')).read()
-    ours = dict(re.findall(r'\b(ncclSuccess|ncclInt32|ncclFloat64|ncclSum)\s*=\s*(\d+)', src))
-    assert set(ours) == {'ncclSuccess', 'ncclInt32', 'ncclFloat64', 'ncclSum'}
-    for name, value in ours.items():
-        m = re.search(r'\b%s\s*=\s*(\d+)' % name, h)
-        assert m and m.group(1) == value, (name, value, m and m.group(1))
-    assert re.search(r'#define\s+NCCL_UNIQUE_ID_BYTES\s+128\b', h) and 'char internal[128]' in src
-    for sym in re.findall(r'sym\("(nccl\w+)"\)', src):
-        assert re.search(r'\b%s\s*\(' % sym, h), sym
+    if not os.path.exists(header) or not shutil.which('g++'):
+        pytest.skip('no rccl.h / g++ on this machine')
+    csrc = os.path.join(REPO, 'planetmapper_amd', 'csrc')
+    cmd = ['g++', '-std=c++17', '-fsyntax-only', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include']
+    check = os.path.join(REPO, 'tests', 'rccl_abi_check.cpp')
+    ok = subprocess.run(cmd + ['-I' + csrc, check], capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    ours = open(os.path.join(csrc, 'pm_rccl_abi.h')).read()
+    for wrong in (ours.replace('using Send_t = int (*)(const void *, size_t,', 'using Send_t = int (*)(const void *, int,'),
+                  ours.replace('Float64 = 8', 'Float64 = 7'), ours.replace('char internal[128]', 'char internal[64]')):
+        assert wrong != ours
+        (tmp_path / 'pm_rccl_abi.h').write_text(wrong)
+        bad = subprocess.run(cmd + ['-I' + str(tmp_path), check], capture_output=True, text=True)
+        assert bad.returncode != 0 and 'static assertion failed' in bad.stderr
+    src = open(os.path.join(csrc, 'pm_comm.hip')).read()
+    assert '#include "pm_rccl_abi.h"' in src and 'PM_RCCL_SYMBOLS(PM_RCCL_BIND)' in src
+    # (nothing in the library declares an nccl type or prototype of its own any more)
+    assert not re.search(r'struct\s+ncclUniqueId\s*\{|\(int \(\*\)\([^)]*\)\)sym\("nccl', src)
+    symbols = re.findall(r'X\(\w+, "(nccl\w+)"\)', ours)
+    assert len(symbols) == 11
     # ... and the loopback transport of the tests exports exactly those symbols
     lb = open(os.path.join(REPO, 'tests', 'loopback', 'loopback_nccl.cpp')).read()
-    for sym in re.findall(r'sym\("(nccl\w+)"\)', src):
+    for sym in symbols:
         assert re.search(r'\b%s\s*\(' % sym, lb), sym

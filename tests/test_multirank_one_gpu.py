@@ -77,6 +77,27 @@ def test_c_abi_sharded_cube_over_the_loopback_transport_threads(world):
     assert nbytes > 0
 
 
+def test_c_abi_sharded_cube_at_config5_shapes_world_8():
+    """
+    BASELINE config 5 as the north star shards it, every number real but the transport: 512 planes of 1024^2 f64 (4 GiB),
+    8 ranks (threads: the pool allows 6 PROCESSES on a card) x 64 planes, the 1 deg map, 33.2 MB per rank in the exchange
+    sequence of pm_exchange_planes (8 exchanges per rank - 7 of 9 planes, one of 1 - each a group of 7 sends and 7
+    receives), from pinned host blocks and from device blocks; every rank's gathered (512, 180, 360) cube bit-equal to the
+    cube mapped by one rank alone.
+    """
+    _build_loopback()
+    world = 8
+    p = subprocess.Popen([sys.executable, WORKER, 'capi', '--threads', '--world', str(world), '--planes', '512', '--size', '1024',
+                          '--cases', 'host,device', '--deadline', '900'], env=_env(PM_LOOPBACK_TIMEOUT_S='300'), stdout=subprocess.PIPE,
+                         stderr=subprocess.STDOUT, text=True)
+    (rep,) = _reports([p], timeout=1000)
+    assert rep['ok'] and not rep['hung'], rep
+    assert all(set(c) == {'host', 'device'} for c in rep['checks'].values()) and len(rep['checks']) == world
+    groups, sends, recvs, nbytes, allreduces, aborts = rep['loopback_stats[groups,sends,recvs,bytes,allreduces,aborts]']
+    assert aborts == 0 and sends == recvs == 2 * world * 8 * (world - 1)  # 2 cases x 8 ranks x 8 exchanges x 7 peers
+    assert nbytes == 2 * world * (world - 1) * 64 * 180 * 360 * 8  # every rank's 64 mapped planes to each of its 7 peers, twice
+
+
 def test_c_abi_sharded_cube_survives_a_failing_transport():
     """the third send of rank 1 fails inside the exchange: every rank returns an error, nobody waits for ever"""
     _build_loopback()
@@ -162,14 +183,15 @@ def test_bench_headline_and_sharded_cube_at_two_ranks_on_one_gpu():
 def test_bench_gives_up_on_a_hanging_extra_section_and_keeps_its_headline():
     """
     The optional sharded-cube section of an N > 1 run is given a deadline (PM_BENCH_EXTRAS_TIMEOUT_S): when it passes -
-    here at once - every rank leaves with status 0 and rank 0 has printed the complete headline line with the section
-    marked as timed out; the measured headline of that N is never lost to a collective that hangs.
+    here at once - rank 0 has printed the complete headline line with the section marked as timed out, and the run leaves
+    with a status of its own (75: not success, not a crash); the measured headline of that N is never lost to a
+    collective that hangs, and a caller that reads the status learns that a section was abandoned.
     """
     repo = os.path.dirname(HERE)
     p = subprocess.run([sys.executable, os.path.join(repo, 'bench.py'), '--gpus', '2', '--shared-gpu', '--size', '1024', '--steps', '10',
                         '--warmup', '2', '--preheat-steps', '5', '--planes', '48'], env=_env(PM_BENCH_EXTRAS_TIMEOUT_S='0.05'),
                        capture_output=True, text=True, timeout=600)
     lines = [json.loads(ln) for ln in p.stdout.splitlines() if ln.startswith('{')]
-    assert p.returncode == 0 and len(lines) == 2, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
+    assert p.returncode == 75 and len(lines) == 2, (p.returncode, p.stdout[-2000:], p.stderr[-2000:])
     assert 'pending' in lines[0]['extras'] and lines[1]['value'] == lines[0]['value']
-    assert 'timed out' in lines[1]['cube_host']['error']
+    assert 'timed out' in lines[1]['cube_host']['error'] and lines[1]['cube_host']['exit_status'] == 75

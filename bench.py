@@ -829,9 +829,37 @@ def api_path_section(g, sz: int, device: int) -> dict:
     reps = [once() for _ in range(7)]
     imgs, maps = [r[0] for r in reps], [r[1] for r in reps]
     tot = [a + b for a, b in reps]
-    ms = lambda ts: {'median': round(float(np.median(ts)) * 1e3, 2), 'min': round(min(ts) * 1e3, 2), 'max': round(max(ts) * 1e3, 2),  # noqa: E731
+    ms = lambda ts: {'median': round(float(np.median(ts)) * 1e3, 3), 'min': round(min(ts) * 1e3, 3), 'max': round(max(ts) * 1e3, 3),  # noqa: E731
                      'reps': len(ts)}
+
+    # The same calls with `device=True`: the planes stay in HBM as DeviceArrays (`__dlpack__` / `__cuda_array_interface__`),
+    # what a GPU-side consumer takes. Timed to the point where the results are complete (engine synchronised).
+    def once_device():
+        obs.set_disc_params(x0, x0, 0.9 * x0, 0.0)  # (cold cache: the previous handles are invalidated, their memory pooled)
+        t0 = time.perf_counter()
+        planes = [getattr(obs, name)(device=True) for name in getters]
+        obs._engine.synchronize()
+        t1 = time.perf_counter()
+        mapped = obs.get_mapped_data(degree_interval=1, device=True)
+        obs._engine.synchronize()
+        t2 = time.perf_counter()
+        assert all(p.shape == (sz, sz) and p.valid for p in planes) and mapped.shape == (1, 180, 360)
+        return t1 - t0, t2 - t1, planes, mapped
+
+    _, _, planes_d, mapped_d = once_device()
+    host_planes = [getattr(obs, name)() for name in getters]
+    same = all(np.array_equal(d.numpy(), h, equal_nan=True) for d, h in zip(planes_d, host_planes)) and np.array_equal(
+        mapped_d.numpy(), obs.get_mapped_data(degree_interval=1), equal_nan=True)
+    del planes_d, mapped_d, host_planes
+    dreps = [once_device()[:2] for _ in range(7)]
+    device_leg = {
+        'calls': 'the same getters with device=True: results left in HBM as DeviceArray (DLPack / __cuda_array_interface__), engine synchronised',
+        'ms_five_backplane_getters': ms([r[0] for r in dreps]),
+        'ms_get_mapped_data': ms([r[1] for r in dreps]),
+        'equal_to_the_numpy_getters': bool(same),
+    }
     return {
+        'device': device_leg,
         'calls': 'Observation(data=(1, %d, %d) f64).get_{lon,lat,phase_angle,incidence_angle,emission_angle}_img() + '
         'get_mapped_data(degree_interval=1), cold cache, through the Python shim' % (sz, sz),
         'ms': ms(tot),

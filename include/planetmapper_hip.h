@@ -398,7 +398,7 @@ int pm_set_chunk_callback(pm_ctx *ctx, pm_chunk_callback cb, void *user);
  * planes); planetmapper_amd allocates those arrays from this pool.
  */
 int pm_host_alloc(pm_ctx *ctx, uint64_t bytes, void **hptr);
-int pm_host_free(pm_ctx *ctx, void *hptr);
+int pm_host_free(pm_ctx *ctx, void *hptr); /* ctx may be NULL: a block that outlived the context that allocated it */
 int pm_host_register(pm_ctx *ctx, void *hptr, uint64_t bytes);
 int pm_host_unregister(pm_ctx *ctx, void *hptr);
 
@@ -407,6 +407,23 @@ int pm_device_malloc(pm_ctx *ctx, uint64_t bytes, void **dptr);
 int pm_device_free(pm_ctx *ctx, void *dptr);
 int pm_memcpy_h2d(pm_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes);
 int pm_memcpy_d2h(pm_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes);
+
+/*
+ * DLPack export of device memory (the results the Python layer leaves in HBM: planetmapper_amd/device_array.py; no
+ * counterpart in the reference, whose getters return numpy arrays - body_xy.py:2586-2630). A `hold` counts the live
+ * exports of one block. pm_dlpack_export returns a DLManagedTensor* (dlpack.h, legacy layout: what a 'dltensor' capsule
+ * carries; device type kDLROCM) whose deleter is C code of this library: a consumer that lets go - from any thread, at
+ * interpreter shutdown - calls into no host language. pm_dlpack_release ends the owner's interest: with no export left
+ * the hold is deleted at once (and the block freed with hipFree if `free_memory`), returns 1; otherwise the LAST
+ * export's deleter does both, returns 0. pm_dlpack_delete runs a managed tensor's deleter (a capsule nobody consumed).
+ * dtype_code: 0 int, 1 unsigned, 2 float (DLDataTypeCode).
+ */
+typedef struct pm_dlpack_hold pm_dlpack_hold;
+pm_dlpack_hold *pm_dlpack_hold_create(void *dptr, int device);
+void *pm_dlpack_export(pm_dlpack_hold *hold, int dtype_code, int bits, int ndim, const int64_t *shape);
+int64_t pm_dlpack_exports(const pm_dlpack_hold *hold);
+int pm_dlpack_release(pm_dlpack_hold *hold, int free_memory);
+void pm_dlpack_delete(void *managed_tensor);
 
 /* State ----------------------------------------------------------------------- */
 /* replaces Body.__init__ state (body.py:323-606) as seen by the pixel loops */

@@ -59,6 +59,7 @@ EXPORTS = (
     'pm_set_option', 'pm_get_option', 'pm_host_alloc', 'pm_host_free', 'pm_host_register',
     'pm_host_unregister', 'pm_shard_bounds', 'pm_comm_unique_id', 'pm_comm_create', 'pm_comm_destroy',
     'pm_map_cube_sharded', 'pm_mapped_data', 'pm_exchange_planes', 'pm_set_chunk_callback',
+    'pm_dlpack_hold_create', 'pm_dlpack_export', 'pm_dlpack_exports', 'pm_dlpack_release', 'pm_dlpack_delete',
 )  # fmt: skip
 
 PM_OPT_GENERAL_KERNEL = 1
@@ -156,6 +157,16 @@ def load() -> ctypes.CDLL:
     lib.pm_set_stream.argtypes = [vp, vp]
     lib.pm_device_malloc.argtypes = [vp, ctypes.c_uint64, ctypes.POINTER(vp)]
     lib.pm_device_free.argtypes = [vp, vp]
+    lib.pm_dlpack_hold_create.restype = vp
+    lib.pm_dlpack_hold_create.argtypes = [vp, c_int]
+    lib.pm_dlpack_export.restype = vp
+    lib.pm_dlpack_export.argtypes = [vp, c_int, c_int, c_int, vp]
+    lib.pm_dlpack_exports.restype = ctypes.c_int64
+    lib.pm_dlpack_exports.argtypes = [vp]
+    lib.pm_dlpack_release.restype = c_int
+    lib.pm_dlpack_release.argtypes = [vp, c_int]
+    lib.pm_dlpack_delete.restype = None
+    lib.pm_dlpack_delete.argtypes = [vp]
     lib.pm_memcpy_h2d.argtypes = [vp, vp, vp, ctypes.c_uint64]
     lib.pm_memcpy_d2h.argtypes = [vp, vp, vp, ctypes.c_uint64]
     lib.pm_set_geometry.argtypes = [vp, ctypes.POINTER(PMGeometry)]

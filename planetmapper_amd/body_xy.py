@@ -231,6 +231,12 @@ class BodyXY:
                 arr = buffers.pop(key)
                 recycle(arr)
                 del arr
+        # device-resident results (`device=True` getters): later accesses of the handles raise; their memory goes back to
+        # the engine once no DLPack consumer holds it
+        for key, val in self._cache.items():
+            if isinstance(key, tuple) and key and key[0] in ('img_dev', 'map_dev', 'mapped_dev'):
+                for arr in (val.values() if isinstance(val, dict) else (val if isinstance(val, tuple) else (val,))):
+                    arr.invalidate()
         self._cache.clear()
 
     def _invalidate_disc_parameters(self) -> None:  # body_xy.py:696-698
@@ -439,6 +445,27 @@ class BodyXY:
                 self._cache[('img', n, alt)] = _readonly(a)
             del out, a
         return {n: self._cache[('img', n, alt)] for n in names}
+
+    def _img_planes_device(self, names: Iterable[str]) -> dict:
+        """
+        The device form of `_img_planes`: the family's planes as `DeviceArray`s (planetmapper_amd/device_array.py) in the
+        engine's HBM, one launch for the missing ones, nothing crosses PCIe. Cached like the host planes (same keys with
+        'img_dev'), invalidated with them by `_clear_cache`.
+        """
+        names = list(names)
+        alt = self._alt_adjustment
+        missing = [n for n in names if ('img_dev', n, alt) not in self._cache]
+        if missing:
+            if not self._test_if_img_size_valid():
+                raise ValueError('nx and ny must be positive to create a backplane image')
+            eng = self._bind()
+            if not hasattr(eng, 'device_array'):
+                raise _lib.UnsupportedError('this engine keeps no results on a device')
+            out = {n: eng.device_array((self._ny, self._nx)) for n in missing}
+            eng.backplanes_img_device(out, alt=alt)
+            for n, a in out.items():
+                self._cache[('img_dev', n, alt)] = a
+        return {n: self._cache[('img_dev', n, alt)] for n in names}
 
     def prefetch_backplane_imgs(self, names: Iterable[str] | None = None, *, alt: float = 0.0) -> None:
         """
@@ -944,10 +971,20 @@ class BodyXY:
                 )
             ) from exc
 
-    def get_backplane_img(self, name: str, *, alt: float = 0.0) -> np.ndarray:
-        """Fresh copy of a backplane image (body_xy.py:2586-2630)."""
+    def get_backplane_img(self, name: str, *, alt: float = 0.0, device: bool = False):
+        """
+        Fresh copy of a backplane image (body_xy.py:2586-2630). `device=True` (not in the reference): the plane where it
+        was computed - a read-only `DeviceArray` in the GPU's HBM (`__dlpack__`, `__cuda_array_interface__`; valid until
+        the disc or the image size changes) instead of a numpy copy that crossed PCIe; default backplanes only.
+        """
         with _AltitudeContext(self, alt):
-            return self.backplanes[self.standardise_backplane_name(name)].get_img().copy()
+            bp = self.backplanes[self.standardise_backplane_name(name)]
+            if device:
+                fn = getattr(bp.get_img, '__func__', None)
+                if fn is None or not getattr(fn, '_pm_device', False):
+                    raise _lib.UnsupportedError(f'backplane {bp.name!r} is a user-registered function of numpy arrays: no device form')
+                return bp.get_img(device=True)
+            return bp.get_img().copy()
 
     def get_backplane_map(self, name: str, **map_kwargs) -> np.ndarray:
         """Fresh copy of a backplane map (body_xy.py:2632-2664)."""
@@ -1023,8 +1060,12 @@ _FAMILIES = {
 
 
 def _make_getters(stem: str, plane: str, family: tuple[str, ...]):
-    def get_img(self: BodyXY) -> np.ndarray:
+    def get_img(self: BodyXY, *, device: bool = False):
+        if device:
+            return self._img_planes_device(family)[plane]
         return self._img_planes(family)[plane]
+
+    get_img._pm_device = True
 
     def get_map(self: BodyXY, **map_kwargs) -> np.ndarray:
         return self._map_planes(family, map_kwargs)[plane]
@@ -1033,7 +1074,7 @@ def _make_getters(stem: str, plane: str, family: tuple[str, ...]):
     get_map.__name__ = f'get_{stem}_map'
     get_img.__doc__ = (
         f'Read-only (ny, nx) float64 array of the {plane} backplane (reference `BodyXY.get_{stem}_img`); '
-        'NaN where undefined.'
+        'NaN where undefined. `device=True`: the same plane as a read-only `DeviceArray` left in the GPU\'s HBM.'
     )
     get_map.__doc__ = (
         f'Read-only (n0, n1) float64 map of the {plane} backplane (reference `BodyXY.get_{stem}_map`).'

@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#include <atomic>
+
 #include "pm_host.hip.h"
 
 namespace pmh {
@@ -603,8 +605,10 @@ int pm_host_alloc(pm_ctx *ctx, uint64_t bytes, void **hptr)
 
 int pm_host_free(pm_ctx *ctx, void *hptr)
 {
-    if (!ctx) return PM_ERR_INVALID_ARGUMENT;
     if (!hptr) return PM_OK;
+    // (ctx == NULL: the context that allocated the block has been destroyed before the block's owner let go of it -
+    //  no stream of ours can still be working on it)
+    if (!ctx) return hipHostFree(hptr) == hipSuccess ? PM_OK : PM_ERR_HIP;
     PM_HIP(ctx, hipSetDevice(ctx->device));
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PM_HIP(ctx, hipHostFree(hptr));
@@ -644,6 +648,94 @@ int pm_device_free(pm_ctx *ctx, void *dptr)
     PM_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PM_HIP(ctx, hipFree(dptr));
     return PM_OK;
+}
+
+// ------------------------------------------------------------------ DLPack export of device memory
+namespace {
+// dlpack.h (legacy DLManagedTensor), restated: the layout a 'dltensor' capsule carries
+struct DLDevice { int32_t device_type, device_id; };
+struct DLDataType { uint8_t code, bits; uint16_t lanes; };
+struct DLTensor { void *data; DLDevice device; int32_t ndim; DLDataType dtype; int64_t *shape; int64_t *strides; uint64_t byte_offset; };
+struct DLManagedTensor { DLTensor dl_tensor; void *manager_ctx; void (*deleter)(DLManagedTensor *); };
+constexpr int kDLROCM = 10;
+struct Export { DLManagedTensor m; int64_t shape[8]; };
+}  // namespace
+struct pm_dlpack_hold {
+    std::atomic<int64_t> exports{0};
+    std::atomic<int> orphaned{0};  // 1: the owner is gone, memory stays; 2: the owner is gone and the last export frees the memory
+    void *dptr = nullptr;
+    int device = 0;
+};
+namespace {
+void hold_finish(pm_dlpack_hold *h, int mode)
+{
+    if (mode == 2 && h->dptr) {
+        (void)hipSetDevice(h->device);
+        (void)hipFree(h->dptr);
+    }
+    delete h;
+}
+void export_deleter(DLManagedTensor *m)
+{
+    if (!m) return;
+    pm_dlpack_hold *h = (pm_dlpack_hold *)m->manager_ctx;
+    delete (Export *)m;  // (m is the first member of its Export)
+    if (h->exports.fetch_sub(1) == 1) {
+        const int mode = h->orphaned.load();
+        if (mode) hold_finish(h, mode);
+    }
+}
+}  // namespace
+
+pm_dlpack_hold *pm_dlpack_hold_create(void *dptr, int device)
+{
+    pm_dlpack_hold *h = new (std::nothrow) pm_dlpack_hold();
+    if (h) {
+        h->dptr = dptr;
+        h->device = device;
+    }
+    return h;
+}
+
+void *pm_dlpack_export(pm_dlpack_hold *hold, int dtype_code, int bits, int ndim, const int64_t *shape)
+{
+    if (!hold || ndim < 0 || ndim > 8 || (ndim && !shape) || hold->orphaned.load()) return nullptr;
+    Export *e = new (std::nothrow) Export();
+    if (!e) return nullptr;
+    for (int i = 0; i < ndim; i++) e->shape[i] = shape[i];
+    e->m.dl_tensor.data = hold->dptr;
+    e->m.dl_tensor.device = {kDLROCM, hold->device};
+    e->m.dl_tensor.ndim = ndim;
+    e->m.dl_tensor.dtype = {(uint8_t)dtype_code, (uint8_t)bits, 1};
+    e->m.dl_tensor.shape = e->shape;
+    e->m.dl_tensor.strides = nullptr;  // C-contiguous
+    e->m.dl_tensor.byte_offset = 0;
+    e->m.manager_ctx = hold;
+    e->m.deleter = export_deleter;
+    hold->exports.fetch_add(1);
+    return &e->m;
+}
+
+int64_t pm_dlpack_exports(const pm_dlpack_hold *hold) { return hold ? hold->exports.load() : 0; }
+
+int pm_dlpack_release(pm_dlpack_hold *hold, int free_memory)
+{
+    if (!hold) return 1;
+    // (an export that ends between the two steps sees `orphaned` set and finishes the hold itself: the exchange
+    //  below makes exactly one side do it)
+    hold->exports.fetch_add(1);  // the owner's own guard
+    hold->orphaned.store(free_memory ? 2 : 1);
+    if (hold->exports.fetch_sub(1) == 1) {
+        hold_finish(hold, free_memory ? 2 : 1);
+        return 1;
+    }
+    return 0;
+}
+
+void pm_dlpack_delete(void *managed_tensor)
+{
+    DLManagedTensor *m = (DLManagedTensor *)managed_tensor;
+    if (m && m->deleter) m->deleter(m);
 }
 
 int pm_memcpy_h2d(pm_ctx *ctx, void *dst_dev, const void *src_host, uint64_t bytes)

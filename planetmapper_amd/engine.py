@@ -8,6 +8,7 @@ Observation classes (the reference-compatible API) are built on it.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Iterable, Mapping
 
 import numpy as np
@@ -107,12 +108,26 @@ class Engine:
         self._plane_bytes = 0
         self._plane_limit = _plane_pool_limit()
         self._free_counts = self._calibrate_recycling()
+        # device memory of invalidated DeviceArrays, kept for the next ones (PLANETMAPPER_DEVICE_POOL_MB, default 8 GiB of 288)
+        self._device_pool: dict[int, list] = {}
+        self._device_pool_bytes = 0
+        self._device_waiting: list = []
+        self._device_pool_limit = int(float(os.environ.get('PLANETMAPPER_DEVICE_POOL_MB', '8192')) * (1 << 20))
         if general_kernel is not None:
             self.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1 if general_kernel else 0)
 
     # ------------------------------------------------------------------ plumbing
     def close(self) -> None:
         self._plane_pool = {}
+        if getattr(self, '_ctx', None):
+            self._device_sweep()
+            for arr in self._device_waiting:
+                arr._orphan()  # (still imported by a consumer: the import's own deleter frees the block)
+            self._device_waiting = []
+            for blocks in self._device_pool.values():
+                for ptr in blocks:
+                    self._lib.pm_device_free(self._ctx, ctypes.c_void_p(ptr))
+            self._device_pool, self._device_pool_bytes = {}, 0
         if getattr(self, '_ctx', None):
             self._lib.pm_destroy(self._ctx)
             self._ctx = None
@@ -201,8 +216,9 @@ class Engine:
     @staticmethod
     def _release_pinned(engine_ref, ptr: int) -> None:
         eng = engine_ref()
-        if eng is not None and getattr(eng, '_ctx', None):
-            eng._lib.pm_host_free(eng._ctx, ctypes.c_void_p(ptr))
+        ctx = getattr(eng, '_ctx', None) if eng is not None else None
+        # (an array that outlives its engine - close() / garbage collection came first - is freed without a context)
+        _lib.load().pm_host_free(ctx, ctypes.c_void_p(ptr))
 
     # ------------------------------------------------------------------ recycled result planes
     def plane_buffer(self, shape) -> np.ndarray:
@@ -251,9 +267,60 @@ class Engine:
         return True
 
     def _calibrate_recycling(self):
-        # the counts `recycle_plane` sees for an array nobody else refers to, measured through the same calls
+        # the counts `recycle_plane` sees for an array nobody else refers to, measured through the same calls ...
         probe = np.frombuffer(bytearray(16), dtype=np.float64).reshape((2,))
-        return self.recycle_plane(probe, _calibrate=True)
+        free = self.recycle_plane(probe, _calibrate=True)
+        # ... and a NEGATIVE check: an array somebody holds (directly, or through a view) must count differently - on an
+        # interpreter where it does not (free-threaded builds, borrowed-reference loads) or that is not CPython the pool
+        # is switched off: recycling an array a user still looks at would overwrite their data
+        import platform
+
+        held = probe
+        viewed = np.frombuffer(bytearray(16), dtype=np.float64).reshape((2,))
+        view = viewed[:1]
+        sound = (platform.python_implementation() == 'CPython' and self.recycle_plane(probe, _calibrate=True) != free
+                 and self.recycle_plane(viewed, _calibrate=True) != free)  # fmt: skip
+        del held, view
+        if not sound:
+            self._plane_limit = 0
+        return free
+
+    # ------------------------------------------------------------------ results that stay on the device
+    def device_array(self, shape, dtype=np.float64):
+        """A `DeviceArray` (planetmapper_amd/device_array.py) of this engine: the memory of a result that stays in HBM."""
+        from .device_array import DeviceArray  # noqa: PLC0415
+
+        return DeviceArray(self, shape, dtype)
+
+    def _device_take(self, nbytes: int) -> int:
+        """device memory for a DeviceArray: a block `_device_give` took back if one of this size is there (a cold getter after
+        a disc change finds the planes of the frame before it: no hipMalloc - 0.1-1 ms per 134 MB plane - in the call)"""
+        self._device_sweep()
+        free = self._device_pool.get(int(nbytes))
+        if free:
+            self._device_pool_bytes -= int(nbytes)
+            return free.pop()
+        return self.device_malloc(max(int(nbytes), 1))
+
+    def _device_wait(self, arr) -> None:
+        """an invalidated DeviceArray a DLPack consumer still imports: its memory is taken back once the consumer lets go"""
+        if arr not in self._device_waiting:
+            self._device_waiting.append(arr)
+
+    def _device_sweep(self) -> None:
+        if self._device_waiting:
+            waiting, self._device_waiting = self._device_waiting, []
+            for arr in waiting:
+                arr._settle()  # (back into the list if still imported)
+
+    def _device_give(self, ptr: int, nbytes: int) -> None:
+        if not getattr(self, '_ctx', None):
+            return  # (the context took its memory with it)
+        if self._device_pool_bytes + nbytes <= self._device_pool_limit:
+            self._device_pool.setdefault(int(nbytes), []).append(ptr)
+            self._device_pool_bytes += int(nbytes)
+        else:
+            self.device_free(ptr)
 
     def pinned_copy(self, arr) -> np.ndarray:
         """`arr` copied into a new pinned array (see `pinned_empty`)."""
@@ -480,7 +547,12 @@ class Engine:
         self, cube, dtype, n_planes: int, x_map, y_map, n0: int, n1: int, out,
         interpolation='linear', propagate_nan=True, spline_smoothing: float = 0.0,
     ) -> None:  # fmt: skip
-        """Enqueue the reprojection of a device-resident cube into a device output."""
+        """
+        Enqueue the reprojection of a device-resident cube into a device output. 'nearest' / 'linear' return with the work
+        on the stream (finish with `synchronize()`). The spline degrees BLOCK the calling thread once per 2 GiB chunk of
+        planes (the read-back that says whether any plane needs its nanmedian), 'smooth' blocks on the map-limits read-back,
+        `spline_smoothing > 0` once per round of the knot search: host work placed behind such a call does not overlap it.
+        """
         self.set_spline_smoothing(spline_smoothing)
         self._check(
             self._lib.pm_map_cube(
@@ -536,7 +608,9 @@ def _plane_pool_limit() -> int:
         ram = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
     except (ValueError, OSError):
         ram = 8 << 30
-    return int(min(8 << 30, ram // 8))
+    # (every rank of a node keeps a pool of its own: the default is the node's budget divided among them)
+    ranks = max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1') or 1))
+    return int(min(8 << 30, ram // 8) // ranks)
 
 
 def device_count() -> int:

@@ -518,12 +518,21 @@ class Observation(BodyXY):
         propagate_nan: bool = True,
         smooth_oversample_by: int = 5,
         smooth_max_oversampled_img_size: int = 10_000,
+        device: bool = False,
         **map_kwargs,
     ) -> np.ndarray:
         """
         Project every plane of `self.data` onto the map: returns a fresh
         (P, n_lat, n_lon) float64 array (copy of the cached result, observation.py:826-872).
+        `device=True` (not in the reference): the mapped cube as a read-only `DeviceArray` left in the GPU's HBM
+        (`__dlpack__` / `__cuda_array_interface__`; valid until the disc or the image size changes) - the cube is uploaded
+        once per Observation, the lon / lat grid once per set of map keywords, x / y maps and mapped planes never leave the GPU.
         """
+        if device:
+            return self._get_mapped_data_device(
+                interpolation=interpolation, spline_smoothing=spline_smoothing, propagate_nan=propagate_nan,
+                smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size, **map_kwargs,
+            )  # fmt: skip
         return self._get_mapped_data(
             interpolation=interpolation,
             spline_smoothing=spline_smoothing,
@@ -532,6 +541,64 @@ class Observation(BodyXY):
             smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
             **map_kwargs,
         ).copy()
+
+    def _data_device(self):
+        """`self.data` in HBM (uploaded once; again if `data` is replaced), in its own dtype where the kernels read that"""
+        from .engine import _DTYPE_CODES  # noqa: PLC0415
+
+        held = self.__dict__.get('_data_dev')
+        if held is None or held[0] is not self.data or not held[1].valid:
+            data = np.ascontiguousarray(self.data if np.dtype(self.data.dtype) in _DTYPE_CODES else np.asarray(self.data, dtype=np.float64))
+            eng = self._bind()
+            arr = eng.device_array(data.shape, data.dtype)
+            eng.h2d(arr.ptr, data)
+            if held is not None:
+                held[1].invalidate()
+            held = self.__dict__['_data_dev'] = (self.data, arr)
+        return held[1]
+
+    def _get_mapped_data_device(self, **kwargs):
+        """the device form of `_get_mapped_data` (same cache key with 'mapped_dev'; cleared - invalidated - with it)"""
+        from .engine import interpolation_code  # noqa: PLC0415
+
+        interpolation_code(kwargs['interpolation'])
+        if kwargs['spline_smoothing'] < 0:
+            raise ValueError('s should be s >= 0.0')
+        key = ('mapped_dev', tuple(sorted((k, _freeze(v)) for k, v in kwargs.items())), self._alt_adjustment)
+        if key not in self._cache:
+            map_kwargs = {k: v for k, v in kwargs.items() if k not in ('interpolation', 'spline_smoothing', 'propagate_nan',
+                                                                       'smooth_oversample_by', 'smooth_max_oversampled_img_size')}  # fmt: skip
+            map_kwargs, alt = self._split_map_kwargs(dict(map_kwargs))
+            mkey = self._map_key(map_kwargs)
+            eng = self._bind()
+            if not hasattr(eng, 'device_array'):
+                raise UnsupportedError('this engine keeps no results on a device')
+            lon, lat = self._get_lonlat_grids(**map_kwargs)
+            n0, n1 = lon.shape
+            gkey = ('lonlat_dev', mkey)
+            grids = self._stable_cache.get(gkey)
+            if grids is None or not grids[0].valid:  # (the grid does not depend on the disc: it stays across `_clear_cache`)
+                grids = (eng.device_array(lon.shape), eng.device_array(lat.shape))
+                eng.h2d(grids[0].ptr, lon)
+                eng.h2d(grids[1].ptr, lat)
+                self._stable_cache[gkey] = grids
+            xkey = ('map_dev', 'xy', mkey, alt)
+            if xkey not in self._cache:
+                xy = (eng.device_array((n0, n1)), eng.device_array((n0, n1)))
+                eng.xy_map_device(grids[0], grids[1], n0, n1, xy[0], xy[1], alt=alt)
+                self._cache[xkey] = xy
+            xm, ym = self._cache[xkey]
+            cube = self._data_device()
+            data = np.asarray(self.data)
+            planes = data.shape[0] if data.ndim == 3 else 1
+            out = eng.device_array((planes, n0, n1))
+            interp = kwargs['interpolation']
+            if interp == 'smooth':
+                eng.set_smooth_options(kwargs['smooth_oversample_by'], kwargs['smooth_max_oversampled_img_size'])
+            smoothing = float(kwargs['spline_smoothing']) if interp not in ('nearest', 'smooth') else 0.0
+            eng.map_cube_device(cube, cube.dtype, planes, xm, ym, n0, n1, out, interp, kwargs['propagate_nan'], spline_smoothing=smoothing)
+            self._cache[key] = out
+        return self._cache[key]
 
     def _get_mapped_data(self, **kwargs) -> np.ndarray:
         """observation.py:874-905: cached per disc parameters / altitude / arguments."""

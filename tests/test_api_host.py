@@ -668,6 +668,12 @@ def test_point_functions_kats(body):
         assert close(body.centric2graphic_lonlat(*a), (nan, nan))
     with pytest.raises(UnsupportedError):
         body.illumination_angles_from_lonlat(0, 0, alt=10.0)
+    # device-resident results need an engine with a device (the CPU stand-in of these tests has none): said, not faked
+    body.set_img_size(5, 4)
+    with pytest.raises(UnsupportedError):
+        body.get_lon_img(device=True)
+    with pytest.raises(UnsupportedError):
+        body.get_backplane_img('EMISSION', device=True)
 
 
 def test_ring_and_limb_point_functions_kats(body):

@@ -397,6 +397,99 @@ def test_reference_api_on_gpu(jupiter):
     assert np.isfinite(b.get_lon_img()).sum() == np.isfinite(b.get_emission_angle_img()).sum() > 9000
 
 
+def test_device_resident_getters_of_the_drop_in_surface(jupiter):
+    """
+    `get_*_img(device=True)`, `get_backplane_img(name, device=True)`, `get_mapped_data(..., device=True)`: the results
+    where they were computed - `DeviceArray`s in HBM read through DLPack (torch.from_dlpack) and
+    `__cuda_array_interface__` - equal to the numpy getters bit for bit, cached like them (base.py:115-138,
+    body_xy.py:2586-2630), invalidated by `_clear_cache` without pulling memory from under a consumer that imported it.
+    """
+    import gc
+
+    import torch
+
+    from planetmapper_amd import Observation
+    from planetmapper_amd._lib import UnsupportedError
+    from planetmapper_amd.device_array import DeviceArray
+
+    rng = np.random.default_rng(11)
+    data = rng.standard_normal((3, 96, 120)).astype(np.float32)
+    data[1, 40:44, 50:53] = np.nan
+    obs = Observation(data=data, geometry=jupiter)
+    obs.set_disc_params(60.3, 47.1, 40.0, 33.0)
+    same = lambda d, h: np.array_equal(d.numpy(), h, equal_nan=True)  # noqa: E731
+    lon_d = obs.get_lon_img(device=True)
+    assert isinstance(lon_d, DeviceArray) and lon_d.shape == (96, 120) and lon_d.dtype == np.float64 and lon_d.valid
+    assert obs.get_lon_img(device=True) is lon_d  # the cache entry itself, like the read-only numpy view
+    t = torch.from_dlpack(lon_d)
+    assert t.is_cuda and t.dtype == torch.float64 and tuple(t.shape) == (96, 120) and t.data_ptr() == lon_d.ptr
+    host = obs.get_lon_img()
+    assert np.array_equal(t.cpu().numpy(), host, equal_nan=True) and same(lon_d, host) and np.isfinite(host).sum() > 3000
+    cai = lon_d.__cuda_array_interface__
+    assert cai['data'] == (lon_d.ptr, True) and cai['shape'] == (96, 120) and cai['typestr'] == '<f8' and cai['version'] == 3
+    assert lon_d.__dlpack_device__() == (10, 0)  # kDLROCM
+    for name in ('EMISSION', 'RA', 'RING-RADIUS', 'LIMB-LAT-GRAPHIC', 'LOCAL-SOLAR-TIME', 'DOPPLER'):
+        assert same(obs.get_backplane_img(name, device=True), obs.get_backplane_img(name)), name
+    assert same(obs.get_backplane_img('LON-GRAPHIC', alt=2500.0, device=True), obs.get_backplane_img('LON-GRAPHIC', alt=2500.0))
+    assert not same(obs.get_backplane_img('LON-GRAPHIC', alt=2500.0, device=True), host)
+    for interp, kw in (('linear', {}), ('nearest', {}), ('cubic', {}), ('smooth', {}), ('linear', {'propagate_nan': False}),
+                       ('cubic', {'spline_smoothing': 96 * 120.0})):
+        m_d = obs.get_mapped_data(interp, degree_interval=10, device=True, **kw)
+        m_h = obs.get_mapped_data(interp, degree_interval=10, **kw)
+        assert isinstance(m_d, DeviceArray) and m_d.shape == (3, 18, 36) and same(m_d, m_h), (interp, kw)
+        assert np.isfinite(m_h).sum() > 100
+    assert obs.get_mapped_data('linear', degree_interval=10, device=True) is obs.get_mapped_data('linear', degree_interval=10, device=True)
+    obs.register_backplane('MINE', 'a user function', lambda: np.zeros((96, 120)), lambda **kw: np.zeros((18, 36)))
+    with pytest.raises(UnsupportedError):
+        obs.get_backplane_img('MINE', device=True)
+    # ---- a new disc: the handles of the old one are dead, a consumer's import is not
+    before = t.clone()
+    mapped_old = obs.get_mapped_data('linear', degree_interval=10, device=True)
+    obs.set_x0(61.3)
+    assert not lon_d.valid and not mapped_old.valid
+    for dead in (lambda: lon_d.ptr, lambda: lon_d.__cuda_array_interface__, lambda: torch.from_dlpack(lon_d), lon_d.numpy):
+        with pytest.raises(ValueError, match='cache entry that has been cleared'):
+            dead()
+    lon_new = obs.get_lon_img(device=True)
+    assert lon_new is not lon_d and lon_new.ptr != t.data_ptr()  # (the imported memory was NOT handed out again)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(t), torch.nan_to_num(before))  # ... nor overwritten
+    assert same(lon_new, obs.get_lon_img()) and not np.array_equal(lon_new.numpy(), host, equal_nan=True)
+    pooled = obs._engine._device_pool_bytes
+    assert lon_d._exports == 1 and lon_d in obs._engine._device_waiting
+    del t
+    gc.collect()
+    assert lon_d._exports == 0
+    obs._engine._device_sweep()
+    assert obs._engine._device_pool_bytes == pooled + 96 * 120 * 8  # the consumer let go: the plane is in the engine's pool
+    nxt = obs.get_lat_img(device=True)  # (LAT of the new disc was computed with LON: cached)
+    obs.set_x0(60.3)
+    assert not nxt.valid and obs._engine._device_pool_bytes > pooled + 96 * 120 * 8
+    again = obs.get_lon_img(device=True)
+    assert same(again, host)  # the first disc again, out of pooled memory
+    # a capsule nobody consumes releases its hold when it is dropped
+    cap = again.__dlpack__()
+    assert again._exports == 1
+    del cap
+    gc.collect()
+    assert again._exports == 0
+    # a consumer that still holds its import when the interpreter goes down: the import's deleter is C code of the library
+    # (a Python callback there is a call into an interpreter that no longer exists)
+    import subprocess
+    import sys
+
+    code = ('import numpy as np, torch\n'
+            'from planetmapper_amd import BodyXY\n'
+            'b = BodyXY("jupiter", scenario="jupiter_hst_2005", sz=64)\n'
+            'keep = [torch.from_dlpack(b.get_lon_img(device=True)), torch.from_dlpack(b.get_emission_angle_img(device=True))]\n'
+            'b.set_x0(30.0)\n'  # one of the imports outlives its cache entry as well
+            'keep.append(torch.from_dlpack(b.get_lon_img(device=True)))\n'
+            'print("alive", len(keep), flush=True)\n')
+    p = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert p.returncode == 0 and 'alive 3' in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+
+
 @pytest.mark.parametrize(
     'name,kw',
     [

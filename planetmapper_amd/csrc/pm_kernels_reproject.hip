@@ -198,6 +198,20 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
     a.out[(size_t)pl * a.n_map + m] = reproject_sample<T>(a, pl, a.x_map[m], a.y_map[m]);
 }
 
+// A plane per XCD (planes in whole groups of 8; the rest take k_reproject). Workgroups are dealt round-robin to the 8 XCDs;
+// here the workgroups an XCD receives are those of ONE plane at a time (plane = 8 * (j / chunks) + xcd): the 64-byte
+// lines that neighbouring map rows share are then found in that XCD's L2 instead of being fetched by several of them.
+// Round 6, config 5 (512 planes of 1024^2 -> 1 deg): 0.459 -> 0.436 ms (same box, alternating runs); same samples, same bits.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_reproject_xcd(const ReprojectArgs a, int chunks)
+{
+    const unsigned wg = blockIdx.x, xcd = wg & 7u, j = wg >> 3;
+    const int pl = (int)((j / (unsigned)chunks) * 8u + xcd);
+    const int m = (int)(j % (unsigned)chunks) * kBlock + threadIdx.x;
+    if (pl >= a.n_planes || m >= a.n_map) return;
+    a.out[(size_t)pl * a.n_map + m] = reproject_sample<T>(a, pl, a.x_map[m], a.y_map[m]);
+}
+
 // ------------------------------------------------------------------ sparse host path: block table
 // A cube in HOST memory mapped onto a coarse grid: what counts is how many bytes cross PCIe and in
 // which request sizes (tools/probes/hip/probe_gather.hip: isolated 128-byte lines 41 GB/s, runs of 256 bytes
@@ -1322,8 +1336,23 @@ dim3 pm_smooth_grid(int n_map, int n_planes)
 template <typename T>
 static void launch_reproject_t(const pm::ReprojectArgs &a, hipStream_t s)
 {
-    dim3 grid((a.n_map + pm::kBlock - 1) / pm::kBlock, a.n_planes);
-    hipLaunchKernelGGL(pm::k_reproject<T>, grid, dim3(pm::kBlock), 0, s, a);
+    const int chunks = (a.n_map + pm::kBlock - 1) / pm::kBlock;
+    const int whole = (a.n_planes / 8) * 8;  // (a group of fewer than 8 planes would leave XCDs idle: those go the plain way)
+    pm::ReprojectArgs rest = a;
+    if (whole && (unsigned long long)whole * (unsigned)chunks < (1ull << 31)) {
+        pm::ReprojectArgs first = a;
+        first.n_planes = whole;
+        hipLaunchKernelGGL(pm::k_reproject_xcd<T>, dim3((unsigned)whole * (unsigned)chunks), dim3(pm::kBlock), 0, s, first, chunks);
+        rest.n_planes = a.n_planes - whole;
+        rest.cube = (const T *)a.cube + (size_t)whole * a.ny * a.nx;
+        rest.out = a.out + (size_t)whole * a.n_map;
+        rest.plane_flags = a.plane_flags ? a.plane_flags + whole : nullptr;
+        rest.plane_stats = a.plane_stats ? a.plane_stats + whole : nullptr;
+    }
+    if (rest.n_planes > 0) {
+        dim3 grid((unsigned)chunks, rest.n_planes);
+        hipLaunchKernelGGL(pm::k_reproject<T>, grid, dim3(pm::kBlock), 0, s, rest);
+    }
 }
 
 template <typename T>

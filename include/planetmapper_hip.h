@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define PM_ABI_VERSION 2 /* 2: pm_geometry.DVT, DAT */
+#define PM_ABI_VERSION 3 /* 2: pm_geometry.DVT, DAT; 3: pm_geometry.WP, pm_dlpack_*, pm_host_free(NULL, ...) */
 
 typedef enum pm_status {
     PM_OK = 0,
@@ -143,6 +143,13 @@ typedef struct pm_geometry {
     double np_angle_rad;    /* Body.north_pole_angle() in radians         body.py:2985 */
     double lst_sun_lon;     /* planetocentric east longitude (rad) of the Sun in the
                                target frame at t0, LT+S (et2lst)           body.py:2364 */
+    double WP[3];       /* the part of the target frame's angular velocity that is NOT about its own z axis (J2000
+                           components, rad/s): the drift of the pole - what the derivative block of sxform holds beyond
+                           wdot. It enters the velocity of a surface point, i.e. the STATE planes only (spkcpt:
+                           Body._state_from_targvec, body.py:2830-2845): Jupiter 7e-14 rad/s = 1e-9 km/s across the
+                           disc in RADIAL-VELOCITY - the one figure the golden plane shows once the observer's
+                           velocity is the ephemeris's own and not a fit. Positions ignore it (1e-17 rad over a disc's
+                           light-time span). */
 
     int32_t west_positive;  /* 1 if Body.positive_longitude_direction == 'W' body.py:528 */
     int32_t reserved;

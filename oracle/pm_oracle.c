@@ -473,6 +473,10 @@ static void spkcpt(const pm_geometry *g, const double *sp, double *pos, double *
     vp[0] = (g->VT[0] + g->DVT[0]) + (g->AT[0] + g->DAT[0]) * d + g->wdot * (z[1] * off[2] - z[2] * off[1]);
     vp[1] = (g->VT[1] + g->DVT[1]) + (g->AT[1] + g->DAT[1]) * d + g->wdot * (z[2] * off[0] - z[0] * off[2]);
     vp[2] = (g->VT[2] + g->DVT[2]) + (g->AT[2] + g->DAT[2]) * d + g->wdot * (z[0] * off[1] - z[1] * off[0]);
+    /* ... and the drift of the pole (sxform's derivative block beyond the spin): pm_geometry.WP */
+    vp[0] += g->WP[1] * off[2] - g->WP[2] * off[1];
+    vp[1] += g->WP[2] * off[0] - g->WP[0] * off[2];
+    vp[2] += g->WP[0] * off[1] - g->WP[1] * off[0];
     double r = norm3(pos);
     double rh[3] = {pos[0] / r, pos[1] / r, pos[2] / r};
     /* light-time rate: lt = |P(et - lt) - O(et)|/c  =>

@@ -206,7 +206,7 @@ def load() -> ctypes.CDLL:
         vp, vp, vp, c_int, c_int, vp, vp, c_int, c_int, c_int, c_int, vp, c_int, c_int,
     ]  # fmt: skip
     del dp
-    if lib.pm_abi_version() != 2:
+    if lib.pm_abi_version() != 3:
         raise ImportError('libplanetmapper_hip.so ABI version mismatch')
     _lib = lib
     return lib

@@ -222,6 +222,7 @@ void fill_params(const pm_ctx *ctx, double alt, pm::Params &p)
         rot(vst, p.VSB_state, 1.0);
         const double ast[3] = {g.AT[0] + g.DAT[0], g.AT[1] + g.DAT[1], g.AT[2] + g.DAT[2]};
         rot(ast, p.ASB_state, 1.0);
+        rot(g.WP, p.WPB, 1.0);
     }
     rot(g.ring_n, p.ring_nb, 1.0);
     rot(g.sub_obsvec, p.sub_obs_b, 1.0);

@@ -96,6 +96,7 @@ struct Params {
     double VOB[3];  // R0 VO
     double VSB_state[3];  // R0 (VT + DVT): the target centre's STATE velocity (radial velocity)
     double ASB_state[3];  // R0 (AT + DAT)
+    double WPB[3];        // R0 WP: the drift of the pole (STATE planes)
     double ira, irc;  // 1 / radii[0], 1 / radii[2]
     double inv_c;     // 1 / clight
     double lat_k;     // (radii[0] / radii[2])^2
@@ -885,7 +886,7 @@ __device__ __forceinline__ double radial_velocity(const Params &p, V3 sp, double
     double d = te - p.t0;
     V3 off = mtxv(R, sp);
     V3 z = {R.m[6], R.m[7], R.m[8]};
-    V3 w = p.g.wdot * cross(z, off);
+    V3 w = p.g.wdot * cross(z, off) + cross(ld3(p.g.WP), off);  // (+ the drift of the pole: pm_geometry.WP)
     // (a STATE's velocity: VT + DVT, see pm_geometry.DVT)
     V3 vp = {fma(p.g.AT[0] + p.g.DAT[0], d, p.g.VT[0] + p.g.DVT[0]) + w.x, fma(p.g.AT[1] + p.g.DAT[1], d, p.g.VT[1] + p.g.DVT[1]) + w.y,
              fma(p.g.AT[2] + p.g.DAT[2], d, p.g.VT[2] + p.g.DVT[2]) + w.z};

@@ -808,8 +808,10 @@ __global__ __launch_bounds__(kSphBlock) void k_disc_sph(const Params p)
                     const double turn = kp->g.wdot * (((kp->g.et - lt) - kp->t0) - d);
                     sv0 = {fma(-turn, sp0.y, sp0.x), fma(turn, sp0.x, sp0.y), sp0.z};
                 }
-                const V3 vp = {fma(kp->ASB_state[0], dv, kp->VSB_state[0]) - kp->g.wdot * sv0.y,
-                               fma(kp->ASB_state[1], dv, kp->VSB_state[1]) + kp->g.wdot * sv0.x, fma(kp->ASB_state[2], dv, kp->VSB_state[2])};
+                // (the point's own motion: the spin about B0's z, and the drift of the pole - pm_geometry.WP, 1e-9 km/s)
+                const V3 wp = cross(v3(kp->WPB[0], kp->WPB[1], kp->WPB[2]), sv0);
+                const V3 vp = {fma(kp->ASB_state[0], dv, kp->VSB_state[0]) - kp->g.wdot * sv0.y + wp.x,
+                               fma(kp->ASB_state[1], dv, kp->VSB_state[1]) + kp->g.wdot * sv0.x + wp.y, fma(kp->ASB_state[2], dv, kp->VSB_state[2]) + wp.z};
                 const V3 vo = v3(kp->VOB[0], kp->VOB[1], kp->VOB[2]);
                 const double dlt = (dot(u, vp - vo) * kp->inv_c) / (1.0 + dot(u, vp) * kp->inv_c);
                 const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;
@@ -1143,8 +1145,9 @@ __global__ __launch_bounds__(kBlock) void k_map_b0(const Params p_, const double
     }
     if (STATE) {
         // spkcpt_c's velocity with the light-time rate (body.py:2830-2850), as the STATE block of k_disc_sph
-        const V3 vp = {fma(p.ASB_state[0], d, p.VSB_state[0]) - wdot * q.y, fma(p.ASB_state[1], d, p.VSB_state[1]) + wdot * q.x,
-                       fma(p.ASB_state[2], d, p.VSB_state[2])};
+        const V3 wp = cross(v3(p.WPB[0], p.WPB[1], p.WPB[2]), q);  // (the drift of the pole: pm_geometry.WP)
+        const V3 vp = {fma(p.ASB_state[0], d, p.VSB_state[0]) - wdot * q.y + wp.x, fma(p.ASB_state[1], d, p.VSB_state[1]) + wdot * q.x + wp.y,
+                       fma(p.ASB_state[2], d, p.VSB_state[2]) + wp.z};
         const V3 vo = {p.VOB[0], p.VOB[1], p.VOB[2]};
         const double dlt = div_fast(dot(u, vp - vo) * p.inv_c, fma(dot(u, vp), p.inv_c, 1.0));
         const double rv = dot((1.0 - dlt) * vp - vo, u) + miss;

@@ -9,7 +9,10 @@ the small part of it that the *host side* of the hot path needs:
 * text kernels (PCK, `pck00010.tpc` style): ``BODYnnn_RADII``, ``_POLE_RA``,
   ``_POLE_DEC``, ``_PM``, ``_NUT_PREC_*`` -> IAU rotation model J2000 -> body-fixed;
 * binary DAF/SPK ephemerides, Chebyshev segment types 2 and 3 (planets, barycentres,
-  Sun, Earth) -> position / velocity / acceleration relative to the SSB.
+  Sun, Earth) -> position / velocity / acceleration relative to the SSB;
+* SPK type 10 (two-line elements of an Earth satellite: the reference's canonical observer, HST,
+  `tests/test_body.py:29-31`): CSPICE `spke10` restated - SGP4 for near-earth orbits from the two
+  bracketing element sets, blended, TEME -> J2000 with the segment's own nutation angles.
 
 Nothing here runs per pixel: it produces the numbers that `geometry.py` packs into
 the geometry block consumed by the HIP kernels.
@@ -266,6 +269,24 @@ class RotationModel:
                 dec -= self.nut_prec_dec[i] * math.sin(theta) * rate
         return math.radians(ra) / JULIAN_CENTURY_S, math.radians(dec) / JULIAN_CENTURY_S
 
+    def angular_velocity(self, et: float) -> np.ndarray:
+        """
+        Angular velocity of the body-fixed frame with respect to J2000, J2000 components, rad/s: with
+        R = rot3(W) rot1(pi/2 - DEC) rot3(pi/2 + RA), d RA/dt about J2000 z, -d DEC/dt about the node
+        (-sin RA, cos RA, 0) and dW/dt about the pole. (What the derivative block of sxform_c encodes.)
+        """
+        ra_dot, dec_dot = self.pole_rates(et)
+        ra, _dec, _w = self.euler_rad(et)
+        pole = self.matrix(et)[2]
+        return (ra_dot * np.array([0.0, 0.0, 1.0]) - dec_dot * np.array([-math.sin(ra), math.cos(ra), 0.0])
+                + self.spin_rate(et) * pole)  # fmt: skip
+
+    def pole_drift(self, et: float) -> np.ndarray:
+        """`angular_velocity` less its component along the pole (which is `body_z_rate`): the motion of the pole itself"""
+        w = self.angular_velocity(et)
+        pole = self.matrix(et)[2]
+        return w - float(w @ pole) * pole
+
     def body_z_rate(self, et: float) -> float:
         """
         Angular velocity of the body-fixed frame about its own +z axis, rad/s: dW/dt plus the component of
@@ -415,10 +436,326 @@ class ChebySegment:
         return cls(records=recs, **kw)
 
 
-def read_spk_segments(path: str) -> list[ChebySegment]:
+# ----------------------------------------------------------------------------------
+# SPK type 10: two-line elements (CSPICE spke10 / spkr10, N0067)
+# ----------------------------------------------------------------------------------
+_ARCSEC = math.pi / 648000.0
+_TWOPI = 2.0 * math.pi
+
+
+class _Sgp4:
     """
-    Read every type 2 / type 3 segment of a binary DAF/SPK file (other types are
-    skipped). Layout: NAIF "DAF Required Reading" / "SPK Required Reading".
+    SGP4 for NEAR-EARTH orbits (period < 225 min) as `spke10` evaluates it since N0067 (Vallado, Crawford, Hujsak & Kelso
+    2006, "Revisiting Spacetrack Report #3": CSPICE xxsgp4i / xxsgp4e), with the geophysical constants of the SEGMENT
+    (J2, J3, J4, KE, QO, SO, ER, AE) in place of WGS-72's. Elements as the type 10 packet holds them: NDT20, NDD60, BSTAR,
+    INCL, NODE0, ECC, OMEGA, M0 (rad), N0 (rad / min), EPOCH (TDB seconds past J2000). Deep-space element sets are refused.
+    """
+
+    def __init__(self, geophs: Sequence[float], el: Sequence[float]) -> None:
+        j2, j3, j4, xke, qo, so, er, _ae = (float(v) for v in geophs[:8])
+        _ndt20, _ndd60, bstar, inclo, nodeo, ecco, argpo, mo, no, epoch = (float(v) for v in el[:10])
+        self.j2, self.xke, self.er, self.epoch, self.bstar = j2, xke, er, epoch, bstar
+        self.inclo, self.nodeo, self.ecco, self.argpo, self.mo = inclo, nodeo, ecco, argpo, mo
+        j3oj2 = j3 / j2
+        ss = so / er + 1.0
+        qzms2t = ((qo - so) / er) ** 4
+        x2o3 = 2.0 / 3.0
+        # initl: the mean motion and semi-major axis without the Kozai terms
+        eccsq = ecco * ecco
+        omeosq = 1.0 - eccsq
+        rteosq = math.sqrt(omeosq)
+        cosio = math.cos(inclo)
+        cosio2 = cosio * cosio
+        ak = (xke / no) ** x2o3
+        d1 = 0.75 * j2 * (3.0 * cosio2 - 1.0) / (rteosq * omeosq)
+        del_ = d1 / (ak * ak)
+        adel = ak * (1.0 - del_ * del_ - del_ * (1.0 / 3.0 + 134.0 * del_ * del_ / 81.0))
+        del_ = d1 / (adel * adel)
+        no = no / (1.0 + del_)
+        ao = (xke / no) ** x2o3
+        sinio = math.sin(inclo)
+        po = ao * omeosq
+        con42 = 1.0 - 5.0 * cosio2
+        con41 = -con42 - cosio2 - cosio2
+        posq = po * po
+        rp = ao * (1.0 - ecco)
+        if _TWOPI / no >= 225.0:
+            raise ValueError('SPK type 10: deep-space element set (period >= 225 min) - only the near-earth model is restated')
+        self.no = no
+        self.isimp = 1 if rp < (220.0 / er + 1.0) else 0
+        sfour, qzms24 = ss, qzms2t
+        perige = (rp - 1.0) * er
+        if perige < 156.0:
+            sfour = perige - 78.0
+            if perige < 98.0:
+                sfour = 20.0
+            qzms24 = ((120.0 - sfour) / er) ** 4
+            sfour = sfour / er + 1.0
+        pinvsq = 1.0 / posq
+        tsi = 1.0 / (ao - sfour)
+        self.eta = eta = ao * ecco * tsi
+        etasq = eta * eta
+        eeta = ecco * eta
+        psisq = abs(1.0 - etasq)
+        coef = qzms24 * tsi**4
+        coef1 = coef / psisq**3.5
+        cc2 = coef1 * no * (ao * (1.0 + 1.5 * etasq + eeta * (4.0 + etasq))
+                            + 0.375 * j2 * tsi / psisq * con41 * (8.0 + 3.0 * etasq * (8.0 + etasq)))  # fmt: skip
+        self.cc1 = cc1 = bstar * cc2
+        cc3 = -2.0 * coef * tsi * j3oj2 * no * sinio / ecco if ecco > 1.0e-4 else 0.0
+        self.x1mth2 = x1mth2 = 1.0 - cosio2
+        self.cc4 = 2.0 * no * coef1 * ao * omeosq * (
+            eta * (2.0 + 0.5 * etasq) + ecco * (0.5 + 2.0 * etasq)
+            - j2 * tsi / (ao * psisq) * (-3.0 * con41 * (1.0 - 2.0 * eeta + etasq * (1.5 - 0.5 * eeta))
+                                         + 0.75 * x1mth2 * (2.0 * etasq - eeta * (1.0 + etasq)) * math.cos(2.0 * argpo)))  # fmt: skip
+        self.cc5 = 2.0 * coef1 * ao * omeosq * (1.0 + 2.75 * (etasq + eeta) + eeta * etasq)
+        cosio4 = cosio2 * cosio2
+        temp1 = 1.5 * j2 * pinvsq * no
+        temp2 = 0.5 * temp1 * j2 * pinvsq
+        temp3 = -0.46875 * j4 * pinvsq * pinvsq * no
+        self.mdot = no + 0.5 * temp1 * rteosq * con41 + 0.0625 * temp2 * rteosq * (13.0 - 78.0 * cosio2 + 137.0 * cosio4)
+        self.argpdot = (-0.5 * temp1 * con42 + 0.0625 * temp2 * (7.0 - 114.0 * cosio2 + 395.0 * cosio4)
+                        + temp3 * (3.0 - 36.0 * cosio2 + 49.0 * cosio4))  # fmt: skip
+        xhdot1 = -temp1 * cosio
+        self.nodedot = xhdot1 + (0.5 * temp2 * (4.0 - 19.0 * cosio2) + 2.0 * temp3 * (3.0 - 7.0 * cosio2)) * cosio
+        self.omgcof = bstar * cc3 * math.cos(argpo)
+        self.xmcof = -x2o3 * coef * bstar / eeta if ecco > 1.0e-4 else 0.0
+        self.nodecf = 3.5 * omeosq * xhdot1 * cc1
+        self.t2cof = 1.5 * cc1
+        self.xlcof = -0.25 * j3oj2 * sinio * (3.0 + 5.0 * cosio) / ((1.0 + cosio) if abs(cosio + 1.0) > 1.5e-12 else 1.5e-12)
+        self.aycof = -0.5 * j3oj2 * sinio
+        self.delmo = (1.0 + eta * math.cos(mo)) ** 3
+        self.sinmao = math.sin(mo)
+        self.x7thm1 = 7.0 * cosio2 - 1.0
+        self.con41 = con41
+        if self.isimp != 1:
+            cc1sq = cc1 * cc1
+            self.d2 = d2 = 4.0 * ao * tsi * cc1sq
+            temp = d2 * tsi * cc1 / 3.0
+            self.d3 = d3 = (17.0 * ao + sfour) * temp
+            self.d4 = d4 = 0.5 * temp * ao * tsi * (221.0 * ao + 31.0 * sfour) * cc1
+            self.t3cof = d2 + 2.0 * cc1sq
+            self.t4cof = 0.25 * (3.0 * d3 + cc1 * (12.0 * d2 + 10.0 * cc1sq))
+            self.t5cof = 0.2 * (3.0 * d4 + 12.0 * cc1 * d3 + 6.0 * d2 * d2 + 15.0 * cc1sq * (2.0 * d2 + cc1sq))
+
+    def state(self, et: float) -> tuple[np.ndarray, np.ndarray]:
+        """position (km) and velocity (km/s) at `et` in TEME, the frame of the elements"""
+        t = (et - self.epoch) / 60.0
+        xke, j2 = self.xke, self.j2
+        # secular gravity and atmospheric drag
+        xmdf = self.mo + self.mdot * t
+        argpdf = self.argpo + self.argpdot * t
+        nodedf = self.nodeo + self.nodedot * t
+        argpm, mm = argpdf, xmdf
+        t2 = t * t
+        nodem = nodedf + self.nodecf * t2
+        tempa = 1.0 - self.cc1 * t
+        tempe = self.bstar * self.cc4 * t
+        templ = self.t2cof * t2
+        if self.isimp != 1:
+            delomg = self.omgcof * t
+            delm = self.xmcof * ((1.0 + self.eta * math.cos(xmdf)) ** 3 - self.delmo)
+            temp = delomg + delm
+            mm = xmdf + temp
+            argpm = argpdf - temp
+            t3 = t2 * t
+            t4 = t3 * t
+            tempa = tempa - self.d2 * t2 - self.d3 * t3 - self.d4 * t4
+            tempe = tempe + self.bstar * self.cc5 * (math.sin(mm) - self.sinmao)
+            templ = templ + self.t3cof * t3 + t4 * (self.t4cof + t * self.t5cof)
+        nm, em, inclm = self.no, self.ecco, self.inclo
+        am = (xke / nm) ** (2.0 / 3.0) * tempa * tempa
+        nm = xke / am**1.5
+        em = max(em - tempe, 1.0e-6)
+        mm = mm + self.no * templ
+        xlm = mm + argpm + nodem
+        nodem = math.fmod(nodem, _TWOPI)
+        argpm = math.fmod(argpm, _TWOPI)
+        xlm = math.fmod(xlm, _TWOPI)
+        mm = math.fmod(xlm - argpm - nodem, _TWOPI)
+        sinip, cosip = math.sin(inclm), math.cos(inclm)
+        # long-period periodics, Kepler's equation
+        axnl = em * math.cos(argpm)
+        temp = 1.0 / (am * (1.0 - em * em))
+        aynl = em * math.sin(argpm) + temp * self.aycof
+        xl = mm + argpm + nodem + temp * self.xlcof * axnl
+        u = math.fmod(xl - nodem, _TWOPI)
+        eo1, tem5, ktr = u, 9999.9, 1
+        sineo1 = coseo1 = 0.0
+        while abs(tem5) >= 1.0e-12 and ktr <= 10:
+            sineo1, coseo1 = math.sin(eo1), math.cos(eo1)
+            tem5 = 1.0 - coseo1 * axnl - sineo1 * aynl
+            tem5 = (u - aynl * coseo1 + axnl * sineo1 - eo1) / tem5
+            if abs(tem5) >= 0.95:
+                tem5 = math.copysign(0.95, tem5)
+            eo1 += tem5
+            ktr += 1
+        # short-period periodics
+        ecose = axnl * coseo1 + aynl * sineo1
+        esine = axnl * sineo1 - aynl * coseo1
+        el2 = axnl * axnl + aynl * aynl
+        pl = am * (1.0 - el2)
+        if pl < 0.0:
+            raise ValueError('SPK type 10: the element set has decayed (semi-latus rectum < 0)')
+        rl = am * (1.0 - ecose)
+        rdotl = math.sqrt(am) * esine / rl
+        rvdotl = math.sqrt(pl) / rl
+        betal = math.sqrt(1.0 - el2)
+        temp = esine / (1.0 + betal)
+        sinu = am / rl * (sineo1 - aynl - axnl * temp)
+        cosu = am / rl * (coseo1 - axnl + aynl * temp)
+        su = math.atan2(sinu, cosu)
+        sin2u = (cosu + cosu) * sinu
+        cos2u = 1.0 - 2.0 * sinu * sinu
+        temp = 1.0 / pl
+        temp1 = 0.5 * j2 * temp
+        temp2 = temp1 * temp
+        mrt = rl * (1.0 - 1.5 * temp2 * betal * self.con41) + 0.5 * temp1 * self.x1mth2 * cos2u
+        su = su - 0.25 * temp2 * self.x7thm1 * sin2u
+        xnode = nodem + 1.5 * temp2 * cosip * sin2u
+        xinc = inclm + 1.5 * temp2 * cosip * sinip * cos2u
+        mvt = rdotl - nm * temp1 * self.x1mth2 * sin2u / xke
+        rvdot = rvdotl + nm * temp1 * (self.x1mth2 * cos2u + 1.5 * self.con41) / xke
+        sinsu, cossu = math.sin(su), math.cos(su)
+        snod, cnod = math.sin(xnode), math.cos(xnode)
+        sini, cosi = math.sin(xinc), math.cos(xinc)
+        xmx, xmy = -snod * cosi, cnod * cosi
+        uvec = np.array([xmx * sinsu + cnod * cossu, xmy * sinsu + snod * cossu, sini * sinsu])
+        vvec = np.array([xmx * cossu - cnod * sinsu, xmy * cossu - snod * sinsu, sini * cossu])
+        return uvec * (mrt * self.er), (mvt * uvec + rvdot * vvec) * (self.er * xke / 60.0)
+
+
+def _j2000_to_teme(et: float, nut_obliquity: float, nut_longitude: float) -> np.ndarray:
+    """
+    J2000 -> TEME (true equator, mean equinox of date) at TDB `et`: IAU 1976 precession (zzeprc76), the IAU 1980 mean
+    obliquity (zzmobliq), the nutation angles GIVEN (a type 10 segment stores them with each element set), and the turn
+    about the true pole by the equation of the equinoxes, d psi cos(true obliquity), that takes the true equinox back to
+    the mean one. The choice among the published variants (which obliquity in the equation of the equinoxes, none of
+    its post-1997 lunar terms) is the one that puts HST where the reference's golden FITS header has it:
+    tests/test_tle_observer.py.
+    """
+    t = et / JULIAN_CENTURY_S
+    zeta = (2306.2181 * t + 0.30188 * t * t + 0.017998 * t**3) * _ARCSEC
+    z = (2306.2181 * t + 1.09468 * t * t + 0.018203 * t**3) * _ARCSEC
+    theta = (2004.3109 * t - 0.42665 * t * t - 0.041833 * t**3) * _ARCSEC
+    mob = (84381.448 - 46.8150 * t - 0.00059 * t * t + 0.001813 * t**3) * _ARCSEC
+    eps = mob + nut_obliquity
+    prec = rotate(-z, 3) @ rotate(theta, 2) @ rotate(-zeta, 3)
+    nut = rotate(-eps, 1) @ rotate(-nut_longitude, 3) @ rotate(mob, 1)
+    return rotate(nut_longitude * math.cos(eps), 3) @ nut @ prec
+
+
+@dataclass
+class TleSegment:
+    """
+    One SPK segment of type 10: the two-line element sets of an Earth satellite (space-track format, converted by NAIF's
+    mkspk), each with the nutation angles and rates of its epoch; `spke10` restated. State at `et`: SGP4 from the
+    two element sets whose epochs bracket `et`, blended with the weight 1/2 + 1/2 cos(pi (et - t1) / (t2 - t1)) (the
+    velocity takes the weight's derivative along), then TEME -> J2000 with the nutation angles interpolated between the two
+    sets (cubic Hermite on the stored angles and rates). Pinned by the reference's golden header - HST on 2005-01-01:
+    position to 3e-7 km of what TARGET RA / DEC / DISTANCE imply, radial-velocity plane to 4e-11 km/s.
+    """
+
+    target: int
+    center: int
+    frame: int
+    et_begin: float
+    et_end: float
+    geophs: np.ndarray  # J2, J3, J4, KE, QO, SO, ER, AE
+    epochs: np.ndarray  # (n,)
+    packets: np.ndarray  # (n, 14): NDT20 NDD60 BSTAR INCL NODE0 ECC OMEGA M0 N0 EPOCH, nutation in obliquity / longitude, their rates
+    spk_type: int = 10
+
+    def covers(self, et: float) -> bool:
+        return self.et_begin <= et <= self.et_end and len(self.epochs) > 0
+
+    def _bracket(self, et: float) -> tuple[int, int]:
+        n = len(self.epochs)
+        i = int(np.searchsorted(self.epochs, et, side='right'))  # epochs[i - 1] <= et < epochs[i]
+        if i <= 0:
+            return 0, 0  # (before the first set / after the last: that set alone, spkr10)
+        if i >= n:
+            return n - 1, n - 1
+        return i - 1, i
+
+    def _j2000_to_teme_at(self, et: float, i1: int, i2: int) -> np.ndarray:
+        n1, n2 = self.packets[i1][10:14], self.packets[i2][10:14]
+        if i1 == i2:
+            ang = n1[:2] + n1[2:] * (et - self.epochs[i1])
+        else:
+            h = self.epochs[i2] - self.epochs[i1]
+            s = (et - self.epochs[i1]) / h
+            ang = ((2 * s**3 - 3 * s**2 + 1) * n1[:2] + (s**3 - 2 * s**2 + s) * h * n1[2:]
+                   + (-2 * s**3 + 3 * s**2) * n2[:2] + (s**3 - s**2) * h * n2[2:])  # fmt: skip
+        return _j2000_to_teme(et, float(ang[0]), float(ang[1]))
+
+    def state(self, et: float) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(position km, velocity km/s, acceleration km/s^2 = two-body estimate) of the satellite wrt the Earth, J2000"""
+        i1, i2 = self._bracket(et)
+        r1, v1 = _Sgp4(self.geophs, self.packets[i1]).state(et)
+        if i1 == i2:
+            r, v = r1, v1
+        else:
+            r2, v2 = _Sgp4(self.geophs, self.packets[i2]).state(et)
+            t1, t2 = self.epochs[i1], self.epochs[i2]
+            arg = (et - t1) * math.pi / (t2 - t1)
+            w = 0.5 + 0.5 * math.cos(arg)
+            dw = -0.5 * math.sin(arg) * math.pi / (t2 - t1)
+            r = w * r1 + (1.0 - w) * r2
+            v = w * v1 + (1.0 - w) * v2 + dw * (r1 - r2)
+        m = self._j2000_to_teme_at(et, i1, i2)
+        # the frame turns (precession 8e-12 rad/s, nutation 3e-12): 5e-8 km/s on a 7 000 km orbit
+        h = 8.0
+        dm = (self._j2000_to_teme_at(et + h, i1, i2) - self._j2000_to_teme_at(et - h, i1, i2)) / (2.0 * h)
+        pos = m.T @ r
+        vel = m.T @ v + dm.T @ r
+        mu = (self.geophs[3] / 60.0) ** 2 * self.geophs[6] ** 3  # KE^2 ER^3 (km^3 / s^2)
+        acc = -mu * pos / float(np.linalg.norm(pos)) ** 3
+        return pos, vel, acc
+
+    def motion(self, et: float) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+        return self.state(et)
+
+    def trimmed(self, et_lo: float, et_hi: float) -> 'TleSegment':
+        """Copy holding only the element sets needed for [et_lo, et_hi]."""
+        lo = max(self._bracket(et_lo)[0] - 1, 0)
+        hi = min(self._bracket(et_hi)[1] + 1, len(self.epochs) - 1)
+        return TleSegment(self.target, self.center, self.frame, max(self.et_begin, float(self.epochs[lo])), min(self.et_end, float(self.epochs[hi])),
+                          np.array(self.geophs), np.array(self.epochs[lo : hi + 1]), np.array(self.packets[lo : hi + 1]))  # fmt: skip
+
+    def to_json(self) -> dict:
+        return {'target': self.target, 'center': self.center, 'frame': self.frame, 'spk_type': 10, 'et_begin': self.et_begin,
+                'et_end': self.et_end, 'geophs': [float(v).hex() for v in self.geophs], 'epochs': [float(v).hex() for v in self.epochs],
+                'packets': [[float(v).hex() for v in p] for p in self.packets]}  # fmt: skip
+
+    @classmethod
+    def from_json(cls, d: dict) -> 'TleSegment':
+        unhex = lambda seq: np.array([float.fromhex(v) for v in seq], dtype=np.float64)  # noqa: E731
+        return cls(d['target'], d['center'], d['frame'], d['et_begin'], d['et_end'], unhex(d['geophs']), unhex(d['epochs']),
+                   np.array([unhex(p) for p in d['packets']], dtype=np.float64).reshape(-1, 14))  # fmt: skip
+
+
+def _read_tle_segment(words: np.ndarray, target: int, center: int, frame: int, et_b: float, et_e: float, a0: int, a1: int) -> TleSegment:
+    """
+    A type 10 segment is a DAF "generic segment" (SPK Required Reading; sgfcon / sgfpkt): 8 constants, N packets of PKTSZ = 14
+    doubles each behind PKTOFF offset words, their N reference epochs, an epoch directory, and 17 words of meta data
+    (CONBAS NCON RDRBAS NRDR RDRTYP REFBAS NREF PDRBAS NPDR PDRTYP PKTBAS NPKT RSVBAS NRSV PKTSZ PKTOFF NMETA).
+    """
+    seg = words[a0 - 1 : a1]
+    meta = [int(v) for v in seg[-17:]]
+    conbas, ncon, refbas, nref, pktbas, npkt, pktsz, pktoff, nmeta = meta[0], meta[1], meta[5], meta[6], meta[10], meta[11], meta[14], meta[15], meta[16]
+    if nmeta != 17 or ncon != 8 or pktsz != 14 or nref != npkt:
+        raise ValueError('unexpected layout of an SPK type 10 segment')
+    stride = pktsz + pktoff
+    packets = np.array(seg[pktbas : pktbas + npkt * stride], dtype=np.float64).reshape(npkt, stride)[:, pktoff:]
+    return TleSegment(target, center, frame, float(et_b), float(et_e), np.array(seg[conbas : conbas + ncon], dtype=np.float64),
+                      np.array(seg[refbas : refbas + nref], dtype=np.float64), packets)  # fmt: skip
+
+
+def read_spk_segments(path: str) -> list:
+    """
+    Read every type 2 / type 3 (`ChebySegment`) and type 10 (`TleSegment`) segment of a binary DAF/SPK
+    file (other types are skipped). Layout: NAIF "DAF Required Reading" / "SPK Required Reading".
     """
     with open(path, 'rb') as f:
         raw = f.read()
@@ -448,6 +785,9 @@ def read_spk_segments(path: str) -> list[ChebySegment]:
                 raw[(off + 2) * 8 : (off + 5) * 8], dtype=e + 'i4'
             )
             target, center, frame, spk_type, a0, a1 = (int(v) for v in ints)
+            if spk_type == 10:
+                segs.append(_read_tle_segment(words, target, center, frame, et_b, et_e, a0, a1))
+                continue
             if spk_type not in (2, 3):
                 continue
             init, intlen, rsize, n = words[a1 - 4 : a1]
@@ -482,16 +822,16 @@ class Ephemeris:
     paths so that this ordering is deterministic).
     """
 
-    segments: list[ChebySegment] = field(default_factory=list)
+    segments: list = field(default_factory=list)  # ChebySegment / TleSegment
 
     @classmethod
     def from_spk_files(cls, paths: Iterable[str]) -> 'Ephemeris':
-        segs: list[ChebySegment] = []
+        segs: list = []
         for p in paths:
             segs.extend(read_spk_segments(p))
         return cls(segs)
 
-    def _find(self, target: int, et: float) -> ChebySegment:
+    def _find(self, target: int, et: float):
         for seg in reversed(self.segments):
             if seg.target == target and seg.covers(et):
                 return seg
@@ -538,7 +878,7 @@ class Ephemeris:
 
     def trimmed(self, bodies: Iterable[int], et_lo: float, et_hi: float) -> 'Ephemeris':
         """Subset sufficient to evaluate `bodies` wrt the SSB within [et_lo, et_hi]."""
-        keep: list[ChebySegment] = []
+        keep: list = []
         seen: set[int] = set()
         todo = list(bodies)
         while todo:
@@ -556,7 +896,7 @@ class Ephemeris:
 
     @classmethod
     def from_json(cls, d: dict) -> 'Ephemeris':
-        return cls([ChebySegment.from_json(s) for s in d['segments']])
+        return cls([(TleSegment if s.get('spk_type') == 10 else ChebySegment).from_json(s) for s in d['segments']])
 
     def dump(self, path: str) -> None:
         with open(path, 'w', encoding='utf-8') as f:

@@ -56,6 +56,7 @@ class PMGeometry(ctypes.Structure):
         ('km_per_arcsec', ctypes.c_double),
         ('np_angle_rad', ctypes.c_double),
         ('lst_sun_lon', ctypes.c_double),
+        ('WP', _D3),
         ('west_positive', ctypes.c_int32),
         ('reserved', ctypes.c_int32),
     ]
@@ -287,6 +288,9 @@ class GeometryBuilder:
         for i in range(9):
             g.R0[i] = R0.flat[i]
         g.wdot = wdot
+        drift = rot.pole_drift(t0)  # (STATE planes only: see pm_geometry.WP)
+        for i in range(3):
+            g.WP[i] = drift[i]
 
         def rot_at(t: float) -> np.ndarray:
             ang = wdot * (t - t0)

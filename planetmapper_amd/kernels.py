@@ -9,8 +9,9 @@ This is the host-side counterpart of `SpiceBase.load_spice_kernels` + `Body.__in
 (`planetmapper/base.py:554-611, 909-1079`, `planetmapper/body.py:323-606`) for the kernel
 types it can read: text PCK (`*.tpc`), text LSK (`*.tls`, optional) and binary SPK with
 Chebyshev segments of type 2 / 3 (`*.bsp`: the DE planetary ephemerides and the satellite
-ephemerides of the giant planets). Observers with other SPK types (e.g. HST's type 10) need
-spiceypy on the host.
+ephemerides of the giant planets) or type 10 (two-line elements of a near-earth satellite: HST, the
+reference's canonical observer, `tests/test_body.py:29-31`). Observers with other SPK types (e.g. a
+spacecraft's type 13 / 18 reconstruction) need spiceypy on the host.
 """
 
 from __future__ import annotations
@@ -35,6 +36,7 @@ BODY_IDS = {
     'HYPERION': 607, 'IAPETUS': 608, 'PHOEBE': 609,
     'URANUS': 799, 'ARIEL': 701, 'UMBRIEL': 702, 'TITANIA': 703, 'OBERON': 704, 'MIRANDA': 705,
     'NEPTUNE': 899, 'TRITON': 801, 'PLUTO': 999, 'CHARON': 901,
+    'HST': -48, 'HUBBLE SPACE TELESCOPE': -48,
 }  # fmt: skip
 
 

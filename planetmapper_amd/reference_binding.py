@@ -126,6 +126,15 @@ def body_z_rate(spice, frame: str, et: float) -> float:
     return float((rot @ w_inertial)[2])
 
 
+def pole_drift(spice, frame: str, et: float) -> np.ndarray:
+    """the frame's angular velocity less its component about the frame's own z axis (J2000 components): pm_geometry.WP"""
+    xf = np.asarray(spice.sxform(J2000, frame, et), dtype=float)
+    rot, drot = xf[:3, :3], xf[3:, :3]
+    skew = drot.T @ rot
+    w_inertial = np.array([skew[2, 1], skew[0, 2], skew[1, 0]])
+    return w_inertial - float(rot[2] @ w_inertial) * rot[2]
+
+
 def geometry_from_body(body, spice=None) -> PMGeometry:
     """
     The engine's geometry block of a reference `planetmapper.Body` (or anything that carries the attributes read here).
@@ -163,6 +172,7 @@ def geometry_from_body(body, spice=None) -> PMGeometry:
     # orientation: the frame at t0 and its rate about its own z axis (R(t0 + d) = Rz(wdot d) R0)
     g.R0[:] = np.asarray(spice.pxform(J2000, body.target_frame, t0), dtype=float).ravel()
     g.wdot = body_z_rate(spice, body.target_frame, t0)
+    g.WP[:] = pole_drift(spice, body.target_frame, t0)
     # what Body.__init__ has already asked of SPICE (body.py:538-588)
     g.sub_sp[:] = [float(x) for x in body._subpoint_targvec]
     g.sub_ray[:] = [float(x) for x in body._subpoint_rayvec]

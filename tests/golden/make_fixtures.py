@@ -164,41 +164,24 @@ def main(ref: str) -> None:
         'pck': rot.to_json(),
         'ephemeris': mini.to_json(),
     }
-    # The observer (HST) ephemeris is an SPK type 10 (TLE) segment that is not
-    # restated; its position follows from the header's apparent target RA/Dec/distance.
-    # Its velocity is not published anywhere, so it is recovered by a 3-parameter
-    # least-squares fit to the golden RADIAL-VELOCITY plane (40 on-disc pixels).
+    # The observer: HST, SPK type 10 (two-line elements; planetmapper_amd.ephem.TleSegment restates spke10) - the element
+    # sets around the epoch travel with the fixture like the Chebyshev records do. Nothing is fitted: position and velocity
+    # of the observer are the ephemeris's own. (Rounds 1-5 took the position from the header's TARGET RA / DEC / DISTANCE
+    # and FITTED the velocity to the golden RADIAL-VELOCITY plane; both are now cross-checks in tests/test_tle_observer.py.)
+    hst = [seg for seg in ephem.read_spk_segments(os.path.join(kdir, 'testing', 'nested', 'directory', 'hst.bsp')) if seg.target == -48]
+    assert len(hst) == 1 and hst[0].center == 399
+    mini.segments.append(hst[0].trimmed(et - 86400.0, et + 86400.0))
+    fixture['ephemeris'] = mini.to_json()
+    fixture['observer_id'] = -48
     from oracle import oracle
 
     gb = GeometryBuilder(mini, rot, 599)
-    tgt = (
-        h['PLANMAP TARGET RA'], h['PLANMAP TARGET DEC'],
-        h['PLANMAP DISTANCE'], h['PLANMAP LIGHT-TIME'],
-    )  # fmt: skip
+    g = gb.build(et, observer_id=-48)
     nav = np.load(os.path.join(HERE, 'golden_test_nav.npz'))
-    rv_gold = nav['RADIAL-VELOCITY']
-    ok = np.isfinite(rv_gold)
-    disc = oracle.make_disc(
-        h['PLANMAP DISC X0'], h['PLANMAP DISC Y0'], h['PLANMAP DISC R0'], 123.456, 7, 10
-    )
-
-    def rv_of(vo):
-        g = gb.build(et, observer_velocity=vo, target_ra_dec_dist_lt=tgt)
-        return oracle.backplanes_img(g, disc, ['RADIAL-VELOCITY'])['RADIAL-VELOCITY'][ok]
-
-    vo = np.array(eph.ssb_state(399, et)[1])
-    for _ in range(4):
-        r0 = rv_of(vo) - rv_gold[ok]
-        jac = np.empty((ok.sum(), 3))
-        for i in range(3):
-            dv = np.zeros(3)
-            dv[i] = 1e-3
-            jac[:, i] = (rv_of(vo + dv) - rv_of(vo - dv)) / 2e-3
-        vo = vo - np.linalg.lstsq(jac, r0, rcond=None)[0]
-    resid = float(np.max(np.abs(rv_of(vo) - rv_gold[ok])))
-    fixture['observer_velocity_fit'] = [float(v) for v in vo]
-    fixture['observer_velocity_fit_residual_km_s'] = resid
-    print('fitted observer velocity', vo, 'residual', resid)
+    ok = np.isfinite(nav['RADIAL-VELOCITY'])
+    disc = oracle.make_disc(h['PLANMAP DISC X0'], h['PLANMAP DISC Y0'], h['PLANMAP DISC R0'], 123.456, 7, 10)
+    rv = oracle.backplanes_img(g, disc, ['RADIAL-VELOCITY'])['RADIAL-VELOCITY']
+    print('HST from its two-line elements: RADIAL-VELOCITY vs golden', float(np.max(np.abs(rv[ok] - nav['RADIAL-VELOCITY'][ok]))), 'km/s')
     with open(os.path.join(DATA, 'jupiter_hst_2005.json'), 'w', encoding='utf-8') as f:
         json.dump(fixture, f, indent=1)
 

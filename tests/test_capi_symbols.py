@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.load()
     for name in _declared_functions():
         assert hasattr(lib, name), f'{name} missing from libplanetmapper_hip.so'
-    assert lib.pm_abi_version() == 2
+    assert lib.pm_abi_version() == 3
 
 
 def test_struct_layouts_match_the_header():

@@ -71,6 +71,9 @@ def test_binding_reproduces_the_geometry_builder_block(name):
     assert abs(b.wdot - g.wdot) * r_c < 1e-13, (name, b.wdot, g.wdot)
     assert abs(b.wdot - g.wdot) * span < 4e-13, name
     assert abs(b.lst_sun_lon - g.lst_sun_lon) < 1e-9, name
+    # the drift of the pole (STATE planes: what sxform's derivative block holds beyond the spin) to 1e-4 of itself - 1e-13 km/s
+    assert np.max(np.abs(vec(b, 'WP') - vec(g, 'WP'))) < 1e-4 * max(np.linalg.norm(vec(g, 'WP')), 1e-16), (name, vec(b, 'WP'), vec(g, 'WP'))
+    assert abs(vec(b, 'WP') @ vec(g, 'R0')[6:9]) < 1e-17
     assert 'spksfs' in spice.calls  # the chain was walked segment by segment
 
 

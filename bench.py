@@ -189,6 +189,18 @@ def profile_record(kernel_prefix, workload: str = 'frame') -> tuple[dict, bool]:
     return total, False
 
 
+def rocprof_fields(rec: dict, alg: int) -> dict:
+    """
+    The profiler's own figure beside the events': the average duration of the step's kernels in the `rocprofv3 --kernel-trace
+    --stats` pass of tools/pmc_profile.sh on THIS build (stamped like the traffic), and the fraction it gives. `kernel_ms` /
+    `frac` are this run's HIP events on this box; boxes of the pool differ by +-10 %, store-bound kernels by more.
+    """
+    if 'rocprof_avg_ns' not in rec:
+        return {}
+    ms = rec['rocprof_avg_ns'] * 1e-6
+    return {'kernel_ms_rocprof': round(ms, 4), 'frac_rocprof': round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+
+
 def algorithmic_bytes(nx: int, ny: int, n_planes: int) -> int:
     """the image kernel reads nothing and writes 8 B per plane per pixel."""
     return nx * ny * 8 * n_planes
@@ -1105,7 +1117,7 @@ def other_workloads(args) -> None:
         # the step IS its kernels here (events around the step on the stream they run on); HBM traffic per step from
         # the stamped --pmc passes of tools/pmc_profile.sh for this workload
         kernels = {'saturn': ('pm::k_disc_sph<5,',), 'all26': ('pm::k_disc_sph<7,', 'pm::k_sky<true>'),
-                   'maps': ('pm::k_map_b0<true, true>',), 'cube': ('pm::k_reproject<double>',)}[args.workload]
+                   'maps': ('pm::k_map_b0<true, true>',), 'cube': ('pm::k_reproject_xcd<double>',)}[args.workload]
         rec, stale = profile_record(kernels, args.workload) if (args.size == 4096 or args.workload in ('cube', 'maps')) else ({}, False)
         line = {
             'metric': metric, 'value': round(n_units * args.steps / dt / 1e6, 2), 'unit': 'Mcell/s' if args.workload == 'maps' else 'Mpix/s',
@@ -1117,7 +1129,8 @@ def other_workloads(args) -> None:
                          'bound': 'hbm', 'achieved': round(alg / (step_ms * 1e-3) / 1e9, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(alg / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                          'traffic': int(rec['hbm_bytes']) if 'hbm_bytes' in rec else None, 'traffic_stale': stale,
-                         'library_sha256': library_sha256()[:16], 'kernel_ms': round(step_ms, 4), 'algorithmic_bytes': alg},
+                         'library_sha256': library_sha256()[:16], 'kernel_ms': round(step_ms, 4), 'algorithmic_bytes': alg,
+                         **rocprof_fields(rec, alg)},
         }
         if d.world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_other(args.workload, g, sz, names if args.workload != 'cube' else (), host_cores(), args.planes)
@@ -1274,6 +1287,7 @@ def headline(args) -> None:
                 'library_sha256': library_sha256()[:16],
                 'kernel_ms': round(kernel_ms, 4),
                 'algorithmic_bytes': alg,
+                **rocprof_fields(rec, alg),
             },
             'step_roofline': {
                 'bound': 'hbm',

@@ -202,6 +202,7 @@ __global__ __launch_bounds__(kBlock) void k_reproject(const ReprojectArgs a)
 // here the workgroups an XCD receives are those of ONE plane at a time (plane = 8 * (j / chunks) + xcd): the 64-byte
 // lines that neighbouring map rows share are then found in that XCD's L2 instead of being fetched by several of them.
 // Round 6, config 5 (512 planes of 1024^2 -> 1 deg): 0.459 -> 0.436 ms (same box, alternating runs); same samples, same bits.
+// (Two / four planes of the same cell per lane - more requests in flight per wave - were slower: 0.461 -> 0.478 / 0.494 ms.)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_reproject_xcd(const ReprojectArgs a, int chunks)
 {

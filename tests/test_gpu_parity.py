@@ -343,18 +343,32 @@ def test_headline_frame_4096_vs_oracle_and_round_trip(engine, oracle, jupiter):
     sz = 4096
     x0 = y0 = (sz - 1) / 2
     r0 = 0.9 * x0
-    engine.set_geometry(jupiter)
-    engine.set_disc(x0, y0, r0, 0.0, sz, sz, True)
-    out = engine.backplanes_img(HEADLINE)
+    from planetmapper_amd import _lib
+
     oracle.set_num_threads(16)
     ref = oracle.backplanes_img(jupiter, oracle.make_disc(x0, y0, r0, 0.0, sz, sz), HEADLINE)
-    stats = _compare(out, ref, HEADLINE, jupiter)
-    print('\n4096^2 HIP vs oracle (max |diff| deg, fraction within flat 1e-9 deg):', stats)
-    assert int(np.isfinite(out['LON-GRAPHIC']).sum()) == int(np.isfinite(ref['LON-GRAPHIC']).sum())
-    # share of on-disc pixels inside the flat 1e-9 deg (measured: LON 99.46 %, LAT 99.998 %, INC / EMI 99.79 %, PHASE 100 %)
-    floor = {'LON-GRAPHIC': 0.99, 'LAT-GRAPHIC': 0.999, 'PHASE': 1.0, 'INCIDENCE': 0.995, 'EMISSION': 0.995}
-    for n in HEADLINE:
-        assert stats[n][1] >= floor[n], (n, stats[n])
+    # The general kernel first, the library's own choice last (`out` below is the headline kernel's). Share of on-disc pixels
+    # inside the flat 1e-9 deg, measured (round 6, observer from the TLE ephemeris; the header-derived observer of rounds 1-5
+    # gives the same to 0.005 %): library's choice LON 99.45 %, LAT 99.997 %, INC / EMI 99.79 %, PHASE 100 %; general kernel
+    # LON 99.04 %, LAT 99.997 %, INC / EMI 99.50 %. (Until round 6 this test ran under whichever kernel the module's
+    # parametrised fixture had left selected - the general one - against the fast kernel's floors: 99.4990 % failed 99.5.)
+    floors = {1: {'LON-GRAPHIC': 0.985, 'LAT-GRAPHIC': 0.999, 'PHASE': 1.0, 'INCIDENCE': 0.99, 'EMISSION': 0.99},
+              0: {'LON-GRAPHIC': 0.99, 'LAT-GRAPHIC': 0.999, 'PHASE': 1.0, 'INCIDENCE': 0.995, 'EMISSION': 0.995}}
+    forced = engine.get_option(_lib.PM_OPT_GENERAL_KERNEL)
+    try:
+        for general in (1, 0):
+            engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, general)
+            engine.set_geometry(jupiter)
+            engine.set_disc(x0, y0, r0, 0.0, sz, sz, True)
+            out = engine.backplanes_img(HEADLINE)
+            stats = _compare(out, ref, HEADLINE, jupiter)
+            which = 'general kernel' if general else 'the kernel the library chooses'
+            print(f'\n4096^2 HIP ({which}) vs oracle (max |diff| deg, fraction within flat 1e-9 deg):', stats)
+            assert int(np.isfinite(out['LON-GRAPHIC']).sum()) == int(np.isfinite(ref['LON-GRAPHIC']).sum())
+            for n in HEADLINE:
+                assert stats[n][1] >= floors[general][n], (general, n, stats[n])
+    finally:
+        engine.set_option(_lib.PM_OPT_GENERAL_KERNEL, forced)
     # round trip on a band of rows through the disc (emission < 85 deg: well conditioned)
     rows = slice(2040, 2056)
     lon, lat, emi = out['LON-GRAPHIC'][rows], out['LAT-GRAPHIC'][rows], out['EMISSION'][rows]

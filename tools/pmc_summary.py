@@ -37,6 +37,14 @@ for k, cs in sorted(acc.items()):
         name = k.replace('void ', '')
         traffic.setdefault(name, {})['fp64_flop'] = 64.0 * (2 * m[f64[0]] + m[f64[1]] + m[f64[2]] + m[f64[3]])
         traffic[name]['fp64_wave_insts'] = sum(m.values())
+# the kernel-trace pass of the same command (pmc_profile.sh: $OUT/stats): the profiler's own average duration per kernel -
+# bench.py prints it beside its HIP-event figure (roofline.kernel_ms_rocprof), so a line read on its own says both
+for f in glob.glob(os.path.join(root, 'stats', '**', '*kernel_stats.csv'), recursive=True):
+    for row in csv.DictReader(open(f)):
+        name = row['Name'].split('(')[0][:60].replace('void ', '')  # (the key of the counter rows above)
+        if name.startswith('pm::'):
+            traffic.setdefault(name, {})['rocprof_avg_ns'] = float(row['AverageNs'])
+            traffic[name]['rocprof_calls'] = int(row['Calls'])
 # which build these counters belong to: bench.py reports them only while the library it has loaded is this one
 import hashlib
 

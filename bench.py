@@ -419,7 +419,7 @@ def rehearse(args) -> None:
 
 # ------------------------------------------------------------------ config 5 fed from host memory
 def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_resident: int, sz: int = 1024,
-                      degree_interval: float = 1.0) -> dict:
+                      degree_interval: float = 1.0, partial: dict | None = None) -> dict:
     """
     BASELINE config 5 as the reference runs it (observation.py:876-905 maps a HOST cube): P x 1024^2
     f64 planes in host memory, contiguous blocks of ceil(P / N) planes per rank
@@ -528,6 +528,9 @@ def cube_host_section(d: Dist, eng, g, planes: int, steps_fed: int, steps_reside
             'Mpix_s_host_fed_plain_allgather': round(pix / t_fed_plain / 1e6, 1),
             'fed_equals_resident_plain_allgather': equal(),
         })
+        if partial is not None:
+            # (what stands if the pipelined protocol below never comes back: the watchdog of the caller prints this)
+            partial.update(sec, ms_per_step_host_fed=sec['ms_per_step_host_fed_plain_allgather'], Mpix_s_host_fed=sec['Mpix_s_host_fed_plain_allgather'])
     # the pipelined protocol. A failure on any rank is agreed on (every rank raises or none does), so the ranks
     # stay in step for whatever follows; the caller records it and keeps the headline.
     error = None
@@ -1320,6 +1323,7 @@ def headline(args) -> None:
             # The complete line (same fields + cube_host) follows when the sections are through.
             print(json.dumps(dict(line, extras='pending: the complete line, with cube_host, follows')), flush=True)
         watchdog = None
+        partial_sec: dict = {}
         if d.world > 1:
             # ... and if the section HANGS (a collective some rank never joins), every rank gives up after a deadline of
             # its own: rank 0 prints the complete line with the section marked as timed out, and every rank leaves with
@@ -1335,8 +1339,9 @@ def headline(args) -> None:
 
             def bail() -> None:
                 if d.rank == 0:
-                    print(json.dumps(dict(line, cube_host={'error': f'timed out after {deadline:.0f} s: section abandoned',
-                                                           'exit_status': EXTRAS_TIMED_OUT_STATUS})), flush=True)
+                    # (with the plain form's measured numbers - map, finish, one all-gather - if the section got that far)
+                    print(json.dumps(dict(line, cube_host=dict(partial_sec, error=f'timed out after {deadline:.0f} s: section abandoned',
+                                                               exit_status=EXTRAS_TIMED_OUT_STATUS))), flush=True)
                     sys.stdout.flush()
                     note = os.environ.get('PM_BENCH_STATUS_FILE')  # (self_launch: the launcher turns every rank status into 1)
                     if note:
@@ -1357,7 +1362,7 @@ def headline(args) -> None:
             except Exception as e:  # noqa: BLE001
                 line['interpolations'] = {'error': f'{type(e).__name__}: {e}'[:300]}
         try:
-            sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50)
+            sec = cube_host_section(d, eng, g, args.planes, steps_fed=7, steps_resident=50, partial=partial_sec)
         except Exception as e:  # noqa: BLE001
             sec = {'error': f'{type(e).__name__}: {e}'[:500]}
         if d.world == 1 and d.rank == 0 and not args.no_shared_gpu and 'error' not in sec:

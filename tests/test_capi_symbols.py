@@ -135,3 +135,56 @@ def test_hand_declared_rccl_abi_matches_the_installed_header(tmp_path):
     lb = open(os.path.join(REPO, 'tests', 'loopback', 'loopback_nccl.cpp')).read()
     for sym in symbols:
         assert re.search(r'\b%s\s*\(' % sym, lb), sym
+
+
+def test_dlpack_export_layout_and_hold_bookkeeping_without_a_gpu():
+    """
+    pm_dlpack_*: the DLManagedTensor a `DeviceArray` hands to torch / cupy is built and released by C code of the library
+    (no Python in a consumer's release). Its layout - dlpack.h's legacy struct, device type kDLROCM - and the hold's counting
+    are host-side code: checked here on a made-up device address (nothing dereferences it; `free_memory` is never asked for).
+    """
+    import ctypes
+
+    from planetmapper_amd import _lib
+
+    lib = _lib.load()
+
+    class DLDevice(ctypes.Structure):
+        _fields_ = [('device_type', ctypes.c_int32), ('device_id', ctypes.c_int32)]
+
+    class DLDataType(ctypes.Structure):
+        _fields_ = [('code', ctypes.c_uint8), ('bits', ctypes.c_uint8), ('lanes', ctypes.c_uint16)]
+
+    class DLTensor(ctypes.Structure):
+        _fields_ = [('data', ctypes.c_void_p), ('device', DLDevice), ('ndim', ctypes.c_int32), ('dtype', DLDataType),
+                    ('shape', ctypes.POINTER(ctypes.c_int64)), ('strides', ctypes.POINTER(ctypes.c_int64)), ('byte_offset', ctypes.c_uint64)]  # fmt: skip
+
+    class DLManagedTensor(ctypes.Structure):
+        _fields_ = [('dl_tensor', DLTensor), ('manager_ctx', ctypes.c_void_p), ('deleter', ctypes.c_void_p)]
+
+    hold = lib.pm_dlpack_hold_create(ctypes.c_void_p(0x7F0000001000), 3)
+    assert hold and lib.pm_dlpack_exports(ctypes.c_void_p(hold)) == 0
+    shape = (ctypes.c_int64 * 3)(5, 180, 360)
+    exports = [lib.pm_dlpack_export(ctypes.c_void_p(hold), 2, 64, 3, ctypes.cast(shape, ctypes.c_void_p)) for _ in range(2)]
+    assert all(exports) and exports[0] != exports[1] and lib.pm_dlpack_exports(ctypes.c_void_p(hold)) == 2
+    m = DLManagedTensor.from_address(exports[0])
+    t = m.dl_tensor
+    assert t.data == 0x7F0000001000 and (t.device.device_type, t.device.device_id) == (10, 3) and t.ndim == 3
+    assert (t.dtype.code, t.dtype.bits, t.dtype.lanes) == (2, 64, 1) and [t.shape[i] for i in range(3)] == [5, 180, 360]
+    assert not t.strides and t.byte_offset == 0 and m.manager_ctx == hold and m.deleter
+    shape[0] = 99  # the export carries its own copy of the shape
+    assert t.shape[0] == 5
+    assert lib.pm_dlpack_export(ctypes.c_void_p(hold), 2, 64, 9, ctypes.cast(shape, ctypes.c_void_p)) is None  # ndim > 8
+    # the owner lets go while two consumers still import: nothing is freed under them, the hold lives until the last deleter
+    assert lib.pm_dlpack_release(ctypes.c_void_p(hold), 0) == 0
+    assert lib.pm_dlpack_export(ctypes.c_void_p(hold), 2, 64, 3, ctypes.cast(shape, ctypes.c_void_p)) is None  # no new exports of an orphan
+    lib.pm_dlpack_delete(ctypes.c_void_p(exports[0]))
+    assert lib.pm_dlpack_exports(ctypes.c_void_p(hold)) == 1
+    lib.pm_dlpack_delete(ctypes.c_void_p(exports[1]))  # (the last one: deletes the hold too)
+    # an owner with no consumer left: released at once
+    hold2 = lib.pm_dlpack_hold_create(ctypes.c_void_p(0x7F0000002000), 0)
+    e = lib.pm_dlpack_export(ctypes.c_void_p(hold2), 1, 8, 1, ctypes.cast((ctypes.c_int64 * 1)(7), ctypes.c_void_p))
+    lib.pm_dlpack_delete(ctypes.c_void_p(e))
+    assert lib.pm_dlpack_exports(ctypes.c_void_p(hold2)) == 0 and lib.pm_dlpack_release(ctypes.c_void_p(hold2), 0) == 1
+    assert lib.pm_dlpack_release(None, 0) == 1 and lib.pm_dlpack_exports(None) == 0
+    lib.pm_dlpack_delete(None)

@@ -883,10 +883,52 @@ class BodyXY:
                 cache[key] = _readonly(a)
         return {n: slot(n)[0][slot(n)[1]] for n in names}
 
-    def get_x_map(self, **map_kwargs) -> np.ndarray:
+    def _lonlat_grids_device(self, map_kwargs: dict) -> tuple:
+        """the map grid in HBM (two `DeviceArray`s; it does not depend on the disc: kept across `_clear_cache`)"""
+        key = ('lonlat_dev', self._map_key(map_kwargs))
+        grids = self._stable_cache.get(key)
+        if grids is None or not grids[0].valid:
+            eng = self._bind()
+            if not hasattr(eng, 'device_array'):
+                raise _lib.UnsupportedError('this engine keeps no results on a device')
+            lon, lat = self._get_lonlat_grids(**map_kwargs)
+            grids = (eng.device_array(lon.shape), eng.device_array(lat.shape))
+            eng.h2d(grids[0].ptr, lon)
+            eng.h2d(grids[1].ptr, lat)
+            self._stable_cache[key] = grids
+        return grids
+
+    def _map_planes_device(self, names: Iterable[str], map_kwargs: dict) -> dict:
+        """
+        The device form of `_map_planes`: map-space planes as `DeviceArray`s, computed from the grid's device copy into HBM,
+        cached like the host planes (x / y maps with the disc, everything else for good).
+        """
+        names = list(names)
+        map_kwargs, alt = self._split_map_kwargs(dict(map_kwargs))
+        mkey = self._map_key(map_kwargs)
+
+        def slot(n: str):
+            return (self._cache if n in ('PIXEL-X', 'PIXEL-Y') else self._stable_cache), ('map_dev', n, mkey)
+
+        missing = [n for n in names if slot(n)[1] not in slot(n)[0] or not slot(n)[0][slot(n)[1]].valid]
+        if missing:
+            lon_d, lat_d = self._lonlat_grids_device(map_kwargs)
+            eng = self._bind()
+            out = {n: eng.device_array(lon_d.shape) for n in missing}
+            eng.backplanes_map_device(out, lon_d, lat_d, lon_d.shape[0], lon_d.shape[1], alt=alt)
+            for n, a in out.items():
+                cache, key = slot(n)
+                cache[key] = a
+        return {n: slot(n)[0][slot(n)[1]] for n in names}
+
+    def get_x_map(self, *, device: bool = False, **map_kwargs):
+        if device:
+            return self._map_planes_device(['PIXEL-X', 'PIXEL-Y'], map_kwargs)['PIXEL-X']
         return self._map_planes(['PIXEL-X', 'PIXEL-Y'], map_kwargs)['PIXEL-X']
 
-    def get_y_map(self, **map_kwargs) -> np.ndarray:
+    def get_y_map(self, *, device: bool = False, **map_kwargs):
+        if device:
+            return self._map_planes_device(['PIXEL-X', 'PIXEL-Y'], map_kwargs)['PIXEL-Y']
         return self._map_planes(['PIXEL-X', 'PIXEL-Y'], map_kwargs)['PIXEL-Y']
 
     # ------------------------------------------------------------------ reprojection
@@ -986,9 +1028,16 @@ class BodyXY:
                 return bp.get_img(device=True)
             return bp.get_img().copy()
 
-    def get_backplane_map(self, name: str, **map_kwargs) -> np.ndarray:
-        """Fresh copy of a backplane map (body_xy.py:2632-2664)."""
-        return self.backplanes[self.standardise_backplane_name(name)].get_map(**map_kwargs).copy()
+    def get_backplane_map(self, name: str, *, device: bool = False, **map_kwargs):
+        """Fresh copy of a backplane map (body_xy.py:2632-2664); `device=True`: the plane as a read-only `DeviceArray` in
+        HBM (see `get_backplane_img`), default backplanes only."""
+        bp = self.backplanes[self.standardise_backplane_name(name)]
+        if device:
+            fn = getattr(bp.get_map, '__func__', None)
+            if fn is None or not getattr(fn, '_pm_device', False):
+                raise _lib.UnsupportedError(f'backplane {bp.name!r} is a user-registered function of numpy arrays: no device form')
+            return bp.get_map(device=True, **map_kwargs)
+        return bp.get_map(**map_kwargs).copy()
 
     def _register_default_backplanes(self) -> None:
         """The 26 default backplanes, same names/order/descriptions as body_xy.py:4198-4356."""
@@ -1067,8 +1116,12 @@ def _make_getters(stem: str, plane: str, family: tuple[str, ...]):
 
     get_img._pm_device = True
 
-    def get_map(self: BodyXY, **map_kwargs) -> np.ndarray:
+    def get_map(self: BodyXY, *, device: bool = False, **map_kwargs):
+        if device:
+            return self._map_planes_device(family, map_kwargs)[plane]
         return self._map_planes(family, map_kwargs)[plane]
+
+    get_map._pm_device = True
 
     get_img.__name__ = f'get_{stem}_img'
     get_map.__name__ = f'get_{stem}_map'
@@ -1077,7 +1130,8 @@ def _make_getters(stem: str, plane: str, family: tuple[str, ...]):
         'NaN where undefined. `device=True`: the same plane as a read-only `DeviceArray` left in the GPU\'s HBM.'
     )
     get_map.__doc__ = (
-        f'Read-only (n0, n1) float64 map of the {plane} backplane (reference `BodyXY.get_{stem}_map`).'
+        f'Read-only (n0, n1) float64 map of the {plane} backplane (reference `BodyXY.get_{stem}_map`). '
+        '`device=True`: the same map as a read-only `DeviceArray` left in the GPU\'s HBM.'
     )
     return get_img, get_map
 
@@ -1087,6 +1141,8 @@ for _stem, (_plane, _family) in _FAMILIES.items():
     setattr(BodyXY, f'get_{_stem}_img', _gi)
     if _stem not in ('x', 'y'):  # get_x_map / get_y_map are defined explicitly above
         setattr(BodyXY, f'get_{_stem}_map', _gm)
+BodyXY.get_x_map._pm_device = True
+BodyXY.get_y_map._pm_device = True
 
 
 class _AltitudeContext:

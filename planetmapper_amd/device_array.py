@@ -3,8 +3,8 @@
 to GPU-side consumers through the two interchange protocols they read: `__dlpack__` / `__dlpack_device__` (torch.from_dlpack,
 cupy.from_dlpack, jax ...) and `__cuda_array_interface__` (CuPy, Numba; version 3, the read-only flag set).
 
-What `BodyXY.get_*_img(device=True)`, `get_backplane_img(name, device=True)` and `Observation.get_mapped_data(...,
-device=True)` return. The numpy forms of those getters move every plane over PCIe (9.4 ms for the five planes of a
+What `BodyXY.get_*_img(device=True)`, `get_*_map(device=True, **map_kwargs)`, `get_backplane_img / _map(name, device=True)`
+and `Observation.get_mapped_data(..., device=True)` return. The numpy forms of those getters move every plane over PCIe (9.4 ms for the five planes of a
 4096^2 frame whose kernel is 0.13 ms); a consumer that works on the GPU takes the planes where they are instead.
 
 Semantics (the device form of the reference's read-only cached arrays, base.py:115-138 / body_xy.py:2586-2630):

@@ -568,26 +568,11 @@ class Observation(BodyXY):
         if key not in self._cache:
             map_kwargs = {k: v for k, v in kwargs.items() if k not in ('interpolation', 'spline_smoothing', 'propagate_nan',
                                                                        'smooth_oversample_by', 'smooth_max_oversampled_img_size')}  # fmt: skip
-            map_kwargs, alt = self._split_map_kwargs(dict(map_kwargs))
-            mkey = self._map_key(map_kwargs)
             eng = self._bind()
             if not hasattr(eng, 'device_array'):
                 raise UnsupportedError('this engine keeps no results on a device')
-            lon, lat = self._get_lonlat_grids(**map_kwargs)
-            n0, n1 = lon.shape
-            gkey = ('lonlat_dev', mkey)
-            grids = self._stable_cache.get(gkey)
-            if grids is None or not grids[0].valid:  # (the grid does not depend on the disc: it stays across `_clear_cache`)
-                grids = (eng.device_array(lon.shape), eng.device_array(lat.shape))
-                eng.h2d(grids[0].ptr, lon)
-                eng.h2d(grids[1].ptr, lat)
-                self._stable_cache[gkey] = grids
-            xkey = ('map_dev', 'xy', mkey, alt)
-            if xkey not in self._cache:
-                xy = (eng.device_array((n0, n1)), eng.device_array((n0, n1)))
-                eng.xy_map_device(grids[0], grids[1], n0, n1, xy[0], xy[1], alt=alt)
-                self._cache[xkey] = xy
-            xm, ym = self._cache[xkey]
+            xm, ym = (self._map_planes_device(['PIXEL-X', 'PIXEL-Y'], dict(map_kwargs))[n] for n in ('PIXEL-X', 'PIXEL-Y'))
+            n0, n1 = xm.shape
             cube = self._data_device()
             data = np.asarray(self.data)
             planes = data.shape[0] if data.ndim == 3 else 1

@@ -453,6 +453,13 @@ def test_device_resident_getters_of_the_drop_in_surface(jupiter):
         assert isinstance(m_d, DeviceArray) and m_d.shape == (3, 18, 36) and same(m_d, m_h), (interp, kw)
         assert np.isfinite(m_h).sum() > 100
     assert obs.get_mapped_data('linear', degree_interval=10, device=True) is obs.get_mapped_data('linear', degree_interval=10, device=True)
+    # map space: the planes of a map grid in HBM (the grid itself uploaded once per set of map keywords)
+    for name in ('PIXEL-X', 'EMISSION', 'LON-CENTRIC', 'RADIAL-VELOCITY', 'LIMB-DISTANCE', 'RING-RADIUS', 'LOCAL-SOLAR-TIME'):
+        for kw in ({'degree_interval': 10}, {'degree_interval': 15, 'alt': 1200.0}, {'projection': 'orthographic', 'size': 24}):
+            assert same(obs.get_backplane_map(name, device=True, **kw), obs.get_backplane_map(name, **kw)), (name, kw)
+    assert same(obs.get_emission_angle_map(device=True, degree_interval=10), obs.get_emission_angle_map(degree_interval=10))
+    assert obs.get_x_map(device=True, degree_interval=10) is obs.get_backplane_map('PIXEL-X', device=True, degree_interval=10)
+    emi_map_d, x_map_d = obs.get_emission_angle_map(device=True, degree_interval=10), obs.get_x_map(device=True, degree_interval=10)
     obs.register_backplane('MINE', 'a user function', lambda: np.zeros((96, 120)), lambda **kw: np.zeros((18, 36)))
     with pytest.raises(UnsupportedError):
         obs.get_backplane_img('MINE', device=True)
@@ -461,6 +468,9 @@ def test_device_resident_getters_of_the_drop_in_surface(jupiter):
     mapped_old = obs.get_mapped_data('linear', degree_interval=10, device=True)
     obs.set_x0(61.3)
     assert not lon_d.valid and not mapped_old.valid
+    assert not x_map_d.valid and emi_map_d.valid  # x / y maps go with the disc; the other map planes do not depend on it
+    assert obs.get_emission_angle_map(device=True, degree_interval=10) is emi_map_d
+    assert same(obs.get_x_map(device=True, degree_interval=10), obs.get_x_map(degree_interval=10))
     for dead in (lambda: lon_d.ptr, lambda: lon_d.__cuda_array_interface__, lambda: torch.from_dlpack(lon_d), lon_d.numpy):
         with pytest.raises(ValueError, match='cache entry that has been cleared'):
             dead()

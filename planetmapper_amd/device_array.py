@@ -69,6 +69,7 @@ class DeviceArray:
         self._ptr = engine._device_take(self.nbytes)
         self._hold = _lib.load().pm_dlpack_hold_create(ctypes.c_void_p(self._ptr), int(engine.device))
         self._valid = True
+        engine._device_arrays.add(self)
 
     # ------------------------------------------------------------------ lifetime
     @property

@@ -112,6 +112,9 @@ class Engine:
         self._device_pool: dict[int, list] = {}
         self._device_pool_bytes = 0
         self._device_waiting: list = []
+        import weakref
+
+        self._device_arrays = weakref.WeakSet()  # every live DeviceArray of this engine: close() takes their memory with it
         self._device_pool_limit = int(float(os.environ.get('PLANETMAPPER_DEVICE_POOL_MB', '8192')) * (1 << 20))
         if general_kernel is not None:
             self.set_option(_lib.PM_OPT_GENERAL_KERNEL, 1 if general_kernel else 0)
@@ -121,8 +124,8 @@ class Engine:
         self._plane_pool = {}
         if getattr(self, '_ctx', None):
             self._device_sweep()
-            for arr in self._device_waiting:
-                arr._orphan()  # (still imported by a consumer: the import's own deleter frees the block)
+            for arr in list(self._device_arrays):
+                arr._orphan()  # (freed now; one a consumer still imports: by that import's own deleter, when it lets go)
             self._device_waiting = []
             for blocks in self._device_pool.values():
                 for ptr in blocks:

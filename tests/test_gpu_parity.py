@@ -497,6 +497,20 @@ def test_device_resident_getters_of_the_drop_in_surface(jupiter):
     del cap
     gc.collect()
     assert again._exports == 0
+    # an engine that is closed takes the memory of its live arrays with it (their handles go invalid); an import a consumer
+    # still holds keeps ITS block until the consumer lets go
+    from planetmapper_amd.engine import Engine
+
+    e2 = Engine(0)
+    kept, imported = e2.device_array((4, 5)), e2.device_array((3,))
+    t2 = torch.from_dlpack(imported)
+    e2.close()
+    assert not kept.valid and not imported.valid and kept._ptr == 0 and imported._ptr == 0
+    t2.fill_(1.0)
+    torch.cuda.synchronize()
+    assert float(t2.sum()) == 3.0
+    del t2, kept, imported
+    gc.collect()
     # a consumer that still holds its import when the interpreter goes down: the import's deleter is C code of the library
     # (a Python callback there is a call into an interpreter that no longer exists)
     import subprocess

@@ -145,3 +145,22 @@ def test_the_kernel_file_itself_and_bodyxy_from_kernels(parts):
     assert g.et == ref.et == 157809664.1839331
     for name in ('T0', 'VO', 'VT', 'WP', 'R0', 'sub_sp'):
         assert np.allclose(np.array(getattr(g, name)[:]), np.array(getattr(ref, name)[:]), rtol=0, atol=1e-9 * max(1.0, np.abs(getattr(ref, name)[:]).max())), name
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_KERNELS), reason='the reference checkout (kernel files) is not on this machine')
+def test_the_whole_span_of_hst_bsp_is_an_orbit():
+    """15 518 element sets, 1990-2023: every epoch sampled gives HST's orbit (no decayed set, no deep-space set, no jump)"""
+    seg = ephem.read_spk_segments(os.path.join(REF_KERNELS, 'testing', 'nested', 'directory', 'hst.bsp'))[0]
+    rng = np.random.default_rng(10)
+    ets = rng.uniform(seg.et_begin + 10.0, seg.et_end - 10.0, 150)
+    for et in ets:
+        p, v, _ = seg.state(float(et))
+        r, speed = float(np.linalg.norm(p)), float(np.linalg.norm(v))
+        assert 6850.0 < r < 7010.0 and 7.50 < speed < 7.65, (et, r, speed)  # 470-630 km above 6378 km, over 33 years of decay and reboosts
+        incl = np.degrees(np.arccos(np.cross(p, v)[2] / np.linalg.norm(np.cross(p, v))))
+        assert 28.3 < incl < 28.7, (et, incl)  # HST's inclination, in J2000 (precession moves the equator by < 0.2 deg over the span)
+    # across element-set epochs the blend is continuous in position and velocity (weights 1 / 0 there)
+    for k in rng.integers(1, len(seg.epochs) - 1, 40):
+        t = float(seg.epochs[k])
+        a, b = seg.state(t - 1e-4), seg.state(t + 1e-4)
+        assert np.linalg.norm(b[0] - a[0] - 2e-4 * a[1]) < 1e-6 and np.linalg.norm(b[1] - a[1]) < 1e-5, k

@@ -317,6 +317,14 @@ int pm_set_stream(pm_ctx *ctx, void *hip_stream);
  *                           makes by the last bit of a sum of ~10^3 squared residuals (a one-ulp change of one input pixel
  *                           flips it; the two outcomes are both smoothing splines FITPACK accepts, percent-level apart).
  *                           0 = every decision of the search was the reference's own beyond rounding.
+ *   PM_OPT_LAST_SM_ILL_CONDITIONED read-only: planes of the latest smoothing-spline call whose search went through a fit beyond
+ *                           what the library's least-squares solve (semi-normal equations + one refinement step: the
+ *                           condition number squared, where FITPACK's Givens QR carries it once) resolves: the refinement
+ *                           still moved the coefficients by more than 1e-10 of their scale (healthy fits: 1e-15 .. 2e-12).
+ *                           Seen on 20-25 sample axes of degree 4-5 - smoothing parameters p ~ 1e7 .. 1e9, or a rank-deficient
+ *                           knot set in the least-squares phase (3 fits in 191 000 of a fuzz soak): the map then differs from
+ *                           scipy's by up to 1e-4 of the data scale (scipy itself moved by 1e-1 between versions on such
+ *                           fits: tests/test_observation.py:1163-1170 of the reference). 0 = every fit converged.
  *   PM_OPT_LAST_STAGE_NS + k read-only, ns: where the latest host-fed pm_map_cube (PM_MEM_HOST / PM_MEM_HOST_CUBE, nearest /
  *                           linear) or pm_map_cube_sharded of this context spent its time. Host clock, always recorded:
  *                           0 the whole pm_map_cube call = 1 + 2 + 5 + 6 + 7; 1 fingerprint of the x / y maps + block-table
@@ -377,6 +385,7 @@ typedef enum pm_option {
     PM_OPT_SPLINE_SEGMENT = 28,
     PM_OPT_LAST_SPLINE_SEGMENT = 29,
     PM_OPT_LAST_SM_KNIFE_EDGES = 30,
+    PM_OPT_LAST_SM_ILL_CONDITIONED = 31,
     PM_OPT_ROUTE_NS_PER_PLANE = 16, /* + route 0..4 */
     PM_OPT_LAST_STAGE_NS = 32       /* + stage 0..12, read-only: see below */
 } pm_option;

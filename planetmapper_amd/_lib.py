@@ -85,6 +85,7 @@ PM_OPT_LAST_LT_PATH = 27
 PM_OPT_SPLINE_SEGMENT = 28
 PM_OPT_LAST_SPLINE_SEGMENT = 29
 PM_OPT_LAST_SM_KNIFE_EDGES = 30
+PM_OPT_LAST_SM_ILL_CONDITIONED = 31
 PM_OPT_ROUTE_NS_PER_PLANE = 16  # + route 0..4
 PM_OPT_LAST_STAGE_NS = 32  # + stage 0..12 (STAGES)
 STAGES = ('total', 'tables', 'plan', 'first_fill', 'collect', 'issue', 'drain', 'finish', 'dma_device', 'kernels_device',

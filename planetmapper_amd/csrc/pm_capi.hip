@@ -541,6 +541,7 @@ int pm_set_option(pm_ctx *ctx, int option, int64_t value)
     case PM_OPT_HYBRID_FETCH_PERMILLE:
     case PM_OPT_LAST_SPLINE_SEGMENT:
     case PM_OPT_LAST_SM_KNIFE_EDGES:
+    case PM_OPT_LAST_SM_ILL_CONDITIONED:
         return fail(ctx, PM_ERR_INVALID_ARGUMENT, "option %d is read-only", option);
     }
     return fail(ctx, PM_ERR_INVALID_ARGUMENT, "unknown option %d", option);
@@ -576,6 +577,7 @@ int pm_get_option(pm_ctx *ctx, int option, int64_t *value)
     case PM_OPT_SPLINE_SEGMENT: *value = ctx->spline_segment; return PM_OK;
     case PM_OPT_LAST_SPLINE_SEGMENT: *value = ctx->last_spline_segment; return PM_OK;
     case PM_OPT_LAST_SM_KNIFE_EDGES: *value = ctx->last_sm_knife_edges; return PM_OK;
+    case PM_OPT_LAST_SM_ILL_CONDITIONED: *value = ctx->last_sm_ill_conditioned; return PM_OK;
     case PM_OPT_LAST_CUBE_ROUTE: *value = ctx->last_cube_route; return PM_OK;
     case PM_OPT_LAST_REDO_PLANES: *value = ctx->last_redo_planes; return PM_OK;
     case PM_OPT_HOST_COPY_THREADS_IN_USE: *value = pipe_copy_threads(ctx); return PM_OK;

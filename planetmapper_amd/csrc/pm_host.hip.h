@@ -96,6 +96,7 @@ struct pm_ctx {
     int *sm_status_host = nullptr;  // pinned: the per-round read-back (smoothing splines); [0] also the interpolating splines' "a plane asked for its median"
     hipEvent_t spline_ev = nullptr; // after the axis-0 solve of reproject_spline_resident
     int last_sm_knife_edges = 0;    // PM_OPT_LAST_SM_KNIFE_EDGES
+    int last_sm_ill_conditioned = 0;  // PM_OPT_LAST_SM_ILL_CONDITIONED
     size_t sm_lds_limit = 0;        // dynamic LDS the smoothing kernels may ask for on THIS context's device (0: not asked yet)
     int spline_segment = 0;         // PM_OPT_SPLINE_SEGMENT: 0 = the library's choice, -1 = never, n = samples per segment
     int last_spline_segment = 0;    // PM_OPT_LAST_SPLINE_SEGMENT

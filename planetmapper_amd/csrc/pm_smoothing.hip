@@ -67,7 +67,21 @@ struct SmPlaneDev {
     int all_nan;  // body_xy.py:1668-1670: the map of an all-NaN image is all NaN
     int plane;    // index in the chunk (cube, output, statistics)
     int knife_edge;  // the knot search took a decision between intervals whose residual shares tie to rounding (sm_add_knot)
+    // the refinement pass of the latest fit, per direction: largest |correction| and largest |coefficient| (bit patterns of
+    // non-negative doubles order like integers: atomicMax), and what k_smb_decide made of them
+    unsigned long long ref_delta[2], ref_scale[2];
+    double refine_ratio;   // max over the directions of correction / scale, latest fit
+    int ill_conditioned;   // a fit of the search whose refinement moved its coefficients by more than kSmIllRatio of their scale
 };
+// A corrected-semi-normal-equations solve squares the condition number of [A; B / p] where FITPACK's Givens QR carries it once:
+// its refinement step converges while cond^2 eps < 1 and then lands on the least-squares solution to ~cond eps. A fit whose
+// refinement step still moves the coefficients by this much of their scale is beyond that - and the fits after it hang on
+// its residual sum (knot placement, the bracket of p). Measured (round-6 soak, 191 000 plane fits, 3 beyond the 1e-7 bar, all
+// on a 20-25 sample axis of degree 4-5): healthy fits 1e-15 .. 2e-12; smoothing parameters p ~ 1e7 .. 1e9 where the knot
+// set leaves combinations of coefficients to the jump rows B / p alone 4.5e-10 and 1.3e-9 (4e-6 and 9e-5 of scale from
+// scipy); a least-squares phase with a rank-deficient knot set 0.58 (its residual sums steer the search of p to another
+// acceptable p: 5e-5). Reported: PM_OPT_LAST_SM_ILL_CONDITIONED.
+constexpr double kSmIllRatio = 1e-10;
 
 // dst[x] = value(x), x < n, by the NT threads of the workgroup: eight requests in flight per thread (a plain loop of
 // load - store pairs waits out every trip to HBM on its own)
@@ -283,7 +297,13 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
         iter = it2 = lastdi = ich1 = ich3 = 0;
         nplus_y = nplus_x = 0;
         poly = 1;
-        if (lane == 0) { P.fits = 0; P.knife_edge = 0; }
+        if (lane == 0) {
+            P.fits = 0;
+            P.knife_edge = 0;
+            P.ill_conditioned = 0;
+            P.refine_ratio = 0.0;
+            P.ref_delta[0] = P.ref_delta[1] = P.ref_scale[0] = P.ref_scale[1] = 0ull;
+        }
     } else {
         // the residual sums of the fit, tile partials added in a fixed order
         for (int i = lane; i < my; i += 64) {
@@ -297,6 +317,19 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
             P.colsum[j] = v;
         }
         __syncthreads();
+        {
+            // how far the refinement passes of the fit just made moved its coefficients, relative to their scale
+            double ratio = 0.0;
+            for (int dir = 0; dir < 2; dir++) {
+                const double dl = __longlong_as_double((long long)P.ref_delta[dir]), sc = __longlong_as_double((long long)P.ref_scale[dir]);
+                if (sc > 0.0) ratio = fmax(ratio, dl / sc);
+            }
+            __syncthreads();
+            if (lane == 0) {
+                P.refine_ratio = ratio;
+                P.ref_delta[0] = P.ref_delta[1] = P.ref_scale[0] = P.ref_scale[1] = 0ull;
+            }
+        }
         fp = wave_sum(P.rowsum, my, lane);
         sm_account(P.y, ny_n, P.rowsum, lane);
         sm_account(P.x, nx_n, P.colsum, lane);
@@ -404,6 +437,10 @@ __global__ __launch_bounds__(64) void k_smb_decide(SmPlaneDev *planes, const Pla
         if (knife_edge && !P.knife_edge) {
             P.knife_edge = 1;
             atomicAdd(&status[8], 1);  // (status[8]: zeroed once per call, not per round)
+        }
+        if (!first && !P.ill_conditioned && P.refine_ratio > kSmIllRatio) {
+            P.ill_conditioned = 1;  // (sticky: every later decision of the search hangs on this fit's residual sum)
+            atomicAdd(&status[9], 1);
         }
         P.phase = phase;
         P.active = phase != 2;
@@ -687,7 +724,8 @@ constexpr int kSmTileIn = 8, kSmGroup = 4;
 // W: entries per row (k + 1 for the collocation rows alone, k + 2 with the jump rows among them)
 template <int K, int W, bool LDS>
 __device__ __forceinline__ void sm_sweep(const SmAxisDev &a, bool merged, const double *__restrict__ in, int si, int nrhs,
-                                         double *__restrict__ c, double *__restrict__ g, int q, int pass, double *smem)
+                                         double *__restrict__ c, double *__restrict__ g, int q, int pass, double *smem,
+                                         unsigned long long *ref_delta = nullptr, unsigned long long *ref_scale = nullptr)
 {
     constexpr int BAND = K + 2, TI = kSmTileIn, GR = kSmGroup;
     const int nc = a.nc(), n_rows = merged ? a.m + a.nb : a.m;
@@ -793,6 +831,7 @@ __device__ __forceinline__ void sm_sweep(const SmAxisDev &a, bool merged, const 
     double x[BAND - 1];
 #pragma unroll
     for (int b = 0; b < BAND - 1; b++) x[b] = 0.0;
+    double dmax = 0.0, cmax = 0.0;  // (second pass: how far the refinement moves this right-hand side's coefficients)
     auto fetch_g = [&](int jt) {
 #pragma unroll
         for (int u = 0; u < TI; u++) tnext[u] = g[(size_t)max(jt - u, 0) * nrhs + q];
@@ -817,7 +856,24 @@ __device__ __forceinline__ void sm_sweep(const SmAxisDev &a, bool merged, const 
 #pragma unroll
             for (int b = BAND - 2; b > 0; b--) x[b] = x[b - 1];
             x[0] = sv;
-            if (jt - u >= 0) c[(size_t)j * nrhs + q] = pass ? cold[u] + sv : sv;
+            if (jt - u >= 0) {
+                const double cn = pass ? cold[u] + sv : sv;
+                c[(size_t)j * nrhs + q] = cn;
+                if (pass) {
+                    dmax = fmax(dmax, fabs(sv));  // (fmax drops a NaN: a fit that went singular reports nothing here)
+                    cmax = fmax(cmax, fabs(cn));
+                }
+            }
+        }
+    }
+    if (pass && ref_delta) {
+        for (int off = 32; off > 0; off >>= 1) {
+            dmax = fmax(dmax, __shfl_xor(dmax, off, 64));
+            cmax = fmax(cmax, __shfl_xor(cmax, off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(ref_delta, (unsigned long long)__double_as_longlong(dmax));
+            atomicMax(ref_scale, (unsigned long long)__double_as_longlong(cmax));
         }
     }
 }
@@ -834,7 +890,7 @@ template <int K, int PASS>
 __global__ __launch_bounds__(kSolveBlock) void k_smb_solve(SmPlaneDev *planes, int dir, int lds)
 {
     extern __shared__ double sm_tables[];
-    const SmPlaneDev &P = planes[blockIdx.y];
+    SmPlaneDev &P = planes[blockIdx.y];
     if (!P.active) return;
     const SmAxisDev &a = dir ? P.x : P.y;
     const int nr = P.y.nc();
@@ -846,8 +902,8 @@ __global__ __launch_bounds__(kSolveBlock) void k_smb_solve(SmPlaneDev *planes, i
     const double *in = PASS ? P.RB : (dir ? P.UT : P.z);
     const int si = PASS ? nrhs : (dir ? nr : P.x.m);
     const bool merged = PASS && a.nb > 0;
-    if (lds) sm_sweep<K, W, true>(a, merged, in, si, nrhs, c, P.G, q, PASS, sm_tables);
-    else sm_sweep<K, W, false>(a, merged, in, si, nrhs, c, P.G, q, PASS, nullptr);
+    if (lds) sm_sweep<K, W, true>(a, merged, in, si, nrhs, c, P.G, q, PASS, sm_tables, &P.ref_delta[dir], &P.ref_scale[dir]);
+    else sm_sweep<K, W, false>(a, merged, in, si, nrhs, c, P.G, q, PASS, nullptr, &P.ref_delta[dir], &P.ref_scale[dir]);
 }
 
 // residuals of every row of a direction's system after the first pass, in the order the second pass walks them:
@@ -1119,8 +1175,9 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
     const hipStream_t st = ctx->stream;
     std::vector<pm::SmPlaneDev> desc(batch);
     const size_t plane_elems = npx;
-    PM_HIP(ctx, hipMemsetAsync(status + 8, 0, sizeof(int), st));
+    PM_HIP(ctx, hipMemsetAsync(status + 8, 0, 2 * sizeof(int), st));
     ctx->last_sm_knife_edges = 0;
+    ctx->last_sm_ill_conditioned = 0;
     for (size_t p0 = 0; p0 < (size_t)a.n_planes; p0 += batch) {
         const int np = (int)std::min(batch, (size_t)a.n_planes - p0);
         pm::ReprojectArgs b = a;
@@ -1180,7 +1237,7 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
                 for (int pl = 0; pl < std::min(np, 4); pl++) {
                     pm::SmPlaneDev d0;
                     PM_HIP(ctx, hipMemcpy(&d0, planes + pl, sizeof(d0), hipMemcpyDeviceToHost));
-                    std::fprintf(stderr, "   plane %d: phase %d knots=(%d,%d) next p=%g last fp=%.17g\n", pl, d0.phase, d0.y.n, d0.x.n, d0.p, d0.fp);
+                    std::fprintf(stderr, "   plane %d: phase %d knots=(%d,%d) next p=%g last fp=%.17g refinement moved %.1e of scale\n", pl, d0.phase, d0.y.n, d0.x.n, d0.p, d0.fp, d0.refine_ratio);
                     if (ctx->trace & 1) {  // (with bit 0 as well: the interior knots themselves)
                         for (const pm::SmAxisDev *ax : {&d0.y, &d0.x}) {
                             std::vector<double> t((size_t)ax->n);
@@ -1221,11 +1278,15 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
                 const int rows1 = m + (any_p ? ncm : 0);
                 const size_t b0 = pm::sm_sweep_lds_bytes(m, k + 1, k, ncm), b1 = pm::sm_sweep_lds_bytes(rows1, k + 2, k, ncm);
                 const dim3 grid((nrhs + pm::kSolveBlock - 1) / pm::kSolveBlock, np), block(pm::kSolveBlock);
+                // (more than one refinement pass does not help where one does not: measured on the three ill-conditioned fits of
+                //  the round-6 soak, 1 .. 4 passes - the iteration needs cond^2 eps < 1 to converge at all)
                 for_degree(k, [&](auto K) {
                     constexpr int kk = decltype(K)::value;
                     hipLaunchKernelGGL((pm::k_smb_solve<kk, 0>), grid, block, b0 <= lds_limit ? b0 : 0, st, planes, dir, b0 <= lds_limit ? 1 : 0);
-                    hipLaunchKernelGGL(pm::k_smb_res, dim3((nrhs + pm::kBlock - 1) / pm::kBlock, (rows1 + pm::kResRows - 1) / pm::kResRows, np), dim3(pm::kBlock), 0, st, planes, dir);
-                    hipLaunchKernelGGL((pm::k_smb_solve<kk, 1>), grid, block, b1 <= lds_limit ? b1 : 0, st, planes, dir, b1 <= lds_limit ? 1 : 0);
+                    {
+                        hipLaunchKernelGGL(pm::k_smb_res, dim3((nrhs + pm::kBlock - 1) / pm::kBlock, (rows1 + pm::kResRows - 1) / pm::kResRows, np), dim3(pm::kBlock), 0, st, planes, dir);
+                        hipLaunchKernelGGL((pm::k_smb_solve<kk, 1>), grid, block, b1 <= lds_limit ? b1 : 0, st, planes, dir, b1 <= lds_limit ? 1 : 0);
+                    }
                 });
             };
             solve(0);
@@ -1245,9 +1306,10 @@ int reproject_smoothing_resident(pm_ctx *ctx, pm::ReprojectArgs a, int dtype, in
         case PM_U16: hipLaunchKernelGGL(pm::k_smb_eval<uint16_t>, ge, bl, 0, st, b, (const pm::SmPlaneDev *)planes); break;
         }
         PM_HIP(ctx, hipGetLastError());
-        PM_HIP(ctx, hipMemcpyAsync(ctx->sm_status_host, status + 8, sizeof(int), hipMemcpyDeviceToHost, st));
+        PM_HIP(ctx, hipMemcpyAsync(ctx->sm_status_host, status + 8, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         PM_HIP(ctx, hipStreamSynchronize(st));
         ctx->last_sm_knife_edges = ctx->sm_status_host[0];  // (cumulative over the batches of the call)
+        ctx->last_sm_ill_conditioned = ctx->sm_status_host[1];
         // (`desc` is rewritten for the next batch: the upload above must have been consumed - it has, every round synchronised)
     }
     return PM_OK;

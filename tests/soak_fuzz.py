@@ -63,6 +63,7 @@ def main():
         print(json.dumps({'knife_edge': [str(v) for v in ke]}), flush=True)
     print(json.dumps({'seeds': args.seeds, 'first': args.first, 'failures': len(failures), 'reported_knife_edges_beyond_bar': len(knife_edges),
                       'smoothing_plane_fits': getattr(S.smoothing_fuzz, 'calls', 0), 'of_them_reported_as_knife_edges': getattr(S.smoothing_fuzz, 'flagged', 0),
+                      'of_them_reported_as_ill_conditioned': getattr(S.smoothing_fuzz, 'ill', 0),
                       'seconds': round(time.time() - t0, 1)}), flush=True)
     return 1 if failures else 0
 

@@ -324,6 +324,9 @@ def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
     (tests/test_smoothing_knife_edge.py: a one-ulp change of one pixel flips it). The library reports such searches
     (PM_OPT_LAST_SM_KNIFE_EDGES); a plane beyond the bar is accepted only in a call that reported one, only within 5 % of
     scale (both outcomes are smoothing splines of the same data and s), and is returned to the caller, who counts them.
+    The other: a fit beyond what semi-normal equations + refinement resolve (20-25 sample axes of degree 4-5 with p ~ 1e8 or
+    a rank-deficient least-squares phase: 3 fits in 191 000 of the round-6 soak, 4e-6 .. 9e-5 of scale) - reported as
+    well (PM_OPT_LAST_SM_ILL_CONDITIONED), accepted only where reported and only within 1e-3.
     """
     from planetmapper_amd import _lib
 
@@ -362,8 +365,10 @@ def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
         for prop in (True, False):
             a = engine.map_cube(cube, xm, ym, (ky, kx), prop, spline_smoothing=s)
             flagged = engine.get_option(_lib.PM_OPT_LAST_SM_KNIFE_EDGES)
+            ill = engine.get_option(_lib.PM_OPT_LAST_SM_ILL_CONDITIONED)
             smoothing_fuzz.calls += n_planes
             smoothing_fuzz.flagged += flagged
+            smoothing_fuzz.ill = getattr(smoothing_fuzz, 'ill', 0) + ill
             b = oracle.map_cube(cube, xm, ym, (ky, kx), prop, spline_smoothing=s)
             assert np.array_equal(np.isnan(a), np.isnan(b)), label
             for p in range(n_planes):
@@ -374,7 +379,10 @@ def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
                     if dev > 1e-7 and flagged > 0 and dev <= 0.05:
                         knife_edges.append(label + (p, prop, dev))
                         continue
-                    assert dev <= 1e-7, label + (p, prop, dev, f'knife edges reported: {flagged}')
+                    if dev > 1e-7 and ill > 0 and dev <= 1e-3:
+                        knife_edges.append(label + (p, prop, dev, 'ill-conditioned fit reported'))
+                        continue
+                    assert dev <= 1e-7, label + (p, prop, dev, f'knife edges reported: {flagged}, ill-conditioned fits: {ill}')
         p = int(rng.integers(0, n_planes))
         assert np.array_equal(engine.map_cube(cube[p : p + 1], xm, ym, (ky, kx), True, spline_smoothing=s)[0],
                               engine.map_cube(cube, xm, ym, (ky, kx), True, spline_smoothing=s)[p], equal_nan=True), label + (p,)
@@ -384,6 +392,19 @@ def smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=8):
 @pytest.mark.parametrize('seed', [20261004, 5])
 def test_random_smoothing_spline_fuzz(engine, oracle, jupiter, seed):
     assert smoothing_fuzz(engine, oracle, jupiter, seed) == []  # (fixed seeds: no plane of these is at a knife edge)
+
+
+def test_ill_conditioned_smoothing_fits_are_reported(engine, oracle, jupiter):
+    """
+    The three planes of the round-6 soak (191 000 fits) that miss the 1e-7 bar without a knife edge: 20-25 sample axes of
+    degree 4-5 whose least-squares systems are conditioned beyond what semi-normal equations + refinement resolve (DESIGN.md
+    section 2). The library must SAY so (PM_OPT_LAST_SM_ILL_CONDITIONED: the refinement step's own measure) - the fuzz then
+    accepts them within 1e-3 of scale and returns them; every other plane of those cubes meets the bar as everywhere.
+    """
+    for seed, n_cases, planes in ((201558, 1, {0}), (201514, 1, {0}), (201498, 5, {2})):
+        tolerated = smoothing_fuzz(engine, oracle, jupiter, seed, n_cases=n_cases)
+        assert tolerated and all(t[-1] == 'ill-conditioned fit reported' and 1e-7 < t[-2] <= 1e-3 for t in tolerated), (seed, tolerated)
+        assert {t[6] for t in tolerated} == planes and {t[1] for t in tolerated} == {n_cases - 1}, (seed, tolerated)
 
 
 def test_smoothing_knife_edge_is_reported_and_lands_on_one_of_scipys_two_answers(engine, oracle, jupiter):

@@ -979,10 +979,33 @@ class BodyXY:
                 smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
             )  # fmt: skip
         elif interp != 'nearest' and spline_smoothing != 0:
-            out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan, spline_smoothing=spline_smoothing)
+            eng = self._bind()
+            out = eng.map_cube(img, x_map, y_map, interp, propagate_nan, spline_smoothing=spline_smoothing)
+            self._warn_about_smoothing_fits(eng)
         else:
             out = self._bind().map_cube(img, x_map, y_map, interp, propagate_nan)
         return out[0] if single else out
+
+    @staticmethod
+    def _warn_about_smoothing_fits(eng) -> None:
+        """
+        Say so when a smoothing-spline fit (`spline_smoothing > 0`) is one scipy itself does not pin down: the library counts
+        the planes whose knot search chose between tied intervals by rounding noise, and those that went through a fit its
+        least-squares solve does not resolve (include/planetmapper_hip.h: PM_OPT_LAST_SM_KNIFE_EDGES / _ILL_CONDITIONED).
+        """
+        if not hasattr(eng, 'get_option'):
+            return
+        ties = eng.get_option(_lib.PM_OPT_LAST_SM_KNIFE_EDGES)
+        ill = eng.get_option(_lib.PM_OPT_LAST_SM_ILL_CONDITIONED)
+        if ties or ill:
+            import warnings
+
+            warnings.warn(
+                f'smoothing spline: {ties} plane(s) whose knot search chose between intervals tied to rounding (scipy\'s own '
+                f'choice there flips under a one-ulp change of the data; the alternatives are percent-level apart), {ill} plane(s) '
+                'with an ill-conditioned fit (up to 1e-4 of the data scale from scipy\'s): both are valid smoothing splines of '
+                'the data for this `spline_smoothing`, not necessarily the one scipy returns',
+                RuntimeWarning, stacklevel=3)  # fmt: skip
 
     # ------------------------------------------------------------------ backplane registry
     @staticmethod

@@ -440,6 +440,18 @@ def test_smoothing_knife_edge_is_reported_and_lands_on_one_of_scipys_two_answers
     print(f'\n[knife edge] scipy / scipy after a one-ulp change of one pixel: {apart:.1e} of scale apart; device - each: {devs[0]:.1e}, {devs[1]:.1e}')
     assert apart > 1e-3
     assert min(devs) <= 1e-7, devs
+    # the drop-in surface says so too (a RuntimeWarning from map_img), and stays quiet otherwise
+    import warnings
+
+    from planetmapper_amd import BodyXY
+
+    body = BodyXY('jupiter', geometry=jupiter, nx=nx, ny=ny)
+    body.set_disc_params((nx - 1) / 2, (ny - 1) / 2, 0.45 * min(nx, ny), np.rad2deg(0.3))
+    with pytest.warns(RuntimeWarning, match='1 plane.s. whose knot search chose between intervals tied to rounding'):
+        body.map_img(plane, interpolation=(ky, kx), spline_smoothing=s, degree_interval=5)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        body.map_img(plane, interpolation=(ky, kx), spline_smoothing=40 * s, degree_interval=5)
     # a search without such a tie reports none (and meets the oracle as everywhere)
     cube, _ = make_cube(3, 300, 260, seed=9)
     xm2, ym2 = setup_maps(engine, oracle, jupiter, 300, 260, deg=3.0)

@@ -276,9 +276,15 @@ class HipBackplanes:
     # ------------------------------------------------------------------ reprojection and the point forms
     def map_img(self, img, *, interpolation='linear', propagate_nan=True, warn_nan=False, spline_smoothing=0, smooth_oversample_by=5,
                 smooth_max_oversampled_img_size=10_000, **map_kwargs):  # body_xy.py:1414  # fmt: skip
-        return self._hip().map_cube(img, self.get_x_map(**map_kwargs), self.get_y_map(**map_kwargs), interpolation, propagate_nan,
-                                    smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
-                                    spline_smoothing=spline_smoothing)[0]  # fmt: skip
+        eng = self._hip()
+        out = eng.map_cube(img, self.get_x_map(**map_kwargs), self.get_y_map(**map_kwargs), interpolation, propagate_nan,
+                           smooth_oversample_by=smooth_oversample_by, smooth_max_oversampled_img_size=smooth_max_oversampled_img_size,
+                           spline_smoothing=spline_smoothing)[0]  # fmt: skip
+        if spline_smoothing and interpolation not in ('nearest', 'smooth'):
+            from .body_xy import BodyXY as _NativeBodyXY  # noqa: PLC0415
+
+            _NativeBodyXY._warn_about_smoothing_fits(eng)  # (a fit scipy itself does not pin down: said, as the native class does)
+        return out
 
     def illumination_angles_from_lonlat(self, lon, lat, *, alt=0.0, planetocentric=False):  # body.py:2295
         """

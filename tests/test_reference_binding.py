@@ -77,6 +77,34 @@ def test_binding_reproduces_the_geometry_builder_block(name):
     assert 'spksfs' in spice.calls  # the chain was walked segment by segment
 
 
+def test_binding_with_an_observer_on_two_line_elements_meets_the_golden_planes():
+    """
+    The reference's own golden geometry - Jupiter from HST, an observer whose SPK is type 10 - through the binding: the
+    observer's state is whatever `spkssb` says (here the stand-in on `ephem.TleSegment`; in a deployment CSPICE's spke10), the
+    block equals GeometryBuilder's, and the oracle on it reproduces the golden RADIAL-VELOCITY plane with nothing fitted.
+    """
+    from oracle import oracle
+    from planetmapper_amd.ephem import Ephemeris, RotationModel
+    from planetmapper_amd.geometry import GeometryBuilder
+    from planetmapper_amd.reference_binding import geometry_from_body
+    from planetmapper_amd.scenarios import scenario_info
+    from spice_standin import DuckBody, SpiceStandIn
+
+    d = scenario_info('jupiter_hst_2005')
+    eph, rot = Ephemeris.from_json(d['ephemeris']), RotationModel.from_json(d['pck'])
+    g = GeometryBuilder(eph, rot, 599).build(d['et'], observer_id=-48)
+    spice = SpiceStandIn(eph, {'IAU_JUPITER': rot}, {'JUPITER': 599, 'SUN': 10, 'EARTH': 399, 'HST': -48})
+    b = geometry_from_body(DuckBody(g, target='JUPITER', target_id=599, observer='HST', frame='IAU_JUPITER'), spice)
+    assert np.array_equal(vec(b, 'VO'), vec(g, 'VO')) and np.array_equal(vec(b, 'T0'), vec(g, 'T0'))
+    assert np.max(np.abs(vec(b, 'WP') - vec(g, 'WP'))) < 1e-4 * np.linalg.norm(vec(g, 'WP'))
+    gold = np.load(os.path.join(GOLDEN, 'golden_test_nav.npz'))
+    ok = np.isfinite(gold['RADIAL-VELOCITY'])
+    disc = oracle.make_disc(2.5, 3.1, 3.9, 123.456, 7, 10)
+    out = oracle.backplanes_img(b, disc, ['RADIAL-VELOCITY', 'LON-GRAPHIC', 'EMISSION'])
+    assert np.max(np.abs(out['RADIAL-VELOCITY'][ok] - gold['RADIAL-VELOCITY'][ok])) <= 1e-10
+    assert np.max(np.abs(out['LON-GRAPHIC'][ok] - gold['LON-GRAPHIC'][ok])) <= 3e-9 and np.max(np.abs(out['EMISSION'][ok] - gold['EMISSION'][ok])) <= 2e-9
+
+
 @pytest.mark.parametrize('name', ['io_like_earth_2009', 'moon_earth_2012', 'saturn_earth_2016'])
 def test_the_rate_about_the_body_z_axis_is_not_the_pm_coefficient(name):
     """

@@ -81,3 +81,13 @@ if __name__ == '__main__':
     np.savez_compressed(os.path.join(HERE, 'smoothing_knife_edge.npz'), plane=plane, degrees=np.array(k), s=np.array(s), knots_y=ty, knots_x=tx,
                         flips=np.array(flips), trials=np.array(tried))
     print('written: base y knots', ty[k[0] + 1 : -k[0] - 1], 'flips', flips, 'trials', tried)
+    # the three planes of the round-6 soak (191 000 fits) beyond the 1e-7 bar without a knife edge: ill-conditioned fits
+    ill = {}
+    for seed, case, pl in ((201558, 0, 0), (201514, 0, 0), (201498, 4, 2)):
+        cube, k, s = soak_case(seed, case)
+        ill[f'plane_{seed}'] = cube[pl]
+        ill[f'degrees_{seed}'] = np.array(k)
+        ill[f's_{seed}'] = np.array(s)
+    healthy, k, s = soak_case(5, 2)
+    ill['plane_healthy'], ill['degrees_healthy'], ill['s_healthy'] = healthy[1], np.array(k), np.array(s)  # (plane 0 of that cube has NaN pixels)
+    np.savez_compressed(os.path.join(HERE, 'smoothing_ill_conditioned.npz'), **ill)

@@ -397,8 +397,8 @@ def test_random_smoothing_spline_fuzz(engine, oracle, jupiter, seed):
 def test_ill_conditioned_smoothing_fits_are_reported(engine, oracle, jupiter):
     """
     The three planes of the round-6 soak (191 000 fits) that miss the 1e-7 bar without a knife edge: 20-25 sample axes of
-    degree 4-5 whose least-squares systems are conditioned beyond what semi-normal equations + refinement resolve (DESIGN.md
-    section 2). The library must SAY so (PM_OPT_LAST_SM_ILL_CONDITIONED: the refinement step's own measure) - the fuzz then
+    degree 4-5 whose fits are ill-conditioned in themselves (scipy's own answer on them moves by 2e-5 .. 2.5e-4 of scale under a
+    one-ulp change of one pixel: tests/test_smoothing_knife_edge.py). The library must SAY so (PM_OPT_LAST_SM_ILL_CONDITIONED: the refinement step's own measure) - the fuzz then
     accepts them within 1e-3 of scale and returns them; every other plane of those cubes meets the bar as everywhere.
     """
     for seed, n_cases, planes in ((201558, 1, {0}), (201514, 1, {0}), (201498, 5, {2})):

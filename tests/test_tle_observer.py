@@ -164,3 +164,27 @@ def test_the_whole_span_of_hst_bsp_is_an_orbit():
         t = float(seg.epochs[k])
         a, b = seg.state(t - 1e-4), seg.state(t + 1e-4)
         assert np.linalg.norm(b[0] - a[0] - 2e-4 * a[1]) < 1e-6 and np.linalg.norm(b[1] - a[1]) < 1e-5, k
+
+
+def test_sgp4_against_the_published_verification_vectors():
+    """
+    Independent of the reference and of its kernels: the near-earth verification case of Vallado, Crawford, Hujsak & Kelso
+    2006 ("Revisiting Spacetrack Report #3", AIAA 2006-6753: satellite 00005, 58002B, epoch 2000-06-27; WGS-72) - TEME
+    position / velocity at 0, 360 and 720 minutes from the epoch, as published with the paper's code (8-9 decimals).
+    The segment-style constants carry KE to 9 digits (7.43669161e-2, as in hst.bsp) where the paper's code derives it from
+    mu: 1e-10 relative, 2e-6 km here.
+    """
+    geophs = [1.082616e-3, -2.53881e-6, -1.65597e-6, 7.43669161e-2, 120.0, 78.0, 6378.135, 1.0]
+    d2r = math.pi / 180.0
+    elements = [0.0, 0.0, 0.28098e-4, 34.2682 * d2r, 348.7242 * d2r, 0.1859667, 331.7664 * d2r, 19.3264 * d2r,
+                10.82419157 * 2.0 * math.pi / 1440.0, 0.0]  # NDT20 NDD60 BSTAR INCL NODE0 ECC OMEGA M0 N0 (rad / min) EPOCH
+    sat = ephem._Sgp4(geophs, elements)
+    published = {
+        0.0: (7022.46529266, -1400.08296755, 0.03995155, 1.893841015, 6.405893759, 4.534807250),
+        360.0: (-7154.03120202, -3783.17682504, -3536.19412294, 4.741887409, -4.151817765, -2.093935425),
+        720.0: (-7134.59340119, 6531.68641334, 3260.27186483, -4.113793027, -2.911922039, -2.557327851),
+    }
+    for minutes, ref in published.items():
+        r, v = sat.state(60.0 * minutes)
+        assert np.max(np.abs(r - np.array(ref[:3]))) < 5e-6, (minutes, r)
+        assert np.max(np.abs(v - np.array(ref[3:]))) < 5e-9, (minutes, v)
